@@ -1,0 +1,455 @@
+/*
+ * oracle/bwgr_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the bWGR Gibbs hot path, used as the parity checker by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing in the product
+ * (bwgr_amd/, include/) may include, link or call this file.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or known answers for this
+ * path and cannot be built or run here (needs R, Rcpp, RcppEigen and
+ * R nmath, none present; /root/reference/src/Rcpp20260726ai.cpp:3).  This file is therefore
+ * pinned only by (a) being a line-by-line restatement of the cited reference lines,
+ * (b) the analytic invariants in tests/test_oracle_invariants.py, (c) Philox known-answer
+ * vectors for the RNG.  Third-party arithmetic it stands in for: Eigen (via RcppEigen,
+ * version unpinned in /root/reference/DESCRIPTION:13-15) reductions dot/squaredNorm/mean/
+ * GEMV, and R nmath rnorm/rchisq/rbinom (replaced by the counter-based contract in
+ * bwgr_rng.h: same distributions, different stream).
+ *
+ * The file is compiled twice (see Makefile):
+ *   -DACC_T=double -DSUF=_w   "wide":     every Eigen reduction accumulates in double and the
+ *                                          Bernoulli log-odds uses the un-rounded norm
+ *                                          difference.  This is the parity target for the GPU.
+ *   -DACC_T=float  -DSUF=_f   "faithful": reductions accumulate in float (8 interleaved
+ *                                          partial sums, as Eigen's packet reduction does) and
+ *                                          the norms are rounded to float before subtraction,
+ *                                          exactly as the reference's types dictate.  This is
+ *                                          the CPU baseline that bench.py times.
+ * Everything else (all scalar arithmetic, the residual vector e, the element-wise updates)
+ * is float in both, as in the reference's Eigen::VectorXf / float locals.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "bwgr_rng.h"
+
+#ifndef ACC_T
+#define ACC_T double
+#define SUF _w
+#define ACC_WIDE 1
+#endif
+#define CAT2(a, b) a##b
+#define CAT(a, b) CAT2(a, b)
+#define FN(name) CAT(name, SUF)
+
+enum { M_BAYESA = 0, M_BAYESB = 1, M_BAYESC = 2, M_BAYESL = 3, M_BAYESRR = 4, M_BAYESCPI = 5, M_BAYESDPI = 6 };
+
+/* ---- Eigen-shaped reductions ------------------------------------------------------------ */
+static inline ACC_T red8(const ACC_T s[8]) {
+  return ((s[0] + s[4]) + (s[2] + s[6])) + ((s[1] + s[5]) + (s[3] + s[7]));
+}
+/* X.col(j).dot(e) */
+static float v_dot(const float *x, const float *e, int64_t n) {
+  ACC_T s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t i = 0;
+  for (; i + 8 <= n; i += 8)
+    for (int l = 0; l < 8; l++) s[l] += (ACC_T)x[i + l] * (ACC_T)e[i + l];
+  for (int l = 0; i < n; i++, l++) s[l] += (ACC_T)x[i] * (ACC_T)e[i];
+  return (float)red8(s);
+}
+/* v.squaredNorm() kept in the accumulator type (caller rounds) */
+static ACC_T v_sqnorm_acc(const float *v, int64_t n) {
+  ACC_T s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t i = 0;
+  for (; i + 8 <= n; i += 8)
+    for (int l = 0; l < 8; l++) s[l] += (ACC_T)v[i + l] * (ACC_T)v[i + l];
+  for (int l = 0; i < n; i++, l++) s[l] += (ACC_T)v[i] * (ACC_T)v[i];
+  return red8(s);
+}
+static float v_sqnorm(const float *v, int64_t n) { return (float)v_sqnorm_acc(v, n); }
+static ACC_T v_sum_acc(const float *v, int64_t n) {
+  ACC_T s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t i = 0;
+  for (; i + 8 <= n; i += 8)
+    for (int l = 0; l < 8; l++) s[l] += (ACC_T)v[i + l];
+  for (int l = 0; i < n; i++, l++) s[l] += (ACC_T)v[i];
+  return red8(s);
+}
+/* v.mean(): Eigen = sum()/size() in the scalar type */
+static float v_mean(const float *v, int64_t n) { return (float)(v_sum_acc(v, n) / (ACC_T)n); }
+
+/* fvar, /root/reference/src/Rcpp20260726ai.cpp:7-9 */
+static float v_fvar(const float *x, int64_t n) {
+  const float m = v_mean(x, n);
+  ACC_T s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t i = 0; i < n; i++) {
+    float dev = x[i] - m;
+    float sq = dev * dev;
+    s[i & 7] += (ACC_T)sq;
+  }
+  return (float)(red8(s) / (ACC_T)(float)(n - 1));
+}
+/* out = e - x*db   (Eigen: e - X.col(j)*(scalar), element-wise in float) */
+static void v_axpy_to(float *out, const float *e, const float *x, float db, int64_t n) {
+  for (int64_t i = 0; i < n; i++) {
+    float t = x[i] * db;
+    out[i] = e[i] - t;
+  }
+}
+/* e -= x*db */
+static void v_axpy(float *e, const float *x, float db, int64_t n) {
+  for (int64_t i = 0; i < n; i++) {
+    float t = x[i] * db;
+    e[i] = e[i] - t;
+  }
+}
+static inline float f_exp(float x) { return (float)exp((double)x); } /* std::exp(float) */
+
+/* R::rnorm(mu, sigma) = mu + sigma*norm_rand() in double, narrowed to float on assignment */
+static inline float draw_norm(float mu, float sd, double z) { return (float)((double)mu + (double)sd * z); }
+
+/* ---- exported helpers --------------------------------------------------------------------- */
+float FN(oracle_fvar)(const float *x, int64_t n) { return v_fvar(x, n); }
+float FN(oracle_dot)(const float *x, const float *e, int64_t n) { return v_dot(x, e, n); }
+
+/* setup block shared by all seven samplers, /root/reference/src/Rcpp20260726ai.cpp:593-598
+ * (identical at :644-649, 707-712, 767-772, 817-822, 863-868, 929-934) */
+void FN(oracle_stats)(const float *X, int64_t n, int64_t p, int64_t ldx, float *xx, float *vx, float *MSx) {
+  for (int64_t j = 0; j < p; j++) {
+    xx[j] = v_sqnorm(X + j * ldx, n);
+    vx[j] = v_fvar(X + j * ldx, n);
+  }
+  *MSx = (float)v_sum_acc(vx, p);
+}
+
+/* philox known-answer access for tests */
+void FN(oracle_philox)(const uint32_t *ctr, const uint32_t *key, uint32_t *out) { orng_philox4x32_10(ctr, key, out); }
+/* variates: kind 0 normal, 1 uniform, 2 chisq(nu) */
+double FN(oracle_variate)(uint64_t seed, int mode, int kind, double nu, uint32_t marker, uint32_t iter, uint32_t purpose, uint32_t k) {
+  orng_t g = { seed, mode };
+  if (kind == 0) return orng_normal(&g, marker, iter, purpose, k);
+  if (kind == 1) return orng_uniform(&g, marker, iter, purpose, k);
+  return orng_chisq(&g, nu, marker, iter, purpose);
+}
+
+/* ---- KMUP: one Gibbs sweep, /root/reference/src/Rcpp20260726ai.cpp:12-38 ----------------------
+ * stable = 0: literal cj/(cj+dj) (underflows to 0/0 = NaN for 0.5*|e|^2/sqrt(Ve) >~ 103, then
+ *             every marker takes the else branch, :25-31);
+ * stable = 1: the algebraically identical 1/(1 + pi/(1-pi)*exp(C(|e2|^2-|e1|^2))), the form the
+ *             reference itself uses in BayesB (:673-674).  The GPU implements stable = 1. */
+int FN(oracle_kmup)(const float *X, int64_t n, int64_t p, int64_t ldx, float *b, float *d, const float *xx,
+                    float *e, const float *L, float Ve, float pi, uint64_t seed, uint32_t iter, int rng_mode,
+                    int stable) {
+  orng_t g = { seed, rng_mode };
+  float *e1 = (float *)malloc(sizeof(float) * n), *e2 = (float *)malloc(sizeof(float) * n);
+  if (!e1 || !e2) return 1;
+  memcpy(e1, e, sizeof(float) * n); memcpy(e2, e, sizeof(float) * n);            /* :14-15 */
+  float b0, b1, b2, cj, dj, pj;
+  float C = -0.5f / sqrtf(Ve);                                                   /* :17 */
+  for (int64_t j = 0; j < p; j++) {                                              /* :18 */
+    const float *xj = X + j * ldx;
+    uint32_t mk = (uint32_t)j;
+    b0 = b[j];                                                                   /* :19 */
+    float den = xx[j] + L[j];
+    b1 = draw_norm((v_dot(xj, e, n) + xx[j] * b0) / den, sqrtf(Ve / den), orng_normal(&g, mk, iter, ORNG_Z1, 0)); /* :20 */
+    b2 = draw_norm(0.0f, sqrtf(Ve / den), orng_normal(&g, mk, iter, ORNG_Z2, 0)); /* :21 */
+    v_axpy_to(e1, e, xj, b1 - b0, n);                                            /* :22 */
+    if (pi > 0) {                                                                /* :23 */
+      v_axpy_to(e2, e, xj, b2 - b0, n);                                          /* :24 */
+      if (stable) {
+#ifdef ACC_WIDE
+        float diff = (float)(v_sqnorm_acc(e2, n) - v_sqnorm_acc(e1, n));
+#else
+        float diff = v_sqnorm(e2, n) - v_sqnorm(e1, n);
+#endif
+        float LR = (pi / (1.0f - pi)) * f_exp(C * diff);
+        pj = 1.0f / (1.0f + LR);
+      } else {
+        cj = (1 - pi) * f_exp(C * v_sqnorm(e1, n));                              /* :25 */
+        dj = (pi)*f_exp(C * v_sqnorm(e2, n));                                    /* :26 */
+        pj = cj / (cj + dj);                                                     /* :27 */
+      }
+      /* R::rbinom(1,pj)==1 ; NaN pj compares false, like rbinom's NaN return */
+      if (orng_uniform(&g, mk, iter, ORNG_U, 0) < (double)pj) {                  /* :28 */
+        b[j] = b1; d[j] = 1; memcpy(e, e1, sizeof(float) * n);                   /* :29 */
+      } else {
+        b[j] = b2; d[j] = 0; memcpy(e, e2, sizeof(float) * n);                   /* :31 */
+      }
+    } else {
+      d[j] = 1; b[j] = b1; memcpy(e, e1, sizeof(float) * n);                     /* :34 */
+    }
+  }
+  free(e1); free(e2);
+  return 0;
+}
+
+/* ---- the seven fused samplers, /root/reference/src/Rcpp20260726ai.cpp:589-987 -----------------
+ * Outputs follow the reference's return lists.  VB has p entries for A/B/L/Dpi and 1 for
+ * C/RR/Cpi.  last_* (optional, may be NULL) receive the chain state after the final iteration:
+ * b, d, e, vb (p entries; the common variance is replicated), scal = {mu, ve, vb_common, pi}. */
+int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64_t p, int64_t ldx,
+                     float it, float bi, float pi_in, float df, float R2, uint64_t seed, int rng_mode,
+                     float *o_mu, float *o_B, float *o_D, float *o_hat, float *o_VB, float *o_ve, float *o_h2,
+                     float *o_MSx, float *o_Pi, float *o_PVAL,
+                     float *last_b, float *last_d, float *last_e, float *last_vb, float *last_scal) {
+  orng_t g = { seed, rng_mode };
+  const uint32_t GM = ORNG_GLOBAL_MARKER;
+  int iit = (int)it, ibi = (int)bi;                                   /* e.g. :611, :642 */
+  float *xx = (float *)malloc(sizeof(float) * p), *vx = (float *)malloc(sizeof(float) * p);
+  float *b = (float *)calloc(p, sizeof(float)), *d = (float *)calloc(p, sizeof(float));
+  float *B = (float *)calloc(p, sizeof(float)), *D = (float *)calloc(p, sizeof(float));
+  float *VBv = (float *)calloc(p, sizeof(float)), *vbv = (float *)malloc(sizeof(float) * p);
+  float *Lmbv = (float *)malloc(sizeof(float) * p);
+  float *e = (float *)malloc(sizeof(float) * n), *e1 = (float *)malloc(sizeof(float) * n), *e2 = (float *)malloc(sizeof(float) * n);
+  if (!xx || !vx || !b || !d || !B || !D || !VBv || !vbv || !Lmbv || !e || !e1 || !e2) return 1;
+
+  float MSx;
+  FN(oracle_stats)(X, n, p, ldx, xx, vx, &MSx);                       /* :593-598 */
+  float vy = v_fvar(y, n);                                            /* :599 */
+  float pi = pi_in;
+  if (model == M_BAYESCPI || model == M_BAYESDPI) pi = 0.5f;          /* :869, :935 */
+  float Sb;
+  if (model == M_BAYESC || model == M_BAYESCPI) Sb = df * (R2)*vy / MSx / (1 - pi);   /* :714, :871 */
+  else Sb = (R2)*df * vy / MSx;                                       /* :600, :651, :775, :824, :937 */
+  float Se = (1 - R2) * df * vy;                                      /* :601 */
+  float Phi = MSx * (1 - R2) / R2;                                    /* :773 (BayesL) */
+  float mu = v_mean(y, n);                                            /* :602 */
+  float b0, b1, b2, eM, h2, C = 0, MU = 0, VE = 0, VBs = 0, Pi = 0, LR, pj, vg, ve = vy, vb = Sb;
+  float Lmb = ve / vb;                                                /* :725, :826, :882 */
+  for (int64_t j = 0; j < p; j++) { vbv[j] = Sb; Lmbv[j] = ve * (1.0f / Sb); }   /* :608-609 cwiseInverse */
+  for (int64_t i = 0; i < n; i++) e[i] = y[i] - mu;                   /* :610 */
+  float Pi0 = pi / (1.0f - pi);                                       /* :665, :726, :883 */
+  const int per_marker_vb = (model == M_BAYESA || model == M_BAYESB || model == M_BAYESL || model == M_BAYESDPI);
+
+  for (int i = 0; i < iit; i++) {
+    uint32_t itx = (uint32_t)i;
+    C = -0.5f / sqrtf(ve);                                            /* :667 (unused by A/L/RR) */
+    ACC_T dsum = 0;
+    for (int64_t j = 0; j < p; j++) {
+      const float *xj = X + j * ldx;
+      uint32_t mk = (uint32_t)j;
+      float lam = per_marker_vb ? Lmbv[j] : Lmb;
+      float den = xx[j] + lam;
+      b0 = b[j];
+      b1 = draw_norm((v_dot(xj, e, n) + xx[j] * b0) / den, sqrtf(ve / den), orng_normal(&g, mk, itx, ORNG_Z1, 0));
+      switch (model) {
+      case M_BAYESA: case M_BAYESL:                                   /* :613-618, :787-792 */
+        b[j] = b1;
+        vbv[j] = (float)((double)(Sb + b1 * b1) / orng_chisq(&g, (double)(df + 1), mk, itx, ORNG_CHI));
+        v_axpy(e, xj, b1 - b0, n);
+        break;
+      case M_BAYESRR:                                                 /* :834-837 */
+        v_axpy(e, xj, b1 - b0, n);
+        b[j] = b1;
+        break;
+      case M_BAYESB: case M_BAYESC:                                   /* :669-681, :729-741 */
+        v_axpy_to(e1, e, xj, b1 - b0, n);
+        v_axpy_to(e2, e, xj, 0 - b0, n);
+        {
+#ifdef ACC_WIDE
+          float diff = (float)(v_sqnorm_acc(e2, n) - v_sqnorm_acc(e1, n));
+#else
+          float diff = v_sqnorm(e2, n) - v_sqnorm(e1, n);
+#endif
+          LR = Pi0 * f_exp(C * diff);
+        }
+        pj = 1.0f / (1.0f + LR);
+        if (orng_uniform(&g, mk, itx, ORNG_U, 0) < (double)pj) {
+          b[j] = b1; d[j] = 1;
+        } else {
+          b[j] = draw_norm(0.0f, sqrtf(ve / den), orng_normal(&g, mk, itx, ORNG_Z2, 0)); d[j] = 0;
+        }
+        if (model == M_BAYESB)
+          vbv[j] = (float)((double)(Sb + b[j] * b[j]) / orng_chisq(&g, (double)(df + 1), mk, itx, ORNG_CHI));
+        v_axpy(e, xj, b[j] - b0, n);
+        break;
+      case M_BAYESCPI:                                                /* :886-900 */
+        b2 = draw_norm(0.0f, sqrtf(ve / den), orng_normal(&g, mk, itx, ORNG_Z2, 0));
+        v_axpy_to(e1, e, xj, b1 - b0, n);
+        v_axpy_to(e2, e, xj, 0 - b0, n);
+        {
+#ifdef ACC_WIDE
+          float diff = (float)(v_sqnorm_acc(e2, n) - v_sqnorm_acc(e1, n));
+#else
+          float diff = v_sqnorm(e2, n) - v_sqnorm(e1, n);
+#endif
+          LR = Pi0 * f_exp(C * diff);
+        }
+        pj = 1.0f / (1.0f + LR);
+        if (orng_uniform(&g, mk, itx, ORNG_U, 0) < (double)pj) { b[j] = b1; d[j] = 1; }
+        else { b[j] = b2; d[j] = 0; }
+        v_axpy(e, xj, b[j] - b0, n);
+        break;
+      case M_BAYESDPI:                                                /* :954-968 */
+        b2 = draw_norm(0.0f, sqrtf(ve / den), orng_normal(&g, mk, itx, ORNG_Z2, 0));
+        v_axpy_to(e1, e, xj, b1 - b0, n);
+        v_axpy_to(e2, e, xj, b2 - b0, n);
+        {
+#ifdef ACC_WIDE
+          float diff = (float)(v_sqnorm_acc(e1, n) - v_sqnorm_acc(e2, n));
+#else
+          float diff = v_sqnorm(e1, n) - v_sqnorm(e2, n);
+#endif
+          pj = (1 - pi) * f_exp(C * diff);
+        }
+        if (pj > 1) pj = 1;
+        if (orng_uniform(&g, mk, itx, ORNG_U, 0) < (double)pj) { b[j] = b1; d[j] = 1; }
+        else { b[j] = b2; d[j] = 0; }
+        vbv[j] = (float)((double)(Sb + b[j] * b[j]) / orng_chisq(&g, (double)(df + 1), mk, itx, ORNG_CHI));
+        v_axpy(e, xj, b[j] - b0, n);
+        break;
+      }
+      dsum += (ACC_T)d[j];
+    }
+    /* intercept, :620-621 */
+    eM = draw_norm(v_mean(e, n), sqrtf(ve / n), orng_normal(&g, GM, itx, ORNG_G_MU, 0));
+    mu += eM;
+    for (int64_t k = 0; k < n; k++) e[k] = e[k] - eM;
+    switch (model) {
+    case M_BAYESA: case M_BAYESB: case M_BAYESDPI:                    /* :622-623, :685-686, :971-972 */
+      ve = (float)((double)(v_sqnorm(e, n) + Se) / orng_chisq(&g, (double)(n + df), GM, itx, ORNG_G_VE));
+      for (int64_t j = 0; j < p; j++) Lmbv[j] = ve * (1.0f / vbv[j]);
+      break;
+    case M_BAYESL:                                                    /* :796-797 */
+      ve = (float)((double)(v_sqnorm(e, n) + Se) / orng_chisq(&g, (double)(n + df), GM, itx, ORNG_G_VE));
+      for (int64_t j = 0; j < p; j++) Lmbv[j] = sqrtf(Phi * ve / vbv[j]);
+      break;
+    case M_BAYESRR:                                                   /* :841-843: ve first */
+      ve = (float)((double)(v_sqnorm(e, n) + Se) / orng_chisq(&g, (double)(n + df), GM, itx, ORNG_G_VE));
+      vb = (float)((double)(v_sqnorm(b, p) + Sb) / orng_chisq(&g, (double)(p + df), GM, itx, ORNG_G_VB));
+      Lmb = ve / vb;
+      break;
+    case M_BAYESC: case M_BAYESCPI:                                   /* :745-747, :903-905: vb first */
+      vb = (float)((double)(v_sqnorm(b, p) + Sb) / orng_chisq(&g, (double)(model == M_BAYESC ? df + p : p + df), GM, itx, ORNG_G_VB));
+      ve = (float)((double)(v_sqnorm(e, n) + Se) / orng_chisq(&g, (double)(n + df), GM, itx, ORNG_G_VE));
+      Lmb = ve / vb;
+      break;
+    }
+    if (model == M_BAYESCPI) {                                        /* :906-907 */
+      pi = (float)(dsum / (ACC_T)p);
+      Sb = df * (R2)*vy / MSx / (1 - pi);
+      /* note: Pi0 is NOT refreshed inside the loop in the reference (:883 is outside) */
+    }
+    if (model == M_BAYESDPI) pi = (float)(dsum / (ACC_T)p);           /* :973 */
+    if (i > ibi) {                                                    /* :624, :687 ... */
+      MU += mu; VE += ve;
+      for (int64_t j = 0; j < p; j++) B[j] += b[j];
+      if (per_marker_vb) for (int64_t j = 0; j < p; j++) VBv[j] += vbv[j];
+      else VBs += vb;
+      if (model != M_BAYESA && model != M_BAYESL && model != M_BAYESRR) for (int64_t j = 0; j < p; j++) D[j] += d[j];
+      if (model == M_BAYESCPI || model == M_BAYESDPI) Pi += pi;
+    }
+  }
+  float MCMC = it - bi;                                               /* :626 */
+  MU /= MCMC; VE /= MCMC;
+  for (int64_t j = 0; j < p; j++) { B[j] /= MCMC; D[j] /= MCMC; }
+  if (per_marker_vb) { for (int64_t j = 0; j < p; j++) VBv[j] /= MCMC; vg = (float)v_sum_acc(VBv, p); }
+  else { VBs /= MCMC; vg = VBs * MSx; }
+  if (model == M_BAYESCPI || model == M_BAYESDPI) Pi = 1 - Pi / MCMC; /* :911, :977 */
+  if (model == M_BAYESCPI) vg = VBs * MSx / Pi;                       /* :913 */
+  h2 = vg / (vg + VE);
+  /* fit = X*B + MU, :629-630 */
+  for (int64_t k = 0; k < n; k++) o_hat[k] = 0;
+  {
+    ACC_T *acc = (ACC_T *)calloc(n, sizeof(ACC_T));
+    for (int64_t j = 0; j < p; j++) { const float *xj = X + j * ldx; ACC_T Bj = (ACC_T)B[j]; for (int64_t k = 0; k < n; k++) acc[k] += (ACC_T)xj[k] * Bj; }
+    for (int64_t k = 0; k < n; k++) { float f = (float)acc[k]; o_hat[k] = f + MU; }
+    free(acc);
+  }
+  *o_mu = MU; *o_ve = VE; *o_h2 = h2; *o_MSx = MSx; *o_Pi = Pi;
+  memcpy(o_B, B, sizeof(float) * p);
+  memcpy(o_D, D, sizeof(float) * p);
+  if (per_marker_vb) memcpy(o_VB, VBv, sizeof(float) * p); else o_VB[0] = VBs;
+  if (o_PVAL) for (int64_t j = 0; j < p; j++) o_PVAL[j] = -1.0f * logf(1.0f - D[j]);   /* :912 */
+  if (last_b) memcpy(last_b, b, sizeof(float) * p);
+  if (last_d) memcpy(last_d, d, sizeof(float) * p);
+  if (last_e) memcpy(last_e, e, sizeof(float) * n);
+  if (last_vb) for (int64_t j = 0; j < p; j++) last_vb[j] = per_marker_vb ? vbv[j] : vb;
+  if (last_scal) { last_scal[0] = mu; last_scal[1] = ve; last_scal[2] = vb; last_scal[3] = pi; }
+  free(xx); free(vx); free(b); free(d); free(B); free(D); free(VBv); free(vbv); free(Lmbv); free(e); free(e1); free(e2);
+  return 0;
+}
+
+/* ---- wgr(): the split shape, /root/reference/R/wgr.R:2-169 (bag = 1, eigK = NULL) ---------------
+ * R arithmetic is double; KMUP is entered through the Rcpp glue that narrows every argument to
+ * float (/root/reference/src/RcppExports.cpp:20-27) and widens the returned b, d, e back to double
+ * (/root/reference/src/Rcpp20260726ai.cpp:37).  X arrives as an R numeric (double) matrix.
+ * o_Vb has p entries when iv (or de) is set, else 1.  Iteration i (1-based in R) uses RNG
+ * iteration word i-1. */
+int FN(oracle_wgr)(const double *y, const double *X, int64_t n, int64_t p, int64_t ldx, int it, int bi, int th,
+                   int iv, int de, double pi, double df, double R2, uint64_t seed, int rng_mode, int stable,
+                   double *o_mu, double *o_b, double *o_Vb, double *o_d, double *o_Ve, double *o_hat, double *o_cxx) {
+  orng_t g = { seed, rng_mode };
+  const uint32_t GM = ORNG_GLOBAL_MARKER;
+  if (de) iv = 1;                                                             /* wgr.R:9 */
+  float *Xf = (float *)malloc(sizeof(float) * n * p);
+  float *bf = (float *)malloc(sizeof(float) * p), *dfl = (float *)malloc(sizeof(float) * p), *xxf = (float *)malloc(sizeof(float) * p);
+  float *Lf = (float *)malloc(sizeof(float) * p), *ef = (float *)malloc(sizeof(float) * n);
+  double *xx = (double *)malloc(sizeof(double) * p), *b = (double *)calloc(p, sizeof(double)), *d = (double *)malloc(sizeof(double) * p);
+  double *Vb = (double *)malloc(sizeof(double) * p), *L = (double *)malloc(sizeof(double) * p), *e = (double *)malloc(sizeof(double) * n);
+  double *B = (double *)calloc(p, sizeof(double)), *D = (double *)calloc(p, sizeof(double)), *VB = (double *)calloc(p, sizeof(double));
+  if (!Xf || !bf || !dfl || !xxf || !Lf || !ef || !xx || !b || !d || !Vb || !L || !e || !B || !D || !VB) return 1;
+  for (int64_t j = 0; j < p; j++) for (int64_t i = 0; i < n; i++) Xf[j * n + i] = (float)X[j * ldx + i];
+  /* post = seq(bi,it,th); mc = length(post)                                   wgr.R:41-42 */
+  int mc = 0; for (int q = bi; q <= it; q += th) mc++;
+  double MSx = 0, sy = 0;
+  for (int64_t j = 0; j < p; j++) {                                           /* wgr.R:46,51 */
+    const double *xj = X + j * ldx; double s2 = 0, s1 = 0;
+    for (int64_t i = 0; i < n; i++) { s2 += xj[i] * xj[i]; s1 += xj[i]; }
+    xx[j] = s2; double m = s1 / (double)n, v = 0;
+    for (int64_t i = 0; i < n; i++) v += (xj[i] - m) * (xj[i] - m);
+    MSx += v / (double)(n - 1);
+    d[j] = 1;                                                                 /* wgr.R:48 */
+  }
+  for (int64_t i = 0; i < n; i++) sy += y[i];
+  double mu = sy / (double)n;                                                 /* wgr.R:49 */
+  double vy = 0; for (int64_t i = 0; i < n; i++) { e[i] = y[i] - mu; vy += e[i] * e[i]; }  /* wgr.R:50,56 */
+  vy /= (double)(n - 1);
+  double Va = MSx, Ve = 1;                                                    /* wgr.R:52-54 */
+  for (int64_t j = 0; j < p; j++) { Vb[j] = Va; L[j] = Vb[j] / Ve; }          /* wgr.R:53,55 (sic) */
+  double Sb = (R2)*df * vy / MSx, Se = (1 - R2) * df * vy;                    /* wgr.R:58-59 */
+  double B0 = 0, VA = 0, VE = 0;
+  for (int i = 1; i <= it; i++) {                                             /* wgr.R:66 */
+    uint32_t itx = (uint32_t)(i - 1);
+    for (int64_t j = 0; j < p; j++) { bf[j] = (float)b[j]; dfl[j] = (float)d[j]; xxf[j] = (float)xx[j]; Lf[j] = (float)L[j]; }
+    for (int64_t k = 0; k < n; k++) ef[k] = (float)e[k];
+    int rc = FN(oracle_kmup)(Xf, n, p, n, bf, dfl, xxf, ef, Lf, (float)Ve, (float)pi, seed, itx, rng_mode, stable);   /* wgr.R:85 */
+    if (rc) return rc;
+    if (pi > 0) for (int64_t j = 0; j < p; j++) d[j] = (double)dfl[j];        /* wgr.R:86 */
+    for (int64_t j = 0; j < p; j++) b[j] = (double)bf[j];                     /* wgr.R:87 */
+    for (int64_t k = 0; k < n; k++) e[k] = (double)ef[k];                     /* wgr.R:88 */
+    if (iv) {                                                                 /* wgr.R:91-111 */
+      if (de) for (int64_t j = 0; j < p; j++) Vb[j] = sqrt(b[j] * b[j] * Ve / MSx);
+      else for (int64_t j = 0; j < p; j++) Vb[j] = (Sb + b[j] * b[j]) / orng_chisq(&g, df + 1, (uint32_t)j, itx, ORNG_CHI);
+    } else {                                                                  /* wgr.R:112-115 */
+      double bb = 0; for (int64_t j = 0; j < p; j++) bb += b[j] * b[j];
+      Va = (bb + Sb) / orng_chisq(&g, df + (double)p, GM, itx, ORNG_G_VB);
+      for (int64_t j = 0; j < p; j++) Vb[j] = Va;
+    }
+    double ee = 0; for (int64_t k = 0; k < n; k++) ee += e[k] * e[k];
+    Ve = (ee + Se) / orng_chisq(&g, (double)n + df, GM, itx, ORNG_G_VE);      /* wgr.R:121 */
+    for (int64_t j = 0; j < p; j++) L[j] = Ve / Vb[j];                        /* wgr.R:122 */
+    for (int64_t k = 0; k < n; k++) e[k] = y[k] - mu;                         /* wgr.R:124 */
+    for (int64_t j = 0; j < p; j++) { const double *xj = X + j * ldx; double bj = b[j]; if (bj != 0) for (int64_t k = 0; k < n; k++) e[k] -= xj[k] * bj; }
+    double me = 0; for (int64_t k = 0; k < n; k++) me += e[k]; me /= (double)n;
+    double mu0 = me + (Ve / (double)n) * orng_normal(&g, GM, itx, ORNG_G_MU, 0);   /* wgr.R:125 sd = Ve/n (sic) */
+    mu += mu0;                                                                /* wgr.R:126 */
+    for (int64_t k = 0; k < n; k++) e[k] -= mu0;                              /* wgr.R:127 */
+    if (i >= bi && ((i - bi) % th) == 0) {                                    /* wgr.R:129 i %in% post */
+      B0 += mu; VE += Ve;
+      for (int64_t j = 0; j < p; j++) { B[j] += b[j]; D[j] += d[j]; }
+      if (iv) for (int64_t j = 0; j < p; j++) VB[j] += Vb[j]; else VA += Va;
+    }
+  }
+  B0 /= mc; VE /= mc;                                                         /* wgr.R:141-145 */
+  double mD = 0; for (int64_t j = 0; j < p; j++) { D[j] /= mc; mD += D[j]; } mD /= (double)p;
+  for (int64_t j = 0; j < p; j++) B[j] = B[j] / mc / mD;                      /* wgr.R:143 */
+  if (iv) { for (int64_t j = 0; j < p; j++) o_Vb[j] = VB[j] / mc; } else o_Vb[0] = VA / mc;
+  for (int64_t k = 0; k < n; k++) o_hat[k] = B0;                              /* wgr.R:152 */
+  for (int64_t j = 0; j < p; j++) { const double *xj = X + j * ldx; double Bj = B[j]; for (int64_t k = 0; k < n; k++) o_hat[k] += xj[k] * Bj; }
+  double cxx = 0; for (int64_t j = 0; j < p; j++) cxx += xx[j]; cxx /= (double)p;
+  *o_mu = B0; *o_Ve = VE; *o_cxx = cxx;
+  memcpy(o_b, B, sizeof(double) * p); memcpy(o_d, D, sizeof(double) * p);
+  free(Xf); free(bf); free(dfl); free(xxf); free(Lf); free(ef); free(xx); free(b); free(d); free(Vb); free(L); free(e); free(B); free(D); free(VB);
+  return 0;
+}

@@ -1,0 +1,133 @@
+"""ctypes front-end of the CPU oracle (oracle/bwgr_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+nothing under bwgr_amd/ does.  `flavour` selects the accumulator width the C file was compiled
+with: "w" (wide, the GPU's parity target) or "f" (float-faithful, the CPU baseline).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MODELS = {"BayesA": 0, "BayesB": 1, "BayesC": 2, "BayesL": 3, "BayesRR": 4, "BayesCpi": 5, "BayesDpi": 6}
+PER_MARKER_VB = {"BayesA", "BayesB", "BayesL", "BayesDpi"}
+PURPOSE = {"Z1": 0, "Z2": 1, "U": 2, "CHI": 3, "G_MU": 16, "G_VE": 17, "G_VB": 18, "G_VK": 19}
+GLOBAL_MARKER = 0xFFFFFFFF
+
+_libs = {}
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = [os.path.join(_HERE, f) for f in ("bwgr_oracle.c", "bwgr_rng.h", "Makefile")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib(fast=False):
+    key = "fast" if fast else "std"
+    if key not in _libs:
+        build()
+        _libs[key] = C.CDLL(os.path.join(_HERE, "liboracle_fast.so" if fast else "liboracle.so"))
+    return _libs[key]
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def as_f32_colmajor(X):
+    """X (n x p, any dtype) -> float32 column-major copy, the reference's Eigen::MatrixXf."""
+    return np.asfortranarray(np.asarray(X), dtype=np.float32)
+
+
+def philox(ctr, key):
+    out = (C.c_uint32 * 4)()
+    lib().oracle_philox_w((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+    return [int(v) for v in out]
+
+
+def variate(seed, kind, marker, it, purpose, k=0, nu=0.0, mode=0):
+    f = lib().oracle_variate_w
+    f.restype = C.c_double
+    kinds = {"normal": 0, "uniform": 1, "chisq": 2}
+    return f(C.c_uint64(seed), C.c_int(mode), C.c_int(kinds[kind]), C.c_double(nu), C.c_uint32(marker),
+             C.c_uint32(it), C.c_uint32(purpose), C.c_uint32(k))
+
+
+def stats(X, flavour="w"):
+    Xf = as_f32_colmajor(X)
+    n, p = Xf.shape
+    xx = np.empty(p, np.float32); vx = np.empty(p, np.float32); msx = C.c_float()
+    getattr(lib(), "oracle_stats_" + flavour)(_fp(Xf), C.c_int64(n), C.c_int64(p), C.c_int64(n), _fp(xx), _fp(vx), C.byref(msx))
+    return xx, vx, float(msx.value)
+
+
+def fvar(x, flavour="w"):
+    x = np.ascontiguousarray(x, np.float32)
+    f = getattr(lib(), "oracle_fvar_" + flavour); f.restype = C.c_float
+    return float(f(_fp(x), C.c_int64(x.size)))
+
+
+def kmup(X, b, d, xx, e, L, Ve, pi, seed=1, it=0, rng_mode=0, stable=1, flavour="w", fast=False):
+    """Reference KMUP(X,b,d,xx,e,L,Ve,pi) -> dict(b,d,e), src/Rcpp20260726ai.cpp:12-38."""
+    Xf = as_f32_colmajor(X)
+    n, p = Xf.shape
+    b = np.array(b, np.float32); d = np.array(d, np.float32); e = np.array(e, np.float32)
+    xx = np.ascontiguousarray(xx, np.float32); L = np.ascontiguousarray(L, np.float32)
+    rc = getattr(lib(fast), "oracle_kmup_" + flavour)(
+        _fp(Xf), C.c_int64(n), C.c_int64(p), C.c_int64(n), _fp(b), _fp(d), _fp(xx), _fp(e), _fp(L),
+        C.c_float(Ve), C.c_float(pi), C.c_uint64(seed), C.c_uint32(it), C.c_int(rng_mode), C.c_int(stable))
+    assert rc == 0
+    return {"b": b, "d": d, "e": e}
+
+
+def bayes(model, y, X, it=1500, bi=500, pi=0.95, df=5.0, R2=0.5, seed=1, rng_mode=0, flavour="w", fast=False):
+    """Reference BayesA/B/C/L/RR/Cpi/Dpi(y,X,it,bi,[pi,]df,R2), src/Rcpp20260726ai.cpp:589-987.
+    Returns the reference's list as a dict plus 'last' (chain state after the final iteration)."""
+    Xf = X if (isinstance(X, np.ndarray) and X.dtype == np.float32 and X.flags.f_contiguous) else as_f32_colmajor(X)
+    n, p = Xf.shape
+    y = np.ascontiguousarray(y, np.float32)
+    per = model in PER_MARKER_VB
+    B = np.zeros(p, np.float32); D = np.zeros(p, np.float32); hat = np.zeros(n, np.float32)
+    VB = np.zeros(p if per else 1, np.float32); PVAL = np.zeros(p, np.float32)
+    mu = C.c_float(); ve = C.c_float(); h2 = C.c_float(); msx = C.c_float(); Pi = C.c_float()
+    lb = np.zeros(p, np.float32); ld = np.zeros(p, np.float32); le = np.zeros(n, np.float32)
+    lvb = np.zeros(p, np.float32); ls = np.zeros(4, np.float32)
+    rc = getattr(lib(fast), "oracle_bayes_" + flavour)(
+        C.c_int(MODELS[model]), _fp(y), _fp(Xf), C.c_int64(n), C.c_int64(p), C.c_int64(n),
+        C.c_float(it), C.c_float(bi), C.c_float(pi), C.c_float(df), C.c_float(R2), C.c_uint64(seed), C.c_int(rng_mode),
+        C.byref(mu), _fp(B), _fp(D), _fp(hat), _fp(VB), C.byref(ve), C.byref(h2), C.byref(msx), C.byref(Pi), _fp(PVAL),
+        _fp(lb), _fp(ld), _fp(le), _fp(lvb), _fp(ls))
+    assert rc == 0
+    out = {"mu": mu.value, "b": B}
+    if model in ("BayesB", "BayesC", "BayesCpi", "BayesDpi"):
+        out["d"] = D
+    if model in ("BayesCpi", "BayesDpi"):
+        out.update({"pi": Pi.value, "hat": hat, "h2": h2.value, "vb": VB if per else float(VB[0]), "ve": ve.value, "PVAL": PVAL})
+    else:
+        out.update({"hat": hat, "vb": VB if per else float(VB[0]), "ve": ve.value, "h2": h2.value, "MSx": msx.value})
+    out["last"] = {"b": lb, "d": ld, "e": le, "vb": lvb, "mu": float(ls[0]), "ve": float(ls[1]), "vb_common": float(ls[2]), "pi": float(ls[3])}
+    return out
+
+
+def wgr(y, X, it=1500, bi=500, th=1, iv=False, de=False, pi=0.0, df=5.0, R2=0.5, seed=1, rng_mode=0, stable=1, flavour="w"):
+    """Reference wgr(y,X,it,bi,th,bag=1,rp=F,iv,de,pi,df,R2,eigK=NULL), R/wgr.R:2-169."""
+    Xd = np.asfortranarray(np.asarray(X), dtype=np.float64)
+    n, p = Xd.shape
+    y = np.ascontiguousarray(y, np.float64)
+    per = bool(iv or de)
+    b = np.zeros(p); d = np.zeros(p); Vb = np.zeros(p if per else 1); hat = np.zeros(n)
+    mu = C.c_double(); Ve = C.c_double(); cxx = C.c_double()
+    rc = getattr(lib(), "oracle_wgr_" + flavour)(
+        _dp(y), _dp(Xd), C.c_int64(n), C.c_int64(p), C.c_int64(n), C.c_int(it), C.c_int(bi), C.c_int(th),
+        C.c_int(int(iv)), C.c_int(int(de)), C.c_double(pi), C.c_double(df), C.c_double(R2), C.c_uint64(seed),
+        C.c_int(rng_mode), C.c_int(stable), C.byref(mu), _dp(b), _dp(Vb), _dp(d), C.byref(Ve), _dp(hat), C.byref(cxx))
+    assert rc == 0
+    return {"mu": mu.value, "b": b, "Vb": Vb if per else float(Vb[0]), "d": d, "Ve": Ve.value, "hat": hat, "cxx": cxx.value}
