@@ -1,0 +1,68 @@
+"""ctypes binding of libbwgr_hip.so (include/bwgr.h).  Fails loudly: there is no CPU fallback."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_lib = None
+
+c_f = C.POINTER(C.c_float)
+c_d = C.POINTER(C.c_double)
+
+
+class BwgrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bwgr status %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        raise ImportError("libbwgr_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `python -m bwgr_amd.build`); bwgr_amd has no CPU fallback")
+    L = C.CDLL(path)
+    L.bwgr_last_error.restype = C.c_char_p
+    vp, i64, u64, u32, i32, f32, f64 = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_int, C.c_float, C.c_double
+    L.bwgr_panel_create.argtypes = [C.POINTER(vp), vp, i32, i32, i64, i64, i64, i32, i32, i32]
+    L.bwgr_panel_destroy.argtypes = [vp]
+    L.bwgr_panel_set_stream.argtypes = [vp, vp]
+    L.bwgr_panel_info.argtypes = [vp, C.POINTER(i64)]
+    L.bwgr_panel_stats.argtypes = [vp, c_f, c_f, c_f]
+    L.bwgr_kmup.argtypes = [vp, c_f, c_f, c_f, c_f, c_f, f32, f32, u64, u32, i32]
+    L.bwgr_chain_create.argtypes = [C.POINTER(vp), vp, i32, vp, i32, f32, f32, f32, f32, f32, u64, i32]
+    L.bwgr_chain_destroy.argtypes = [vp]
+    L.bwgr_chain_run.argtypes = [vp, i32]
+    L.bwgr_chain_sync.argtypes = [vp]
+    L.bwgr_chain_iterations.argtypes = [vp, C.POINTER(i32)]
+    L.bwgr_chain_result.argtypes = [vp] + [c_f] * 10
+    L.bwgr_chain_state.argtypes = [vp] + [c_f] * 5
+    L.bwgr_chain_sweep_ms.argtypes = [vp, c_f, C.POINTER(i32)]
+    L.bwgr_bayes.argtypes = [vp, i32, c_f, f32, f32, f32, f32, f32, u64, i32] + [c_f] * 10
+    L.bwgr_wgr.argtypes = [vp, c_d, i32, i32, i32, i32, i32, f64, f64, f64, u64, i32] + [c_d] * 7
+    L.bwgr_synth_genotypes.argtypes = [vp, i64, i64, i64, u64, vp, i32, vp]
+    L.bwgr_debug_variates.argtypes = [i32, u64, i32, f64, u32, u32, u32, i32, c_d]
+    L.bwgr_device_count.argtypes = [C.POINTER(i32)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise BwgrError(rc, lib().bwgr_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().bwgr_device_count(C.byref(n))
+    return n.value
+
+
+EXPORTS = ["bwgr_abi_version", "bwgr_last_error", "bwgr_device_count", "bwgr_panel_create", "bwgr_panel_destroy",
+           "bwgr_panel_set_stream", "bwgr_panel_info", "bwgr_panel_stats", "bwgr_kmup", "bwgr_chain_create",
+           "bwgr_chain_destroy", "bwgr_chain_run", "bwgr_chain_sync", "bwgr_chain_iterations", "bwgr_chain_result",
+           "bwgr_chain_state", "bwgr_chain_sweep_ms", "bwgr_bayes", "bwgr_wgr", "bwgr_synth_genotypes",
+           "bwgr_debug_variates"]

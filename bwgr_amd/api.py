@@ -1,0 +1,270 @@
+"""Host-side mirror of the reference's R interface for the Gibbs hot path.
+
+Same names, argument order, defaults and return-list element names/order as
+  KMUP(X,b,d,xx,e,L,Ve,pi)                          R/RcppExports.R:4-6
+  BayesA/BayesL/BayesRR/BayesCpi/BayesDpi(y,X,it=1500,bi=500,df=5,R2=0.5)   R/RcppExports.R:48-74
+  BayesB/BayesC(y,X,it=1500,bi=500,pi=0.95,df=5,R2=0.5)
+  wgr(y,X,it=1500,bi=500,th=1,bag=1,rp=FALSE,iv=FALSE,de=FALSE,pi=0,df=5,R2=0.5,eigK=NULL,VarK=0.95,verb=FALSE)
+                                                    R/wgr.R:2-8
+R is not available in the build image, so the host layer above the C ABI is Python (see
+INTEGRATION.md for the R .Call shim that binds the same entry points).  Everything numerical happens in
+libbwgr_hip.so on the GPU; this module only marshals arrays.  `seed=None` draws the seed from numpy's
+global stream, so numpy.random.seed() plays the role of R's set.seed().
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import c_f, c_d, check
+
+MODELS = {"BayesA": 0, "BayesB": 1, "BayesC": 2, "BayesL": 3, "BayesRR": 4, "BayesCpi": 5, "BayesDpi": 6}
+_PER_MARKER_VB = {"BayesA", "BayesB", "BayesL", "BayesDpi"}
+X_I8, X_F32, X_F64 = 0, 1, 2
+HOST, DEVICE = 0, 1
+
+
+def _seed(seed):
+    if seed is None:
+        return int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
+    return int(seed) & 0xFFFFFFFFFFFFFFFF
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_f)
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_d)
+
+
+class Panel:
+    """Genotype matrix X staged once in HBM (column-major, rows zero-padded to the slab grid), together with
+    xx, vx, MSx (src/Rcpp20260726ai.cpp:593-598) and the block-diagonal Gram used by the blocked sweep.
+
+    X may be a numpy array (n x p; int8, float32 or float64 -- an all-integer float matrix within int8 range is
+    stored as int8 unless as_int8=False) or a torch CUDA tensor holding the column-major matrix as shape
+    (p, ldx) int8/float32 (row j of the tensor = column j of X)."""
+
+    def __init__(self, X, n=None, device=0, block=0, nwg=0, as_int8=None):
+        L = _lib.lib()
+        self._h = C.c_void_p()
+        self._keep = None
+        if hasattr(X, "data_ptr"):  # torch tensor on the GPU, (p, ldx)
+            import torch
+            assert X.is_cuda and X.dim() == 2 and X.is_contiguous(), "device X must be a contiguous (p, ldx) CUDA tensor"
+            p, ldx = X.shape
+            n = ldx if n is None else int(n)
+            xtype = {torch.int8: X_I8, torch.float32: X_F32, torch.float64: X_F64}[X.dtype]
+            device = X.device.index or 0
+            torch.cuda.synchronize(X.device)
+            check(L.bwgr_panel_create(C.byref(self._h), C.c_void_p(X.data_ptr()), xtype, DEVICE, n, p, ldx, device, block, nwg))
+        else:
+            X = np.asarray(X)
+            assert X.ndim == 2, "X must be n x p"
+            n, p = X.shape
+            if X.dtype != np.int8:
+                if as_int8 is None:
+                    as_int8 = bool(np.issubdtype(X.dtype, np.integer) or
+                                   (X.size and np.all(X == np.rint(X)) and np.abs(X).max() <= 127))
+                if as_int8:
+                    X = X.astype(np.int8)
+                elif X.dtype not in (np.float32, np.float64):
+                    X = X.astype(np.float64)
+            Xc = np.asfortranarray(X)
+            xtype = {np.dtype(np.int8): X_I8, np.dtype(np.float32): X_F32, np.dtype(np.float64): X_F64}[Xc.dtype]
+            check(L.bwgr_panel_create(C.byref(self._h), Xc.ctypes.data_as(C.c_void_p), xtype, HOST, n, p, n, device, block, nwg))
+        info = (C.c_int64 * 8)()
+        check(L.bwgr_panel_info(self._h, info))
+        self.n, self.p, self.ld, self.block, self.nwg, self.slab_rows, self.x_bytes, self.gram_bytes = [int(v) for v in info]
+        self.device = device
+
+    def set_stream(self, stream_ptr):
+        check(_lib.lib().bwgr_panel_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def stats(self):
+        xx = np.empty(self.p, np.float32); vx = np.empty(self.p, np.float32); msx = C.c_float()
+        check(_lib.lib().bwgr_panel_stats(self._h, _fp(xx), _fp(vx), C.byref(msx)))
+        return xx, vx, float(msx.value)
+
+    def close(self):
+        if self._h:
+            _lib.lib().bwgr_panel_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _as_panel(X, **kw):
+    return (X, False) if isinstance(X, Panel) else (Panel(X, **kw), True)
+
+
+class Chain:
+    """One MCMC chain of a fused sampler, stepping interface over bwgr_chain_* (state stays on the GPU)."""
+
+    def __init__(self, panel, model, y, it=1500, bi=500, pi=0.95, df=5.0, R2=0.5, seed=None, rng_mode=0):
+        self.panel, self.model = panel, model
+        self._h = C.c_void_p()
+        self.it, self.bi = int(it), int(bi)
+        if hasattr(y, "data_ptr"):
+            import torch
+            assert y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and y.numel() == panel.n
+            torch.cuda.synchronize(y.device)
+            yptr, loc = C.c_void_p(y.data_ptr()), DEVICE
+        else:
+            self._y = np.ascontiguousarray(y, np.float32)
+            assert self._y.size == panel.n, "length(y) must equal nrow(X)"
+            yptr, loc = self._y.ctypes.data_as(C.c_void_p), HOST
+        check(_lib.lib().bwgr_chain_create(C.byref(self._h), panel._h, MODELS[model], yptr, loc, float(it), float(bi),
+                                            float(pi), float(df), float(R2), C.c_uint64(_seed(seed)), int(rng_mode)))
+
+    def run(self, iters):
+        check(_lib.lib().bwgr_chain_run(self._h, int(iters)))
+
+    def sync(self):
+        check(_lib.lib().bwgr_chain_sync(self._h))
+
+    def sweep_ms(self):
+        ms = C.c_float(); nl = C.c_int()
+        check(_lib.lib().bwgr_chain_sweep_ms(self._h, C.byref(ms), C.byref(nl)))
+        return float(ms.value), int(nl.value)
+
+    def state(self):
+        p, n = self.panel.p, self.panel.n
+        b = np.empty(p, np.float32); d = np.empty(p, np.float32); e = np.empty(n, np.float32)
+        vb = np.empty(p, np.float32); s = np.empty(4, np.float32)
+        check(_lib.lib().bwgr_chain_state(self._h, _fp(b), _fp(d), _fp(e), _fp(vb), _fp(s)))
+        return {"b": b, "d": d, "e": e, "vb": vb, "mu": float(s[0]), "ve": float(s[1]), "vb_common": float(s[2]), "pi": float(s[3])}
+
+    def result(self):
+        """The reference's return list (names and order), src/Rcpp20260726ai.cpp:631-634, 694-698, 916-920."""
+        p, n, model = self.panel.p, self.panel.n, self.model
+        per = model in _PER_MARKER_VB
+        B = np.empty(p, np.float32); D = np.empty(p, np.float32); hat = np.empty(n, np.float32)
+        VB = np.empty(p if per else 1, np.float32); PV = np.empty(p, np.float32)
+        mu = C.c_float(); ve = C.c_float(); h2 = C.c_float(); msx = C.c_float(); Pi = C.c_float()
+        check(_lib.lib().bwgr_chain_result(self._h, C.byref(mu), _fp(B), _fp(D), _fp(hat), _fp(VB), C.byref(ve), C.byref(h2),
+                                            C.byref(msx), C.byref(Pi), _fp(PV)))
+        vb = VB if per else float(VB[0])
+        if model in ("BayesA", "BayesL", "BayesRR"):
+            return {"mu": mu.value, "b": B, "hat": hat, "vb": vb, "ve": ve.value, "h2": h2.value, "MSx": msx.value}
+        if model in ("BayesB", "BayesC"):
+            return {"mu": mu.value, "b": B, "d": D, "hat": hat, "vb": vb, "ve": ve.value, "h2": h2.value, "MSx": msx.value}
+        return {"mu": mu.value, "b": B, "d": D, "pi": Pi.value, "hat": hat, "h2": h2.value, "vb": vb, "ve": ve.value, "PVAL": PV}
+
+    def close(self):
+        if self._h:
+            _lib.lib().bwgr_chain_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _fused(model, y, X, it, bi, pi, df, R2, seed, rng_mode, return_state=False, **panel_kw):
+    P, own = _as_panel(X, **panel_kw)
+    ch = Chain(P, model, y, it, bi, pi, df, R2, seed, rng_mode)
+    try:
+        ch.run(int(it))
+        out = ch.result()
+        if return_state:
+            out["last"] = ch.state()
+        return out
+    finally:
+        ch.close()
+        if own:
+            P.close()
+
+
+def BayesA(y, X, it=1500, bi=500, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw):
+    return _fused("BayesA", y, X, it, bi, 0.0, df, R2, seed, rng_mode, **kw)
+
+
+def BayesB(y, X, it=1500, bi=500, pi=0.95, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw):
+    return _fused("BayesB", y, X, it, bi, pi, df, R2, seed, rng_mode, **kw)
+
+
+def BayesC(y, X, it=1500, bi=500, pi=0.95, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw):
+    return _fused("BayesC", y, X, it, bi, pi, df, R2, seed, rng_mode, **kw)
+
+
+def BayesL(y, X, it=1500, bi=500, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw):
+    return _fused("BayesL", y, X, it, bi, 0.0, df, R2, seed, rng_mode, **kw)
+
+
+def BayesRR(y, X, it=1500, bi=500, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw):
+    return _fused("BayesRR", y, X, it, bi, 0.0, df, R2, seed, rng_mode, **kw)
+
+
+def BayesCpi(y, X, it=1500, bi=500, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw):
+    return _fused("BayesCpi", y, X, it, bi, 0.0, df, R2, seed, rng_mode, **kw)
+
+
+def BayesDpi(y, X, it=1500, bi=500, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw):
+    return _fused("BayesDpi", y, X, it, bi, 0.0, df, R2, seed, rng_mode, **kw)
+
+
+def KMUP(X, b, d, xx, e, L, Ve, pi, *, seed=None, it=0, rng_mode=0, **panel_kw):
+    """One Gibbs sweep; returns list(b=, d=, e=) like src/Rcpp20260726ai.cpp:37.  Inputs are not modified."""
+    P, own = _as_panel(X, **panel_kw)
+    try:
+        b = np.array(b, np.float32); d = np.array(d, np.float32); e = np.array(e, np.float32)
+        xx = np.ascontiguousarray(xx, np.float32); L = np.ascontiguousarray(L, np.float32)
+        assert b.size == P.p and d.size == P.p and xx.size == P.p and L.size == P.p and e.size == P.n
+        check(_lib.lib().bwgr_kmup(P._h, _fp(b), _fp(d), _fp(xx), _fp(e), _fp(L), float(Ve), float(pi),
+                                    C.c_uint64(_seed(seed)), C.c_uint32(int(it)), int(rng_mode)))
+        return {"b": b, "d": d, "e": e}
+    finally:
+        if own:
+            P.close()
+
+
+def wgr(y, X, it=1500, bi=500, th=1, bag=1, rp=False, iv=False, de=False, pi=0, df=5, R2=0.5, eigK=None, VarK=0.95,
+        verb=False, *, seed=None, rng_mode=0, **panel_kw):
+    """wgr(), R/wgr.R:2-169, device-resident.  bag != 1 (KMUP2) and eigK are SURVEY section 8(f) rows f1/f2 and are
+    not built in this round: they raise instead of silently running something else."""
+    if bag != 1 or rp:
+        raise NotImplementedError("wgr(bag != 1): the KMUP2 bagging path (SURVEY section 8 f1) is not built yet")
+    if eigK is not None:
+        raise NotImplementedError("wgr(eigK=...): the polygenic kernel term (SURVEY section 8 f2) is not built yet")
+    y = np.asarray(y, np.float64)
+    if np.isnan(y).any():   # R/wgr.R:34-39: drop rows with missing y
+        keep = ~np.isnan(y)
+        y = y[keep]
+        if isinstance(X, Panel):
+            raise ValueError("missing y with a pre-built Panel: drop the rows before staging X")
+        X = np.asarray(X)[keep]
+    if not isinstance(X, Panel) and not hasattr(X, "data_ptr"):
+        X = np.asarray(X)
+        if np.issubdtype(X.dtype, np.floating) and np.isnan(X).any():   # R/wgr.R:12-18 mean imputation
+            X = X.astype(np.float64, copy=True)
+            cm = np.nanmean(X, axis=0); cm[np.isnan(cm)] = 0.0
+            idx = np.where(np.isnan(X)); X[idx] = cm[idx[1]]
+    P, own = _as_panel(X, **panel_kw)
+    try:
+        n, p = P.n, P.p
+        per = bool(iv or de)
+        b = np.zeros(p); d = np.zeros(p); Vb = np.zeros(p if per else 1); hat = np.zeros(n)
+        mu = C.c_double(); Ve = C.c_double(); cxx = C.c_double()
+        yc = np.ascontiguousarray(y, np.float64)
+        check(_lib.lib().bwgr_wgr(P._h, _dp(yc), int(it), int(bi), int(th), int(bool(iv)), int(bool(de)), float(pi), float(df),
+                                   float(R2), C.c_uint64(_seed(seed)), int(rng_mode), C.byref(mu), _dp(b), _dp(Vb), _dp(d),
+                                   C.byref(Ve), _dp(hat), C.byref(cxx)))
+        return {"mu": mu.value, "b": b, "Vb": Vb if per else float(Vb[0]), "d": d, "Ve": Ve.value, "hat": hat, "cxx": cxx.value}
+    finally:
+        if own:
+            P.close()
+
+
+def debug_variates(seed, kind, marker0, count, it=0, purpose=0, nu=0.0, device=0):
+    out = np.empty(count, np.float64)
+    kinds = {"normal": 0, "uniform": 1, "chisq": 2}
+    check(_lib.lib().bwgr_debug_variates(device, C.c_uint64(seed), kinds[kind], float(nu), C.c_uint32(marker0), C.c_uint32(it),
+                                          C.c_uint32(purpose), int(count), _dp(out)))
+    return out

@@ -1,0 +1,913 @@
+// bwgr_amd/csrc/bwgr_hip.hip -- libbwgr_hip.so: C ABI (include/bwgr.h) + setup / per-iteration / finalisation
+// kernels around the blocked sweep (sweep.hip.h).  gfx950 only; there is no CPU path in this library.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <algorithm>
+#include "../../include/bwgr.h"
+#include "rng.hip.h"
+#include "sweep.hip.h"
+
+using namespace bwgr;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+  return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(BWGR_EHIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define CHK(x) do { int r_ = (x); if (r_ != BWGR_OK) return r_; } while (0)
+
+extern "C" const char *bwgr_last_error(void) { return g_err; }
+extern "C" int bwgr_abi_version(void) { return BWGR_ABI_VERSION; }
+extern "C" int bwgr_device_count(int *count) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { (void)hipGetLastError(); c = 0; }
+  if (count) *count = c;
+  return BWGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+// block-wide sum; result valid in every thread.  red must hold >= 17 doubles.
+__device__ inline double block_sum(double v, double *red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { double s = 0; for (int w = 0; w < nw; ++w) s += red[w]; red[16] = s; }
+  __syncthreads();
+  return red[16];
+}
+
+__device__ __forceinline__ float xval(const int8_t *X, int64_t i) { return (float)X[i]; }
+__device__ __forceinline__ float xval(const float *X, int64_t i) { return X[i]; }
+
+// ---- upload conversion: src (n x p, ldx) -> X (ld x p), zero padded rows ----
+template <typename ST, typename XT>
+__global__ void k_convert(const ST *src, int64_t ldx, XT *X, int64_t ld, int n, int64_t j0, int64_t ncols) {
+  const int64_t total = ncols * ld;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t jj = idx / ld, i = idx - jj * ld;
+    XT v = (XT)0;
+    if (i < n) v = (XT)src[jj * ldx + i];
+    X[(j0 + jj) * ld + i] = v;
+  }
+}
+
+__global__ void k_f2d(const float *src, double *dst, int64_t n, int64_t ld) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ld; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (i < n) ? (double)src[i] : 0.0;
+}
+__global__ void k_d2f(const double *src, float *dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+
+// ---- a10: xx[j] = |X_j|^2, vx[j] = fvar(X_j)   (src/Rcpp20260726ai.cpp:7-9, 593-597); one wave per column ----
+template <typename XT>
+__global__ void k_stats(const XT *X, int64_t ld, int n, int p, float *xx, float *vx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j >= p) return;
+  const XT *xj = X + j * ld;
+  double s1 = 0, s2 = 0;
+  for (int i = lane; i < n; i += 64) { const float v = xval(xj, i); s1 += (double)v; s2 += (double)v * (double)v; }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  s1 = __shfl(s1, 0, 64); s2 = __shfl(s2, 0, 64);
+  const float mean = (float)(s1 / (double)n);
+  double sv = 0;
+  for (int i = lane; i < n; i += 64) { const float dev = xval(xj, i) - mean; const float sq = dev * dev; sv += (double)sq; }
+  sv = wave_sum(sv);
+  if (lane == 0) { xx[j] = (float)s2; vx[j] = (float)(sv / (double)(float)(n - 1)); }
+}
+
+// deterministic two-stage sum of a float vector into a double
+__global__ void k_sum_stage1(const float *v, int64_t n, double *part) {
+  __shared__ double red[17];
+  double s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += (double)v[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void k_sum_stage2(const double *part, int nparts, float *out_f) {
+  __shared__ double red[17];
+  double s = 0;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) *out_f = (float)s;
+}
+
+// ---- block-diagonal Gram G_B = X_B' X_B (setup; exact int32 for int8 genotypes) ----
+// 256 threads as a 16 x 16 grid, thread (tj,tk) owns G[tj+16a][tk+16c], a,c < m/16.
+template <int TJ>
+__global__ __launch_bounds__(256) void k_gram_i8(const int8_t *X, int64_t ld, int p, int m, int32_t *gram) {
+  constexpr int RC = 128, RW = RC / 4 + 1;  // rows per chunk, dwords per column in LDS (padded)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t *tile = reinterpret_cast<int32_t *>(smem);
+  const int blk = blockIdx.x, j0 = blk * m, mB = min(m, p - j0);
+  const int tj = threadIdx.x >> 4, tk = threadIdx.x & 15;
+  int32_t acc[TJ][TJ];
+#pragma unroll
+  for (int a = 0; a < TJ; ++a)
+#pragma unroll
+    for (int c = 0; c < TJ; ++c) acc[a][c] = 0;
+  for (int64_t r0 = 0; r0 < ld; r0 += RC) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < m * (RC / 4); c += 256) {
+      const int jj = c / (RC / 4), w = c - jj * (RC / 4);
+      int32_t v = 0;
+      if (jj < mB) v = *reinterpret_cast<const int32_t *>(X + (int64_t)(j0 + jj) * ld + r0 + 4 * w);
+      tile[jj * RW + w] = v;
+    }
+    __syncthreads();
+    for (int w = 0; w < RC / 4; ++w) {
+      int32_t av[TJ], bv[TJ];
+#pragma unroll
+      for (int a = 0; a < TJ; ++a) { av[a] = tile[(tj + 16 * a) * RW + w]; bv[a] = tile[(tk + 16 * a) * RW + w]; }
+#pragma unroll
+      for (int a = 0; a < TJ; ++a)
+#pragma unroll
+        for (int c = 0; c < TJ; ++c) acc[a][c] = __builtin_amdgcn_sdot4(av[a], bv[c], acc[a][c], false);
+    }
+  }
+  int32_t *g = gram + (size_t)blk * m * m;
+#pragma unroll
+  for (int a = 0; a < TJ; ++a)
+#pragma unroll
+    for (int c = 0; c < TJ; ++c) g[(size_t)(tj + 16 * a) * m + (tk + 16 * c)] = acc[a][c];
+}
+
+template <int TJ>
+__global__ __launch_bounds__(256) void k_gram_f32(const float *X, int64_t ld, int p, int m, double *gram) {
+  constexpr int RC = 64, RW = RC + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *tile = reinterpret_cast<float *>(smem);
+  const int blk = blockIdx.x, j0 = blk * m, mB = min(m, p - j0);
+  const int tj = threadIdx.x >> 4, tk = threadIdx.x & 15;
+  double acc[TJ][TJ];
+#pragma unroll
+  for (int a = 0; a < TJ; ++a)
+#pragma unroll
+    for (int c = 0; c < TJ; ++c) acc[a][c] = 0.0;
+  for (int64_t r0 = 0; r0 < ld; r0 += RC) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < m * RC; c += 256) {
+      const int jj = c / RC, w = c - jj * RC;
+      tile[jj * RW + w] = (jj < mB) ? X[(int64_t)(j0 + jj) * ld + r0 + w] : 0.0f;
+    }
+    __syncthreads();
+    for (int w = 0; w < RC; ++w) {
+      double av[TJ], bv[TJ];
+#pragma unroll
+      for (int a = 0; a < TJ; ++a) { av[a] = (double)tile[(tj + 16 * a) * RW + w]; bv[a] = (double)tile[(tk + 16 * a) * RW + w]; }
+#pragma unroll
+      for (int a = 0; a < TJ; ++a)
+#pragma unroll
+        for (int c = 0; c < TJ; ++c) acc[a][c] = fma(av[a], bv[c], acc[a][c]);
+    }
+  }
+  double *g = gram + (size_t)blk * m * m;
+#pragma unroll
+  for (int a = 0; a < TJ; ++a)
+#pragma unroll
+    for (int c = 0; c < TJ; ++c) g[(size_t)(tj + 16 * a) * m + (tk + 16 * c)] = acc[a][c];
+}
+
+// ---- chain setup (src/Rcpp20260726ai.cpp:599-610 and the identical blocks of the other samplers) ----
+struct InitArgs {
+  const float *y; double *e; int n, p; int64_t ld; int model; float pi, df, R2; float MSx; ChainScalars *sc;
+};
+__global__ void k_chain_init(const InitArgs a) {
+  __shared__ double red[17];
+  double s = 0;
+  for (int i = threadIdx.x; i < a.n; i += blockDim.x) s += (double)a.y[i];
+  s = block_sum(s, red);
+  const float mu = (float)(s / (double)a.n);               // y.mean()
+  double sv = 0;
+  for (int i = threadIdx.x; i < a.n; i += blockDim.x) { const float dev = a.y[i] - mu; const float sq = dev * dev; sv += (double)sq; }
+  sv = block_sum(sv, red);
+  const float vy = (float)(sv / (double)(float)(a.n - 1));   // fvar(y)
+  for (int i = threadIdx.x; i < a.ld; i += blockDim.x) { const float t = (i < a.n) ? (a.y[i] - mu) : 0.0f; a.e[i] = (double)t; }
+  if (threadIdx.x == 0) {
+    float pi = a.pi;
+    if (a.model == BWGR_BAYESCPI || a.model == BWGR_BAYESDPI) pi = 0.5f;
+    float Sb;
+    if (a.model == BWGR_BAYESC || a.model == BWGR_BAYESCPI) Sb = a.df * (a.R2) * vy / a.MSx / (1 - pi);
+    else Sb = (a.R2) * a.df * vy / a.MSx;
+    ChainScalars sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.ve = vy; sc.vb = Sb; sc.lam = vy / Sb; sc.pi = pi;
+    sc.Sb = Sb; sc.Se = (1 - a.R2) * a.df * vy; sc.C = -0.5f / sqrtf(vy); sc.odds = pi / (1.0f - pi);
+    sc.mu = mu; sc.dfp1 = a.df + 1; sc.vy = vy; sc.MSx = a.MSx;
+    *a.sc = sc;
+  }
+}
+__global__ void k_marker_init(float *b, float *d, float *vb, float *lam, float *B, float *D, float *VB, int p,
+                              const ChainScalars *sc) {
+  const float Sb = sc->Sb, ve = sc->ve;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < p; j += gridDim.x * blockDim.x) {
+    b[j] = 0; d[j] = 0; B[j] = 0; D[j] = 0; VB[j] = 0;
+    vb[j] = Sb;
+    lam[j] = ve * (1.0f / Sb);   // ve * vb.cwiseInverse()
+  }
+}
+
+// ---- per-iteration tail: intercept, residual / marker variances, pi (one workgroup) ----
+struct TailArgs {
+  double *e; int n, p; int model; float df, R2, Phi; int accumulate; uint32_t iter; Rng rng; ChainScalars *sc;
+};
+__global__ __launch_bounds__(1024) void k_tail(const TailArgs a) {
+  __shared__ double red[17];
+  ChainScalars &sc = *a.sc;
+  const float ve0 = sc.ve;
+  double s = 0;
+  for (int i = threadIdx.x; i < a.n; i += blockDim.x) s += a.e[i];
+  s = block_sum(s, red);
+  const float me = (float)(s / (double)a.n);                                        // e.mean()
+  const double z = rng_normal(a.rng, RNG_GLOBAL_MARKER, a.iter, RNG_G_MU, 0);
+  const float eM = (float)((double)me + (double)sqrtf(ve0 / a.n) * z);              // :620
+  double ss = 0;
+  for (int i = threadIdx.x; i < a.n; i += blockDim.x) { const double v = a.e[i] - (double)eM; a.e[i] = v; ss = fma(v, v, ss); }
+  ss = block_sum(ss, red);
+  if (threadIdx.x == 0) {
+    const float ssf = (float)ss;                                                    // e.squaredNorm()
+    const float b2f = (float)sc.sum_b2;                                             // b.squaredNorm()
+    float ve = ve0, vb = sc.vb, pi = sc.pi, Sb = sc.Sb;
+    const float mu = sc.mu + eM;
+    const double chi_e = rng_chisq(a.rng, (double)(a.n + a.df), RNG_GLOBAL_MARKER, a.iter, RNG_G_VE);
+    switch (a.model) {
+      case BWGR_BAYESA: case BWGR_BAYESB: case BWGR_BAYESDPI: case BWGR_BAYESL:
+        ve = (float)((double)(ssf + sc.Se) / chi_e);
+        break;
+      case BWGR_BAYESRR: {
+        ve = (float)((double)(ssf + sc.Se) / chi_e);
+        const double chi_b = rng_chisq(a.rng, (double)(a.p + a.df), RNG_GLOBAL_MARKER, a.iter, RNG_G_VB);
+        vb = (float)((double)(b2f + Sb) / chi_b);
+        sc.lam = ve / vb;
+      } break;
+      case BWGR_BAYESC: case BWGR_BAYESCPI: {
+        const double chi_b = rng_chisq(a.rng, (double)(a.df + a.p), RNG_GLOBAL_MARKER, a.iter, RNG_G_VB);
+        vb = (float)((double)(b2f + Sb) / chi_b);
+        ve = (float)((double)(ssf + sc.Se) / chi_e);
+        sc.lam = ve / vb;
+      } break;
+    }
+    if (a.model == BWGR_BAYESCPI) {
+      pi = (float)(sc.sum_d / (double)a.p);
+      Sb = a.df * (a.R2) * sc.vy / sc.MSx / (1 - pi);
+    }
+    if (a.model == BWGR_BAYESDPI) pi = (float)(sc.sum_d / (double)a.p);
+    sc.ve = ve; sc.vb = vb; sc.pi = pi; sc.Sb = Sb; sc.mu = mu;
+    sc.C = -0.5f / sqrtf(ve);
+    sc.sum_d = 0.0; sc.sum_b2 = 0.0;
+    if (a.accumulate) { sc.MU += mu; sc.VE += ve; sc.VBs += vb; sc.Pi += pi; }
+  }
+}
+// per-marker part of the tail: lambda_j for the next sweep and the posterior sums
+__global__ void k_marker_tail(const float *b, const float *d, const float *vb, float *lam, float *B, float *D, float *VB,
+                              int p, int model, float Phi, int accumulate, const ChainScalars *sc) {
+  const float ve = sc->ve;
+  const bool per = (model == BWGR_BAYESA || model == BWGR_BAYESB || model == BWGR_BAYESDPI || model == BWGR_BAYESL);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < p; j += gridDim.x * blockDim.x) {
+    if (per) {
+      const float v = vb[j];
+      lam[j] = (model == BWGR_BAYESL) ? sqrtf(Phi * ve / v) : ve * (1.0f / v);
+      if (accumulate) VB[j] += v;
+    }
+    if (accumulate) { B[j] += b[j]; D[j] += d[j]; }
+  }
+}
+
+// ---- finalisation ----
+__global__ void k_final_markers(float *B, float *D, float *VB, float *pval, int p, float MCMC, int per) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < p; j += gridDim.x * blockDim.x) {
+    B[j] /= MCMC; D[j] /= MCMC;
+    if (per) VB[j] /= MCMC;
+    if (pval) pval[j] = -1.0f * logf(1.0f - D[j]);
+  }
+}
+// partial[c][i] = sum_{j in column chunk c} x_ij * coef_j   (fp64), 4 rows per thread
+template <typename XT, typename CT>
+__global__ __launch_bounds__(256) void k_gemv_part(const XT *X, int64_t ld, int p, const CT *coef, int cols_per_chunk, double *part) {
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= ld) return;
+  const int c = blockIdx.y;
+  const int ja = c * cols_per_chunk, jb = min(p, ja + cols_per_chunk);
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (int j = ja; j < jb; ++j) {
+    const double cj = (double)coef[j];
+    if (cj == 0.0) continue;
+    const XT *xp = X + (int64_t)j * ld + i0;
+    float x0, x1, x2, x3;
+    if constexpr (sizeof(XT) == 1) {
+      const uint32_t w = *reinterpret_cast<const uint32_t *>(xp);
+      x0 = (float)(int8_t)(w & 0xFF); x1 = (float)(int8_t)((w >> 8) & 0xFF); x2 = (float)(int8_t)((w >> 16) & 0xFF); x3 = (float)(int8_t)(w >> 24);
+    } else {
+      const float4 v = *reinterpret_cast<const float4 *>(xp);
+      x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w;
+    }
+    a0 = fma((double)x0, cj, a0); a1 = fma((double)x1, cj, a1); a2 = fma((double)x2, cj, a2); a3 = fma((double)x3, cj, a3);
+  }
+  double *o = part + (int64_t)c * ld + i0;
+  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+}
+__global__ void k_hat_finish(const double *part, int64_t ld, int nchunks, int n, float MU, float *hat) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0;
+  for (int c = 0; c < nchunks; ++c) s += part[(int64_t)c * ld + i];
+  const float f = (float)s;
+  hat[i] = f + MU;
+}
+
+// ---- synthetic genotypes: 4 rows per thread ----
+__global__ void k_synth(int8_t *X, int64_t ld, int n, int64_t p, uint32_t k0, uint32_t k1, float *freq) {
+  const int64_t quads = ld / 4;
+  const int64_t total = p * quads;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = idx / quads, q = idx - j * quads;
+    const uint4 fj = philox4x32_10((uint32_t)j, 0u, 33u, 0u, k0, k1);
+    const float f = 0.05f + 0.45f * ((float)(fj.x >> 8) * (1.0f / 16777216.0f));
+    const uint32_t thr = (uint32_t)(f * 16777216.0f);
+    if (q == 0 && freq) freq[j] = f;
+    const uint4 a = philox4x32_10((uint32_t)q, (uint32_t)j, 32u, 0u, k0, k1);
+    const uint4 c = philox4x32_10((uint32_t)q, (uint32_t)j, 32u, 1u, k0, k1);
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    uint32_t packed = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      uint32_t g = ((w[2 * r] >> 8) < thr) + ((w[2 * r + 1] >> 8) < thr);
+      if (q * 4 + r >= n) g = 0;
+      packed |= g << (8 * r);
+    }
+    *reinterpret_cast<uint32_t *>(X + j * ld + q * 4) = packed;
+  }
+}
+
+__global__ void k_debug_variates(Rng g, int kind, double nu, uint32_t marker0, uint32_t iter, uint32_t purpose, int count, double *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t mk = marker0 + (uint32_t)i;
+  double v;
+  if (kind == 0) v = rng_normal(g, mk, iter, purpose, 0);
+  else if (kind == 1) v = rng_uniform(g, mk, iter, purpose, 0);
+  else v = rng_chisq(g, nu, mk, iter, purpose);
+  out[i] = v;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host objects
+// ------------------------------------------------------------------------------------------------
+struct bwgr_panel {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t n = 0, p = 0, ld = 0;
+  int is_f32 = 0;
+  int m = 0, K = 0, R = 0;
+  int64_t nblocks = 0;
+  void *X = nullptr, *gram = nullptr;
+  size_t x_bytes = 0, gram_bytes = 0;
+  float *xx = nullptr, *vx = nullptr, *msx_dev = nullptr;
+  float MSx = 0;
+  double *xpart = nullptr;
+  uint32_t *xflags = nullptr;
+  size_t lds_bytes = 0;
+};
+
+struct bwgr_chain {
+  bwgr_panel *P = nullptr;
+  int model = 0, iit = 0, ibi = 0, done = 0, rng_mode = 0;
+  float itf = 0, bif = 0, pi = 0, df = 0, R2 = 0, Phi = 0;
+  uint64_t seed = 0;
+  float *y = nullptr, *b = nullptr, *d = nullptr, *vb = nullptr, *lam = nullptr;
+  double *e = nullptr;
+  float *B = nullptr, *D = nullptr, *VB = nullptr;
+  ChainScalars *sc = nullptr;
+  std::vector<hipEvent_t> ev;  // pairs around each sweep launch since the last query
+  float ms_acc = 0; int launch_acc = 0;
+  bool finalized = false;
+};
+
+static Rng make_rng(uint64_t seed, int mode) {
+  Rng g; g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.degenerate = (mode == BWGR_RNG_DEGENERATE); return g;
+}
+
+static int require_device(int device) {
+  int c = 0; bwgr_device_count(&c);
+  if (c <= 0) return fail(BWGR_ENODEV, "no HIP device visible: libbwgr_hip has no CPU fallback");
+  if (device < 0 || device >= c) return fail(BWGR_EINVAL, "device %d out of range (%d visible)", device, c);
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(BWGR_ENODEV, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+  HIPCHK(hipSetDevice(device));
+  return BWGR_OK;
+}
+
+template <typename XT> static int max_slab_rows(int m) {
+  int best = 0;
+  for (int R = 128; R <= 4096; R += 128)
+    if (sweep_lds_bytes<XT>(m, R) <= (size_t)160 * 1024) best = R;
+  return best;
+}
+
+static int launch_sweep(bwgr_panel *P, SweepArgs &a) {
+  if (P->K > 1) HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
+  if (P->is_f32) hipLaunchKernelGGL(k_sweep<float>, dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
+  else hipLaunchKernelGGL(k_sweep<int8_t>, dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
+  HIPCHK(hipGetLastError());
+  return BWGR_OK;
+}
+
+static void fill_panel_args(const bwgr_panel *P, SweepArgs &a) {
+  a.X = P->X; a.ld = P->ld; a.gram = P->gram;
+  a.n = (int)P->n; a.p = (int)P->p; a.m = P->m; a.K = P->K; a.R = P->R;
+  a.blk_begin = 0; a.blk_end = (int)P->nblocks;
+  a.xpart = P->xpart; a.xflags = P->xflags;
+}
+
+// ------------------------------------------------------------------------------------------------
+// panel
+// ------------------------------------------------------------------------------------------------
+template <typename ST, typename XT>
+static int upload(bwgr_panel *P, const void *X, int memloc, int64_t ldx) {
+  const int64_t n = P->n, p = P->p;
+  XT *dst = reinterpret_cast<XT *>(P->X);
+  if (memloc == BWGR_DEVICE) {
+    hipLaunchKernelGGL((k_convert<ST, XT>), dim3(4096), dim3(256), 0, P->stream, reinterpret_cast<const ST *>(X), ldx, dst, P->ld, (int)n, (int64_t)0, p);
+    HIPCHK(hipGetLastError());
+    return BWGR_OK;
+  }
+  // host source: stage column chunks of <= 256 MiB
+  const int64_t col_bytes = ldx * (int64_t)sizeof(ST);
+  int64_t cols = std::max<int64_t>(1, ((int64_t)256 << 20) / std::max<int64_t>(1, col_bytes));
+  cols = std::min(cols, p);
+  ST *stage = nullptr;
+  HIPCHK(hipMalloc(&stage, (size_t)(cols * col_bytes)));
+  for (int64_t j0 = 0; j0 < p; j0 += cols) {
+    const int64_t nc = std::min(cols, p - j0);
+    // the last column may be shorter than ldx in the caller's allocation: copy n rows of it separately
+    const size_t bytes = (size_t)((nc - 1) * col_bytes + n * (int64_t)sizeof(ST));
+    hipError_t e = hipMemcpyAsync(stage, reinterpret_cast<const ST *>(X) + j0 * ldx, bytes, hipMemcpyHostToDevice, P->stream);
+    if (e != hipSuccess) { hipFree(stage); return fail(BWGR_EHIP, "upload memcpy failed: %s", hipGetErrorString(e)); }
+    hipLaunchKernelGGL((k_convert<ST, XT>), dim3(2048), dim3(256), 0, P->stream, stage, ldx, dst, P->ld, (int)n, j0, nc);
+    e = hipStreamSynchronize(P->stream);
+    if (e != hipSuccess) { hipFree(stage); return fail(BWGR_EHIP, "upload convert failed: %s", hipGetErrorString(e)); }
+  }
+  HIPCHK(hipFree(stage));
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
+  if (!P) return BWGR_OK;
+  (void)hipSetDevice(P->device);
+  hipFree(P->X); hipFree(P->gram); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev); hipFree(P->xpart); hipFree(P->xflags);
+  delete P;
+  return BWGR_OK;
+}
+
+static int panel_setup(bwgr_panel *P) {
+  const int p = (int)P->p, n = (int)P->n;
+  // a10: xx, vx, MSx
+  const int wpb = 4;
+  if (P->is_f32) hipLaunchKernelGGL(k_stats<float>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const float *)P->X, P->ld, n, p, P->xx, P->vx);
+  else hipLaunchKernelGGL(k_stats<int8_t>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const int8_t *)P->X, P->ld, n, p, P->xx, P->vx);
+  HIPCHK(hipGetLastError());
+  {
+    const int nparts = 256;
+    double *part = nullptr;
+    HIPCHK(hipMalloc(&part, sizeof(double) * nparts));
+    hipLaunchKernelGGL(k_sum_stage1, dim3(nparts), dim3(256), 0, P->stream, P->vx, (int64_t)p, part);
+    hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, P->stream, part, nparts, P->msx_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&P->MSx, P->msx_dev, sizeof(float), hipMemcpyDeviceToHost, P->stream));
+    HIPCHK(hipStreamSynchronize(P->stream));
+    HIPCHK(hipFree(part));
+  }
+  // block-diagonal Gram
+  const int m = P->m, TJ = m / 16;
+  if (P->is_f32) {
+    const size_t lds = (size_t)m * 65 * sizeof(float);
+    double *g = (double *)P->gram; const float *X = (const float *)P->X;
+    switch (TJ) {
+      case 1: hipLaunchKernelGGL(k_gram_f32<1>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+      case 2: hipLaunchKernelGGL(k_gram_f32<2>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+      case 3: hipLaunchKernelGGL(k_gram_f32<3>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+      default: hipLaunchKernelGGL(k_gram_f32<4>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+    }
+  } else {
+    const size_t lds = (size_t)m * 33 * sizeof(int32_t);
+    int32_t *g = (int32_t *)P->gram; const int8_t *X = (const int8_t *)P->X;
+    switch (TJ) {
+      case 1: hipLaunchKernelGGL(k_gram_i8<1>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+      case 2: hipLaunchKernelGGL(k_gram_i8<2>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+      case 3: hipLaunchKernelGGL(k_gram_i8<3>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+      case 4: hipLaunchKernelGGL(k_gram_i8<4>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+      case 5: hipLaunchKernelGGL(k_gram_i8<5>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+      case 6: hipLaunchKernelGGL(k_gram_i8<6>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+      case 7: hipLaunchKernelGGL(k_gram_i8<7>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+      default: hipLaunchKernelGGL(k_gram_i8<8>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(P->stream));
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int memloc, int64_t n, int64_t p,
+                                 int64_t ldx, int device, int block, int nwg) {
+  if (!out || !X) return fail(BWGR_EINVAL, "panel_create: null pointer");
+  *out = nullptr;
+  if (n < 2 || p < 1 || ldx < n) return fail(BWGR_EINVAL, "panel_create: need n >= 2, p >= 1, ldx >= n (n=%lld p=%lld ldx=%lld)", (long long)n, (long long)p, (long long)ldx);
+  if (n > 0x7FFFFF00ll || p > 0x7FFFFF00ll) return fail(BWGR_EINVAL, "panel_create: n and p must fit 31 bits");
+  if (xtype != BWGR_X_I8 && xtype != BWGR_X_F32 && xtype != BWGR_X_F64) return fail(BWGR_EINVAL, "panel_create: bad xtype %d", xtype);
+  if (memloc != BWGR_HOST && memloc != BWGR_DEVICE) return fail(BWGR_EINVAL, "panel_create: bad memloc %d", memloc);
+  CHK(require_device(device));
+  bwgr_panel *P = new bwgr_panel();
+  P->device = device; P->n = n; P->p = p; P->is_f32 = (xtype != BWGR_X_I8);
+  const int mmax = P->is_f32 ? 64 : SW_MAXM;
+  int m = block > 0 ? block : mmax;
+  if (m > mmax) { delete P; return fail(BWGR_EINVAL, "panel_create: block %d > %d (limit for this genotype type)", m, mmax); }
+  m = (int)std::min<int64_t>(m, ((p + 15) / 16) * 16);
+  m = ((m + 15) / 16) * 16;
+  P->m = m;
+  const int Rmax = P->is_f32 ? max_slab_rows<float>(m) : max_slab_rows<int8_t>(m);
+  int K = nwg > 0 ? nwg : (int)((n + Rmax - 1) / Rmax);
+  int R = (int)((((n + K - 1) / K) + 127) / 128) * 128;
+  if (K > 256 || R > Rmax) {
+    delete P;
+    return fail(BWGR_EINVAL, "panel_create: n=%lld needs %d slab workgroups of %d rows (limits: 256 workgroups, %d rows)", (long long)n, K, R, Rmax);
+  }
+  P->K = K; P->R = R; P->ld = (int64_t)K * R;
+  P->nblocks = (p + m - 1) / m;
+  P->lds_bytes = P->is_f32 ? sweep_lds_bytes<float>(m, R) : sweep_lds_bytes<int8_t>(m, R);
+  P->x_bytes = (size_t)P->ld * (size_t)p * (P->is_f32 ? 4 : 1);
+  P->gram_bytes = (size_t)P->nblocks * m * m * (P->is_f32 ? 8 : 4);
+  int rc = BWGR_OK;
+  auto bail = [&](int code) { bwgr_panel_destroy(P); return code; };
+#define PCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return bail(fail(BWGR_EHIP, "%s failed: %s", #x, hipGetErrorString(e_))); } while (0)
+  PCHK(hipMalloc(&P->X, P->x_bytes));
+  PCHK(hipMalloc(&P->gram, P->gram_bytes));
+  PCHK(hipMalloc(&P->xx, sizeof(float) * p));
+  PCHK(hipMalloc(&P->vx, sizeof(float) * p));
+  PCHK(hipMalloc(&P->msx_dev, sizeof(float)));
+  PCHK(hipMalloc(&P->xpart, sizeof(double) * 2 * (size_t)K * SW_MAXM));
+  PCHK(hipMalloc(&P->xflags, sizeof(uint32_t) * ((size_t)K + 1) * SW_FLAG_STRIDE));
+  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<int8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#undef PCHK
+  if (xtype == BWGR_X_I8) rc = upload<int8_t, int8_t>(P, X, memloc, ldx);
+  else if (xtype == BWGR_X_F32) rc = upload<float, float>(P, X, memloc, ldx);
+  else rc = upload<double, float>(P, X, memloc, ldx);
+  if (rc != BWGR_OK) return bail(rc);
+  rc = panel_setup(P);
+  if (rc != BWGR_OK) return bail(rc);
+  *out = P;
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_panel_set_stream(bwgr_panel *P, void *hip_stream) {
+  if (!P) return fail(BWGR_EINVAL, "null panel");
+  P->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_panel_info(const bwgr_panel *P, int64_t info[8]) {
+  if (!P || !info) return fail(BWGR_EINVAL, "null pointer");
+  info[0] = P->n; info[1] = P->p; info[2] = P->ld; info[3] = P->m; info[4] = P->K; info[5] = P->R;
+  info[6] = (int64_t)P->x_bytes; info[7] = (int64_t)P->gram_bytes;
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_panel_stats(bwgr_panel *P, float *xx, float *vx, float *MSx) {
+  if (!P) return fail(BWGR_EINVAL, "null panel");
+  HIPCHK(hipSetDevice(P->device));
+  if (xx) HIPCHK(hipMemcpy(xx, P->xx, sizeof(float) * P->p, hipMemcpyDeviceToHost));
+  if (vx) HIPCHK(hipMemcpy(vx, P->vx, sizeof(float) * P->p, hipMemcpyDeviceToHost));
+  if (MSx) *MSx = P->MSx;
+  return BWGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// KMUP
+// ------------------------------------------------------------------------------------------------
+extern "C" int bwgr_kmup(bwgr_panel *P, float *b, float *d, const float *xx, float *e, const float *L, float Ve,
+                         float pi, uint64_t seed, uint32_t iter, int rng_mode) {
+  if (!P || !b || !d || !xx || !e || !L) return fail(BWGR_EINVAL, "kmup: null pointer");
+  HIPCHK(hipSetDevice(P->device));
+  const size_t pb = sizeof(float) * P->p;
+  float *db = nullptr, *dd = nullptr, *dxx = nullptr, *dL = nullptr, *de = nullptr, *dvb = nullptr;
+  double *de64 = nullptr;
+  ChainScalars *sc = nullptr;
+  HIPCHK(hipMalloc(&db, pb)); HIPCHK(hipMalloc(&dd, pb)); HIPCHK(hipMalloc(&dxx, pb)); HIPCHK(hipMalloc(&dL, pb)); HIPCHK(hipMalloc(&dvb, pb));
+  HIPCHK(hipMalloc(&de, sizeof(float) * P->n)); HIPCHK(hipMalloc(&de64, sizeof(double) * P->ld)); HIPCHK(hipMalloc(&sc, sizeof(ChainScalars)));
+  HIPCHK(hipMemcpyAsync(db, b, pb, hipMemcpyHostToDevice, P->stream));
+  HIPCHK(hipMemcpyAsync(dd, d, pb, hipMemcpyHostToDevice, P->stream));
+  HIPCHK(hipMemcpyAsync(dxx, xx, pb, hipMemcpyHostToDevice, P->stream));
+  HIPCHK(hipMemcpyAsync(dL, L, pb, hipMemcpyHostToDevice, P->stream));
+  HIPCHK(hipMemcpyAsync(de, e, sizeof(float) * P->n, hipMemcpyHostToDevice, P->stream));
+  hipLaunchKernelGGL(k_f2d, dim3(64), dim3(256), 0, P->stream, de, de64, P->n, P->ld);
+  ChainScalars h; memset(&h, 0, sizeof(h));
+  h.ve = Ve; h.pi = pi; h.C = -0.5f / sqrtf(Ve); h.odds = pi / (1.0f - pi); h.dfp1 = 1.0f;
+  HIPCHK(hipMemcpyAsync(sc, &h, sizeof(h), hipMemcpyHostToDevice, P->stream));
+  SweepArgs a; memset(&a, 0, sizeof(a));
+  fill_panel_args(P, a);
+  a.flags = SWF_LAM_VEC | (pi > 0 ? (SWF_SELECT | SWF_ALT_B2) : 0);
+  a.e = de64; a.b = db; a.d = dd; a.vb = dvb; a.xx = dxx; a.lam = dL; a.sc = sc;
+  a.iter = iter; a.rng = make_rng(seed, rng_mode);
+  int rc = launch_sweep(P, a);
+  if (rc == BWGR_OK) {
+    HIPCHK(hipMemcpyAsync(b, db, pb, hipMemcpyDeviceToHost, P->stream));
+    HIPCHK(hipMemcpyAsync(d, dd, pb, hipMemcpyDeviceToHost, P->stream));
+    hipLaunchKernelGGL(k_d2f, dim3(64), dim3(256), 0, P->stream, de64, de, P->n);
+    HIPCHK(hipMemcpyAsync(e, de, sizeof(float) * P->n, hipMemcpyDeviceToHost, P->stream));
+    HIPCHK(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, P->stream));
+    HIPCHK(hipStreamSynchronize(P->stream));
+    if (h.error) rc = fail(BWGR_ETIMEOUT, "kmup: a workgroup exchange timed out inside the sweep kernel");
+  }
+  hipFree(db); hipFree(dd); hipFree(dxx); hipFree(dL); hipFree(de); hipFree(de64); hipFree(dvb); hipFree(sc);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused chains
+// ------------------------------------------------------------------------------------------------
+static bool per_marker_vb(int model) { return model == BWGR_BAYESA || model == BWGR_BAYESB || model == BWGR_BAYESL || model == BWGR_BAYESDPI; }
+static bool has_d(int model) { return model == BWGR_BAYESB || model == BWGR_BAYESC || model == BWGR_BAYESCPI || model == BWGR_BAYESDPI; }
+
+extern "C" int bwgr_chain_destroy(bwgr_chain *C) {
+  if (!C) return BWGR_OK;
+  (void)hipSetDevice(C->P->device);
+  for (hipEvent_t ev : C->ev) hipEventDestroy(ev);
+  hipFree(C->y); hipFree(C->e); hipFree(C->b); hipFree(C->d); hipFree(C->vb); hipFree(C->lam);
+  hipFree(C->B); hipFree(C->D); hipFree(C->VB); hipFree(C->sc);
+  delete C;
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_chain_create(bwgr_chain **out, bwgr_panel *P, int model, const float *y, int memloc, float it,
+                                 float bi, float pi, float df, float R2, uint64_t seed, int rng_mode) {
+  if (!out || !P || !y) return fail(BWGR_EINVAL, "chain_create: null pointer");
+  *out = nullptr;
+  if (model < BWGR_BAYESA || model > BWGR_BAYESDPI) return fail(BWGR_EINVAL, "chain_create: bad model %d", model);
+  HIPCHK(hipSetDevice(P->device));
+  bwgr_chain *C = new bwgr_chain();
+  C->P = P; C->model = model; C->itf = it; C->bif = bi; C->iit = (int)it; C->ibi = (int)bi;
+  C->pi = pi; C->df = df; C->R2 = R2; C->seed = seed; C->rng_mode = rng_mode;
+  C->Phi = P->MSx * (1 - R2) / R2;
+  const size_t pb = sizeof(float) * P->p;
+  auto bail = [&](int code) { bwgr_chain_destroy(C); return code; };
+#define CCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return bail(fail(BWGR_EHIP, "%s failed: %s", #x, hipGetErrorString(e_))); } while (0)
+  CCHK(hipMalloc(&C->y, sizeof(float) * P->n)); CCHK(hipMalloc(&C->e, sizeof(double) * P->ld));
+  CCHK(hipMalloc(&C->b, pb)); CCHK(hipMalloc(&C->d, pb)); CCHK(hipMalloc(&C->vb, pb)); CCHK(hipMalloc(&C->lam, pb));
+  CCHK(hipMalloc(&C->B, pb)); CCHK(hipMalloc(&C->D, pb)); CCHK(hipMalloc(&C->VB, pb)); CCHK(hipMalloc(&C->sc, sizeof(ChainScalars)));
+  CCHK(hipMemcpyAsync(C->y, y, sizeof(float) * P->n, memloc == BWGR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, P->stream));
+  InitArgs ia; ia.y = C->y; ia.e = C->e; ia.n = (int)P->n; ia.p = (int)P->p; ia.ld = P->ld; ia.model = model;
+  ia.pi = pi; ia.df = df; ia.R2 = R2; ia.MSx = P->MSx; ia.sc = C->sc;
+  hipLaunchKernelGGL(k_chain_init, dim3(1), dim3(1024), 0, P->stream, ia);
+  hipLaunchKernelGGL(k_marker_init, dim3(1024), dim3(256), 0, P->stream, C->b, C->d, C->vb, C->lam, C->B, C->D, C->VB, (int)P->p, C->sc);
+  CCHK(hipGetLastError());
+  CCHK(hipStreamSynchronize(P->stream));
+#undef CCHK
+  *out = C;
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_chain_run(bwgr_chain *C, int iters) {
+  if (!C) return fail(BWGR_EINVAL, "null chain");
+  if (iters < 0 || C->done + iters > C->iit) return fail(BWGR_EINVAL, "chain_run: %d more iterations would exceed it=%d (done %d)", iters, C->iit, C->done);
+  bwgr_panel *P = C->P;
+  HIPCHK(hipSetDevice(P->device));
+  const int model = C->model;
+  const bool per = per_marker_vb(model);
+  for (int k = 0; k < iters; ++k) {
+    const int i = C->done;
+    SweepArgs a; memset(&a, 0, sizeof(a));
+    fill_panel_args(P, a);
+    int fl = 0;
+    if (has_d(model)) fl |= SWF_SELECT;
+    if (model == BWGR_BAYESDPI) fl |= SWF_ALT_B2 | SWF_MH;
+    if (per) fl |= SWF_LAM_VEC | SWF_VB_VEC;
+    a.flags = fl;
+    a.e = C->e; a.b = C->b; a.d = C->d; a.vb = C->vb; a.xx = P->xx; a.lam = C->lam; a.sc = C->sc;
+    a.iter = (uint32_t)i; a.rng = make_rng(C->seed, C->rng_mode);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    if (P->K > 1) HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
+    HIPCHK(hipEventRecord(e0, P->stream));
+    if (P->is_f32) hipLaunchKernelGGL(k_sweep<float>, dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
+    else hipLaunchKernelGGL(k_sweep<int8_t>, dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, P->stream));
+    C->ev.push_back(e0); C->ev.push_back(e1);
+    const int accumulate = (i > C->ibi) ? 1 : 0;   // if(i>ibi), src/Rcpp20260726ai.cpp:624
+    TailArgs t; t.e = C->e; t.n = (int)P->n; t.p = (int)P->p; t.model = model; t.df = C->df; t.R2 = C->R2; t.Phi = C->Phi;
+    t.accumulate = accumulate; t.iter = (uint32_t)i; t.rng = make_rng(C->seed, C->rng_mode); t.sc = C->sc;
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), 0, P->stream, t);
+    hipLaunchKernelGGL(k_marker_tail, dim3(std::min<int64_t>(2048, (P->p + 255) / 256)), dim3(256), 0, P->stream,
+                       C->b, C->d, C->vb, C->lam, C->B, C->D, C->VB, (int)P->p, model, C->Phi, accumulate, C->sc);
+    HIPCHK(hipGetLastError());
+    C->done++;
+    // bound the number of live events
+    if (C->ev.size() >= 4096) {
+      float ms; int nl;
+      bwgr_chain_sweep_ms(C, &ms, &nl);
+    }
+  }
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_chain_sync(bwgr_chain *C) {
+  if (!C) return fail(BWGR_EINVAL, "null chain");
+  HIPCHK(hipSetDevice(C->P->device));
+  HIPCHK(hipStreamSynchronize(C->P->stream));
+  ChainScalars h;
+  HIPCHK(hipMemcpy(&h, C->sc, sizeof(h), hipMemcpyDeviceToHost));
+  if (h.error) return fail(BWGR_ETIMEOUT, "a workgroup exchange timed out inside the sweep kernel (chain state is invalid)");
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_chain_iterations(const bwgr_chain *C, int *done) {
+  if (!C || !done) return fail(BWGR_EINVAL, "null pointer");
+  *done = C->done;
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_chain_sweep_ms(bwgr_chain *C, float *avg_ms, int *launches) {
+  if (!C) return fail(BWGR_EINVAL, "null chain");
+  HIPCHK(hipSetDevice(C->P->device));
+  HIPCHK(hipStreamSynchronize(C->P->stream));
+  float total = 0; int nl = 0;
+  for (size_t k = 0; k + 1 < C->ev.size(); k += 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, C->ev[k], C->ev[k + 1]));
+    total += ms; nl++;
+    hipEventDestroy(C->ev[k]); hipEventDestroy(C->ev[k + 1]);
+  }
+  C->ev.clear();
+  C->ms_acc += total; C->launch_acc += nl;
+  if (avg_ms && launches) {
+    *launches = C->launch_acc;
+    *avg_ms = C->launch_acc ? C->ms_acc / C->launch_acc : 0.0f;
+    C->ms_acc = 0; C->launch_acc = 0;
+  }
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_chain_state(bwgr_chain *C, float *b, float *d, float *e, float *vb, float *scal) {
+  if (!C) return fail(BWGR_EINVAL, "null chain");
+  CHK(bwgr_chain_sync(C));
+  bwgr_panel *P = C->P;
+  const size_t pb = sizeof(float) * P->p;
+  ChainScalars h;
+  HIPCHK(hipMemcpy(&h, C->sc, sizeof(h), hipMemcpyDeviceToHost));
+  if (b) HIPCHK(hipMemcpy(b, C->b, pb, hipMemcpyDeviceToHost));
+  if (d) HIPCHK(hipMemcpy(d, C->d, pb, hipMemcpyDeviceToHost));
+  if (e) {
+    float *ef = nullptr;
+    HIPCHK(hipMalloc(&ef, sizeof(float) * P->n));
+    hipLaunchKernelGGL(k_d2f, dim3(64), dim3(256), 0, P->stream, C->e, ef, P->n);
+    HIPCHK(hipMemcpyAsync(e, ef, sizeof(float) * P->n, hipMemcpyDeviceToHost, P->stream));
+    HIPCHK(hipStreamSynchronize(P->stream));
+    hipFree(ef);
+  }
+  if (vb) {
+    if (per_marker_vb(C->model)) HIPCHK(hipMemcpy(vb, C->vb, pb, hipMemcpyDeviceToHost));
+    else for (int64_t j = 0; j < P->p; ++j) vb[j] = h.vb;
+  }
+  if (scal) { scal[0] = h.mu; scal[1] = h.ve; scal[2] = h.vb; scal[3] = h.pi; }
+  return BWGR_OK;
+}
+
+// hat = X*B + MU   (src/Rcpp20260726ai.cpp:629-630), fp64 accumulation, deterministic two-stage
+template <typename CT>
+static int gemv_hat(bwgr_panel *P, const CT *coef_dev, float MU, float *hat_dev) {
+  const int nchunks = (int)std::min<int64_t>(64, std::max<int64_t>(1, P->p / 512));
+  const int cpc = (int)((P->p + nchunks - 1) / nchunks);
+  double *part = nullptr;
+  HIPCHK(hipMalloc(&part, sizeof(double) * (size_t)nchunks * P->ld));
+  dim3 grid((unsigned)((P->ld / 4 + 255) / 256), (unsigned)nchunks);
+  if (P->is_f32) hipLaunchKernelGGL((k_gemv_part<float, CT>), grid, dim3(256), 0, P->stream, (const float *)P->X, P->ld, (int)P->p, coef_dev, cpc, part);
+  else hipLaunchKernelGGL((k_gemv_part<int8_t, CT>), grid, dim3(256), 0, P->stream, (const int8_t *)P->X, P->ld, (int)P->p, coef_dev, cpc, part);
+  hipLaunchKernelGGL(k_hat_finish, dim3((unsigned)((P->n + 255) / 256)), dim3(256), 0, P->stream, part, P->ld, nchunks, (int)P->n, MU, hat_dev);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(P->stream));
+  HIPCHK(hipFree(part));
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_chain_result(bwgr_chain *C, float *mu, float *b, float *d, float *hat, float *vb, float *ve,
+                                 float *h2, float *MSx, float *pi, float *pval) {
+  if (!C) return fail(BWGR_EINVAL, "null chain");
+  if (C->done != C->iit) return fail(BWGR_EINVAL, "chain_result: %d of %d iterations run", C->done, C->iit);
+  CHK(bwgr_chain_sync(C));
+  bwgr_panel *P = C->P;
+  const size_t pb = sizeof(float) * P->p;
+  const bool per = per_marker_vb(C->model);
+  const float MCMC = C->itf - C->bif;                                              // :626
+  float *pval_dev = nullptr;
+  if (pval) HIPCHK(hipMalloc(&pval_dev, pb));
+  if (!C->finalized) {
+    hipLaunchKernelGGL(k_final_markers, dim3(1024), dim3(256), 0, P->stream, C->B, C->D, C->VB, pval_dev, (int)P->p, MCMC, per ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    C->finalized = true;
+  } else if (pval_dev) {
+    hipLaunchKernelGGL(k_final_markers, dim3(1024), dim3(256), 0, P->stream, C->B, C->D, C->VB, pval_dev, (int)P->p, 1.0f, per ? 1 : 0);
+  }
+  ChainScalars h;
+  HIPCHK(hipMemcpyAsync(&h, C->sc, sizeof(h), hipMemcpyDeviceToHost, P->stream));
+  HIPCHK(hipStreamSynchronize(P->stream));
+  const float MU = h.MU / MCMC, VE = h.VE / MCMC;
+  float VBs = h.VBs / MCMC, Pi = 0, vg;
+  if (C->model == BWGR_BAYESCPI || C->model == BWGR_BAYESDPI) Pi = 1 - h.Pi / MCMC;   // :911
+  if (per) {
+    // vg = VB.sum()
+    double *part = nullptr; float *sdev = nullptr;
+    HIPCHK(hipMalloc(&part, sizeof(double) * 256)); HIPCHK(hipMalloc(&sdev, sizeof(float)));
+    hipLaunchKernelGGL(k_sum_stage1, dim3(256), dim3(256), 0, P->stream, C->VB, (int64_t)P->p, part);
+    hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, P->stream, part, 256, sdev);
+    HIPCHK(hipMemcpy(&vg, sdev, sizeof(float), hipMemcpyDeviceToHost));
+    hipFree(part); hipFree(sdev);
+  } else {
+    vg = VBs * P->MSx;
+    if (C->model == BWGR_BAYESCPI) vg = VBs * P->MSx / Pi;                         // :913
+  }
+  if (mu) *mu = MU;
+  if (ve) *ve = VE;
+  if (h2) *h2 = vg / (vg + VE);
+  if (MSx) *MSx = P->MSx;
+  if (pi) *pi = Pi;
+  if (b) HIPCHK(hipMemcpy(b, C->B, pb, hipMemcpyDeviceToHost));
+  if (d) HIPCHK(hipMemcpy(d, C->D, pb, hipMemcpyDeviceToHost));
+  if (vb) { if (per) HIPCHK(hipMemcpy(vb, C->VB, pb, hipMemcpyDeviceToHost)); else vb[0] = VBs; }
+  if (pval) { HIPCHK(hipMemcpy(pval, pval_dev, pb, hipMemcpyDeviceToHost)); hipFree(pval_dev); }
+  if (hat) {
+    float *hat_dev = nullptr;
+    HIPCHK(hipMalloc(&hat_dev, sizeof(float) * P->n));
+    int rc = gemv_hat<float>(P, C->B, MU, hat_dev);
+    if (rc == BWGR_OK) HIPCHK(hipMemcpy(hat, hat_dev, sizeof(float) * P->n, hipMemcpyDeviceToHost));
+    hipFree(hat_dev);
+    CHK(rc);
+  }
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_bayes(bwgr_panel *P, int model, const float *y, float it, float bi, float pi, float df, float R2,
+                          uint64_t seed, int rng_mode, float *mu, float *b, float *d, float *hat, float *vb, float *ve,
+                          float *h2, float *MSx, float *pi_out, float *pval) {
+  bwgr_chain *C = nullptr;
+  CHK(bwgr_chain_create(&C, P, model, y, BWGR_HOST, it, bi, pi, df, R2, seed, rng_mode));
+  int rc = bwgr_chain_run(C, (int)it);
+  if (rc == BWGR_OK) rc = bwgr_chain_result(C, mu, b, d, hat, vb, ve, h2, MSx, pi_out, pval);
+  bwgr_chain_destroy(C);
+  return rc;
+}
+
+extern "C" int bwgr_wgr(bwgr_panel *, const double *, int, int, int, int, int, double, double, double, uint64_t, int,
+                        double *, double *, double *, double *, double *, double *, double *) {
+  return fail(BWGR_EINVAL, "bwgr_wgr: not built yet");
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic data and test hooks
+// ------------------------------------------------------------------------------------------------
+extern "C" int bwgr_synth_genotypes(void *Xdev, int64_t n, int64_t p, int64_t ldx, uint64_t seed, float *freq_dev,
+                                    int device, void *hip_stream) {
+  if (!Xdev || n < 1 || p < 1 || ldx < n || (ldx & 3)) return fail(BWGR_EINVAL, "synth: need ldx >= n and ldx %% 4 == 0");
+  CHK(require_device(device));
+  hipLaunchKernelGGL(k_synth, dim3(8192), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), (int8_t *)Xdev, ldx, (int)n, p,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), freq_dev);
+  HIPCHK(hipGetLastError());
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_debug_variates(int device, uint64_t seed, int kind, double nu, uint32_t marker0, uint32_t iter,
+                                   uint32_t purpose, int count, double *out_host) {
+  if (!out_host || count < 1) return fail(BWGR_EINVAL, "debug_variates: bad arguments");
+  CHK(require_device(device));
+  double *dev = nullptr;
+  HIPCHK(hipMalloc(&dev, sizeof(double) * count));
+  hipLaunchKernelGGL(k_debug_variates, dim3((count + 255) / 256), dim3(256), 0, 0, make_rng(seed, 0), kind, nu, marker0, iter, purpose, count, dev);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out_host, dev, sizeof(double) * count, hipMemcpyDeviceToHost));
+  HIPCHK(hipFree(dev));
+  return BWGR_OK;
+}

@@ -1,0 +1,138 @@
+/*
+ * include/bwgr.h -- C ABI of libbwgr_hip.so, the MI355X (gfx950) Gibbs sweep engine that stands
+ * behind bWGR's wgr()/KMUP and the standalone Bayes* samplers.
+ *
+ * Plain pointers and sizes only; no torch / Rcpp / Eigen types.  Every entry point names the
+ * reference interface it replaces (paths relative to the bWGR source tree).  The reference-side
+ * binding (an R .Call shim, plus the ctypes stub used by this repo's host layer) is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - All functions return 0 (BWGR_OK) or a bwgr_status code; bwgr_last_error() gives the text.
+ *     HIP failures never abort the process (the reference's BEGIN_RCPP/END_RCPP turns C++
+ *     exceptions into R conditions, src/RcppExports.cpp:17,30; the shim maps non-zero to Rf_error).
+ *   - Inputs are never modified unless documented as in/out; outputs are caller-allocated
+ *     (the Rcpp glue passes every Eigen argument by value, src/RcppExports.cpp:20-27).
+ *   - X is column-major n x p with leading dimension ldx (R / Eigen::MatrixXf layout).
+ *   - `seed` replaces R's global RNG stream (Rcpp::RNGScope, src/RcppExports.cpp:19); the R
+ *     front-end derives it from unif_rand() so set.seed() still governs repeatability.
+ *   - There is no CPU fallback: without a gfx950 device every compute entry returns BWGR_ENODEV.
+ */
+#ifndef BWGR_H
+#define BWGR_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BWGR_ABI_VERSION 1
+
+enum bwgr_status {
+  BWGR_OK = 0,
+  BWGR_EINVAL = 1,   /* bad argument */
+  BWGR_EHIP = 2,     /* a HIP runtime call failed */
+  BWGR_ENOMEM = 3,
+  BWGR_ETIMEOUT = 4, /* an in-kernel workgroup exchange gave up (bounded spin) */
+  BWGR_ENODEV = 5    /* no usable GPU */
+};
+enum bwgr_xtype { BWGR_X_I8 = 0, BWGR_X_F32 = 1, BWGR_X_F64 = 2 }; /* F64 (an R numeric matrix) is narrowed
+                                                                     to float on upload, as the Rcpp glue does
+                                                                     on every call (src/RcppExports.cpp:20) */
+enum bwgr_memloc { BWGR_HOST = 0, BWGR_DEVICE = 1 };
+enum bwgr_model {
+  BWGR_BAYESA = 0,   /* src/Rcpp20260726ai.cpp:589-635 */
+  BWGR_BAYESB = 1,   /* :638-699 */
+  BWGR_BAYESC = 2,   /* :702-759 */
+  BWGR_BAYESL = 3,   /* :762-809 */
+  BWGR_BAYESRR = 4,  /* :812-855 */
+  BWGR_BAYESCPI = 5, /* :858-921 */
+  BWGR_BAYESDPI = 6  /* :924-987 */
+};
+enum bwgr_rng_mode { BWGR_RNG_PHILOX = 0, BWGR_RNG_DEGENERATE = 1 /* z=0, chi2=mean, u=0.5 (tests) */ };
+
+typedef struct bwgr_panel bwgr_panel; /* genotype matrix resident in HBM + per-marker setup */
+typedef struct bwgr_chain bwgr_chain; /* one MCMC chain: residual, effects, variances, posterior sums */
+
+int bwgr_abi_version(void);
+const char *bwgr_last_error(void);
+int bwgr_device_count(int *count);
+
+/* ---- panel: X staged once, column-major in HBM ------------------------------------------------
+ * Replaces the per-call SEXP -> Eigen::MatrixXf conversion of X (src/RcppExports.cpp:20, :198 ...).
+ * block = markers per exact block (0 = auto, <= 128); nwg = row-slab workgroups (0 = auto).
+ * Builds xx, vx, MSx (src/Rcpp20260726ai.cpp:593-598) and the block-diagonal Gram used by the
+ * blocked sweep. */
+int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int memloc, int64_t n, int64_t p, int64_t ldx,
+                      int device, int block, int nwg);
+int bwgr_panel_destroy(bwgr_panel *P);
+int bwgr_panel_set_stream(bwgr_panel *P, void *hip_stream); /* NULL = the default stream */
+/* geometry actually chosen: info[0]=n, [1]=p, [2]=ld (padded rows), [3]=block, [4]=nwg, [5]=slab rows,
+ * [6]=bytes of X resident, [7]=bytes of Gram resident */
+int bwgr_panel_info(const bwgr_panel *P, int64_t info[8]);
+/* xx[j] = |X_j|^2, vx[j] = fvar(X_j), MSx = sum vx   (host outputs; any may be NULL) */
+int bwgr_panel_stats(bwgr_panel *P, float *xx, float *vx, float *MSx);
+
+/* ---- KMUP: one Gibbs sweep over all markers ---------------------------------------------------
+ * Replaces SEXP KMUP(X,b,d,xx,e,L,Ve,pi), src/Rcpp20260726ai.cpp:12-38 / _bWGR_KMUP,
+ * src/RcppExports.cpp:16-31.  b, d (p) and e (n) are in/out host vectors; xx, L (p) inputs.
+ * `iter` is the iteration word of the RNG counter (wgr passes its loop index - 1).
+ * Inclusion probability uses the stable form 1/(1+pi/(1-pi)*exp(C(|e2|^2-|e1|^2))), which equals the
+ * reference's cj/(cj+dj) wherever that does not underflow to NaN. */
+int bwgr_kmup(bwgr_panel *P, float *b, float *d, const float *xx, float *e, const float *L, float Ve, float pi,
+              uint64_t seed, uint32_t iter, int rng_mode);
+
+/* ---- fused chains: BayesA/B/C/L/RR/Cpi/Dpi ---------------------------------------------------------
+ * Replaces SEXP Bayes*(y, X, it, bi, [pi,] df, R2), src/Rcpp20260726ai.cpp:589-987 /
+ * _bWGR_BayesA.._bWGR_BayesDpi, src/RcppExports.cpp:177-290.  y: n floats (host or device per
+ * memloc).  it/bi are floats cast to int, as in the reference (:611, :642).  pi is ignored by
+ * A/L/RR/Cpi/Dpi. */
+int bwgr_chain_create(bwgr_chain **out, bwgr_panel *P, int model, const float *y, int memloc, float it, float bi,
+                      float pi, float df, float R2, uint64_t seed, int rng_mode);
+int bwgr_chain_destroy(bwgr_chain *C);
+/* run the next `iters` MCMC iterations (sweep + intercept + variance draws + posterior sums);
+ * asynchronous on the panel's stream */
+int bwgr_chain_run(bwgr_chain *C, int iters);
+/* wait for the stream and report in-kernel exchange failures */
+int bwgr_chain_sync(bwgr_chain *C);
+/* iterations completed so far */
+int bwgr_chain_iterations(const bwgr_chain *C, int *done);
+/* posterior means and fitted values, the reference's return list (host outputs, any may be NULL):
+ *   mu, b[p], d[p], hat[n], vb[p] (A/B/L/Dpi) or vb[1] (C/RR/Cpi), ve, h2, MSx, pi (Cpi/Dpi), PVAL[p] */
+int bwgr_chain_result(bwgr_chain *C, float *mu, float *b, float *d, float *hat, float *vb, float *ve, float *h2,
+                      float *MSx, float *pi, float *pval);
+/* current chain state (host outputs, any may be NULL): b[p], d[p], e[n], vb[p] (common variance
+ * replicated), scal[4] = {mu, ve, vb_common, pi} */
+int bwgr_chain_state(bwgr_chain *C, float *b, float *d, float *e, float *vb, float *scal);
+/* device-time of the sweep kernel alone, averaged over the launches since the last call (ms);
+ * measured with hipEvents on the stream the kernel runs on */
+int bwgr_chain_sweep_ms(bwgr_chain *C, float *avg_ms, int *launches);
+
+/* one-call form: create + run(it) + result + destroy */
+int bwgr_bayes(bwgr_panel *P, int model, const float *y, float it, float bi, float pi, float df, float R2,
+               uint64_t seed, int rng_mode, float *mu, float *b, float *d, float *hat, float *vb, float *ve,
+               float *h2, float *MSx, float *pi_out, float *pval);
+
+/* ---- wgr(): the R-level driver, device-resident ---------------------------------------------------
+ * Replaces the iteration body and setup/teardown of wgr(), R/wgr.R:41-168 (bag = 1, eigK = NULL in
+ * this round).  y is the R numeric vector (double).  Outputs as wgr's return list: mu, b[p],
+ * Vb[p] (iv/de) or Vb[1], d[p], Ve, hat[n], cxx. */
+int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, int de, double pi, double df, double R2,
+             uint64_t seed, int rng_mode, double *mu, double *b, double *Vb, double *d, double *Ve, double *hat,
+             double *cxx);
+
+/* ---- synthetic panels ----------------------------------------------------------
+ * X_ij ~ Binomial(2, f_j), f_j ~ U(0.05,0.5), int8 column-major written to device memory Xdev
+ * (ldx >= n); freq (p floats, device, may be NULL) receives f_j. */
+int bwgr_synth_genotypes(void *Xdev, int64_t n, int64_t p, int64_t ldx, uint64_t seed, float *freq_dev, int device,
+                         void *hip_stream);
+
+/* ---- test hooks -----------------------------------------------------------------------------------
+ * variates of the RNG contract computed on the device: kind 0 normal, 1 uniform, 2 chisq(nu);
+ * out[i] for marker = marker0 + i. */
+int bwgr_debug_variates(int device, uint64_t seed, int kind, double nu, uint32_t marker0, uint32_t iter,
+                        uint32_t purpose, int count, double *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -16,16 +16,21 @@
  * bwgr_rng.h: same distributions, different stream).
  *
  * The file is compiled twice (see Makefile):
- *   -DACC_T=double -DSUF=_w   "wide":     every Eigen reduction accumulates in double and the
- *                                          Bernoulli log-odds uses the un-rounded norm
- *                                          difference.  This is the parity target for the GPU.
+ *   -DACC_T=double -DSUF=_w   "wide":     every Eigen reduction accumulates in double, the
+ *                                          residual vector e (and the e1/e2 temporaries) is carried
+ *                                          in double, and the Bernoulli log-odds uses the un-rounded
+ *                                          norm difference.  This is the parity target for the GPU:
+ *                                          the same algorithm with the float round-off of the
+ *                                          n-vector arithmetic removed, so that it is independent
+ *                                          of summation order and of how markers are blocked.
  *   -DACC_T=float  -DSUF=_f   "faithful": reductions accumulate in float (8 interleaved
  *                                          partial sums, as Eigen's packet reduction does) and
  *                                          the norms are rounded to float before subtraction,
  *                                          exactly as the reference's types dictate.  This is
  *                                          the CPU baseline that bench.py times.
- * Everything else (all scalar arithmetic, the residual vector e, the element-wise updates)
- * is float in both, as in the reference's Eigen::VectorXf / float locals.
+ * All scalar arithmetic (effects, variances, lambda, probabilities) is float in both, as in the
+ * reference's float locals; in the faithful flavour e is float too (Eigen::VectorXf).  The two
+ * flavours are compared with each other in tests/test_oracle_invariants.py.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -38,6 +43,11 @@
 #define SUF _w
 #define ACC_WIDE 1
 #endif
+#ifdef ACC_WIDE
+typedef double E_T;   /* residual vector element */
+#else
+typedef float E_T;
+#endif
 #define CAT2(a, b) a##b
 #define CAT(a, b) CAT2(a, b)
 #define FN(name) CAT(name, SUF)
@@ -49,7 +59,7 @@ static inline ACC_T red8(const ACC_T s[8]) {
   return ((s[0] + s[4]) + (s[2] + s[6])) + ((s[1] + s[5]) + (s[3] + s[7]));
 }
 /* X.col(j).dot(e) */
-static float v_dot(const float *x, const float *e, int64_t n) {
+static float v_dot(const float *x, const E_T *e, int64_t n) {
   ACC_T s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int64_t i = 0;
   for (; i + 8 <= n; i += 8)
@@ -75,6 +85,24 @@ static ACC_T v_sum_acc(const float *v, int64_t n) {
   for (int l = 0; i < n; i++, l++) s[l] += (ACC_T)v[i];
   return red8(s);
 }
+/* the same reductions over the residual vector (E_T) */
+static ACC_T e_sqnorm_acc(const E_T *v, int64_t n) {
+  ACC_T s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t i = 0;
+  for (; i + 8 <= n; i += 8)
+    for (int l = 0; l < 8; l++) s[l] += (ACC_T)v[i + l] * (ACC_T)v[i + l];
+  for (int l = 0; i < n; i++, l++) s[l] += (ACC_T)v[i] * (ACC_T)v[i];
+  return red8(s);
+}
+static float e_sqnorm(const E_T *v, int64_t n) { return (float)e_sqnorm_acc(v, n); }
+static float e_mean(const E_T *v, int64_t n) {
+  ACC_T s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t i = 0;
+  for (; i + 8 <= n; i += 8)
+    for (int l = 0; l < 8; l++) s[l] += (ACC_T)v[i + l];
+  for (int l = 0; i < n; i++, l++) s[l] += (ACC_T)v[i];
+  return (float)(red8(s) / (ACC_T)n);
+}
 /* v.mean(): Eigen = sum()/size() in the scalar type */
 static float v_mean(const float *v, int64_t n) { return (float)(v_sum_acc(v, n) / (ACC_T)n); }
 
@@ -90,16 +118,16 @@ static float v_fvar(const float *x, int64_t n) {
   return (float)(red8(s) / (ACC_T)(float)(n - 1));
 }
 /* out = e - x*db   (Eigen: e - X.col(j)*(scalar), element-wise in float) */
-static void v_axpy_to(float *out, const float *e, const float *x, float db, int64_t n) {
+static void v_axpy_to(E_T *out, const E_T *e, const float *x, float db, int64_t n) {
   for (int64_t i = 0; i < n; i++) {
-    float t = x[i] * db;
+    E_T t = (E_T)x[i] * (E_T)db;
     out[i] = e[i] - t;
   }
 }
 /* e -= x*db */
-static void v_axpy(float *e, const float *x, float db, int64_t n) {
+static void v_axpy(E_T *e, const float *x, float db, int64_t n) {
   for (int64_t i = 0; i < n; i++) {
-    float t = x[i] * db;
+    E_T t = (E_T)x[i] * (E_T)db;
     e[i] = e[i] - t;
   }
 }
@@ -110,7 +138,10 @@ static inline float draw_norm(float mu, float sd, double z) { return (float)((do
 
 /* ---- exported helpers --------------------------------------------------------------------- */
 float FN(oracle_fvar)(const float *x, int64_t n) { return v_fvar(x, n); }
-float FN(oracle_dot)(const float *x, const float *e, int64_t n) { return v_dot(x, e, n); }
+float FN(oracle_dot)(const float *x, const float *e, int64_t n) {
+  E_T *t = (E_T *)malloc(sizeof(E_T) * n); for (int64_t i = 0; i < n; i++) t[i] = e[i];
+  float r = v_dot(x, t, n); free(t); return r;
+}
 
 /* setup block shared by all seven samplers, /root/reference/src/Rcpp20260726ai.cpp:593-598
  * (identical at :644-649, 707-712, 767-772, 817-822, 863-868, 929-934) */
@@ -138,12 +169,12 @@ double FN(oracle_variate)(uint64_t seed, int mode, int kind, double nu, uint32_t
  * stable = 1: the algebraically identical 1/(1 + pi/(1-pi)*exp(C(|e2|^2-|e1|^2))), the form the
  *             reference itself uses in BayesB (:673-674).  The GPU implements stable = 1. */
 int FN(oracle_kmup)(const float *X, int64_t n, int64_t p, int64_t ldx, float *b, float *d, const float *xx,
-                    float *e, const float *L, float Ve, float pi, uint64_t seed, uint32_t iter, int rng_mode,
+                    float *e_io, const float *L, float Ve, float pi, uint64_t seed, uint32_t iter, int rng_mode,
                     int stable) {
   orng_t g = { seed, rng_mode };
-  float *e1 = (float *)malloc(sizeof(float) * n), *e2 = (float *)malloc(sizeof(float) * n);
-  if (!e1 || !e2) return 1;
-  memcpy(e1, e, sizeof(float) * n); memcpy(e2, e, sizeof(float) * n);            /* :14-15 */
+  E_T *e = (E_T *)malloc(sizeof(E_T) * n), *e1 = (E_T *)malloc(sizeof(E_T) * n), *e2 = (E_T *)malloc(sizeof(E_T) * n);
+  if (!e || !e1 || !e2) return 1;
+  for (int64_t i = 0; i < n; i++) e[i] = e1[i] = e2[i] = (E_T)e_io[i];            /* :14-15 */
   float b0, b1, b2, cj, dj, pj;
   float C = -0.5f / sqrtf(Ve);                                                   /* :17 */
   for (int64_t j = 0; j < p; j++) {                                              /* :18 */
@@ -158,28 +189,29 @@ int FN(oracle_kmup)(const float *X, int64_t n, int64_t p, int64_t ldx, float *b,
       v_axpy_to(e2, e, xj, b2 - b0, n);                                          /* :24 */
       if (stable) {
 #ifdef ACC_WIDE
-        float diff = (float)(v_sqnorm_acc(e2, n) - v_sqnorm_acc(e1, n));
+        float diff = (float)(e_sqnorm_acc(e2, n) - e_sqnorm_acc(e1, n));
 #else
-        float diff = v_sqnorm(e2, n) - v_sqnorm(e1, n);
+        float diff = e_sqnorm(e2, n) - e_sqnorm(e1, n);
 #endif
         float LR = (pi / (1.0f - pi)) * f_exp(C * diff);
         pj = 1.0f / (1.0f + LR);
       } else {
-        cj = (1 - pi) * f_exp(C * v_sqnorm(e1, n));                              /* :25 */
-        dj = (pi)*f_exp(C * v_sqnorm(e2, n));                                    /* :26 */
+        cj = (1 - pi) * f_exp(C * e_sqnorm(e1, n));                              /* :25 */
+        dj = (pi)*f_exp(C * e_sqnorm(e2, n));                                    /* :26 */
         pj = cj / (cj + dj);                                                     /* :27 */
       }
       /* R::rbinom(1,pj)==1 ; NaN pj compares false, like rbinom's NaN return */
       if (orng_uniform(&g, mk, iter, ORNG_U, 0) < (double)pj) {                  /* :28 */
-        b[j] = b1; d[j] = 1; memcpy(e, e1, sizeof(float) * n);                   /* :29 */
+        b[j] = b1; d[j] = 1; memcpy(e, e1, sizeof(E_T) * n);                     /* :29 */
       } else {
-        b[j] = b2; d[j] = 0; memcpy(e, e2, sizeof(float) * n);                   /* :31 */
+        b[j] = b2; d[j] = 0; memcpy(e, e2, sizeof(E_T) * n);                     /* :31 */
       }
     } else {
-      d[j] = 1; b[j] = b1; memcpy(e, e1, sizeof(float) * n);                     /* :34 */
+      d[j] = 1; b[j] = b1; memcpy(e, e1, sizeof(E_T) * n);                       /* :34 */
     }
   }
-  free(e1); free(e2);
+  for (int64_t i = 0; i < n; i++) e_io[i] = (float)e[i];                          /* :37 */
+  free(e); free(e1); free(e2);
   return 0;
 }
 
@@ -200,7 +232,7 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
   float *B = (float *)calloc(p, sizeof(float)), *D = (float *)calloc(p, sizeof(float));
   float *VBv = (float *)calloc(p, sizeof(float)), *vbv = (float *)malloc(sizeof(float) * p);
   float *Lmbv = (float *)malloc(sizeof(float) * p);
-  float *e = (float *)malloc(sizeof(float) * n), *e1 = (float *)malloc(sizeof(float) * n), *e2 = (float *)malloc(sizeof(float) * n);
+  E_T *e = (E_T *)malloc(sizeof(E_T) * n), *e1 = (E_T *)malloc(sizeof(E_T) * n), *e2 = (E_T *)malloc(sizeof(E_T) * n);
   if (!xx || !vx || !b || !d || !B || !D || !VBv || !vbv || !Lmbv || !e || !e1 || !e2) return 1;
 
   float MSx;
@@ -217,7 +249,7 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
   float b0, b1, b2, eM, h2, C = 0, MU = 0, VE = 0, VBs = 0, Pi = 0, LR, pj, vg, ve = vy, vb = Sb;
   float Lmb = ve / vb;                                                /* :725, :826, :882 */
   for (int64_t j = 0; j < p; j++) { vbv[j] = Sb; Lmbv[j] = ve * (1.0f / Sb); }   /* :608-609 cwiseInverse */
-  for (int64_t i = 0; i < n; i++) e[i] = y[i] - mu;                   /* :610 */
+  for (int64_t i = 0; i < n; i++) { float t = y[i] - mu; e[i] = t; } /* :610 */
   float Pi0 = pi / (1.0f - pi);                                       /* :665, :726, :883 */
   const int per_marker_vb = (model == M_BAYESA || model == M_BAYESB || model == M_BAYESL || model == M_BAYESDPI);
 
@@ -247,9 +279,9 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
         v_axpy_to(e2, e, xj, 0 - b0, n);
         {
 #ifdef ACC_WIDE
-          float diff = (float)(v_sqnorm_acc(e2, n) - v_sqnorm_acc(e1, n));
+          float diff = (float)(e_sqnorm_acc(e2, n) - e_sqnorm_acc(e1, n));
 #else
-          float diff = v_sqnorm(e2, n) - v_sqnorm(e1, n);
+          float diff = e_sqnorm(e2, n) - e_sqnorm(e1, n);
 #endif
           LR = Pi0 * f_exp(C * diff);
         }
@@ -269,9 +301,9 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
         v_axpy_to(e2, e, xj, 0 - b0, n);
         {
 #ifdef ACC_WIDE
-          float diff = (float)(v_sqnorm_acc(e2, n) - v_sqnorm_acc(e1, n));
+          float diff = (float)(e_sqnorm_acc(e2, n) - e_sqnorm_acc(e1, n));
 #else
-          float diff = v_sqnorm(e2, n) - v_sqnorm(e1, n);
+          float diff = e_sqnorm(e2, n) - e_sqnorm(e1, n);
 #endif
           LR = Pi0 * f_exp(C * diff);
         }
@@ -286,9 +318,9 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
         v_axpy_to(e2, e, xj, b2 - b0, n);
         {
 #ifdef ACC_WIDE
-          float diff = (float)(v_sqnorm_acc(e1, n) - v_sqnorm_acc(e2, n));
+          float diff = (float)(e_sqnorm_acc(e1, n) - e_sqnorm_acc(e2, n));
 #else
-          float diff = v_sqnorm(e1, n) - v_sqnorm(e2, n);
+          float diff = e_sqnorm(e1, n) - e_sqnorm(e2, n);
 #endif
           pj = (1 - pi) * f_exp(C * diff);
         }
@@ -302,26 +334,26 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
       dsum += (ACC_T)d[j];
     }
     /* intercept, :620-621 */
-    eM = draw_norm(v_mean(e, n), sqrtf(ve / n), orng_normal(&g, GM, itx, ORNG_G_MU, 0));
+    eM = draw_norm(e_mean(e, n), sqrtf(ve / n), orng_normal(&g, GM, itx, ORNG_G_MU, 0));
     mu += eM;
     for (int64_t k = 0; k < n; k++) e[k] = e[k] - eM;
     switch (model) {
     case M_BAYESA: case M_BAYESB: case M_BAYESDPI:                    /* :622-623, :685-686, :971-972 */
-      ve = (float)((double)(v_sqnorm(e, n) + Se) / orng_chisq(&g, (double)(n + df), GM, itx, ORNG_G_VE));
+      ve = (float)((double)(e_sqnorm(e, n) + Se) / orng_chisq(&g, (double)(n + df), GM, itx, ORNG_G_VE));
       for (int64_t j = 0; j < p; j++) Lmbv[j] = ve * (1.0f / vbv[j]);
       break;
     case M_BAYESL:                                                    /* :796-797 */
-      ve = (float)((double)(v_sqnorm(e, n) + Se) / orng_chisq(&g, (double)(n + df), GM, itx, ORNG_G_VE));
+      ve = (float)((double)(e_sqnorm(e, n) + Se) / orng_chisq(&g, (double)(n + df), GM, itx, ORNG_G_VE));
       for (int64_t j = 0; j < p; j++) Lmbv[j] = sqrtf(Phi * ve / vbv[j]);
       break;
     case M_BAYESRR:                                                   /* :841-843: ve first */
-      ve = (float)((double)(v_sqnorm(e, n) + Se) / orng_chisq(&g, (double)(n + df), GM, itx, ORNG_G_VE));
+      ve = (float)((double)(e_sqnorm(e, n) + Se) / orng_chisq(&g, (double)(n + df), GM, itx, ORNG_G_VE));
       vb = (float)((double)(v_sqnorm(b, p) + Sb) / orng_chisq(&g, (double)(p + df), GM, itx, ORNG_G_VB));
       Lmb = ve / vb;
       break;
     case M_BAYESC: case M_BAYESCPI:                                   /* :745-747, :903-905: vb first */
       vb = (float)((double)(v_sqnorm(b, p) + Sb) / orng_chisq(&g, (double)(model == M_BAYESC ? df + p : p + df), GM, itx, ORNG_G_VB));
-      ve = (float)((double)(v_sqnorm(e, n) + Se) / orng_chisq(&g, (double)(n + df), GM, itx, ORNG_G_VE));
+      ve = (float)((double)(e_sqnorm(e, n) + Se) / orng_chisq(&g, (double)(n + df), GM, itx, ORNG_G_VE));
       Lmb = ve / vb;
       break;
     }
@@ -363,7 +395,7 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
   if (o_PVAL) for (int64_t j = 0; j < p; j++) o_PVAL[j] = -1.0f * logf(1.0f - D[j]);   /* :912 */
   if (last_b) memcpy(last_b, b, sizeof(float) * p);
   if (last_d) memcpy(last_d, d, sizeof(float) * p);
-  if (last_e) memcpy(last_e, e, sizeof(float) * n);
+  if (last_e) for (int64_t k = 0; k < n; k++) last_e[k] = (float)e[k];
   if (last_vb) for (int64_t j = 0; j < p; j++) last_vb[j] = per_marker_vb ? vbv[j] : vb;
   if (last_scal) { last_scal[0] = mu; last_scal[1] = ve; last_scal[2] = vb; last_scal[3] = pi; }
   free(xx); free(vx); free(b); free(d); free(B); free(D); free(VBv); free(vbv); free(Lmbv); free(e); free(e1); free(e2);

@@ -1,0 +1,39 @@
+import os
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def tpod():
+    d = np.load(os.path.join(ROOT, "tests", "golden", "tpod.npz"))
+    return {"y": d["y"].astype(np.float64), "gen": np.asfortranarray(d["gen"]), "fam": d["fam"], "chr": d["chr"]}
+
+
+def scaled_err(a, b):
+    """max |a-b| / max |b|: the relative error of a vector against the scale of the reference vector.
+    (Element-wise relative error is meaningless for effects that pass through zero.)"""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    denom = max(float(np.max(np.abs(b))) if b.size else 0.0, 1e-300)
+    return float(np.max(np.abs(a - b))) / denom if b.size else 0.0
+
+
+def synth_small(n, p, seed, h2=0.5, causal=0.05):
+    """Small synthetic panel in the spirit of BASELINE.md section 3 (numpy, host)."""
+    rs = np.random.RandomState(seed)
+    f = rs.uniform(0.05, 0.5, p)
+    X = (rs.uniform(size=(n, p)) < f).astype(np.int8) + (rs.uniform(size=(n, p)) < f).astype(np.int8)
+    nc = max(1, int(p * causal))
+    idx = rs.choice(p, nc, replace=False)
+    g = X[:, idx].astype(np.float64) @ rs.normal(size=nc)
+    g = (g - g.mean()) / (g.std() + 1e-12)
+    y = g * np.sqrt(h2) + rs.normal(size=n) * np.sqrt(1 - h2)
+    return np.asfortranarray(X), y

@@ -1,0 +1,115 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerance: north_star asks for 1e-6 relative on effects / variance components with a fixed RNG seed.  Vectors are
+compared as max|gpu-oracle| / max|oracle| (TOL below); scalars as plain relative error.  The oracle flavour is "w"
+(double accumulators in the Eigen reductions), see oracle/bwgr_oracle.c header.
+"""
+import numpy as np
+import pytest
+
+from conftest import scaled_err, synth_small
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+ALL_MODELS = ["BayesA", "BayesB", "BayesC", "BayesL", "BayesRR", "BayesCpi", "BayesDpi"]
+
+
+def _rel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-300)
+
+
+def test_rng_contract_matches_oracle():
+    import bwgr_amd
+    from oracle import oracle as O
+    seed = 0x1234567887654321
+    for kind, purpose, nu in [("normal", 0, 0.0), ("normal", 1, 0.0), ("uniform", 2, 0.0), ("chisq", 3, 6.0),
+                              ("chisq", 3, 1.5), ("chisq", 17, 201.0), ("chisq", 3, 0.7)]:
+        dev = bwgr_amd.debug_variates(seed, kind, 5, 512, it=9, purpose=purpose, nu=nu)
+        ref = np.array([O.variate(seed, kind, 5 + i, 9, purpose, nu=nu) for i in range(512)])
+        assert np.max(np.abs(dev - ref) / np.maximum(np.abs(ref), 1e-300)) < 1e-12, (kind, purpose, nu)
+
+
+def test_panel_stats_tpod(tpod):
+    import bwgr_amd
+    from oracle import oracle as O
+    P = bwgr_amd.Panel(tpod["gen"])
+    xx, vx, msx = P.stats()
+    oxx, ovx, omsx = O.stats(tpod["gen"])
+    assert np.array_equal(xx, oxx)             # integer sums of squares: exact
+    assert scaled_err(vx, ovx) < 1e-7
+    assert _rel(msx, omsx) < 1e-7
+    P.close()
+
+
+@pytest.mark.parametrize("pi", [0.0, 0.3])
+@pytest.mark.parametrize("block,nwg", [(0, 0), (16, 1), (64, 1)])
+def test_kmup_sweep_tpod(tpod, pi, block, nwg):
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = tpod["gen"], tpod["y"]
+    n, p = X.shape
+    rs = np.random.RandomState(5)
+    xx = (X.astype(np.float64) ** 2).sum(0)
+    b = rs.normal(size=p) * 0.01
+    d = np.ones(p)
+    e = (y - y.mean() - X.astype(np.float64) @ b)
+    L = np.full(p, 120.0) * rs.uniform(0.5, 2.0, p)
+    Ve = 0.03
+    g = bwgr_amd.KMUP(X, b, d, xx, e, L, Ve, pi, seed=77, it=3, block=block, nwg=nwg)
+    o = O.kmup(X, b, d, xx, e, L, Ve, pi, seed=77, it=3)
+    assert scaled_err(g["b"], o["b"]) < TOL
+    assert scaled_err(g["e"], o["e"]) < TOL
+    assert np.array_equal(g["d"], o["d"])
+
+
+@pytest.mark.parametrize("model", ALL_MODELS)
+def test_short_chain_tpod(tpod, model):
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = tpod["gen"], tpod["y"]
+    P = bwgr_amd.Panel(X)
+    ch = bwgr_amd.Chain(P, model, y, it=20, bi=5, pi=0.9, df=5, R2=0.5, seed=11)
+    ch.run(20)
+    g = ch.result(); st = ch.state()
+    o = O.bayes(model, y, X, it=20, bi=5, pi=0.9, df=5, R2=0.5, seed=11)
+    assert scaled_err(g["b"], o["b"]) < TOL
+    assert scaled_err(g["hat"], o["hat"]) < TOL
+    assert _rel(g["ve"], o["ve"]) < TOL and _rel(g["mu"], o["mu"]) < TOL and _rel(g["h2"], o["h2"]) < 5 * TOL
+    assert scaled_err(np.atleast_1d(g["vb"]), np.atleast_1d(o["vb"])) < 5 * TOL
+    if "d" in o:
+        assert np.array_equal(g["d"], o["d"])
+    assert scaled_err(st["e"], o["last"]["e"]) < TOL
+    assert scaled_err(st["b"], o["last"]["b"]) < TOL
+    assert _rel(st["ve"], o["last"]["ve"]) < TOL
+    ch.close(); P.close()
+
+
+@pytest.mark.parametrize("model,nwg,block", [("BayesA", 2, 32), ("BayesB", 3, 64), ("BayesRR", 4, 128), ("BayesCpi", 2, 48)])
+def test_short_chain_multi_workgroup(model, nwg, block):
+    """Row slabs across several workgroups: exercises the in-kernel all-gather of slab partials."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = synth_small(700, 900, seed=3)
+    P = bwgr_amd.Panel(X, nwg=nwg, block=block)
+    assert P.nwg == nwg
+    ch = bwgr_amd.Chain(P, model, y, it=12, bi=3, pi=0.9, seed=5)
+    ch.run(12)
+    g = ch.result(); st = ch.state()
+    o = O.bayes(model, y, X, it=12, bi=3, pi=0.9, seed=5)
+    assert scaled_err(g["b"], o["b"]) < TOL
+    assert scaled_err(st["e"], o["last"]["e"]) < TOL
+    assert _rel(g["ve"], o["ve"]) < TOL
+    ch.close(); P.close()
+
+
+def test_float_panel_centered():
+    """Non-integer X (centred genotypes) goes through the fp32 panel path."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = synth_small(300, 200, seed=9)
+    Xc = (X - X.mean(0)).astype(np.float32)
+    g = bwgr_amd.BayesRR(y, Xc, it=10, bi=2, seed=4)
+    o = O.bayes("BayesRR", y, Xc, it=10, bi=2, seed=4)
+    assert scaled_err(g["b"], o["b"]) < TOL
+    assert scaled_err(g["hat"], o["hat"]) < TOL
