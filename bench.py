@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""bench.py -- MCMC iterations/second of the bWGR Gibbs hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c4|c3|c2]
+
+One "step" = one MCMC iteration of the fused sampler: the full marker sweep plus that model's intercept / variance
+draws and posterior sums (everything inside for(i...) of src/Rcpp20260726ai.cpp:666-688), with X, y and all chain
+state resident in HBM before the timed region.  The default workload is the configuration BASELINE.json's target is
+quoted on: synthetic n=10,000 x p=1,000,000 int8 genotypes, BayesB with 1 % of markers in the model (bWGR pi=0.99).
+It fits one GPU (10.2 GB of X), and for N > 1 the same panel is marker-sharded across ranks (strong scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and, at N=1, `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n, p, model, bWGR pi)
+    "c2": (5000, 50000, "BayesA", 0.0),
+    "c3": (10000, 500000, "BayesB", 0.99),
+    "c4": (10000, 1000000, "BayesB", 0.99),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(Xs_host, y_host, model, pi, p_total, budget_s=20.0):
+    """Times the oracle's float-faithful restatement (1 thread) on a column slice of the same panel and scales the
+    sweep time linearly in p (the sweep is O(n*p))."""
+    import numpy as np
+    from oracle import oracle as O
+    n, ps = Xs_host.shape
+    Xf = np.asfortranarray(Xs_host, dtype=np.float32)
+
+    def run(it):
+        t = time.perf_counter()
+        O.bayes(model, y_host, Xf, it=it, bi=0, pi=pi, seed=1, flavour="f", fast=True)
+        return time.perf_counter() - t
+
+    t1 = run(1)
+    t3 = run(3)
+    per_sweep = max((t3 - t1) / 2.0, 1e-9)
+    extra = int(max(0, min(40, (budget_s - t1 - t3) / per_sweep - 1)))
+    if extra >= 2:
+        tk = run(1 + extra)
+        per_sweep = (tk - t1) / extra
+    full_sweep = per_sweep * (p_total / ps)
+    return {"value": 1.0 / full_sweep, "unit": "iter/s", "cores": 1, "kind": "port",
+            "sample": "oracle float-faithful BayesX restatement (gcc -O3 -march=native, 1 thread, fp32 X) on the first %d "
+                      "of %d markers at n=%d, %.3f s per slice sweep, scaled linearly in p; host has %d cores"
+                      % (ps, p_total, n, per_sweep, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--nwg", type=int, default=0)
+    ap.add_argument("--sync-every", type=int, default=0, help="markers per rank between residual all-reduces (N>1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-slice", type=int, default=20000)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import bwgr_amd
+    from bwgr_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    n, p, model, pi = WORKLOADS[args.workload]
+    K, W = args.steps, args.warmup
+    if bwgr_amd.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: bwgr_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = local_rank
+
+    if world > 1:
+        from bwgr_amd import dist as bdist
+        out = bdist.bench_sharded(args, n, p, model, pi, K, W, rank, world, dev)
+        if rank == 0:
+            print(json.dumps(out))
+        return
+
+    # ---- single GPU ----
+    t_setup = time.perf_counter()
+    X = synth.genotypes(n, p, device=dev)
+    g = synth.phenotype(X, n)
+    y = synth.scale_phenotype(g)
+    Xs_host = None
+    if not args.no_cpu:
+        ps = min(args.cpu_slice, p)
+        Xs_host = X[:ps, :n].cpu().numpy().T   # (n, ps) view, column-major
+    P = bwgr_amd.Panel(X, n=n, device=dev, block=args.block, nwg=args.nwg)
+    del X
+    torch.cuda.empty_cache()
+    ch = bwgr_amd.Chain(P, model, y, it=W + K, bi=W, pi=pi, df=5, R2=0.5, seed=synth.SEED)
+    setup_s = time.perf_counter() - t_setup
+    ch.run(W)
+    ch.sync()
+    ch.sweep_ms()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ch.run(K)
+    ch.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    sweep_ms, launches = ch.sweep_ms()
+    st = ch.state()
+    elapsed = t1 - t0
+    alg_bytes = float(n) * float(p) * 1.0      # every genotype byte read once per sweep
+    achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+    out = {
+        "metric": "MCMC iter/sec (full marker sweep)", "value": K / elapsed, "unit": "iter/s", "n_gpus": 1,
+        "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32 scalars, f64 residual/accumulation, int8 genotypes", "data": "synthetic",
+        "config": {"workload": "%s: synthetic n=%d x p=%d int8, %s%s, exact chain (blocked sweep, block=%d, %d slab "
+                               "workgroups x %d rows)" % (args.workload, n, p, model,
+                                                          " pi=%.2f (1%% in model)" % pi if pi else "", P.block, P.nwg, P.slab_rows),
+                   "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": 1},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_sweep<int8>",
+                     "kernel_ms": sweep_ms, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes},
+        "setup_s": setup_s,
+        "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d": float(st["d"].mean())},
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(Xs_host, y.cpu().numpy(), model, pi, p)
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    ch.close(); P.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,13 @@ struct ChainScalars {
   uint32_t pad;
 };
 
+// per-marker constants of one sweep, produced chip-wide by k_prestage before the sweep kernel starts (they depend on
+// the previous iteration's b and lambda and on the RNG counters only, never on the residual)
+struct StageBuf;
+struct PreStage {
+  StageBuf *blocks;   // one StageBuf per marker block, filled by k_prestage
+};
+
 struct SweepArgs {
   const void *X; int64_t ld;    // column-major, ld = K*R rows (zero padded)
   const void *gram;             // [nblocks][m][m]
@@ -64,20 +71,22 @@ struct SweepArgs {
   ChainScalars *sc;
   uint32_t iter;
   Rng rng;
+  PreStage ps;
   double *xpart;                // [2][K][SW_MAXM]
   uint32_t *xflags;             // [K*SW_FLAG_STRIDE] epochs, then the abort word
+  unsigned long long *stamps;   // diagnostic build only (-DBWGR_STAMPS): per-phase cycle sums of workgroup 0
 };
 
 template <typename XT> struct XTraits;
-template <> struct XTraits<int8_t> { using GT = int32_t; static constexpr int PER16 = 16; };
-template <> struct XTraits<float> { using GT = double; static constexpr int PER16 = 4; };
+template <> struct XTraits<int8_t> { using GT = int32_t; static constexpr int PER16 = 16; static constexpr int MAXM = 128; };
+template <> struct XTraits<float> { using GT = double; static constexpr int PER16 = 4; static constexpr int MAXM = 64; };
 
 // padded LDS row length (elements) so that consecutive markers start on odd multiples of 16 B
 template <typename XT> __host__ __device__ inline int tile_rp(int R) { return R + XTraits<XT>::PER16; }
 
 struct StageBuf {               // per-block per-marker constants, lane = marker
-  float b0[SW_MAXM], xxb0[SW_MAXM], den[SW_MAXM], b2[SW_MAXM];
-  double sdz1[SW_MAXM], u[SW_MAXM], chi[SW_MAXM];
+  float b0[SW_MAXM], xxb0[SW_MAXM], b2[SW_MAXM], drej[SW_MAXM];
+  double rden[SW_MAXM], sdz1[SW_MAXM], u[SW_MAXM], chi[SW_MAXM];
 };
 
 template <typename XT> __host__ __device__ inline size_t sweep_lds_bytes(int m, int R) {
@@ -89,7 +98,7 @@ template <typename XT> __host__ __device__ inline size_t sweep_lds_bytes(int m, 
   s += (size_t)R * sizeof(double);                             // e slab
   s += 2 * sizeof(StageBuf);
   s += (size_t)(SW_THREADS / 64) * SW_MAXM * sizeof(double);   // row-group partials (up to 8 groups)
-  s += SW_MAXM * sizeof(double);                               // r0
+  s += 3 * SW_MAXM * sizeof(double);                           // r0, speculative correction s, Gram diagonal
   s += 3 * SW_MAXM * sizeof(float);                            // delta, bnew, dnew
   s += 64;                                                     // control words
   return s;
@@ -113,43 +122,134 @@ __device__ __forceinline__ double ld_agent_f64(const double *p) {
                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-// cooperative copy of one block's slab tile X[rows of wg, markers j0..j0+mB) into LDS
+// cooperative copy of one block's slab tile X[rows of wg, markers j0..j0+mB) into LDS; loads are issued in
+// batches of 8 per thread before any is stored, so a thread pays one HBM latency per batch, not per chunk
 template <typename XT>
 __device__ inline void load_tile(XT *tile, const XT *X, int64_t ld, int row0, int R, int Rp, int j0, int mB,
                                  int tid0, int nthreads) {
   constexpr int PER = XTraits<XT>::PER16;
+  constexpr int BATCH = 8;
   const int cpr = R / PER;  // 16-byte chunks per marker
   const int total = mB * cpr;
-  for (int c = tid0; c < total; c += nthreads) {
-    const int jj = c / cpr, ii = c - jj * cpr;
-    const uint4 v = *reinterpret_cast<const uint4 *>(X + (int64_t)(j0 + jj) * ld + row0 + ii * PER);
-    *reinterpret_cast<uint4 *>(tile + (size_t)jj * Rp + ii * PER) = v;
+  for (int cb = tid0; cb < total; cb += BATCH * nthreads) {
+    uint4 v[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int c = cb + u * nthreads;
+      if (c < total) {
+        const int jj = c / cpr, ii = c - jj * cpr;
+        v[u] = *reinterpret_cast<const uint4 *>(X + (int64_t)(j0 + jj) * ld + row0 + ii * PER);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int c = cb + u * nthreads;
+      if (c < total) {
+        const int jj = c / cpr, ii = c - jj * cpr;
+        *reinterpret_cast<uint4 *>(tile + (size_t)jj * Rp + ii * PER) = v[u];
+      }
+    }
   }
 }
 
-// per-marker constants of one block (thread = marker)
-__device__ inline void stage_marker(StageBuf &st, int t, int j, const SweepArgs &a, float ve, float lam_common,
-                                    float dfp1) {
-  const float b0 = a.b[j];
-  const float xxj = a.xx[j];
-  const float lamj = (a.flags & SWF_LAM_VEC) ? a.lam[j] : lam_common;
-  const float den = xxj + lamj;
-  const float sd = sqrtf(ve / den);
-  const uint32_t mk = (uint32_t)j;
-  st.b0[t] = b0;
-  st.xxb0[t] = xxj * b0;
-  st.den[t] = den;
-  st.sdz1[t] = (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z1, 0);
-  const bool need_b2 = (a.flags & SWF_SELECT) != 0;
-  st.b2[t] = need_b2 ? (float)((double)0.0f + (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z2, 0)) : 0.0f;
-  st.u[t] = need_b2 ? rng_uniform(a.rng, mk, a.iter, RNG_U, 0) : 0.0;
-  st.chi[t] = (a.flags & SWF_VB_VEC) ? rng_chisq(a.rng, (double)dfp1, mk, a.iter, RNG_CHI) : 1.0;
+// k_prestage: one thread per (marker, piece); piece 0: in-model normal, 1: alternative normal, 2: Bernoulli uniform,
+// 3: chi-square.  Restates the per-marker scalar set-up of src/Rcpp20260726ai.cpp:20-21 / :615-617 / :670-680.
+__global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
+  const ChainScalars &sc = *a.sc;
+  const float ve = sc.ve, lam_common = sc.lam, dfp1 = sc.dfp1;
+  const int64_t nm = j_end - j_begin;
+  for (int64_t task = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; task < 4 * nm; task += (int64_t)gridDim.x * blockDim.x) {
+    const int piece = (int)(task / nm);
+    const int j = j_begin + (int)(task - (int64_t)piece * nm);
+    StageBuf &st = a.ps.blocks[j / a.m];
+    const int t = j % a.m;
+    const float b0 = a.b[j];
+    const float xxj = a.xx[j];
+    const float lamj = (a.flags & SWF_LAM_VEC) ? a.lam[j] : lam_common;
+    const float den = xxj + lamj;
+    const float sd = sqrtf(ve / den);
+    const uint32_t mk = (uint32_t)j;
+    const bool sel = (a.flags & SWF_SELECT) != 0;
+    if (piece == 0) {
+      st.b0[t] = b0;
+      st.xxb0[t] = xxj * b0;
+      st.rden[t] = 1.0 / (double)den;   // (float)(a * rden) equals the float quotient a/den except ~1e-8 of the time
+      st.sdz1[t] = (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z1, 0);
+    } else if (piece == 1) {
+      const float b2 = sel ? (float)((double)0.0f + (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z2, 0)) : 0.0f;
+      st.b2[t] = b2;
+      st.drej[t] = sel ? (b2 - b0) : 0.0f;   // the step a marker takes when it is NOT included
+    } else if (piece == 2) {
+      st.u[t] = sel ? rng_uniform(a.rng, mk, a.iter, RNG_U, 0) : 0.0;
+    } else {
+      st.chi[t] = (a.flags & SWF_VB_VEC) ? rng_chisq(a.rng, (double)dfp1, mk, a.iter, RNG_CHI) : 1.0;
+    }
+  }
+}
+// block constants global -> LDS: one StageBuf is sizeof(StageBuf)/16 chunks, at most one per thread
+__device__ inline void stage_block(StageBuf &st, int blk, const SweepArgs &a, int tid0, int nthreads) {
+  constexpr int NCH = (int)(sizeof(StageBuf) / 16);
+  static_assert(sizeof(StageBuf) % 16 == 0, "StageBuf must be a multiple of 16 bytes");
+  const uint4 *src = reinterpret_cast<const uint4 *>(a.ps.blocks + blk);
+  uint4 *dst = reinterpret_cast<uint4 *>(&st);
+  for (int c = tid0; c < NCH; c += nthreads) dst[c] = src[c];
 }
 
-template <typename XT>
+#ifdef BWGR_STAMPS
+#define STAMP(k) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+// Gram block -> LDS, keeping only entries (row, col > row): row = a finalized marker, col = a later marker it
+// corrects.  A lane's r therefore stops changing once its own marker is final.  The diagonal goes to gdiag_s.
+template <typename GT>
+__device__ __forceinline__ void put_gram4(GT *gram_s, double *gdiag_s, int m, int e0, const GT v[4]) {
+  const int row = (int)(((float)e0 + 0.5f) * (1.0f / (float)m)), col0 = e0 - row * m;   // exact for e0 < 2^14
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = col0 + c;
+    gram_s[e0 + c] = (col > row) ? v[c] : (GT)0;
+    if (col == row) gdiag_s[row] = (double)v[c];
+  }
+}
+
+// what marker t does given its current r: the in-model draw b1 and (SELECT) the inclusion decision
+struct LaneConst {
+  float b0, xxb0, b2, drej;
+  double rden, sdz1, u, gjj;
+};
+__device__ __forceinline__ float lane_b1(double r, const LaneConst &c) {
+  const float a = (float)r + c.xxb0;
+  const float mean = (float)((double)a * c.rden);
+  return (float)((double)mean + c.sdz1);
+}
+__device__ __forceinline__ bool lane_accept(double r, float b1, const LaneConst &c, int flags, float Cc, float odds,
+                                            float one_minus_pi) {
+  const float d1f = b1 - c.b0;
+  const float d2f = (flags & SWF_ALT_B2) ? (c.b2 - c.b0) : (0.0f - c.b0);
+  const double D1 = (double)d1f, D2 = (double)d2f;
+  const double diffd = 2.0 * r * (D1 - D2) + c.gjj * (D2 * D2 - D1 * D1);   // |e2|^2 - |e1|^2, e_k = e - x d_k
+  float pj;
+  if (flags & SWF_MH) {
+    const float diff = (float)(-diffd);
+    pj = one_minus_pi * expf(Cc * diff);
+    if (pj > 1.0f) pj = 1.0f;
+  } else {
+    const float diff = (float)diffd;
+    const float LR = odds * expf(Cc * diff);
+    pj = 1.0f / (1.0f + LR);
+  }
+  return c.u < (double)pj;
+}
+
+template <typename XT, bool SELECT>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
   using GT = typename XTraits<XT>::GT;
   constexpr int PER = XTraits<XT>::PER16;
+  constexpr int GPT = 16 / sizeof(GT);            // Gram entries per 16-byte chunk
+  constexpr int MAXMX = XTraits<XT>::MAXM;
+  constexpr int GCH = (MAXMX * MAXMX / GPT + (SW_THREADS - 64) - 1) / (SW_THREADS - 64);  // chunks per prefetch thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wg = blockIdx.x;
@@ -168,6 +268,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
   StageBuf *stage = reinterpret_cast<StageBuf *>(smem + off); off += 2 * sizeof(StageBuf);
   double *part_s = reinterpret_cast<double *>(smem + off); off += (size_t)(SW_THREADS / 64) * SW_MAXM * sizeof(double);
   double *r0_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
+  double *spec_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
+  double *gdiag_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
   float *delta_s = reinterpret_cast<float *>(smem + off); off += SW_MAXM * sizeof(float);
   float *bnew_s = reinterpret_cast<float *>(smem + off); off += SW_MAXM * sizeof(float);
   float *dnew_s = reinterpret_cast<float *>(smem + off); off += SW_MAXM * sizeof(float);
@@ -177,27 +279,58 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
   const GT *gram = reinterpret_cast<const GT *>(a.gram);
 
   // scalars of this iteration
-  const float ve = a.sc->ve, lam_common = a.sc->lam, Cc = a.sc->C, odds = a.sc->odds;
-  const float one_minus_pi = 1.0f - a.sc->pi, Sb = a.sc->Sb, dfp1 = a.sc->dfp1;
+  const float Cc = a.sc->C, odds = a.sc->odds;
+  const float one_minus_pi = 1.0f - a.sc->pi, Sb = a.sc->Sb;
 
   const int nb = a.blk_end - a.blk_begin;
   const int mpad = (m <= 64) ? 64 : 128;
   const int ngroups = SW_THREADS / mpad;     // row groups of the dot phase
   const int rows_per_group = R / ngroups;    // R is a multiple of 128, so a multiple of 16
+  const int gchunks = m * m / GPT;           // 16-byte chunks of one Gram block
 
   for (int i = tid; i < R; i += SW_THREADS) e_s[i] = a.e[row0 + i];
   if (tid == 0) ctrl_s[0] = 1;
+
+  // speculative correction of a block: spec[j] = sum_{k<j} G_kj * drej_k  (SELECT only; 4 k-ranges per marker)
+  auto spec_matvec = [&](const StageBuf &stn, int mBn) {
+    if (SELECT) {
+      const int part = tid >> 7, j = tid & 127;
+      if (j < mBn) {
+        double acc = 0.0;
+        const int k0 = part * 32, k1 = min(k0 + 32, min(j, mBn));
+        for (int k = k0; k < k1; ++k) acc = fma((double)gram_s[(size_t)k * m + j], (double)stn.drej[k], acc);
+        part_s[part * SW_MAXM + j] = acc;
+      }
+      __syncthreads();
+      if (tid < mBn) spec_s[tid] = (part_s[tid] + part_s[SW_MAXM + tid]) + (part_s[2 * SW_MAXM + tid] + part_s[3 * SW_MAXM + tid]);
+    }
+  };
 
   // prologue: tile, constants and Gram block of the first block
   {
     const int j0 = a.blk_begin * m;
     const int mB = min(m, a.p - j0);
     load_tile<XT>(tile0, X, a.ld, row0, R, Rp, j0, mB, tid, SW_THREADS);
-    if (tid < mB) stage_marker(stage[0], tid, j0 + tid, a, ve, lam_common, dfp1);
+    stage_block(stage[0], a.blk_begin, a, tid, SW_THREADS);
     const GT *gsrc = gram + (size_t)a.blk_begin * m * m;
-    for (int c = tid; c < m * m; c += SW_THREADS) gram_s[c] = gsrc[c];
+    for (int c = tid; c < gchunks; c += SW_THREADS) {
+      GT v[GPT];
+      *reinterpret_cast<uint4 *>(v) = *reinterpret_cast<const uint4 *>(gsrc + (size_t)c * GPT);
+      if constexpr (GPT == 4) put_gram4<GT>(gram_s, gdiag_s, m, c * 4, v);
+      else {
+        const int e0 = c * 2, row = e0 / m, col = e0 - row * m;
+        gram_s[e0] = (col > row) ? v[0] : (GT)0; gram_s[e0 + 1] = (col + 1 > row) ? v[1] : (GT)0;
+        if (col == row) gdiag_s[row] = (double)v[0];
+        if (col + 1 == row) gdiag_s[row] = (double)v[1];
+      }
+    }
+    __syncthreads();
+    spec_matvec(stage[0], mB);
   }
   double sum_d = 0.0, sum_b2 = 0.0;  // meaningful in wave 0 only
+#ifdef BWGR_STAMPS
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int s = 0; s < nb; ++s) {
     const int blk = a.blk_begin + s;
@@ -207,7 +340,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
     XT *tile = buf ? tile1 : tile0;
     XT *tile_next = buf ? tile0 : tile1;
     StageBuf &st = stage[buf];
-    __syncthreads();  // tile, stage[buf], gram_s, e_s of this block are in place
+    __syncthreads();  // tile, stage[buf], gram_s, spec_s, e_s of this block are in place
+    STAMP(0);
 
     // ---- slab partial dots: lane = marker, row groups across the workgroup ----
     {
@@ -249,6 +383,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
       }
     }
     __syncthreads();
+    STAMP(1);
 
     // ---- combine row groups, all-gather the K slab partials ----
     double mine = 0.0;
@@ -281,7 +416,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
             if (lane == 0) __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(1);
         }
         if (lane == 0) ctrl_s[0] = ok;
       }
@@ -290,90 +425,119 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
         if (tid == 0) a.sc->error = 1u;
         return;
       }
-      if (tid < mB) {
+      if (tid < mB) {   // fixed summation order w = 0..K-1; loads issued 8 at a time
         double r = 0.0;
-        for (int w = 0; w < K; ++w) r += ld_agent_f64(slot + (size_t)w * SW_MAXM + tid);
+        for (int w0 = 0; w0 < K; w0 += 8) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = (w0 + u < K) ? ld_agent_f64(slot + (size_t)(w0 + u) * SW_MAXM + tid) : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) r += v[u];
+        }
         r0_s[tid] = r;
       }
     } else {
       if (tid < mB) r0_s[tid] = mine;
     }
     __syncthreads();
+    STAMP(2);
 
     // ---- wave 0: the in-block recurrence; waves 1..7: stream in the next block ----
+    GT gpre[GCH][GPT];   // next Gram block in flight (prefetch waves)
+    const bool have_next = (s + 1 < nb);
     if (wave == 0) {
       const int ngrp = (mB + 63) >> 6;
       double r[2];
-      r[0] = (lane < mB) ? r0_s[lane] : 0.0;
-      r[1] = (64 + lane < mB) ? r0_s[64 + lane] : 0.0;
+      LaneConst lc[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = 64 * q + lane;
+        const bool live = t < mB;
+        r[q] = live ? (SELECT ? (r0_s[t] - spec_s[t]) : r0_s[t]) : 0.0;
+        lc[q].b0 = live ? st.b0[t] : 0.0f; lc[q].xxb0 = live ? st.xxb0[t] : 0.0f;
+        lc[q].b2 = live ? st.b2[t] : 0.0f; lc[q].drej = live ? st.drej[t] : 0.0f;
+        lc[q].rden = live ? st.rden[t] : 1.0; lc[q].sdz1 = live ? st.sdz1[t] : 0.0;
+        lc[q].u = live ? st.u[t] : 2.0; lc[q].gjj = live ? gdiag_s[t] : 0.0;
+      }
+      unsigned long long accmask[2] = {0ull, 0ull};
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         if (q < ngrp) {
           const int base = 64 * q;
-          const int t = base + lane;
-          const bool live = t < mB;
-          const float c_b0 = live ? st.b0[t] : 0.0f, c_xxb0 = live ? st.xxb0[t] : 0.0f;
-          const float c_den = live ? st.den[t] : 1.0f, c_b2 = live ? st.b2[t] : 0.0f;
-          const double c_sdz1 = live ? st.sdz1[t] : 0.0, c_u = live ? st.u[t] : 0.0;
-          const double c_gjj = live ? (double)gram_s[(size_t)t * m + t] : 0.0;
-          float o_b = 0.0f, o_d = 0.0f, o_delta = 0.0f;
           const int cnt = min(64, mB - base);
-          for (int l = 0; l < cnt; ++l) {
-            const double rj = readlane_f64(r[q], l);
-            const float b0 = readlane_f32(c_b0, l);
-            const float xxb0 = readlane_f32(c_xxb0, l);
-            const float den = readlane_f32(c_den, l);
-            const double sdz1 = readlane_f64(c_sdz1, l);
-            const float mean = ((float)rj + xxb0) / den;
-            const float b1 = (float)((double)mean + sdz1);
-            float bn = b1, dn = 1.0f;
-            if (a.flags & SWF_SELECT) {
-              const float b2 = readlane_f32(c_b2, l);
-              const double u = readlane_f64(c_u, l);
-              const double gjj = readlane_f64(c_gjj, l);
-              const float d1f = b1 - b0;
-              const float d2f = (a.flags & SWF_ALT_B2) ? (b2 - b0) : (0.0f - b0);
-              const double D1 = (double)d1f, D2 = (double)d2f;
-              // |e2|^2 - |e1|^2 with e_k = e - x d_k
-              const double diffd = 2.0 * rj * (D1 - D2) + gjj * (D2 * D2 - D1 * D1);
-              float pj;
-              if (a.flags & SWF_MH) {
-                const float diff = (float)(-diffd);
-                pj = one_minus_pi * expf(Cc * diff);
-                if (pj > 1.0f) pj = 1.0f;
-              } else {
-                const float diff = (float)diffd;
-                const float LR = odds * expf(Cc * diff);
-                pj = 1.0f / (1.0f + LR);
+          if (!SELECT) {
+            // every marker takes its in-model draw: finalize lanes in order, one broadcast per marker
+            GT gnext0 = gram_s[(size_t)base * m + base + lane];
+            GT gnext1 = (q == 0 && ngrp > 1) ? gram_s[(size_t)base * m + 64 + lane] : (GT)0;
+            for (int l = 0; l < cnt; ++l) {
+              const GT g0 = gnext0, g1 = gnext1;
+              if (l + 1 < cnt) {   // Gram row of the next marker: independent of the recurrence, fetch early
+                gnext0 = gram_s[(size_t)(base + l + 1) * m + base + lane];
+                if (q == 0 && ngrp > 1) gnext1 = gram_s[(size_t)(base + l + 1) * m + 64 + lane];
               }
-              const bool acc = u < (double)pj;
-              bn = acc ? b1 : b2;
-              dn = acc ? 1.0f : 0.0f;
+              const float b1 = lane_b1(r[q], lc[q]);
+              const float dl = b1 - lc[q].b0;
+              const double dd = (double)readlane_f32(dl, l);
+              r[q] = fma(-(double)g0, dd, r[q]);
+              if (q == 0 && ngrp > 1) r[1] = fma(-(double)g1, dd, r[1]);
             }
-            const float delta = bn - b0;
-            const double dd = (double)delta;
-            const GT *grow = gram_s + (size_t)(base + l) * m;
-            if (q == 0) {
-              r[0] = fma(-(double)grow[lane], dd, r[0]);
-              if (ngrp > 1) r[1] = fma(-(double)((64 + lane < m) ? grow[64 + lane] : (GT)0), dd, r[1]);
-            } else {
-              r[1] = fma(-(double)((64 + lane < m) ? grow[64 + lane] : (GT)0), dd, r[1]);
+          } else {
+            // speculative rounds: lanes >= front decide as if every earlier unfinalized marker is rejected
+            // (their step drej is already inside r); the first accepted lane is fixed up, the rest re-decide.
+            int front = 0;
+            while (front < cnt) {
+              const float b1 = lane_b1(r[q], lc[q]);
+              const bool acc = lane_accept(r[q], b1, lc[q], a.flags, Cc, odds, one_minus_pi);
+              const unsigned long long bal = __ballot(acc && lane >= front && lane < cnt);
+              if (bal == 0ull) break;
+              const int js = __ffsll((long long)bal) - 1;
+              const float corr_f1 = b1 - lc[q].b0;          // the accepted step
+              const double corr = (double)readlane_f32(corr_f1, js) - (double)readlane_f32(lc[q].drej, js);
+              const GT *grow = gram_s + (size_t)(base + js) * m;
+              r[q] = fma(-(double)grow[base + lane], corr, r[q]);
+              if (q == 0 && ngrp > 1) r[1] = fma(-(double)grow[64 + lane], corr, r[1]);
+              accmask[q] |= (1ull << js);
+              front = js + 1;
             }
-            if (lane == l) { o_b = bn; o_d = dn; o_delta = delta; }
-            sum_d += (double)dn;
-            sum_b2 = fma((double)bn, (double)bn, sum_b2);
           }
-          if (live) { delta_s[t] = o_delta; bnew_s[t] = o_b; dnew_s[t] = o_d; }
         }
       }
-    } else if (s + 1 < nb) {
-      const int j1 = j0 + m;
-      const int mB1 = min(m, a.p - j1);
-      load_tile<XT>(tile_next, X, a.ld, row0, R, Rp, j1, mB1, tid - 64, SW_THREADS - 64);
-      const int t = tid - 64;
-      if (t < mB1) stage_marker(stage[buf ^ 1], t, j1 + t, a, ve, lam_common, dfp1);
+      // every lane's r is now final for its own marker: produce the outputs in parallel
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = 64 * q + lane;
+        if (t < mB) {
+          const float b1 = lane_b1(r[q], lc[q]);
+          const bool inc = SELECT ? (((accmask[q] >> lane) & 1ull) != 0ull) : true;
+          const float bn = inc ? b1 : lc[q].b2;
+          const float dn = inc ? 1.0f : 0.0f;
+          delta_s[t] = bn - lc[q].b0; bnew_s[t] = bn; dnew_s[t] = dn;
+          sum_d += (double)dn;
+          sum_b2 = fma((double)bn, (double)bn, sum_b2);
+        }
+      }
+      STAMP(6);
+    } else {
+      if (have_next) {
+        const int j1 = j0 + m;
+        const int mB1 = min(m, a.p - j1);
+        const GT *gsrc = gram + (size_t)(blk + 1) * m * m;
+#pragma unroll
+        for (int k = 0; k < GCH; ++k) {
+          const int c = (tid - 64) + k * (SW_THREADS - 64);
+          if (c < gchunks) *reinterpret_cast<uint4 *>(gpre[k]) = *reinterpret_cast<const uint4 *>(gsrc + (size_t)c * GPT);
+        }
+        // constants of the next block: load issued before the tile's loads are consumed (one latency, not two)
+        constexpr int NCH = (int)(sizeof(StageBuf) / 16);
+        static_assert(NCH <= SW_THREADS - 64, "one StageBuf chunk per prefetch thread");
+        uint4 spre = make_uint4(0, 0, 0, 0);
+        if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 1)[tid - 64];
+        load_tile<XT>(tile_next, X, a.ld, row0, R, Rp, j1, mB1, tid - 64, SW_THREADS - 64);
+        if (tid - 64 < NCH) reinterpret_cast<uint4 *>(&stage[buf ^ 1])[tid - 64] = spre;
+      }
     }
     __syncthreads();
+    STAMP(3);
 
     // ---- outputs of the block (workgroup 0 is the only writer of marker state) ----
     if (wg == 0 && tid < mB) {
@@ -382,25 +546,67 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
       a.d[j0 + tid] = dnew_s[tid];
       if (a.flags & SWF_VB_VEC) a.vb[j0 + tid] = (float)((double)(Sb + bn * bn) / st.chi[tid]);
     }
-    // ---- slab update e_i <- e_i - x_ij * delta_j, j ascending (x*delta is exact in fp64) ----
-    for (int i = tid; i < R; i += SW_THREADS) {
-      double ev = e_s[i];
-      const XT *tp = tile + i;
-      for (int jj = 0; jj < mB; ++jj) {
-        const double xv = (double)tp[(size_t)jj * Rp];
-        ev = fma(-xv, (double)delta_s[jj], ev);
+    // ---- next Gram block into LDS (the recurrence no longer reads gram_s) ----
+    if (wave != 0 && have_next) {
+#pragma unroll
+      for (int k = 0; k < GCH; ++k) {
+        const int c = (tid - 64) + k * (SW_THREADS - 64);
+        if (c < gchunks) {
+          if constexpr (GPT == 4) put_gram4<GT>(gram_s, gdiag_s, m, c * 4, gpre[k]);
+          else {
+            const int e0 = c * 2, row = e0 / m, col = e0 - row * m;
+            gram_s[e0] = (col > row) ? gpre[k][0] : (GT)0; gram_s[e0 + 1] = (col + 1 > row) ? gpre[k][1] : (GT)0;
+            if (col == row) gdiag_s[row] = (double)gpre[k][0];
+            if (col + 1 == row) gdiag_s[row] = (double)gpre[k][1];
+          }
+        }
       }
-      e_s[i] = ev;
     }
-    // ---- Gram block of the next block (gram_s is free once the recurrence has finished) ----
-    if (s + 1 < nb) {
-      const GT *gsrc = gram + (size_t)(blk + 1) * m * m;
-      for (int c = tid; c < m * m; c += SW_THREADS) gram_s[c] = gsrc[c];
+    // ---- slab update e_i -= sum_j x_ij delta_j: rows x marker parts across the workgroup (fp64, x*delta exact) ----
+    {
+      const int nparts = (R >= SW_THREADS) ? 1 : SW_THREADS / R;        // R in {128, 256, 512, ...}
+      const int per = (mB + nparts - 1) / nparts;
+      for (int i0 = 0; i0 < R; i0 += SW_THREADS) {
+        const int i = i0 + (tid % R), part = (R >= SW_THREADS) ? 0 : tid / R;
+        double acc = 0.0;
+        if (i < R) {
+          const int ja = part * per, jb = min(mB, ja + per);
+          const XT *tp = tile + i;
+          int jj = ja;
+          for (; jj + 8 <= jb; jj += 8) {
+            double xv[8]; float dv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xv[u] = (double)tp[(size_t)(jj + u) * Rp]; dv[u] = delta_s[jj + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fma(xv[u], (double)dv[u], acc);
+          }
+          for (; jj < jb; ++jj) acc = fma((double)tp[(size_t)jj * Rp], (double)delta_s[jj], acc);
+        }
+        if (nparts == 1) { if (i < R) e_s[i] -= acc; }
+        else {
+          part_s[part * R + i] = acc;     // nparts*R == SW_THREADS doubles <= part_s capacity (1024)
+          __syncthreads();
+          if (tid < R) { double t = 0.0; for (int q = 0; q < nparts; ++q) t += part_s[q * R + tid]; e_s[tid] -= t; }
+        }
+      }
     }
+    STAMP(4);
+    if (have_next) {
+      __syncthreads();   // gram_s, gdiag_s, stage[buf^1] complete; part_s free
+      spec_matvec(stage[buf ^ 1], min(m, a.p - (j0 + m)));
+    }
+    STAMP(5);
   }
   __syncthreads();
   for (int i = tid; i < R; i += SW_THREADS) a.e[row0 + i] = e_s[i];
-  if (wg == 0 && tid == 0) { a.sc->sum_d += sum_d; a.sc->sum_b2 += sum_b2; }
+  if (wg == 0 && wave == 0) {   // per-lane partial sums of wave 0 -> chain scalars
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum_d += __shfl_down(sum_d, o, 64); sum_b2 += __shfl_down(sum_b2, o, 64); }
+    if (lane == 0) { a.sc->sum_d += sum_d; a.sc->sum_b2 += sum_b2; }
+  }
+#ifdef BWGR_STAMPS
+  if (wg == 0 && tid == 0 && a.stamps) for (int k = 0; k < 8; ++k) a.stamps[k] += ph[k];
+#endif
 }
 
 }  // namespace bwgr

@@ -122,9 +122,11 @@ int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, int
 
 /* ---- synthetic panels ----------------------------------------------------------
  * X_ij ~ Binomial(2, f_j), f_j ~ U(0.05,0.5), int8 column-major written to device memory Xdev
- * (ldx >= n); freq (p floats, device, may be NULL) receives f_j. */
-int bwgr_synth_genotypes(void *Xdev, int64_t n, int64_t p, int64_t ldx, uint64_t seed, float *freq_dev, int device,
-                         void *hip_stream);
+ * (ldx >= n); freq (p floats, device, may be NULL) receives f_j.  The p columns written are columns
+ * col0 .. col0+p-1 of the (conceptually unbounded) panel of this seed, so marker shards of one panel can be
+ * generated independently on different GPUs. */
+int bwgr_synth_genotypes(void *Xdev, int64_t n, int64_t p, int64_t ldx, int64_t col0, uint64_t seed, float *freq_dev,
+                         int device, void *hip_stream);
 
 /* ---- test hooks -----------------------------------------------------------------------------------
  * variates of the RNG contract computed on the device: kind 0 normal, 1 uniform, 2 chisq(nu);
