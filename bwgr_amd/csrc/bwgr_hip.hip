@@ -336,6 +336,153 @@ __global__ void k_hat_finish(const double *part, int64_t ld, int nchunks, int n,
   hat[i] = f + MU;
 }
 
+
+// ---- wgr(): R-side (double) steps around the KMUP sweep, R/wgr.R:41-168 --------------------------------------------
+struct WgrScalars {
+  double mu, Ve, Va, Sb, Se, MSx, vy, bb, B0, VE, VA, sumD, cxx;
+};
+// per-column double statistics as R computes them: xx = crossprod, var = sum((x-mean)^2)/(n-1); one wave per column
+template <typename XT>
+__global__ void k_stats64(const XT *X, int64_t ld, int n, int p, double *xx, double *vx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j >= p) return;
+  const XT *xj = X + j * ld;
+  double s1 = 0, s2 = 0;
+  for (int i = lane; i < n; i += 64) { const double v = (double)xval(xj, i); s1 += v; s2 = fma(v, v, s2); }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  s1 = __shfl(s1, 0, 64); s2 = __shfl(s2, 0, 64);
+  const double mean = s1 / (double)n;
+  double sv = 0;
+  for (int i = lane; i < n; i += 64) { const double dev = (double)xval(xj, i) - mean; sv = fma(dev, dev, sv); }
+  sv = wave_sum(sv);
+  if (lane == 0) { xx[j] = s2; vx[j] = sv / (double)(n - 1); }
+}
+__global__ void k_dsum_stage1(const double *v, int64_t n, double *part, int square) {
+  __shared__ double red[17];
+  double s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += square ? v[i] * v[i] : v[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// setup: mu = mean(y), e = y - mu, vy = var(y), MSx, priors (R/wgr.R:49-59); part = 256 partial sums of column variances,
+// part2 = 256 partial sums of xx
+__global__ void k_wgr_init(const double *y, double *eR, int n, int64_t ld, const double *part, const double *part2, int p,
+                           double df, double R2, WgrScalars *ws) {
+  __shared__ double red[17];
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += y[i];
+  s = block_sum(s, red);
+  const double mu = s / (double)n;
+  double sv = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { const double dev = y[i] - mu; sv += dev * dev; }
+  sv = block_sum(sv, red);
+  double ms = 0, sx = 0;
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) { ms += part[i]; sx += part2[i]; }
+  ms = block_sum(ms, red);
+  sx = block_sum(sx, red);
+  for (int64_t i = threadIdx.x; i < ld; i += blockDim.x) eR[i] = (i < n) ? (y[i] - mu) : 0.0;
+  if (threadIdx.x == 0) {
+    WgrScalars w; memset(&w, 0, sizeof(w));
+    w.mu = mu; w.vy = sv / (double)(n - 1); w.MSx = ms; w.Ve = 1.0; w.Va = ms;
+    w.Sb = (R2) * df * w.vy / ms; w.Se = (1 - R2) * df * w.vy; w.cxx = sx / (double)p;
+    *ws = w;
+  }
+}
+__global__ void k_wgr_marker_init(double *bR, double *dR, double *VbR, double *LR, double *B, double *D, double *VB, int p, const WgrScalars *ws) {
+  const double Va = ws->Va, Ve = ws->Ve;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < p; j += gridDim.x * blockDim.x) {
+    bR[j] = 0; dR[j] = 1; VbR[j] = Va; LR[j] = Va / Ve; B[j] = 0; D[j] = 0; VB[j] = 0;   // L = Vb/Ve (sic), R/wgr.R:55
+  }
+}
+// narrowing at the .Call boundary (src/RcppExports.cpp:20-27): double R vectors -> float KMUP arguments
+__global__ void k_wgr_pre(const double *bR, const double *dR, const double *LR, const double *xx64, const double *eR, float *bf, float *df_,
+                          float *Lf, float *xxf, double *e64, int p, int n, int64_t ld, float pi, const WgrScalars *ws, ChainScalars *sc) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = gid; j < p; j += gsz) { bf[j] = (float)bR[j]; df_[j] = (float)dR[j]; Lf[j] = (float)LR[j]; xxf[j] = (float)xx64[j]; }
+  for (int64_t i = gid; i < ld; i += gsz) e64[i] = (i < n) ? (double)(float)eR[i] : 0.0;
+  if (gid == 0) {
+    ChainScalars c; memset(&c, 0, sizeof(c));
+    const float Ve = (float)ws->Ve;
+    c.ve = Ve; c.pi = pi; c.C = -0.5f / sqrtf(Ve); c.odds = pi / (1.0f - pi); c.dfp1 = 1.0f;
+    *sc = c;
+  }
+}
+// widening of KMUP's outputs + marker-variance step (R/wgr.R:86-111)
+__global__ void k_wgr_post(const float *bf, const float *df_, double *bR, double *dR, double *VbR, int p, int use_d, int iv, int de,
+                           double dfv, uint32_t iter, Rng rng, const WgrScalars *ws) {
+  const double Sb = ws->Sb, Ve = ws->Ve, MSx = ws->MSx;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < p; j += gridDim.x * blockDim.x) {
+    const double b = (double)bf[j];
+    bR[j] = b;
+    if (use_d) dR[j] = (double)df_[j];
+    if (iv) VbR[j] = de ? sqrt(b * b * Ve / MSx) : (Sb + b * b) / rng_chisq(rng, dfv + 1.0, (uint32_t)j, iter, RNG_CHI);
+  }
+}
+// Va (common variance) and Ve draws (R/wgr.R:113,121); e64 holds KMUP's residual (float values)
+__global__ __launch_bounds__(1024) void k_wgr_scal(const double *e64, int n, int p, const double *bbpart, int iv, double dfv, uint32_t iter, Rng rng, WgrScalars *ws) {
+  __shared__ double red[17];
+  double ee = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { const double v = (double)(float)e64[i]; ee += v * v; }
+  ee = block_sum(ee, red);
+  double bb = 0;
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) bb += bbpart[i];
+  bb = block_sum(bb, red);
+  if (threadIdx.x == 0) {
+    if (!iv) ws->Va = (bb + ws->Sb) / rng_chisq(rng, dfv + (double)p, RNG_GLOBAL_MARKER, iter, RNG_G_VB);
+    ws->Ve = (ee + ws->Se) / rng_chisq(rng, (double)n + dfv, RNG_GLOBAL_MARKER, iter, RNG_G_VE);
+    ws->bb = bb;
+  }
+}
+// L = Ve/Vb (R/wgr.R:122) and posterior sums of the marker vectors (R/wgr.R:130-134)
+__global__ void k_wgr_L(const double *bR, const double *dR, double *VbR, double *LR, double *B, double *D, double *VB, int p, int iv, int accumulate, const WgrScalars *ws) {
+  const double Ve = ws->Ve, Va = ws->Va;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < p; j += gridDim.x * blockDim.x) {
+    if (!iv) VbR[j] = Va;
+    LR[j] = Ve / VbR[j];
+    if (accumulate) { B[j] += bR[j]; D[j] += dR[j]; if (iv) VB[j] += VbR[j]; }
+  }
+}
+// e = y - mu - X b from the fp64 partial products (R/wgr.R:124)
+__global__ void k_wgr_efinish(const double *part, int64_t ld, int nchunks, int n, const double *y, double *eR, const WgrScalars *ws) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0;
+  for (int c = 0; c < nchunks; ++c) s += part[(int64_t)c * ld + i];
+  eR[i] = y[i] - ws->mu - s;
+}
+// intercept (R/wgr.R:125-127) and scalar posterior sums
+__global__ __launch_bounds__(1024) void k_wgr_mu(double *eR, int n, int iv, int accumulate, uint32_t iter, Rng rng, WgrScalars *ws) {
+  __shared__ double red[17];
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += eR[i];
+  s = block_sum(s, red);
+  const double mu0 = s / (double)n + (ws->Ve / (double)n) * rng_normal(rng, RNG_GLOBAL_MARKER, iter, RNG_G_MU, 0);   // sd = Ve/n (sic)
+  for (int i = threadIdx.x; i < n; i += blockDim.x) eR[i] -= mu0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ws->mu += mu0;
+    if (accumulate) { ws->B0 += ws->mu; ws->VE += ws->Ve; if (!iv) ws->VA += ws->Va; }
+  }
+}
+// posterior means (R/wgr.R:141-145)
+__global__ void k_wgr_final(double *B, double *D, double *VB, int p, double mc, const double *dpart, int iv, WgrScalars *ws) {
+  __shared__ double red[17];
+  double sd = 0;
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) sd += dpart[i];
+  sd = block_sum(sd, red);
+  const double meanD = sd / mc / (double)p;
+  for (int j = threadIdx.x; j < p; j += blockDim.x) { D[j] = D[j] / mc; B[j] = B[j] / mc / meanD; if (iv) VB[j] = VB[j] / mc; }
+  if (threadIdx.x == 0) ws->sumD = sd;
+}
+__global__ void k_hat64_finish(const double *part, int64_t ld, int nchunks, int n, double B0, double *hat) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0;
+  for (int c = 0; c < nchunks; ++c) s += part[(int64_t)c * ld + i];
+  hat[i] = B0 + s;
+}
+
 // ---- synthetic genotypes: 4 rows per thread ----
 __global__ void k_synth(int8_t *X, int64_t ld, int n, int64_t p, int64_t col0, uint32_t k0, uint32_t k1, float *freq) {
   const int64_t quads = ld / 4;
@@ -918,9 +1065,107 @@ extern "C" int bwgr_bayes(bwgr_panel *P, int model, const float *y, float it, fl
   return rc;
 }
 
-extern "C" int bwgr_wgr(bwgr_panel *, const double *, int, int, int, int, int, double, double, double, uint64_t, int,
-                        double *, double *, double *, double *, double *, double *, double *) {
-  return fail(BWGR_EINVAL, "bwgr_wgr: not built yet");
+// X * coef (fp64 partial products per column chunk); caller finishes.  Returns nchunks and the device buffer.
+template <typename CT>
+static int gemv_parts(bwgr_panel *P, const CT *coef_dev, double **part_out, int *nchunks_out) {
+  const int nchunks = (int)std::min<int64_t>(64, std::max<int64_t>(1, P->p / 512));
+  const int cpc = (int)((P->p + nchunks - 1) / nchunks);
+  double *part = *part_out;
+  if (!part) HIPCHK(hipMalloc(&part, sizeof(double) * (size_t)nchunks * P->ld));
+  dim3 grid((unsigned)((P->ld / 4 + 255) / 256), (unsigned)nchunks);
+  if (P->is_f32) hipLaunchKernelGGL((k_gemv_part<float, CT>), grid, dim3(256), 0, P->stream, (const float *)P->X, P->ld, (int)P->p, coef_dev, cpc, part);
+  else hipLaunchKernelGGL((k_gemv_part<int8_t, CT>), grid, dim3(256), 0, P->stream, (const int8_t *)P->X, P->ld, (int)P->p, coef_dev, cpc, part);
+  HIPCHK(hipGetLastError());
+  *part_out = part; *nchunks_out = nchunks;
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, int de, double pi, double df, double R2,
+                        uint64_t seed, int rng_mode, double *mu, double *b, double *Vb, double *d, double *Ve, double *hat,
+                        double *cxx) {
+  if (!P || !y) return fail(BWGR_EINVAL, "wgr: null pointer");
+  if (it < 1 || bi < 0 || th < 1) return fail(BWGR_EINVAL, "wgr: need it >= 1, bi >= 0, th >= 1");
+  if (de) iv = 1;                                                                  // R/wgr.R:9
+  HIPCHK(hipSetDevice(P->device));
+  const int p = (int)P->p, n = (int)P->n;
+  const size_t pd = sizeof(double) * p, pf = sizeof(float) * p;
+  const Rng rng = make_rng(seed, rng_mode);
+  int mc = 0; for (int q = bi; q <= it; q += th) mc++;                             // post = seq(bi,it,th)
+  if (mc < 1) return fail(BWGR_EINVAL, "wgr: seq(bi,it,th) is empty");
+  std::vector<void *> owned;
+  auto dalloc = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, bytes) != hipSuccess) return nullptr; owned.push_back(q); return q; };
+  auto cleanup = [&]() { for (void *q : owned) hipFree(q); };
+  double *yd = (double *)dalloc(sizeof(double) * n), *eR = (double *)dalloc(sizeof(double) * P->ld), *e64 = (double *)dalloc(sizeof(double) * P->ld);
+  double *xx64 = (double *)dalloc(pd), *vx64 = (double *)dalloc(pd), *bR = (double *)dalloc(pd), *dR = (double *)dalloc(pd);
+  double *VbR = (double *)dalloc(pd), *LR = (double *)dalloc(pd), *B = (double *)dalloc(pd), *D = (double *)dalloc(pd), *VB = (double *)dalloc(pd);
+  float *bf = (float *)dalloc(pf), *dfl = (float *)dalloc(pf), *Lf = (float *)dalloc(pf), *xxf = (float *)dalloc(pf), *vbf = (float *)dalloc(pf);
+  double *part1 = (double *)dalloc(sizeof(double) * 256), *part2 = (double *)dalloc(sizeof(double) * 256), *hatd = (double *)dalloc(sizeof(double) * n);
+  WgrScalars *ws = (WgrScalars *)dalloc(sizeof(WgrScalars));
+  ChainScalars *sc = (ChainScalars *)dalloc(sizeof(ChainScalars));
+  if (!yd || !eR || !e64 || !xx64 || !vx64 || !bR || !dR || !VbR || !LR || !B || !D || !VB || !bf || !dfl || !Lf || !xxf || !vbf || !part1 || !part2 || !hatd || !ws || !sc) {
+    cleanup(); return fail(BWGR_ENOMEM, "wgr: device allocation failed");
+  }
+  int rc = BWGR_OK;
+  double *gpart = nullptr; int nchunks = 0;
+#define WCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = fail(BWGR_EHIP, "%s failed: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
+  {
+    WCHK(hipMemcpyAsync(yd, y, sizeof(double) * n, hipMemcpyHostToDevice, P->stream));
+    const int wpb = 4;
+    if (P->is_f32) hipLaunchKernelGGL(k_stats64<float>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const float *)P->X, P->ld, n, p, xx64, vx64);
+    else hipLaunchKernelGGL(k_stats64<int8_t>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const int8_t *)P->X, P->ld, n, p, xx64, vx64);
+    hipLaunchKernelGGL(k_dsum_stage1, dim3(256), dim3(256), 0, P->stream, vx64, (int64_t)p, part1, 0);
+    hipLaunchKernelGGL(k_dsum_stage1, dim3(256), dim3(256), 0, P->stream, xx64, (int64_t)p, part2, 0);
+    hipLaunchKernelGGL(k_wgr_init, dim3(1), dim3(1024), 0, P->stream, yd, eR, n, P->ld, part1, part2, p, df, R2, ws);
+    hipLaunchKernelGGL(k_wgr_marker_init, dim3(1024), dim3(256), 0, P->stream, bR, dR, VbR, LR, B, D, VB, p, ws);
+    WCHK(hipGetLastError());
+    const unsigned pg = (unsigned)std::min<int64_t>(2048, (P->p + 255) / 256);
+    for (int i = 1; i <= it; ++i) {                                                // R/wgr.R:66
+      const uint32_t itx = (uint32_t)(i - 1);
+      const int accumulate = (i >= bi && ((i - bi) % th) == 0) ? 1 : 0;            // i %in% post
+      hipLaunchKernelGGL(k_wgr_pre, dim3(pg), dim3(256), 0, P->stream, bR, dR, LR, xx64, eR, bf, dfl, Lf, xxf, e64, p, n, P->ld, (float)pi, ws, sc);
+      SweepArgs a; memset(&a, 0, sizeof(a));
+      fill_panel_args(P, a);
+      a.flags = SWF_LAM_VEC | (pi > 0 ? (SWF_SELECT | SWF_ALT_B2) : 0);
+      a.e = e64; a.b = bf; a.d = dfl; a.vb = vbf; a.xx = xxf; a.lam = Lf; a.sc = sc; a.iter = itx; a.rng = rng;
+      rc = launch_sweep(P, a);                                                     // KMUP, R/wgr.R:85
+      if (rc != BWGR_OK) goto done;
+      hipLaunchKernelGGL(k_wgr_post, dim3(pg), dim3(256), 0, P->stream, bf, dfl, bR, dR, VbR, p, pi > 0 ? 1 : 0, iv, de, df, itx, rng, ws);
+      hipLaunchKernelGGL(k_dsum_stage1, dim3(256), dim3(256), 0, P->stream, bR, (int64_t)p, part1, 1);
+      hipLaunchKernelGGL(k_wgr_scal, dim3(1), dim3(1024), 0, P->stream, e64, n, p, part1, iv, df, itx, rng, ws);
+      hipLaunchKernelGGL(k_wgr_L, dim3(pg), dim3(256), 0, P->stream, bR, dR, VbR, LR, B, D, VB, p, iv, accumulate, ws);
+      rc = gemv_parts<double>(P, bR, &gpart, &nchunks);
+      if (rc != BWGR_OK) goto done;
+      hipLaunchKernelGGL(k_wgr_efinish, dim3((n + 255) / 256), dim3(256), 0, P->stream, gpart, P->ld, nchunks, n, yd, eR, ws);
+      hipLaunchKernelGGL(k_wgr_mu, dim3(1), dim3(1024), 0, P->stream, eR, n, iv, accumulate, itx, rng, ws);
+      WCHK(hipGetLastError());
+      if ((i & 63) == 0) WCHK(hipStreamSynchronize(P->stream));                    // bound the launch queue
+    }
+    hipLaunchKernelGGL(k_dsum_stage1, dim3(256), dim3(256), 0, P->stream, D, (int64_t)p, part1, 0);
+    hipLaunchKernelGGL(k_wgr_final, dim3(1), dim3(1024), 0, P->stream, B, D, VB, p, (double)mc, part1, iv, ws);
+    WgrScalars h; ChainScalars hc;
+    WCHK(hipMemcpyAsync(&h, ws, sizeof(h), hipMemcpyDeviceToHost, P->stream));
+    WCHK(hipMemcpyAsync(&hc, sc, sizeof(hc), hipMemcpyDeviceToHost, P->stream));
+    WCHK(hipStreamSynchronize(P->stream));
+    if (hc.error) { rc = fail(BWGR_ETIMEOUT, "wgr: a workgroup exchange timed out inside the sweep kernel"); goto done; }
+    const double B0 = h.B0 / mc;
+    rc = gemv_parts<double>(P, B, &gpart, &nchunks);                               // HAT = B0 + gen0 %*% B, R/wgr.R:152
+    if (rc != BWGR_OK) goto done;
+    hipLaunchKernelGGL(k_hat64_finish, dim3((n + 255) / 256), dim3(256), 0, P->stream, gpart, P->ld, nchunks, n, B0, hatd);
+    WCHK(hipGetLastError());
+    if (mu) *mu = B0;
+    if (Ve) *Ve = h.VE / mc;
+    if (cxx) *cxx = h.cxx;
+    if (b) WCHK(hipMemcpy(b, B, pd, hipMemcpyDeviceToHost));
+    if (d) WCHK(hipMemcpy(d, D, pd, hipMemcpyDeviceToHost));
+    if (Vb) { if (iv) WCHK(hipMemcpy(Vb, VB, pd, hipMemcpyDeviceToHost)); else Vb[0] = h.VA / mc; }
+    if (hat) WCHK(hipMemcpy(hat, hatd, sizeof(double) * n, hipMemcpyDeviceToHost));
+  }
+done:
+#undef WCHK
+  (void)hipStreamSynchronize(P->stream);
+  if (gpart) hipFree(gpart);
+  cleanup();
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

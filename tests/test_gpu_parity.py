@@ -113,3 +113,29 @@ def test_float_panel_centered():
     o = O.bayes("BayesRR", y, Xc, it=10, bi=2, seed=4)
     assert scaled_err(g["b"], o["b"]) < TOL
     assert scaled_err(g["hat"], o["hat"]) < TOL
+
+
+# wgr() settings of man/wgr.Rd:82: BRR (defaults), BayesA (iv), BayesB (iv, pi>0), BayesC (pi>0), BayesL (de)
+@pytest.mark.parametrize("name,kw", [("BRR", {}), ("BayesA", {"iv": True}), ("BayesB", {"iv": True, "pi": 0.5}),
+                                     ("BayesC", {"pi": 0.5}), ("BayesL", {"de": True}), ("thin", {"th": 3, "bi": 4})])
+def test_wgr_tpod(tpod, name, kw):
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = tpod["gen"], tpod["y"]
+    args = dict(it=25, bi=5, th=1, df=5, R2=0.5)
+    args.update(kw)
+    g = bwgr_amd.wgr(y, X, seed=21, **args)
+    o = O.wgr(y, X, seed=21, **args)
+    assert list(g.keys()) == ["mu", "b", "Vb", "d", "Ve", "hat", "cxx"]
+    assert scaled_err(g["b"], o["b"]) < TOL and scaled_err(g["hat"], o["hat"]) < TOL
+    assert scaled_err(np.atleast_1d(g["Vb"]), np.atleast_1d(o["Vb"])) < 5 * TOL
+    assert _rel(g["Ve"], o["Ve"]) < TOL and _rel(g["mu"], o["mu"]) < TOL and _rel(g["cxx"], o["cxx"]) < 1e-12
+    assert scaled_err(g["d"], o["d"]) < 1e-12
+
+
+def test_wgr_unbuilt_rows_raise(tpod):
+    import bwgr_amd
+    with pytest.raises(NotImplementedError):
+        bwgr_amd.wgr(tpod["y"], tpod["gen"], it=5, bi=1, bag=0.5)
+    with pytest.raises(NotImplementedError):
+        bwgr_amd.wgr(tpod["y"], tpod["gen"], it=5, bi=1, eigK={"values": [1.0], "vectors": [[1.0]]})
