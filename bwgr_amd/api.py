@@ -105,7 +105,10 @@ def _as_panel(X, **kw):
 class Chain:
     """One MCMC chain of a fused sampler, stepping interface over bwgr_chain_* (state stays on the GPU)."""
 
-    def __init__(self, panel, model, y, it=1500, bi=500, pi=0.95, df=5.0, R2=0.5, seed=None, rng_mode=0):
+    def __init__(self, panel, model, y, it=1500, bi=500, pi=0.95, df=5.0, R2=0.5, seed=None, rng_mode=0, shard=None,
+                 e_ext=None):
+        """shard = (marker0, p_total, MSx_total) makes this the chain of one marker shard (bwgr_chain_create_sharded);
+        e_ext = a torch float64 CUDA tensor of panel.ld entries that will hold the (replicated) residual."""
         self.panel, self.model = panel, model
         self._h = C.c_void_p()
         self.it, self.bi = int(it), int(bi)
@@ -118,14 +121,42 @@ class Chain:
             self._y = np.ascontiguousarray(y, np.float32)
             assert self._y.size == panel.n, "length(y) must equal nrow(X)"
             yptr, loc = self._y.ctypes.data_as(C.c_void_p), HOST
-        check(_lib.lib().bwgr_chain_create(C.byref(self._h), panel._h, MODELS[model], yptr, loc, float(it), float(bi),
-                                            float(pi), float(df), float(R2), C.c_uint64(_seed(seed)), int(rng_mode)))
+        if shard is None and e_ext is None:
+            check(_lib.lib().bwgr_chain_create(C.byref(self._h), panel._h, MODELS[model], yptr, loc, float(it), float(bi),
+                                                float(pi), float(df), float(R2), C.c_uint64(_seed(seed)), int(rng_mode)))
+        else:
+            marker0, p_total, msx_total = shard if shard is not None else (0, panel.p, panel.stats()[2])
+            eptr = None
+            if e_ext is not None:
+                import torch
+                assert e_ext.is_cuda and e_ext.dtype == torch.float64 and e_ext.is_contiguous() and e_ext.numel() == panel.ld
+                self._e_ext = e_ext
+                eptr = C.c_void_p(e_ext.data_ptr())
+            check(_lib.lib().bwgr_chain_create_sharded(C.byref(self._h), panel._h, MODELS[model], yptr, loc, float(it), float(bi),
+                                                        float(pi), float(df), float(R2), C.c_uint64(_seed(seed)), int(rng_mode),
+                                                        int(marker0), int(p_total), float(msx_total), eptr))
+        self.nblocks = (panel.p + panel.block - 1) // panel.block
 
     def run(self, iters):
         check(_lib.lib().bwgr_chain_run(self._h, int(iters)))
 
     def sync(self):
         check(_lib.lib().bwgr_chain_sync(self._h))
+
+    def sweep_blocks(self, lo, hi):
+        check(_lib.lib().bwgr_chain_sweep_blocks(self._h, int(lo), int(hi)))
+
+    def get_sums(self):
+        s = np.zeros(2, np.float64)
+        check(_lib.lib().bwgr_chain_get_sums(self._h, _dp(s)))
+        return s
+
+    def end_iteration(self, sums_total=None):
+        if sums_total is None:
+            check(_lib.lib().bwgr_chain_end_iteration(self._h, None))
+        else:
+            s = np.ascontiguousarray(sums_total, np.float64)
+            check(_lib.lib().bwgr_chain_end_iteration(self._h, _dp(s)))
 
     def sweep_ms(self):
         ms = C.c_float(); nl = C.c_int()

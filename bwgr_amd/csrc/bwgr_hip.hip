@@ -551,6 +551,9 @@ struct bwgr_chain {
   double *e = nullptr;
   float *B = nullptr, *D = nullptr, *VB = nullptr;
   ChainScalars *sc = nullptr;
+  int64_t marker0 = 0, p_total = 0;   // sharding: global id of local marker 0, markers over all ranks
+  float MSx_eff = 0;                  // MSx over all ranks
+  bool e_owned = true;
   std::vector<hipEvent_t> ev;  // pairs around each sweep launch since the last query
   float ms_acc = 0; int launch_acc = 0;
   bool finalized = false;
@@ -841,31 +844,35 @@ extern "C" int bwgr_chain_destroy(bwgr_chain *C) {
   if (!C) return BWGR_OK;
   (void)hipSetDevice(C->P->device);
   for (hipEvent_t ev : C->ev) hipEventDestroy(ev);
-  hipFree(C->y); hipFree(C->e); hipFree(C->b); hipFree(C->d); hipFree(C->vb); hipFree(C->lam);
+  hipFree(C->y); if (C->e_owned) hipFree(C->e); hipFree(C->b); hipFree(C->d); hipFree(C->vb); hipFree(C->lam);
   hipFree(C->B); hipFree(C->D); hipFree(C->VB); hipFree(C->sc);
   delete C;
   return BWGR_OK;
 }
 
-extern "C" int bwgr_chain_create(bwgr_chain **out, bwgr_panel *P, int model, const float *y, int memloc, float it,
-                                 float bi, float pi, float df, float R2, uint64_t seed, int rng_mode) {
+extern "C" int bwgr_chain_create_sharded(bwgr_chain **out, bwgr_panel *P, int model, const float *y, int memloc, float it,
+                                         float bi, float pi, float df, float R2, uint64_t seed, int rng_mode, int64_t marker0,
+                                         int64_t p_total, float MSx_total, double *e_ext) {
   if (!out || !P || !y) return fail(BWGR_EINVAL, "chain_create: null pointer");
   *out = nullptr;
   if (model < BWGR_BAYESA || model > BWGR_BAYESDPI) return fail(BWGR_EINVAL, "chain_create: bad model %d", model);
+  if (marker0 < 0 || p_total < marker0 + P->p || p_total > 0xFFFFFFF0ll) return fail(BWGR_EINVAL, "chain_create: bad shard [%lld,+%lld) of %lld", (long long)marker0, (long long)P->p, (long long)p_total);
   HIPCHK(hipSetDevice(P->device));
   bwgr_chain *C = new bwgr_chain();
   C->P = P; C->model = model; C->itf = it; C->bif = bi; C->iit = (int)it; C->ibi = (int)bi;
   C->pi = pi; C->df = df; C->R2 = R2; C->seed = seed; C->rng_mode = rng_mode;
-  C->Phi = P->MSx * (1 - R2) / R2;
+  C->marker0 = marker0; C->p_total = p_total; C->MSx_eff = MSx_total;
+  C->Phi = MSx_total * (1 - R2) / R2;
   const size_t pb = sizeof(float) * P->p;
   auto bail = [&](int code) { bwgr_chain_destroy(C); return code; };
 #define CCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return bail(fail(BWGR_EHIP, "%s failed: %s", #x, hipGetErrorString(e_))); } while (0)
-  CCHK(hipMalloc(&C->y, sizeof(float) * P->n)); CCHK(hipMalloc(&C->e, sizeof(double) * P->ld));
+  CCHK(hipMalloc(&C->y, sizeof(float) * P->n));
+  if (e_ext) { C->e = e_ext; C->e_owned = false; } else CCHK(hipMalloc(&C->e, sizeof(double) * P->ld));
   CCHK(hipMalloc(&C->b, pb)); CCHK(hipMalloc(&C->d, pb)); CCHK(hipMalloc(&C->vb, pb)); CCHK(hipMalloc(&C->lam, pb));
   CCHK(hipMalloc(&C->B, pb)); CCHK(hipMalloc(&C->D, pb)); CCHK(hipMalloc(&C->VB, pb)); CCHK(hipMalloc(&C->sc, sizeof(ChainScalars)));
   CCHK(hipMemcpyAsync(C->y, y, sizeof(float) * P->n, memloc == BWGR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, P->stream));
   InitArgs ia; ia.y = C->y; ia.e = C->e; ia.n = (int)P->n; ia.p = (int)P->p; ia.ld = P->ld; ia.model = model;
-  ia.pi = pi; ia.df = df; ia.R2 = R2; ia.MSx = P->MSx; ia.sc = C->sc;
+  ia.pi = pi; ia.df = df; ia.R2 = R2; ia.MSx = MSx_total; ia.sc = C->sc;
   hipLaunchKernelGGL(k_chain_init, dim3(1), dim3(1024), 0, P->stream, ia);
   hipLaunchKernelGGL(k_marker_init, dim3(1024), dim3(256), 0, P->stream, C->b, C->d, C->vb, C->lam, C->B, C->D, C->VB, (int)P->p, C->sc);
   CCHK(hipGetLastError());
@@ -875,46 +882,79 @@ extern "C" int bwgr_chain_create(bwgr_chain **out, bwgr_panel *P, int model, con
   return BWGR_OK;
 }
 
+extern "C" int bwgr_chain_create(bwgr_chain **out, bwgr_panel *P, int model, const float *y, int memloc, float it,
+                                 float bi, float pi, float df, float R2, uint64_t seed, int rng_mode) {
+  if (!P) return fail(BWGR_EINVAL, "chain_create: null pointer");
+  return bwgr_chain_create_sharded(out, P, model, y, memloc, it, bi, pi, df, R2, seed, rng_mode, 0, P->p, P->MSx, nullptr);
+}
+
+extern "C" int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end) {
+  if (!C) return fail(BWGR_EINVAL, "null chain");
+  bwgr_panel *P = C->P;
+  if (blk_begin < 0 || blk_end > P->nblocks || blk_begin >= blk_end) return fail(BWGR_EINVAL, "sweep_blocks: bad range [%d,%d) of %lld", blk_begin, blk_end, (long long)P->nblocks);
+  if (C->done >= C->iit) return fail(BWGR_EINVAL, "sweep_blocks: all %d iterations already run", C->iit);
+  HIPCHK(hipSetDevice(P->device));
+  const int model = C->model;
+  SweepArgs a; memset(&a, 0, sizeof(a));
+  fill_panel_args(P, a);
+  a.blk_begin = blk_begin; a.blk_end = blk_end;
+  int fl = 0;
+  if (has_d(model)) fl |= SWF_SELECT;
+  if (model == BWGR_BAYESDPI) fl |= SWF_ALT_B2 | SWF_MH;
+  if (per_marker_vb(model)) fl |= SWF_LAM_VEC | SWF_VB_VEC;
+  a.flags = fl;
+  a.e = C->e; a.b = C->b; a.d = C->d; a.vb = C->vb; a.xx = P->xx; a.lam = C->lam; a.sc = C->sc;
+  a.iter = (uint32_t)C->done; a.marker0 = (uint32_t)C->marker0; a.rng = make_rng(C->seed, C->rng_mode);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  if (P->K > 1) HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
+  launch_prestage(P, a);
+  HIPCHK(hipEventRecord(e0, P->stream));
+  launch_sweep_kernel(P, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e1, P->stream));
+  C->ev.push_back(e0); C->ev.push_back(e1);
+  if (C->ev.size() >= 4096) CHK(bwgr_chain_sweep_ms(C, nullptr, nullptr));   // bound the number of live events
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_chain_get_sums(bwgr_chain *C, double sums[2]) {
+  if (!C || !sums) return fail(BWGR_EINVAL, "null pointer");
+  HIPCHK(hipSetDevice(C->P->device));
+  ChainScalars h;
+  HIPCHK(hipMemcpyAsync(&h, C->sc, sizeof(h), hipMemcpyDeviceToHost, C->P->stream));
+  HIPCHK(hipStreamSynchronize(C->P->stream));
+  if (h.error) return fail(BWGR_ETIMEOUT, "a workgroup exchange timed out inside the sweep kernel (chain state is invalid)");
+  sums[0] = h.sum_d; sums[1] = h.sum_b2;
+  return BWGR_OK;
+}
+
+__global__ void k_set_sums(ChainScalars *sc, double sd, double sb2) { sc->sum_d = sd; sc->sum_b2 = sb2; }
+
+extern "C" int bwgr_chain_end_iteration(bwgr_chain *C, const double sums_total[2]) {
+  if (!C) return fail(BWGR_EINVAL, "null chain");
+  if (C->done >= C->iit) return fail(BWGR_EINVAL, "end_iteration: all %d iterations already run", C->iit);
+  bwgr_panel *P = C->P;
+  HIPCHK(hipSetDevice(P->device));
+  const int model = C->model, i = C->done;
+  if (sums_total) hipLaunchKernelGGL(k_set_sums, dim3(1), dim3(1), 0, P->stream, C->sc, sums_total[0], sums_total[1]);
+  const int accumulate = (i > C->ibi) ? 1 : 0;   // if(i>ibi), src/Rcpp20260726ai.cpp:624
+  TailArgs t; t.e = C->e; t.n = (int)P->n; t.p = (int)C->p_total; t.model = model; t.df = C->df; t.R2 = C->R2; t.Phi = C->Phi;
+  t.accumulate = accumulate; t.iter = (uint32_t)i; t.rng = make_rng(C->seed, C->rng_mode); t.sc = C->sc;
+  hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), 0, P->stream, t);
+  hipLaunchKernelGGL(k_marker_tail, dim3((unsigned)std::min<int64_t>(2048, (P->p + 255) / 256)), dim3(256), 0, P->stream,
+                     C->b, C->d, C->vb, C->lam, C->B, C->D, C->VB, (int)P->p, model, C->Phi, accumulate, C->sc);
+  HIPCHK(hipGetLastError());
+  C->done++;
+  return BWGR_OK;
+}
+
 extern "C" int bwgr_chain_run(bwgr_chain *C, int iters) {
   if (!C) return fail(BWGR_EINVAL, "null chain");
   if (iters < 0 || C->done + iters > C->iit) return fail(BWGR_EINVAL, "chain_run: %d more iterations would exceed it=%d (done %d)", iters, C->iit, C->done);
-  bwgr_panel *P = C->P;
-  HIPCHK(hipSetDevice(P->device));
-  const int model = C->model;
-  const bool per = per_marker_vb(model);
   for (int k = 0; k < iters; ++k) {
-    const int i = C->done;
-    SweepArgs a; memset(&a, 0, sizeof(a));
-    fill_panel_args(P, a);
-    int fl = 0;
-    if (has_d(model)) fl |= SWF_SELECT;
-    if (model == BWGR_BAYESDPI) fl |= SWF_ALT_B2 | SWF_MH;
-    if (per) fl |= SWF_LAM_VEC | SWF_VB_VEC;
-    a.flags = fl;
-    a.e = C->e; a.b = C->b; a.d = C->d; a.vb = C->vb; a.xx = P->xx; a.lam = C->lam; a.sc = C->sc;
-    a.iter = (uint32_t)i; a.rng = make_rng(C->seed, C->rng_mode);
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    if (P->K > 1) HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
-    launch_prestage(P, a);
-    HIPCHK(hipEventRecord(e0, P->stream));
-    launch_sweep_kernel(P, a);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e1, P->stream));
-    C->ev.push_back(e0); C->ev.push_back(e1);
-    const int accumulate = (i > C->ibi) ? 1 : 0;   // if(i>ibi), src/Rcpp20260726ai.cpp:624
-    TailArgs t; t.e = C->e; t.n = (int)P->n; t.p = (int)P->p; t.model = model; t.df = C->df; t.R2 = C->R2; t.Phi = C->Phi;
-    t.accumulate = accumulate; t.iter = (uint32_t)i; t.rng = make_rng(C->seed, C->rng_mode); t.sc = C->sc;
-    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), 0, P->stream, t);
-    hipLaunchKernelGGL(k_marker_tail, dim3(std::min<int64_t>(2048, (P->p + 255) / 256)), dim3(256), 0, P->stream,
-                       C->b, C->d, C->vb, C->lam, C->B, C->D, C->VB, (int)P->p, model, C->Phi, accumulate, C->sc);
-    HIPCHK(hipGetLastError());
-    C->done++;
-    // bound the number of live events
-    if (C->ev.size() >= 4096) {
-      float ms; int nl;
-      bwgr_chain_sweep_ms(C, &ms, &nl);
-    }
+    CHK(bwgr_chain_sweep_blocks(C, 0, (int)C->P->nblocks));
+    CHK(bwgr_chain_end_iteration(C, nullptr));
   }
   return BWGR_OK;
 }
@@ -1031,13 +1071,13 @@ extern "C" int bwgr_chain_result(bwgr_chain *C, float *mu, float *b, float *d, f
     HIPCHK(hipMemcpy(&vg, sdev, sizeof(float), hipMemcpyDeviceToHost));
     hipFree(part); hipFree(sdev);
   } else {
-    vg = VBs * P->MSx;
-    if (C->model == BWGR_BAYESCPI) vg = VBs * P->MSx / Pi;                         // :913
+    vg = VBs * C->MSx_eff;
+    if (C->model == BWGR_BAYESCPI) vg = VBs * C->MSx_eff / Pi;                         // :913
   }
   if (mu) *mu = MU;
   if (ve) *ve = VE;
   if (h2) *h2 = vg / (vg + VE);
-  if (MSx) *MSx = P->MSx;
+  if (MSx) *MSx = C->MSx_eff;
   if (pi) *pi = Pi;
   if (b) HIPCHK(hipMemcpy(b, C->B, pb, hipMemcpyDeviceToHost));
   if (d) HIPCHK(hipMemcpy(d, C->D, pb, hipMemcpyDeviceToHost));

@@ -70,6 +70,7 @@ struct SweepArgs {
   const float *xx, *lam;
   ChainScalars *sc;
   uint32_t iter;
+  uint32_t marker0;             // global id of local marker 0 (RNG counters use global ids)
   Rng rng;
   PreStage ps;
   double *xpart;                // [2][K][SW_MAXM]
@@ -168,7 +169,7 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
     const float lamj = (a.flags & SWF_LAM_VEC) ? a.lam[j] : lam_common;
     const float den = xxj + lamj;
     const float sd = sqrtf(ve / den);
-    const uint32_t mk = (uint32_t)j;
+    const uint32_t mk = a.marker0 + (uint32_t)j;
     const bool sel = (a.flags & SWF_SELECT) != 0;
     if (piece == 0) {
       st.b0[t] = b0;

@@ -1,0 +1,163 @@
+"""Marker-sharded multi-GPU sampler: one process per GPU, torch.distributed over RCCL/xGMI.
+
+Rank g owns the columns [g*p/G, (g+1)*p/G) of X and the matching b, d, vb, lambda slices; the residual e (n fp64
+values, 80 KB at n=10k) is replicated.  Between synchronisations every rank sweeps `blocks_per_sync` of its own marker
+blocks against its local copy of e (exactly, with the blocked sweep kernel); at the boundary ONE all-reduce(sum) of
+the residual delta (e - e_at_boundary) makes the copies identical again.  Per iteration one more tiny all-reduce
+carries {sum d, sum b^2}; the intercept / variance draws are then computed redundantly and identically on every rank
+(same RNG counters).  The message is latency-bound (80 KB), so the number of boundaries per sweep, not the link
+bandwidth, is what costs: keep p_local/blocks_per_sync small.
+
+This is a partitioned ("independent-block") Gibbs sampler: for G > 1 markers on different ranks do not see each other's
+updates until the next boundary, so it is NOT the reference's chain -- parity is statistical (posterior means within
+Monte-Carlo error), and `blocks_per_sync` trades mixing fidelity for speed.  G = 1 takes no exchange path at all and
+is the exact chain.
+
+The driver is engine-agnostic: an engine exposes sweep_blocks / residual / set_residual / sums / end_iteration over
+torch tensors.  The product engine is HipShardEngine (bwgr_amd.Chain on the GPU).  tests/test_dist_gloo.py drives the
+same driver on CPU over gloo with a checker engine.
+"""
+import math
+import os
+import time
+
+import numpy as np
+
+
+class HipShardEngine:
+    def __init__(self, panel, model, y, it, bi, pi, df, R2, seed, marker0, p_total, msx_total):
+        import torch
+        from .api import Chain
+        self.panel = panel
+        self.e = torch.zeros(panel.ld, dtype=torch.float64, device="cuda:%d" % panel.device)
+        self.chain = Chain(panel, model, y, it=it, bi=bi, pi=pi, df=df, R2=R2, seed=seed,
+                           shard=(marker0, p_total, msx_total), e_ext=self.e)
+        self.nblocks = self.chain.nblocks
+
+    def sweep_blocks(self, lo, hi):
+        self.chain.sweep_blocks(lo, hi)
+
+    def residual(self):
+        return self.e
+
+    def set_residual(self, t):
+        self.e.copy_(t)
+
+    def sums(self):
+        import torch
+        return torch.as_tensor(self.chain.get_sums(), device=self.e.device)
+
+    def end_iteration(self, sums_total):
+        self.chain.end_iteration(None if sums_total is None else sums_total.detach().cpu().numpy())
+
+
+def sync_rounds(nblocks_local, blocks_per_sync, world):
+    """Every rank must enter the same number of all-reduces per sweep even when shards differ by a block."""
+    import torch
+    import torch.distributed as dist
+    r = math.ceil(nblocks_local / blocks_per_sync)
+    if world > 1:
+        t = torch.tensor([r], dtype=torch.int64, device=_comm_device())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        r = int(t.item())
+    return r
+
+
+def _comm_device():
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def run_iterations(engine, iters, blocks_per_sync, world, rounds=None):
+    """`iters` MCMC iterations of the sharded sampler.  world == 1: no exchange (the exact chain)."""
+    import torch.distributed as dist
+    nb = engine.nblocks
+    if world == 1:
+        for _ in range(iters):
+            engine.sweep_blocks(0, nb)
+            engine.end_iteration(None)
+        return
+    bps = max(1, int(blocks_per_sync))
+    if rounds is None:
+        rounds = sync_rounds(nb, bps, world)
+    for _ in range(iters):
+        for r in range(rounds):
+            lo, hi = r * bps, min(nb, (r + 1) * bps)
+            e0 = engine.residual().clone()
+            if lo < hi:
+                engine.sweep_blocks(lo, hi)
+            delta = engine.residual() - e0
+            dist.all_reduce(delta)                  # RCCL over xGMI (gloo in the CPU tests): n fp64 values
+            engine.set_residual(e0 + delta)
+        s = engine.sums()
+        dist.all_reduce(s)
+        engine.end_iteration(s)
+
+
+def shard_bounds(p, world, rank, block):
+    """Contiguous column shards aligned to the marker block size."""
+    nblk = (p + block - 1) // block
+    per = (nblk + world - 1) // world
+    lo = min(p, rank * per * block)
+    hi = min(p, (rank + 1) * per * block)
+    if hi <= lo:
+        raise ValueError("rank %d of %d would own no markers: p=%d has only %d blocks of %d" % (rank, world, p, nblk, block))
+    return lo, hi
+
+
+def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
+    """bench.py's N > 1 leg: strong scaling of one panel over `world` GPUs."""
+    import torch
+    import torch.distributed as dist
+    import bwgr_amd
+    from . import synth
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    block = args.block if args.block > 0 else 128
+    lo, hi = shard_bounds(p, world, rank, block)
+    X = synth.genotypes(n, hi - lo, col0=lo, device=dev)
+    g = synth.phenotype(X, n, col0=lo, p_total=p)
+    dist.all_reduce(g)
+    y = synth.scale_phenotype(g)
+    P = bwgr_amd.Panel(X, n=n, device=dev, block=block, nwg=args.nwg)
+    del X
+    torch.cuda.empty_cache()
+    msx = torch.tensor([P.stats()[2]], dtype=torch.float64, device="cuda:%d" % dev)
+    dist.all_reduce(msx)
+    eng = HipShardEngine(P, model, y, W + K, W, pi, 5.0, 0.5, synth.SEED, lo, p, float(msx.item()))
+    markers_per_sync = args.sync_every if args.sync_every > 0 else 16384
+    bps = max(1, markers_per_sync // P.block)
+    rounds = sync_rounds(eng.nblocks, bps, world)
+    run_iterations(eng, W, bps, world, rounds)
+    eng.chain.sync(); eng.chain.sweep_ms()
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_iterations(eng, K, bps, world, rounds)
+    eng.chain.sync()
+    dist.barrier(); torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda:%d" % dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    ms, launches = eng.chain.sweep_ms()
+    sweep_ms_per_iter = ms * launches / K
+    st = eng.chain.state()
+    alg = float(n) * float(hi - lo)
+    ach = alg / (sweep_ms_per_iter * 1e-3) / 1e9
+    out = {
+        "metric": "MCMC iter/sec (full marker sweep)", "value": K / elapsed, "unit": "iter/s", "n_gpus": world, "steps": K,
+        "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 scalars, f64 residual/accumulation, int8 genotypes", "data": "synthetic",
+        "config": {"workload": "%s: synthetic n=%d x p=%d int8, %s%s, markers sharded over %d GPUs (%d per rank), residual "
+                               "all-reduce (n fp64) every %d markers per rank = %d per sweep; partitioned Gibbs (statistical "
+                               "parity for N>1)" % (args.workload, n, p, model, " pi=%.2f" % pi if pi else "", world, hi - lo,
+                                                    bps * P.block, rounds),
+                   "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": 1, "block": P.block,
+                   "slab_workgroups": P.nwg, "sync_rounds_per_sweep": rounds},
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                     "kernel": "k_sweep<int8> (rank 0, all launches of one sweep summed)", "kernel_ms": sweep_ms_per_iter,
+                     "launches": launches, "algorithmic_bytes_per_launch": alg},
+        "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d_rank0": float(st["d"].mean())},
+    }
+    dist.destroy_process_group()
+    return out

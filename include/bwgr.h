@@ -107,6 +107,23 @@ int bwgr_chain_state(bwgr_chain *C, float *b, float *d, float *e, float *vb, flo
  * measured with hipEvents on the stream the kernel runs on */
 int bwgr_chain_sweep_ms(bwgr_chain *C, float *avg_ms, int *launches);
 
+/* ---- marker-sharded chains (one rank per GPU) ----------------------------------------
+ * The panel holds this rank's columns [marker0, marker0 + p_local) of a p_total-marker panel; the residual is
+ * replicated on every rank in e_ext (device, `ld` doubles from bwgr_panel_info, caller-owned, e.g. a torch tensor,
+ * so that the caller can all-reduce residual deltas with RCCL between block ranges).  RNG counters use global marker
+ * ids, MSx_total is the all-rank sum of the panels' MSx.  An iteration is then
+ *     for each range: bwgr_chain_sweep_blocks(C, lo, hi); <caller: all-reduce (e - e_at_range_start)>;
+ *     bwgr_chain_get_sums(C, s); <caller: all-reduce s>; bwgr_chain_end_iteration(C, s_total);
+ * With one rank and one range this is exactly bwgr_chain_run(C, 1).  With several ranks markers on different ranks
+ * are updated against a residual that is only synchronised at range boundaries: a partitioned Gibbs sampler, NOT
+ * the reference's chain (parity is statistical). */
+int bwgr_chain_create_sharded(bwgr_chain **out, bwgr_panel *P, int model, const float *y, int memloc, float it, float bi,
+                              float pi, float df, float R2, uint64_t seed, int rng_mode, int64_t marker0,
+                              int64_t p_total, float MSx_total, double *e_ext);
+int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end);
+int bwgr_chain_get_sums(bwgr_chain *C, double sums[2]);              /* {sum d, sum b^2} of this rank's sweep */
+int bwgr_chain_end_iteration(bwgr_chain *C, const double sums_total[2]); /* NULL: use this rank's own sums */
+
 /* one-call form: create + run(it) + result + destroy */
 int bwgr_bayes(bwgr_panel *P, int model, const float *y, float it, float bi, float pi, float df, float R2,
                uint64_t seed, int rng_mode, float *mu, float *b, float *d, float *hat, float *vb, float *ve,

@@ -170,7 +170,7 @@ double FN(oracle_variate)(uint64_t seed, int mode, int kind, double nu, uint32_t
  *             reference itself uses in BayesB (:673-674).  The GPU implements stable = 1. */
 int FN(oracle_kmup)(const float *X, int64_t n, int64_t p, int64_t ldx, float *b, float *d, const float *xx,
                     float *e_io, const float *L, float Ve, float pi, uint64_t seed, uint32_t iter, int rng_mode,
-                    int stable) {
+                    int stable, uint32_t marker0) {
   orng_t g = { seed, rng_mode };
   E_T *e = (E_T *)malloc(sizeof(E_T) * n), *e1 = (E_T *)malloc(sizeof(E_T) * n), *e2 = (E_T *)malloc(sizeof(E_T) * n);
   if (!e || !e1 || !e2) return 1;
@@ -179,7 +179,7 @@ int FN(oracle_kmup)(const float *X, int64_t n, int64_t p, int64_t ldx, float *b,
   float C = -0.5f / sqrtf(Ve);                                                   /* :17 */
   for (int64_t j = 0; j < p; j++) {                                              /* :18 */
     const float *xj = X + j * ldx;
-    uint32_t mk = (uint32_t)j;
+    uint32_t mk = marker0 + (uint32_t)j;   /* RNG counters carry global marker ids (0 offset = the reference's single panel) */
     b0 = b[j];                                                                   /* :19 */
     float den = xx[j] + L[j];
     b1 = draw_norm((v_dot(xj, e, n) + xx[j] * b0) / den, sqrtf(Ve / den), orng_normal(&g, mk, iter, ORNG_Z1, 0)); /* :20 */
@@ -445,7 +445,7 @@ int FN(oracle_wgr)(const double *y, const double *X, int64_t n, int64_t p, int64
     uint32_t itx = (uint32_t)(i - 1);
     for (int64_t j = 0; j < p; j++) { bf[j] = (float)b[j]; dfl[j] = (float)d[j]; xxf[j] = (float)xx[j]; Lf[j] = (float)L[j]; }
     for (int64_t k = 0; k < n; k++) ef[k] = (float)e[k];
-    int rc = FN(oracle_kmup)(Xf, n, p, n, bf, dfl, xxf, ef, Lf, (float)Ve, (float)pi, seed, itx, rng_mode, stable);   /* wgr.R:85 */
+    int rc = FN(oracle_kmup)(Xf, n, p, n, bf, dfl, xxf, ef, Lf, (float)Ve, (float)pi, seed, itx, rng_mode, stable, 0u);   /* wgr.R:85 */
     if (rc) return rc;
     if (pi > 0) for (int64_t j = 0; j < p; j++) d[j] = (double)dfl[j];        /* wgr.R:86 */
     for (int64_t j = 0; j < p; j++) b[j] = (double)bf[j];                     /* wgr.R:87 */

@@ -75,7 +75,7 @@ def fvar(x, flavour="w"):
     return float(f(_fp(x), C.c_int64(x.size)))
 
 
-def kmup(X, b, d, xx, e, L, Ve, pi, seed=1, it=0, rng_mode=0, stable=1, flavour="w", fast=False):
+def kmup(X, b, d, xx, e, L, Ve, pi, seed=1, it=0, rng_mode=0, stable=1, flavour="w", fast=False, marker0=0):
     """Reference KMUP(X,b,d,xx,e,L,Ve,pi) -> dict(b,d,e), src/Rcpp20260726ai.cpp:12-38."""
     Xf = as_f32_colmajor(X)
     n, p = Xf.shape
@@ -83,7 +83,7 @@ def kmup(X, b, d, xx, e, L, Ve, pi, seed=1, it=0, rng_mode=0, stable=1, flavour=
     xx = np.ascontiguousarray(xx, np.float32); L = np.ascontiguousarray(L, np.float32)
     rc = getattr(lib(fast), "oracle_kmup_" + flavour)(
         _fp(Xf), C.c_int64(n), C.c_int64(p), C.c_int64(n), _fp(b), _fp(d), _fp(xx), _fp(e), _fp(L),
-        C.c_float(Ve), C.c_float(pi), C.c_uint64(seed), C.c_uint32(it), C.c_int(rng_mode), C.c_int(stable))
+        C.c_float(Ve), C.c_float(pi), C.c_uint64(seed), C.c_uint32(it), C.c_int(rng_mode), C.c_int(stable), C.c_uint32(marker0))
     assert rc == 0
     return {"b": b, "d": d, "e": e}
 

@@ -139,3 +139,64 @@ def test_wgr_unbuilt_rows_raise(tpod):
         bwgr_amd.wgr(tpod["y"], tpod["gen"], it=5, bi=1, bag=0.5)
     with pytest.raises(NotImplementedError):
         bwgr_amd.wgr(tpod["y"], tpod["gen"], it=5, bi=1, eigK={"values": [1.0], "vectors": [[1.0]]})
+
+
+def test_sharded_entry_points_world1_equals_run(tpod):
+    """sweep_blocks over ranges + end_iteration == bwgr_chain_run (the G = 1 path of bwgr_amd/dist.py)."""
+    import bwgr_amd
+    X, y = tpod["gen"], tpod["y"]
+    P = bwgr_amd.Panel(X, block=32)
+    a = bwgr_amd.Chain(P, "BayesB", y, it=6, bi=1, pi=0.8, seed=3); a.run(6); sa = a.state()
+    b = bwgr_amd.Chain(P, "BayesB", y, it=6, bi=1, pi=0.8, seed=3)
+    for _ in range(6):
+        for lo in range(0, b.nblocks, 5):
+            b.sweep_blocks(lo, min(b.nblocks, lo + 5))
+        b.end_iteration(None)
+    sb = b.state()
+    for k in ("b", "d", "e", "vb"):
+        assert np.array_equal(sa[k], sb[k]), k
+    assert sa["ve"] == sb["ve"] and sa["mu"] == sb["mu"]
+    a.close(); b.close(); P.close()
+
+
+def test_two_shards_on_one_gpu_match_cpu_checker():
+    """Two marker shards ('ranks') in one process with a hand-rolled residual exchange, against the CPU checker engine
+    (tests/shard_checker.py) doing the same partitioned sampler: global marker ids, MSx_total, p_total, external e."""
+    import torch
+    import bwgr_amd
+    from bwgr_amd.dist import HipShardEngine, shard_bounds
+    from oracle import oracle as O
+    from shard_checker import OracleRREngine
+    X, y = synth_small(300, 160, seed=14, causal=0.2)
+    n, p = X.shape
+    msx = float(O.stats(X)[2])
+    spans = [shard_bounds(p, 2, r, 16) for r in range(2)]
+    panels = [bwgr_amd.Panel(np.asfortranarray(X[:, lo:hi]), block=16) for lo, hi in spans]
+    gpu = [HipShardEngine(panels[r], "BayesRR", y, 6, 0, 0.0, 5.0, 0.5, 41, spans[r][0], p, msx) for r in range(2)]
+    cpu = [OracleRREngine(X[:, lo:hi], y, lo, p, msx, 5.0, 0.5, 41, block=16) for lo, hi in spans]
+
+    def iteration(engs, bps):
+        nb = max(e.nblocks for e in engs)
+        for r in range(0, nb, bps):
+            e0 = [e.residual().clone() for e in engs]
+            for e in engs:
+                if r < e.nblocks:
+                    e.sweep_blocks(r, min(e.nblocks, r + bps))
+            delta = sum((e.residual() - z).cpu() for e, z in zip(engs, e0))
+            for e, z in zip(engs, e0):
+                e.set_residual(z + delta.to(z.device))
+        s = sum(e.sums().cpu() for e in engs)
+        for e in engs:
+            e.end_iteration(s)
+
+    for _ in range(6):
+        iteration(gpu, 2); iteration(cpu, 2)
+    for r in range(2):
+        st = gpu[r].chain.state()
+        assert scaled_err(st["b"], cpu[r].b) < 2e-5
+        assert scaled_err(gpu[r].e[:n].cpu().numpy(), cpu[r].e.numpy()) < 2e-5
+        assert _rel(st["ve"], cpu[r].ve) < 2e-5 and _rel(st["mu"], cpu[r].mu) < 2e-5
+    for g in gpu:
+        g.chain.close()
+    for P in panels:
+        P.close()
