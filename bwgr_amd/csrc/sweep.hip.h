@@ -565,12 +565,14 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
     }
     // ---- slab update e_i -= sum_j x_ij delta_j: rows x marker parts across the workgroup (fp64, x*delta exact) ----
     {
-      const int nparts = (R >= SW_THREADS) ? 1 : SW_THREADS / R;        // R in {128, 256, 512, ...}
+      const int nparts = (R >= SW_THREADS) ? 1 : SW_THREADS / R;        // R is a multiple of 128; threads beyond nparts*R idle
       const int per = (mB + nparts - 1) / nparts;
       for (int i0 = 0; i0 < R; i0 += SW_THREADS) {
-        const int i = i0 + (tid % R), part = (R >= SW_THREADS) ? 0 : tid / R;
+        const int part = (R >= SW_THREADS) ? 0 : tid / R;
+        const int i = (R >= SW_THREADS) ? i0 + tid : tid - part * R;
+        const bool active = (i < R) && (part < nparts);
         double acc = 0.0;
-        if (i < R) {
+        if (active) {
           const int ja = part * per, jb = min(mB, ja + per);
           const XT *tp = tile + i;
           int jj = ja;
@@ -583,9 +585,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
           }
           for (; jj < jb; ++jj) acc = fma((double)tp[(size_t)jj * Rp], (double)delta_s[jj], acc);
         }
-        if (nparts == 1) { if (i < R) e_s[i] -= acc; }
+        if (nparts == 1) { if (active) e_s[i] -= acc; }
         else {
-          part_s[part * R + i] = acc;     // nparts*R == SW_THREADS doubles <= part_s capacity (1024)
+          if (active) part_s[part * R + i] = acc;     // nparts*R <= SW_THREADS doubles <= part_s capacity (1024)
           __syncthreads();
           if (tid < R) { double t = 0.0; for (int q = 0; q < nparts; ++q) t += part_s[q * R + tid]; e_s[tid] -= t; }
         }

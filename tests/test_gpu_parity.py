@@ -200,3 +200,21 @@ def test_two_shards_on_one_gpu_match_cpu_checker():
         g.chain.close()
     for P in panels:
         P.close()
+
+
+@pytest.mark.parametrize("n,p,block,nwg", [(130, 70, 16, 0), (300, 200, 16, 0), (300, 200, 128, 0), (500, 150, 64, 0),
+                                           (700, 260, 128, 0), (700, 100, 48, 2), (1100, 300, 128, 0), (1100, 130, 32, 9)])
+@pytest.mark.parametrize("model", ["BayesA", "BayesB"])
+def test_geometry_sweep(model, n, p, block, nwg):
+    """Slab rows R in {128, 256, 384, 512}, 1..9 workgroups, ragged last block: every launch geometry the panel
+    heuristics can pick must give the oracle's chain."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = synth_small(n, p, seed=n + p)
+    P = bwgr_amd.Panel(X, block=block, nwg=nwg)
+    ch = bwgr_amd.Chain(P, model, y, it=5, bi=1, pi=0.8, seed=8)
+    ch.run(5)
+    st = ch.state()
+    o = O.bayes(model, y, X, it=5, bi=1, pi=0.8, seed=8)["last"]
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL, (P.nwg, P.slab_rows)
+    ch.close(); P.close()
