@@ -1,0 +1,30 @@
+# rshim/bwgr_hip.R -- R front-end over rshim/bwgr_shim.c: same names, argument order, defaults and return lists as
+# R/RcppExports.R:4-6,48-74 and R/wgr.R:2-8, so that sourcing this file after library(bWGR) switches the Gibbs hot path to
+# the MI355X engine.  SOURCE ONLY (no R in the build image; see INTEGRATION.md).
+# dyn.load("bwgrhip.so")
+
+.bwgr_panel <- function(X, device = 0L) if (inherits(X, "externalptr")) X else .Call("bwgrhip_panel", X, as.integer(device))
+.bwgr_iter <- local({ i <- -1L; function() { i <<- i + 1L; i } })   # iteration word of the RNG counter for bare KMUP calls
+
+KMUP <- function(X, b, d, xx, e, L, Ve, pi) .Call("bwgrhip_KMUP", .bwgr_panel(X), as.double(b), as.double(d), as.double(xx), as.double(e), as.double(L), as.double(Ve), as.double(pi), .bwgr_iter())
+
+.bwgr_fused <- function(model, y, X, it, bi, pi, df, R2) .Call("bwgrhip_Bayes", as.integer(model), as.double(y), .bwgr_panel(X), as.double(it), as.double(bi), as.double(pi), as.double(df), as.double(R2))
+BayesA   <- function(y, X, it = 1500, bi = 500, df = 5, R2 = 0.5) .bwgr_fused(0L, y, X, it, bi, 0, df, R2)
+BayesB   <- function(y, X, it = 1500, bi = 500, pi = 0.95, df = 5, R2 = 0.5) .bwgr_fused(1L, y, X, it, bi, pi, df, R2)
+BayesC   <- function(y, X, it = 1500, bi = 500, pi = 0.95, df = 5, R2 = 0.5) .bwgr_fused(2L, y, X, it, bi, pi, df, R2)
+BayesL   <- function(y, X, it = 1500, bi = 500, df = 5, R2 = 0.5) .bwgr_fused(3L, y, X, it, bi, 0, df, R2)
+BayesRR  <- function(y, X, it = 1500, bi = 500, df = 5, R2 = 0.5) .bwgr_fused(4L, y, X, it, bi, 0, df, R2)
+BayesCpi <- function(y, X, it = 1500, bi = 500, df = 5, R2 = 0.5) .bwgr_fused(5L, y, X, it, bi, 0, df, R2)
+BayesDpi <- function(y, X, it = 1500, bi = 500, df = 5, R2 = 0.5) .bwgr_fused(6L, y, X, it, bi, 0, df, R2)
+
+wgr <- function(y, X, it = 1500, bi = 500, th = 1, bag = 1, rp = FALSE, iv = FALSE, de = FALSE, pi = 0, df = 5, R2 = 0.5,
+                eigK = NULL, VarK = 0.95, verb = FALSE) {
+  if (bag != 1 || !is.null(eigK)) stop("bag != 1 (KMUP2) and eigK are not built in the MI355X engine yet; call bWGR::wgr")
+  if (anyNA(X)) {                       # R/wgr.R:12-18
+    imp <- function(x) { x[is.na(x)] <- mean(x, na.rm = TRUE); x[is.nan(x)] <- 0; x }
+    X <- apply(X, 2, imp)
+  }
+  if (anyNA(y)) { mis <- which(is.na(y)); y <- y[-mis]; X <- X[-mis, ] }   # R/wgr.R:34-39
+  .Call("bwgrhip_wgr", as.double(y), .bwgr_panel(X), as.integer(it), as.integer(bi), as.integer(th), as.logical(iv), as.logical(de),
+        as.double(pi), as.double(df), as.double(R2))
+}
