@@ -62,13 +62,13 @@ __device__ __forceinline__ float xval(const float *X, int64_t i) { return X[i]; 
 
 // ---- upload conversion: src (n x p, ldx) -> X (ld x p), zero padded rows ----
 template <typename ST, typename XT>
-__global__ void k_convert(const ST *src, int64_t ldx, XT *X, int64_t ld, int n, int64_t j0, int64_t ncols) {
+__global__ void k_convert(const ST *src, int64_t ldx, XT *X, int64_t ld, int n, int64_t j0, int64_t ncols, int R, int64_t p) {
   const int64_t total = ncols * ld;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t jj = idx / ld, i = idx - jj * ld;
     XT v = (XT)0;
     if (i < n) v = (XT)src[jj * ldx + i];
-    X[(j0 + jj) * ld + i] = v;
+    X[xoff(i, j0 + jj, R, p)] = v;
   }
 }
 
@@ -81,18 +81,17 @@ __global__ void k_d2f(const double *src, float *dst, int64_t n) {
 
 // ---- a10: xx[j] = |X_j|^2, vx[j] = fvar(X_j)   (src/Rcpp20260726ai.cpp:7-9, 593-597); one wave per column ----
 template <typename XT>
-__global__ void k_stats(const XT *X, int64_t ld, int n, int p, float *xx, float *vx) {
+__global__ void k_stats(const XT *X, int R, int n, int p, float *xx, float *vx) {
   const int lane = threadIdx.x & 63;
   const int64_t j = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (j >= p) return;
-  const XT *xj = X + j * ld;
   double s1 = 0, s2 = 0;
-  for (int i = lane; i < n; i += 64) { const float v = xval(xj, i); s1 += (double)v; s2 += (double)v * (double)v; }
+  for (int i = lane; i < n; i += 64) { const float v = xval(X, xoff(i, j, R, p)); s1 += (double)v; s2 += (double)v * (double)v; }
   s1 = wave_sum(s1); s2 = wave_sum(s2);
   s1 = __shfl(s1, 0, 64); s2 = __shfl(s2, 0, 64);
   const float mean = (float)(s1 / (double)n);
   double sv = 0;
-  for (int i = lane; i < n; i += 64) { const float dev = xval(xj, i) - mean; const float sq = dev * dev; sv += (double)sq; }
+  for (int i = lane; i < n; i += 64) { const float dev = xval(X, xoff(i, j, R, p)) - mean; const float sq = dev * dev; sv += (double)sq; }
   sv = wave_sum(sv);
   if (lane == 0) { xx[j] = (float)s2; vx[j] = (float)(sv / (double)(float)(n - 1)); }
 }
@@ -116,7 +115,7 @@ __global__ void k_sum_stage2(const double *part, int nparts, float *out_f) {
 // ---- block-diagonal Gram G_B = X_B' X_B (setup; exact int32 for int8 genotypes) ----
 // 256 threads as a 16 x 16 grid, thread (tj,tk) owns G[tj+16a][tk+16c], a,c < m/16.
 template <int TJ>
-__global__ __launch_bounds__(256) void k_gram_i8(const int8_t *X, int64_t ld, int p, int m, int32_t *gram) {
+__global__ __launch_bounds__(256) void k_gram_i8(const int8_t *X, int64_t ld, int R, int p, int m, int32_t *gram) {
   constexpr int RC = 128, RW = RC / 4 + 1;  // rows per chunk, dwords per column in LDS (padded)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t *tile = reinterpret_cast<int32_t *>(smem);
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(256) void k_gram_i8(const int8_t *X, int64_t ld, in
     for (int c = threadIdx.x; c < m * (RC / 4); c += 256) {
       const int jj = c / (RC / 4), w = c - jj * (RC / 4);
       int32_t v = 0;
-      if (jj < mB) v = *reinterpret_cast<const int32_t *>(X + (int64_t)(j0 + jj) * ld + r0 + 4 * w);
+      if (jj < mB) v = *reinterpret_cast<const int32_t *>(X + xoff(r0 + 4 * w, j0 + jj, R, p));
       tile[jj * RW + w] = v;
     }
     __syncthreads();
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(256) void k_gram_i8(const int8_t *X, int64_t ld, in
 }
 
 template <int TJ>
-__global__ __launch_bounds__(256) void k_gram_f32(const float *X, int64_t ld, int p, int m, double *gram) {
+__global__ __launch_bounds__(256) void k_gram_f32(const float *X, int64_t ld, int R, int p, int m, double *gram) {
   constexpr int RC = 64, RW = RC + 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *tile = reinterpret_cast<float *>(smem);
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(256) void k_gram_f32(const float *X, int64_t ld, in
     __syncthreads();
     for (int c = threadIdx.x; c < m * RC; c += 256) {
       const int jj = c / RC, w = c - jj * RC;
-      tile[jj * RW + w] = (jj < mB) ? X[(int64_t)(j0 + jj) * ld + r0 + w] : 0.0f;
+      tile[jj * RW + w] = (jj < mB) ? X[xoff(r0 + w, j0 + jj, R, p)] : 0.0f;
     }
     __syncthreads();
     for (int w = 0; w < RC; ++w) {
@@ -304,7 +303,7 @@ __global__ void k_final_markers(float *B, float *D, float *VB, float *pval, int 
 }
 // partial[c][i] = sum_{j in column chunk c} x_ij * coef_j   (fp64), 4 rows per thread
 template <typename XT, typename CT>
-__global__ __launch_bounds__(256) void k_gemv_part(const XT *X, int64_t ld, int p, const CT *coef, int cols_per_chunk, double *part) {
+__global__ __launch_bounds__(256) void k_gemv_part(const XT *X, int64_t ld, int R, int p, const CT *coef, int cols_per_chunk, double *part) {
   const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i0 >= ld) return;
   const int c = blockIdx.y;
@@ -313,7 +312,7 @@ __global__ __launch_bounds__(256) void k_gemv_part(const XT *X, int64_t ld, int 
   for (int j = ja; j < jb; ++j) {
     const double cj = (double)coef[j];
     if (cj == 0.0) continue;
-    const XT *xp = X + (int64_t)j * ld + i0;
+    const XT *xp = X + xoff(i0, j, R, p);
     float x0, x1, x2, x3;
     if constexpr (sizeof(XT) == 1) {
       const uint32_t w = *reinterpret_cast<const uint32_t *>(xp);
@@ -343,18 +342,17 @@ struct WgrScalars {
 };
 // per-column double statistics as R computes them: xx = crossprod, var = sum((x-mean)^2)/(n-1); one wave per column
 template <typename XT>
-__global__ void k_stats64(const XT *X, int64_t ld, int n, int p, double *xx, double *vx) {
+__global__ void k_stats64(const XT *X, int R, int n, int p, double *xx, double *vx) {
   const int lane = threadIdx.x & 63;
   const int64_t j = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (j >= p) return;
-  const XT *xj = X + j * ld;
   double s1 = 0, s2 = 0;
-  for (int i = lane; i < n; i += 64) { const double v = (double)xval(xj, i); s1 += v; s2 = fma(v, v, s2); }
+  for (int i = lane; i < n; i += 64) { const double v = (double)xval(X, xoff(i, j, R, p)); s1 += v; s2 = fma(v, v, s2); }
   s1 = wave_sum(s1); s2 = wave_sum(s2);
   s1 = __shfl(s1, 0, 64); s2 = __shfl(s2, 0, 64);
   const double mean = s1 / (double)n;
   double sv = 0;
-  for (int i = lane; i < n; i += 64) { const double dev = (double)xval(xj, i) - mean; sv = fma(dev, dev, sv); }
+  for (int i = lane; i < n; i += 64) { const double dev = (double)xval(X, xoff(i, j, R, p)) - mean; sv = fma(dev, dev, sv); }
   sv = wave_sum(sv);
   if (lane == 0) { xx[j] = s2; vx[j] = sv / (double)(n - 1); }
 }
@@ -578,7 +576,7 @@ static int require_device(int device) {
 template <typename XT> static int max_slab_rows(int m) {
   int best = 0;
   for (int R = 128; R <= 4096; R += 128)
-    if (sweep_lds_bytes<XT>(m, R) <= (size_t)160 * 1024) best = R;
+    if (sweep_lds_bytes<XT>(m, R) <= (size_t)160 * 1024 && (size_t)m * R * sizeof(XT) <= (size_t)SW_TCH * 16 * (SW_THREADS - 64)) best = R;
   return best;
 }
 
@@ -622,7 +620,7 @@ static int upload(bwgr_panel *P, const void *X, int memloc, int64_t ldx) {
   const int64_t n = P->n, p = P->p;
   XT *dst = reinterpret_cast<XT *>(P->X);
   if (memloc == BWGR_DEVICE) {
-    hipLaunchKernelGGL((k_convert<ST, XT>), dim3(4096), dim3(256), 0, P->stream, reinterpret_cast<const ST *>(X), ldx, dst, P->ld, (int)n, (int64_t)0, p);
+    hipLaunchKernelGGL((k_convert<ST, XT>), dim3(4096), dim3(256), 0, P->stream, reinterpret_cast<const ST *>(X), ldx, dst, P->ld, (int)n, (int64_t)0, p, P->R, p);
     HIPCHK(hipGetLastError());
     return BWGR_OK;
   }
@@ -638,7 +636,7 @@ static int upload(bwgr_panel *P, const void *X, int memloc, int64_t ldx) {
     const size_t bytes = (size_t)((nc - 1) * col_bytes + n * (int64_t)sizeof(ST));
     hipError_t e = hipMemcpyAsync(stage, reinterpret_cast<const ST *>(X) + j0 * ldx, bytes, hipMemcpyHostToDevice, P->stream);
     if (e != hipSuccess) { hipFree(stage); return fail(BWGR_EHIP, "upload memcpy failed: %s", hipGetErrorString(e)); }
-    hipLaunchKernelGGL((k_convert<ST, XT>), dim3(2048), dim3(256), 0, P->stream, stage, ldx, dst, P->ld, (int)n, j0, nc);
+    hipLaunchKernelGGL((k_convert<ST, XT>), dim3(2048), dim3(256), 0, P->stream, stage, ldx, dst, P->ld, (int)n, j0, nc, P->R, p);
     e = hipStreamSynchronize(P->stream);
     if (e != hipSuccess) { hipFree(stage); return fail(BWGR_EHIP, "upload convert failed: %s", hipGetErrorString(e)); }
   }
@@ -659,8 +657,8 @@ static int panel_setup(bwgr_panel *P) {
   const int p = (int)P->p, n = (int)P->n;
   // a10: xx, vx, MSx
   const int wpb = 4;
-  if (P->is_f32) hipLaunchKernelGGL(k_stats<float>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const float *)P->X, P->ld, n, p, P->xx, P->vx);
-  else hipLaunchKernelGGL(k_stats<int8_t>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const int8_t *)P->X, P->ld, n, p, P->xx, P->vx);
+  if (P->is_f32) hipLaunchKernelGGL(k_stats<float>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const float *)P->X, P->R, n, p, P->xx, P->vx);
+  else hipLaunchKernelGGL(k_stats<int8_t>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const int8_t *)P->X, P->R, n, p, P->xx, P->vx);
   HIPCHK(hipGetLastError());
   {
     const int nparts = 256;
@@ -679,23 +677,23 @@ static int panel_setup(bwgr_panel *P) {
     const size_t lds = (size_t)m * 65 * sizeof(float);
     double *g = (double *)P->gram; const float *X = (const float *)P->X;
     switch (TJ) {
-      case 1: hipLaunchKernelGGL(k_gram_f32<1>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
-      case 2: hipLaunchKernelGGL(k_gram_f32<2>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
-      case 3: hipLaunchKernelGGL(k_gram_f32<3>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
-      default: hipLaunchKernelGGL(k_gram_f32<4>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+      case 1: hipLaunchKernelGGL(k_gram_f32<1>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+      case 2: hipLaunchKernelGGL(k_gram_f32<2>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+      case 3: hipLaunchKernelGGL(k_gram_f32<3>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+      default: hipLaunchKernelGGL(k_gram_f32<4>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
     }
   } else {
     const size_t lds = (size_t)m * 33 * sizeof(int32_t);
     int32_t *g = (int32_t *)P->gram; const int8_t *X = (const int8_t *)P->X;
     switch (TJ) {
-      case 1: hipLaunchKernelGGL(k_gram_i8<1>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
-      case 2: hipLaunchKernelGGL(k_gram_i8<2>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
-      case 3: hipLaunchKernelGGL(k_gram_i8<3>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
-      case 4: hipLaunchKernelGGL(k_gram_i8<4>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
-      case 5: hipLaunchKernelGGL(k_gram_i8<5>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
-      case 6: hipLaunchKernelGGL(k_gram_i8<6>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
-      case 7: hipLaunchKernelGGL(k_gram_i8<7>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
-      default: hipLaunchKernelGGL(k_gram_i8<8>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, p, m, g); break;
+      case 1: hipLaunchKernelGGL(k_gram_i8<1>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+      case 2: hipLaunchKernelGGL(k_gram_i8<2>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+      case 3: hipLaunchKernelGGL(k_gram_i8<3>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+      case 4: hipLaunchKernelGGL(k_gram_i8<4>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+      case 5: hipLaunchKernelGGL(k_gram_i8<5>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+      case 6: hipLaunchKernelGGL(k_gram_i8<6>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+      case 7: hipLaunchKernelGGL(k_gram_i8<7>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+      default: hipLaunchKernelGGL(k_gram_i8<8>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
     }
   }
   HIPCHK(hipGetLastError());
@@ -744,8 +742,8 @@ extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int
   PCHK(hipMalloc(&P->xflags, sizeof(uint32_t) * ((size_t)K + 1) * SW_FLAG_STRIDE));
   PCHK(hipMalloc(&P->ps.blocks, sizeof(StageBuf) * (size_t)P->nblocks));
 #ifdef BWGR_STAMPS
-  PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 8));
-  PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 8));
+  PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 12));
+  PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 12));
 #endif
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<int8_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<int8_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -764,9 +762,9 @@ extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int
 
 #ifdef BWGR_STAMPS
 // diagnostic build only: cumulative per-phase s_memtime ticks of workgroup 0 (not part of include/bwgr.h)
-extern "C" int bwgr_debug_stamps(bwgr_panel *P, unsigned long long out[8]) {
-  HIPCHK(hipMemcpy(out, P->stamps, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 8));
+extern "C" int bwgr_debug_stamps(bwgr_panel *P, unsigned long long out[12]) {
+  HIPCHK(hipMemcpy(out, P->stamps, sizeof(unsigned long long) * 12, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 12));
   return BWGR_OK;
 }
 #endif
@@ -1029,8 +1027,8 @@ static int gemv_hat(bwgr_panel *P, const CT *coef_dev, float MU, float *hat_dev)
   double *part = nullptr;
   HIPCHK(hipMalloc(&part, sizeof(double) * (size_t)nchunks * P->ld));
   dim3 grid((unsigned)((P->ld / 4 + 255) / 256), (unsigned)nchunks);
-  if (P->is_f32) hipLaunchKernelGGL((k_gemv_part<float, CT>), grid, dim3(256), 0, P->stream, (const float *)P->X, P->ld, (int)P->p, coef_dev, cpc, part);
-  else hipLaunchKernelGGL((k_gemv_part<int8_t, CT>), grid, dim3(256), 0, P->stream, (const int8_t *)P->X, P->ld, (int)P->p, coef_dev, cpc, part);
+  if (P->is_f32) hipLaunchKernelGGL((k_gemv_part<float, CT>), grid, dim3(256), 0, P->stream, (const float *)P->X, P->ld, P->R, (int)P->p, coef_dev, cpc, part);
+  else hipLaunchKernelGGL((k_gemv_part<int8_t, CT>), grid, dim3(256), 0, P->stream, (const int8_t *)P->X, P->ld, P->R, (int)P->p, coef_dev, cpc, part);
   hipLaunchKernelGGL(k_hat_finish, dim3((unsigned)((P->n + 255) / 256)), dim3(256), 0, P->stream, part, P->ld, nchunks, (int)P->n, MU, hat_dev);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(P->stream));
@@ -1113,8 +1111,8 @@ static int gemv_parts(bwgr_panel *P, const CT *coef_dev, double **part_out, int 
   double *part = *part_out;
   if (!part) HIPCHK(hipMalloc(&part, sizeof(double) * (size_t)nchunks * P->ld));
   dim3 grid((unsigned)((P->ld / 4 + 255) / 256), (unsigned)nchunks);
-  if (P->is_f32) hipLaunchKernelGGL((k_gemv_part<float, CT>), grid, dim3(256), 0, P->stream, (const float *)P->X, P->ld, (int)P->p, coef_dev, cpc, part);
-  else hipLaunchKernelGGL((k_gemv_part<int8_t, CT>), grid, dim3(256), 0, P->stream, (const int8_t *)P->X, P->ld, (int)P->p, coef_dev, cpc, part);
+  if (P->is_f32) hipLaunchKernelGGL((k_gemv_part<float, CT>), grid, dim3(256), 0, P->stream, (const float *)P->X, P->ld, P->R, (int)P->p, coef_dev, cpc, part);
+  else hipLaunchKernelGGL((k_gemv_part<int8_t, CT>), grid, dim3(256), 0, P->stream, (const int8_t *)P->X, P->ld, P->R, (int)P->p, coef_dev, cpc, part);
   HIPCHK(hipGetLastError());
   *part_out = part; *nchunks_out = nchunks;
   return BWGR_OK;
@@ -1151,8 +1149,8 @@ extern "C" int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, 
   {
     WCHK(hipMemcpyAsync(yd, y, sizeof(double) * n, hipMemcpyHostToDevice, P->stream));
     const int wpb = 4;
-    if (P->is_f32) hipLaunchKernelGGL(k_stats64<float>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const float *)P->X, P->ld, n, p, xx64, vx64);
-    else hipLaunchKernelGGL(k_stats64<int8_t>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const int8_t *)P->X, P->ld, n, p, xx64, vx64);
+    if (P->is_f32) hipLaunchKernelGGL(k_stats64<float>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const float *)P->X, P->R, n, p, xx64, vx64);
+    else hipLaunchKernelGGL(k_stats64<int8_t>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const int8_t *)P->X, P->R, n, p, xx64, vx64);
     hipLaunchKernelGGL(k_dsum_stage1, dim3(256), dim3(256), 0, P->stream, vx64, (int64_t)p, part1, 0);
     hipLaunchKernelGGL(k_dsum_stage1, dim3(256), dim3(256), 0, P->stream, xx64, (int64_t)p, part2, 0);
     hipLaunchKernelGGL(k_wgr_init, dim3(1), dim3(1024), 0, P->stream, yd, eR, n, P->ld, part1, part2, p, df, R2, ws);

@@ -60,7 +60,7 @@ struct PreStage {
 };
 
 struct SweepArgs {
-  const void *X; int64_t ld;    // column-major, ld = K*R rows (zero padded)
+  const void *X; int64_t ld;    // slab-major: element (row i, marker j) at ((i/R)*p + j)*R + i%R; ld = K*R padded rows
   const void *gram;             // [nblocks][m][m]
   int n, p, m, K, R;
   int blk_begin, blk_end;
@@ -99,8 +99,8 @@ template <typename XT> __host__ __device__ inline size_t sweep_lds_bytes(int m, 
   s += (size_t)R * sizeof(double);                             // e slab
   s += 2 * sizeof(StageBuf);
   s += (size_t)(SW_THREADS / 64) * SW_MAXM * sizeof(double);   // row-group partials (up to 8 groups)
-  s += 3 * SW_MAXM * sizeof(double);                           // r0, speculative correction s, Gram diagonal
-  s += 3 * SW_MAXM * sizeof(float);                            // delta, bnew, dnew
+  s += 4 * SW_MAXM * sizeof(double);                           // r0, speculative correction s, Gram diagonal, delta
+  s += 2 * SW_MAXM * sizeof(float);                            // bnew, dnew
   s += 64;                                                     // control words
   return s;
 }
@@ -123,35 +123,29 @@ __device__ __forceinline__ double ld_agent_f64(const double *p) {
                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-// cooperative copy of one block's slab tile X[rows of wg, markers j0..j0+mB) into LDS; loads are issued in
-// batches of 8 per thread before any is stored, so a thread pays one HBM latency per batch, not per chunk
-template <typename XT>
-__device__ inline void load_tile(XT *tile, const XT *X, int64_t ld, int row0, int R, int Rp, int j0, int mB,
-                                 int tid0, int nthreads) {
-  constexpr int PER = XTraits<XT>::PER16;
-  constexpr int BATCH = 8;
-  const int cpr = R / PER;  // 16-byte chunks per marker
-  const int total = mB * cpr;
-  for (int cb = tid0; cb < total; cb += BATCH * nthreads) {
-    uint4 v[BATCH];
-#pragma unroll
-    for (int u = 0; u < BATCH; ++u) {
-      const int c = cb + u * nthreads;
-      if (c < total) {
-        const int jj = c / cpr, ii = c - jj * cpr;
-        v[u] = *reinterpret_cast<const uint4 *>(X + (int64_t)(j0 + jj) * ld + row0 + ii * PER);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < BATCH; ++u) {
-      const int c = cb + u * nthreads;
-      if (c < total) {
-        const int jj = c / cpr, ii = c - jj * cpr;
-        *reinterpret_cast<uint4 *>(tile + (size_t)jj * Rp + ii * PER) = v[u];
-      }
-    }
-  }
+// slab-major addressing of the resident panel: workgroup w's rows of marker j are the contiguous run
+// X[(w*p + j)*R .. +R), so a block's tile is ONE contiguous mB*R run (one DRAM/TLB page stream per workgroup)
+__host__ __device__ inline size_t xoff(int64_t i, int64_t j, int R, int64_t p) {
+  const int64_t w = i / R;
+  return (size_t)((w * p + j) * R + (i - w * R));
 }
+
+// cooperative copy of one block's slab tile into LDS (marker-major, padded rows), split in two halves so that the
+// loads of block s+2 can be in flight (in registers) during the whole of block s+1: first-touch HBM latency on an
+// almost idle fabric is ~3 us, a block period is ~10 us.  SW_TCH chunks of 16 B per thread bound the tile size
+// (checked on the host: m*R*sizeof(x) <= SW_TCH*16*(SW_THREADS-64)).
+static constexpr int SW_TCH = 5;
+// Plain scalar locals tp0..tp4 (an aggregate here ends up in scratch memory).  TILE_ISSUE(j0, mB) starts the loads of
+// the tile of block [j0, j0+mB); TILE_COMMIT(dst, mB) stores them to LDS.  Both use the prefetch waves' numbering.
+#define BWGR_TILE_EACH(X) X(0, tp0) X(1, tp1) X(2, tp2) X(3, tp3) X(4, tp4)
+#define BWGR_ISSUE1(u, name) { const int c_ = (tid - 64) + (u) * (SW_THREADS - 64); if (c_ < tot_) name = src_[c_]; }
+#define TILE_ISSUE(j0_, mB_) do { const int tot_ = (mB_) * (R / PER); \
+    const uint4 *src_ = reinterpret_cast<const uint4 *>(X + (size_t)(j0_) * R); BWGR_TILE_EACH(BWGR_ISSUE1) } while (0)
+#define BWGR_COMMIT1(u, name) { const int c_ = (tid - 64) + (u) * (SW_THREADS - 64); if (c_ < tot_) { \
+    const int jj_ = (int)(((float)c_ + 0.5f) * rcpr_), ii_ = c_ - jj_ * cpr_;   /* exact: c < 2^14 */ \
+    *reinterpret_cast<uint4 *>((dst_) + (size_t)jj_ * Rp + ii_ * PER) = name; } }
+#define TILE_COMMIT(dstp, mB_) do { XT *dst_ = (dstp); const int cpr_ = R / PER; const int tot_ = (mB_) * cpr_; \
+    const float rcpr_ = 1.0f / (float)cpr_; BWGR_TILE_EACH(BWGR_COMMIT1) } while (0)
 
 // k_prestage: one thread per (marker, piece); piece 0: in-model normal, 1: alternative normal, 2: Bernoulli uniform,
 // 3: chi-square.  Restates the per-marker scalar set-up of src/Rcpp20260726ai.cpp:20-21 / :615-617 / :670-680.
@@ -271,12 +265,12 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
   double *r0_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
   double *spec_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
   double *gdiag_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
-  float *delta_s = reinterpret_cast<float *>(smem + off); off += SW_MAXM * sizeof(float);
+  double *delta_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
   float *bnew_s = reinterpret_cast<float *>(smem + off); off += SW_MAXM * sizeof(float);
   float *dnew_s = reinterpret_cast<float *>(smem + off); off += SW_MAXM * sizeof(float);
   volatile int *ctrl_s = reinterpret_cast<volatile int *>(smem + off);
 
-  const XT *X = reinterpret_cast<const XT *>(a.X);
+  const XT *X = reinterpret_cast<const XT *>(a.X) + (size_t)wg * a.p * R;   // this workgroup's slab stream
   const GT *gram = reinterpret_cast<const GT *>(a.gram);
 
   // scalars of this iteration
@@ -289,6 +283,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
   const int rows_per_group = R / ngroups;    // R is a multiple of 128, so a multiple of 16
   const int gchunks = m * m / GPT;           // 16-byte chunks of one Gram block
 
+  uint4 tp0 = make_uint4(0, 0, 0, 0), tp1 = tp0, tp2 = tp0, tp3 = tp0, tp4 = tp0;   // tile prefetch registers
   for (int i = tid; i < R; i += SW_THREADS) e_s[i] = a.e[row0 + i];
   if (tid == 0) ctrl_s[0] = 1;
 
@@ -311,7 +306,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
   {
     const int j0 = a.blk_begin * m;
     const int mB = min(m, a.p - j0);
-    load_tile<XT>(tile0, X, a.ld, row0, R, Rp, j0, mB, tid, SW_THREADS);
+    if (wave != 0) { TILE_ISSUE(j0, mB); TILE_COMMIT(tile0, mB); }
     stage_block(stage[0], a.blk_begin, a, tid, SW_THREADS);
     const GT *gsrc = gram + (size_t)a.blk_begin * m * m;
     for (int c = tid; c < gchunks; c += SW_THREADS) {
@@ -329,8 +324,12 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
     spec_matvec(stage[0], mB);
   }
   double sum_d = 0.0, sum_b2 = 0.0;  // meaningful in wave 0 only
+  if (wave != 0 && nb > 1) {          // prefetch waves: tile of block s+1 in flight, committed during block s
+    const int j1 = (a.blk_begin + 1) * m;
+    TILE_ISSUE(j1, min(m, a.p - j1));
+  }
 #ifdef BWGR_STAMPS
-  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+  unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
 
   for (int s = 0; s < nb; ++s) {
@@ -426,16 +425,24 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
         if (tid == 0) a.sc->error = 1u;
         return;
       }
-      if (tid < mB) {   // fixed summation order w = 0..K-1; loads issued 8 at a time
-        double r = 0.0;
-        for (int w0 = 0; w0 < K; w0 += 8) {
-          double v[8];
+      {   // 4 threads per marker, each gathers a quarter of the workgroups (<= 16 loads in one batch, fixed order);
+          // quarters are combined in a fixed order too, so every workgroup forms the same bits
+        const int qd = tid >> 7, t = tid & 127;
+        const int wq = (K + 3) >> 2;
+        for (int wbase = 0; wbase < wq; wbase += 16) {
+          double v[16];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = (w0 + u < K) ? ld_agent_f64(slot + (size_t)(w0 + u) * SW_MAXM + tid) : 0.0;
+          for (int u = 0; u < 16; ++u) {
+            const int w = qd * wq + wbase + u;
+            v[u] = (t < mB && wbase + u < wq && w < K) ? ld_agent_f64(slot + (size_t)w * SW_MAXM + t) : 0.0;
+          }
+          double r = 0.0;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) r += v[u];
+          for (int u = 0; u < 16; ++u) r += v[u];
+          if (wbase == 0) part_s[qd * SW_MAXM + t] = r; else part_s[qd * SW_MAXM + t] += r;
         }
-        r0_s[tid] = r;
+        __syncthreads();
+        if (tid < mB) r0_s[tid] = (part_s[tid] + part_s[SW_MAXM + tid]) + (part_s[2 * SW_MAXM + tid] + part_s[3 * SW_MAXM + tid]);
       }
     } else {
       if (tid < mB) r0_s[tid] = mine;
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
           const bool inc = SELECT ? (((accmask[q] >> lane) & 1ull) != 0ull) : true;
           const float bn = inc ? b1 : lc[q].b2;
           const float dn = inc ? 1.0f : 0.0f;
-          delta_s[t] = bn - lc[q].b0; bnew_s[t] = bn; dnew_s[t] = dn;
+          delta_s[t] = (double)(bn - lc[q].b0); bnew_s[t] = bn; dnew_s[t] = dn;
           sum_d += (double)dn;
           sum_b2 = fma((double)bn, (double)bn, sum_b2);
         }
@@ -523,18 +530,37 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
         const int j1 = j0 + m;
         const int mB1 = min(m, a.p - j1);
         const GT *gsrc = gram + (size_t)(blk + 1) * m * m;
+#ifdef BWGR_STAMPS
+        unsigned long long w1t0 = 0;
+        if (tid == 64) w1t0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
         for (int k = 0; k < GCH; ++k) {
           const int c = (tid - 64) + k * (SW_THREADS - 64);
           if (c < gchunks) *reinterpret_cast<uint4 *>(gpre[k]) = *reinterpret_cast<const uint4 *>(gsrc + (size_t)c * GPT);
         }
+#ifdef BWGR_STAMPS
+        if (tid == 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[10] += t_ - w1t0; }
+#endif
         // constants of the next block: load issued before the tile's loads are consumed (one latency, not two)
         constexpr int NCH = (int)(sizeof(StageBuf) / 16);
         static_assert(NCH <= SW_THREADS - 64, "one StageBuf chunk per prefetch thread");
         uint4 spre = make_uint4(0, 0, 0, 0);
         if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 1)[tid - 64];
-        load_tile<XT>(tile_next, X, a.ld, row0, R, Rp, j1, mB1, tid - 64, SW_THREADS - 64);
+#ifdef BWGR_STAMPS
+        if (tid == 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[11] += t_ - w1t0; }
+#endif
+        TILE_COMMIT(tile_next, mB1);                                                     // issued one block ago
+        if (s + 2 < nb) { const int j2 = j1 + m; TILE_ISSUE(j2, min(m, a.p - j2)); }
         if (tid - 64 < NCH) reinterpret_cast<uint4 *>(&stage[buf ^ 1])[tid - 64] = spre;
+#ifdef BWGR_STAMPS
+        if (tid == 64) {
+          const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+          ph[8] += t1 - w1t0; ph[9] += t2 - t1;
+        }
+#endif
       }
     }
     __syncthreads();
@@ -563,10 +589,15 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
         }
       }
     }
-    // ---- slab update e_i -= sum_j x_ij delta_j: rows x marker parts across the workgroup (fp64, x*delta exact) ----
+    __syncthreads();   // gram_s / gdiag_s of the next block and stage[buf^1] are complete
+    // ---- slab update e_i -= sum_j x_ij delta_j (rows x marker parts, fp64, x*delta exact) fused with the next block's
+    //      speculative correction spec[j] = sum_{k<j} G_kj * drej_k (SELECT): one pass, one reduction barrier ----
     {
       const int nparts = (R >= SW_THREADS) ? 1 : SW_THREADS / R;        // R is a multiple of 128; threads beyond nparts*R idle
       const int per = (mB + nparts - 1) / nparts;
+      double *upd_s = part_s;                                           // nparts*R <= 512 doubles
+      double *spp_s = part_s + (SW_THREADS / 64) * SW_MAXM / 2;         // 4 x 128 doubles
+      const int mBn = have_next ? min(m, a.p - (j0 + m)) : 0;
       for (int i0 = 0; i0 < R; i0 += SW_THREADS) {
         const int part = (R >= SW_THREADS) ? 0 : tid / R;
         const int i = (R >= SW_THREADS) ? i0 + tid : tid - part * R;
@@ -577,27 +608,37 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
           const XT *tp = tile + i;
           int jj = ja;
           for (; jj + 8 <= jb; jj += 8) {
-            double xv[8]; float dv[8];
+            double xv[8], dv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { xv[u] = (double)tp[(size_t)(jj + u) * Rp]; dv[u] = delta_s[jj + u]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fma(xv[u], (double)dv[u], acc);
+            for (int u = 0; u < 8; ++u) acc = fma(xv[u], dv[u], acc);
           }
-          for (; jj < jb; ++jj) acc = fma((double)tp[(size_t)jj * Rp], (double)delta_s[jj], acc);
+          for (; jj < jb; ++jj) acc = fma((double)tp[(size_t)jj * Rp], delta_s[jj], acc);
         }
-        if (nparts == 1) { if (active) e_s[i] -= acc; }
+        if (SELECT && i0 == 0 && have_next) {
+          const StageBuf &stn = stage[buf ^ 1];
+          const int sp = tid >> 7, j = tid & 127;
+          if (j < mBn) {
+            double sa = 0.0;
+            const int k0 = sp * 32, k1 = min(k0 + 32, min(j, mBn));
+            for (int k = k0; k < k1; ++k) sa = fma((double)gram_s[(size_t)k * m + j], (double)stn.drej[k], sa);
+            spp_s[sp * SW_MAXM + j] = sa;
+          }
+        }
+        if (nparts == 1 && !(SELECT && i0 == 0 && have_next)) { if (active) e_s[i] -= acc; }
         else {
-          if (active) part_s[part * R + i] = acc;     // nparts*R <= SW_THREADS doubles <= part_s capacity (1024)
+          if (nparts > 1 && active) upd_s[part * R + i] = acc;
           __syncthreads();
-          if (tid < R) { double t = 0.0; for (int q = 0; q < nparts; ++q) t += part_s[q * R + tid]; e_s[tid] -= t; }
+          if (nparts == 1) { if (active) e_s[i] -= acc; }
+          else if (tid < R) { double t = 0.0; for (int q = 0; q < nparts; ++q) t += upd_s[q * R + tid]; e_s[tid] -= t; }
+          if (SELECT && i0 == 0 && have_next && tid < mBn)
+            spec_s[tid] = (spp_s[tid] + spp_s[SW_MAXM + tid]) + (spp_s[2 * SW_MAXM + tid] + spp_s[3 * SW_MAXM + tid]);
+          if (i0 + SW_THREADS < R) __syncthreads();   // upd_s is reused by the next row chunk
         }
       }
     }
     STAMP(4);
-    if (have_next) {
-      __syncthreads();   // gram_s, gdiag_s, stage[buf^1] complete; part_s free
-      spec_matvec(stage[buf ^ 1], min(m, a.p - (j0 + m)));
-    }
     STAMP(5);
   }
   __syncthreads();
@@ -609,6 +650,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
   }
 #ifdef BWGR_STAMPS
   if (wg == 0 && tid == 0 && a.stamps) for (int k = 0; k < 8; ++k) a.stamps[k] += ph[k];
+  if (wg == 0 && tid == 64 && a.stamps) for (int k = 8; k < 12; ++k) a.stamps[k] += ph[k];
 #endif
 }
 

@@ -12,19 +12,19 @@ import numpy as np, torch
 import bwgr_amd
 from bwgr_amd import synth, _lib
 wl = {"c2": (5000, 50000, "BayesA", 0.0), "c4s": (10000, 100000, "BayesB", 0.99)}
-names = ["top-barrier", "dot", "combine+exchange", "wait for prefetch waves", "outputs+update", "spec matvec", "recurrence (wave 0)"]
+names = ["top-barrier", "dot", "combine+exchange", "wait for prefetch waves", "outputs+update", "spec matvec", "recurrence (wave 0)", "-", "wave1: prefetch until tile+stage stored", "wave1: residual vmcnt(0)", "wave1: t(gram loads landed)", "wave1: t(+stage landed)"]
 for key in sys.argv[1:] or ["c2", "c4s"]:
     n, p, model, pi = wl[key]
     X = synth.genotypes(n, p); y = synth.scale_phenotype(synth.phenotype(X, n))
     P = bwgr_amd.Panel(X, n=n); del X
     ch = bwgr_amd.Chain(P, model, y, it=4, bi=0, pi=pi, seed=1)
     ch.run(1); ch.sync()
-    out = (C.c_ulonglong * 8)(); _lib.lib().bwgr_debug_stamps(P._h, out)
+    out = (C.c_ulonglong * 12)(); _lib.lib().bwgr_debug_stamps(P._h, out)
     ch.run(3); ch.sync()
     _lib.lib().bwgr_debug_stamps(P._h, out)
-    v = np.array(list(out)[:7], float); nblk = 3 * ((p + P.block - 1) // P.block)
+    v = np.array(list(out)[:12], float); nblk = 3 * ((p + P.block - 1) // P.block)
     print(key, model, "n=%d p=%d K=%d m=%d" % (n, p, P.nwg, P.block), "ticks/block (100MHz? s_memtime):")
     for nm, x in zip(names, v):
-        print("   %-22s %9.0f ticks/block  %5.1f%%" % (nm, x / nblk, 100 * x / v.sum()))
+        print("   %-42s %9.0f ticks/block  %5.1f%%" % (nm, x / nblk, 100 * x / v[:7].sum()))
     ms, nl = ch.sweep_ms(); print("   sweep ms", ms)
     ch.close(); P.close()
