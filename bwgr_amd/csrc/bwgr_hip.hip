@@ -11,6 +11,8 @@
 #include "../../include/bwgr.h"
 #include "rng.hip.h"
 #include "sweep.hip.h"
+#include "sweep2.hip.h"
+#include <stdlib.h>
 
 using namespace bwgr;
 
@@ -152,6 +154,80 @@ __global__ __launch_bounds__(256) void k_gram_i8(const int8_t *X, int64_t ld, in
     for (int c = 0; c < TJ; ++c) g[(size_t)(tj + 16 * a) * m + (tk + 16 * c)] = acc[a][c];
 }
 
+// off-diagonal blocks for the lag-1 pipeline: gramx[blk][k][j] = X_{(blk-1)m+k} . X_{blk*m+j}, blk >= 1
+template <int TJ>
+__global__ __launch_bounds__(256) void k_gramx_i8(const int8_t *X, int64_t ld, int R, int p, int m, int32_t *gramx) {
+  constexpr int RC = 128, RW = RC / 4 + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t *ta = reinterpret_cast<int32_t *>(smem), *tb = ta + (size_t)m * RW;
+  const int blk = blockIdx.x + 1, ja0 = (blk - 1) * m, jb0 = blk * m, mBb = min(m, p - jb0);
+  const int tj = threadIdx.x >> 4, tk = threadIdx.x & 15;
+  int32_t acc[TJ][TJ];
+#pragma unroll
+  for (int a = 0; a < TJ; ++a)
+#pragma unroll
+    for (int c = 0; c < TJ; ++c) acc[a][c] = 0;
+  for (int64_t r0 = 0; r0 < ld; r0 += RC) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < m * (RC / 4); c += 256) {
+      const int jj = c / (RC / 4), w = c - jj * (RC / 4);
+      ta[jj * RW + w] = *reinterpret_cast<const int32_t *>(X + xoff(r0 + 4 * w, ja0 + jj, R, p));
+      tb[jj * RW + w] = (jj < mBb) ? *reinterpret_cast<const int32_t *>(X + xoff(r0 + 4 * w, jb0 + jj, R, p)) : 0;
+    }
+    __syncthreads();
+    for (int w = 0; w < RC / 4; ++w) {
+      int32_t av[TJ], bv[TJ];
+#pragma unroll
+      for (int a = 0; a < TJ; ++a) { av[a] = ta[(tj + 16 * a) * RW + w]; bv[a] = tb[(tk + 16 * a) * RW + w]; }
+#pragma unroll
+      for (int a = 0; a < TJ; ++a)
+#pragma unroll
+        for (int c = 0; c < TJ; ++c) acc[a][c] = __builtin_amdgcn_sdot4(av[a], bv[c], acc[a][c], false);
+    }
+  }
+  int32_t *g = gramx + (size_t)blk * m * m;
+#pragma unroll
+  for (int a = 0; a < TJ; ++a)
+#pragma unroll
+    for (int c = 0; c < TJ; ++c) g[(size_t)(tj + 16 * a) * m + (tk + 16 * c)] = acc[a][c];
+}
+template <int TJ>
+__global__ __launch_bounds__(256) void k_gramx_f32(const float *X, int64_t ld, int R, int p, int m, double *gramx) {
+  constexpr int RC = 64, RW = RC + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *ta = reinterpret_cast<float *>(smem), *tb = ta + (size_t)m * RW;
+  const int blk = blockIdx.x + 1, ja0 = (blk - 1) * m, jb0 = blk * m, mBb = min(m, p - jb0);
+  const int tj = threadIdx.x >> 4, tk = threadIdx.x & 15;
+  double acc[TJ][TJ];
+#pragma unroll
+  for (int a = 0; a < TJ; ++a)
+#pragma unroll
+    for (int c = 0; c < TJ; ++c) acc[a][c] = 0.0;
+  for (int64_t r0 = 0; r0 < ld; r0 += RC) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < m * RC; c += 256) {
+      const int jj = c / RC, w = c - jj * RC;
+      ta[jj * RW + w] = X[xoff(r0 + w, ja0 + jj, R, p)];
+      tb[jj * RW + w] = (jj < mBb) ? X[xoff(r0 + w, jb0 + jj, R, p)] : 0.0f;
+    }
+    __syncthreads();
+    for (int w = 0; w < RC; ++w) {
+      double av[TJ], bv[TJ];
+#pragma unroll
+      for (int a = 0; a < TJ; ++a) { av[a] = (double)ta[(tj + 16 * a) * RW + w]; bv[a] = (double)tb[(tk + 16 * a) * RW + w]; }
+#pragma unroll
+      for (int a = 0; a < TJ; ++a)
+#pragma unroll
+        for (int c = 0; c < TJ; ++c) acc[a][c] = fma(av[a], bv[c], acc[a][c]);
+    }
+  }
+  double *g = gramx + (size_t)blk * m * m;
+#pragma unroll
+  for (int a = 0; a < TJ; ++a)
+#pragma unroll
+    for (int c = 0; c < TJ; ++c) g[(size_t)(tj + 16 * a) * m + (tk + 16 * c)] = acc[a][c];
+}
+
 template <int TJ>
 __global__ __launch_bounds__(256) void k_gram_f32(const float *X, int64_t ld, int R, int p, int m, double *gram) {
   constexpr int RC = 64, RW = RC + 1;
@@ -186,6 +262,19 @@ __global__ __launch_bounds__(256) void k_gram_f32(const float *X, int64_t ld, in
   for (int a = 0; a < TJ; ++a)
 #pragma unroll
     for (int c = 0; c < TJ; ++c) g[(size_t)(tj + 16 * a) * m + (tk + 16 * c)] = acc[a][c];
+}
+
+// strict upper triangle of the diagonal Gram blocks, row-packed: entry (k, j>k) at k(m-1) - k(k-1)/2 + (j-k-1)
+template <typename GT>
+__global__ void k_gram_pack(const GT *gram, GT *gramp, int m, int pstride, int64_t nblocks) {
+  const int64_t blk = blockIdx.x;
+  const GT *G = gram + (size_t)blk * m * m;
+  GT *P = gramp + (size_t)blk * pstride;
+  for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
+    const int k = e / m, j = e - k * m;
+    if (j > k) P[k * (m - 1) - k * (k - 1) / 2 + (j - k - 1)] = G[e];
+  }
+  for (int e = m * (m - 1) / 2 + threadIdx.x; e < pstride; e += blockDim.x) P[e] = (GT)0;
 }
 
 // ---- chain setup (src/Rcpp20260726ai.cpp:599-610 and the identical blocks of the other samplers) ----
@@ -529,13 +618,16 @@ struct bwgr_panel {
   int is_f32 = 0;
   int m = 0, K = 0, R = 0;
   int64_t nblocks = 0;
-  void *X = nullptr, *gram = nullptr;
+  void *X = nullptr, *gram = nullptr, *gramx = nullptr, *gramp = nullptr;
+  int pstride = 0;
   size_t x_bytes = 0, gram_bytes = 0;
   float *xx = nullptr, *vx = nullptr, *msx_dev = nullptr;
   float MSx = 0;
-  double *xpart = nullptr;
+  double *xpart = nullptr, *qpart = nullptr;
+  unsigned long long *dgran = nullptr;
   uint32_t *xflags = nullptr;
-  size_t lds_bytes = 0;
+  size_t lds_bytes = 0, lds2_bytes = 0;
+  int sweep_version = 2;   // 2: streamer/sequencer pipeline (k_sweep2); 1: replicated recurrence (k_sweep)
   unsigned long long *stamps = nullptr;   // diagnostic build only
   PreStage ps = {};
 };
@@ -580,14 +672,42 @@ template <typename XT> static int max_slab_rows(int m) {
   return best;
 }
 
+// polled words are zeroed before every launch (epochs count within a launch)
+static int reset_exchange(bwgr_panel *P) {
+  if (P->sweep_version == 2) {
+    HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
+    HIPCHK(hipMemsetAsync(P->dgran, 0, sizeof(unsigned long long) * S2_NSLOT * SW_MAXM, P->stream));
+  } else if (P->K > 1) {
+    HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
+  }
+  return BWGR_OK;
+}
+
 static void launch_prestage(bwgr_panel *P, const SweepArgs &a) {
   const int j0 = a.blk_begin * a.m, j1 = (int)std::min<int64_t>(P->p, (int64_t)a.blk_end * a.m);
   const int64_t tasks = 4ll * (j1 - j0);
   hipLaunchKernelGGL(k_prestage, dim3((unsigned)std::min<int64_t>(4096, (tasks + 255) / 256)), dim3(256), 0, P->stream, a, j0, j1);
+  if (P->sweep_version == 2) {
+    const int sel = (a.flags & SWF_SELECT) ? 1 : 0;
+    const unsigned nb = (unsigned)(a.blk_end - a.blk_begin);
+    if (P->is_f32) hipLaunchKernelGGL(k_spec<double>, dim3(nb), dim3(128), 0, P->stream, a, a.blk_begin, sel);
+    else hipLaunchKernelGGL(k_spec<int32_t>, dim3(nb), dim3(128), 0, P->stream, a, a.blk_begin, sel);
+  }
 }
 
 static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a) {
   const bool sel = (a.flags & SWF_SELECT) != 0;
+  if (P->sweep_version == 2) {
+    const dim3 grid(P->K + 1), blk(SW_THREADS);
+    if (P->is_f32) {
+      if (sel) hipLaunchKernelGGL((k_sweep2<float, true>), grid, blk, P->lds2_bytes, P->stream, a);
+      else hipLaunchKernelGGL((k_sweep2<float, false>), grid, blk, P->lds2_bytes, P->stream, a);
+    } else {
+      if (sel) hipLaunchKernelGGL((k_sweep2<int8_t, true>), grid, blk, P->lds2_bytes, P->stream, a);
+      else hipLaunchKernelGGL((k_sweep2<int8_t, false>), grid, blk, P->lds2_bytes, P->stream, a);
+    }
+    return;
+  }
   if (P->is_f32) {
     if (sel) hipLaunchKernelGGL((k_sweep<float, true>), dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
     else hipLaunchKernelGGL((k_sweep<float, false>), dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
@@ -598,7 +718,7 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a) {
 }
 
 static int launch_sweep(bwgr_panel *P, SweepArgs &a) {
-  if (P->K > 1) HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
+  CHK(reset_exchange(P));
   launch_prestage(P, a);
   launch_sweep_kernel(P, a);
   HIPCHK(hipGetLastError());
@@ -610,6 +730,7 @@ static void fill_panel_args(const bwgr_panel *P, SweepArgs &a) {
   a.n = (int)P->n; a.p = (int)P->p; a.m = P->m; a.K = P->K; a.R = P->R;
   a.blk_begin = 0; a.blk_end = (int)P->nblocks;
   a.xpart = P->xpart; a.xflags = P->xflags; a.stamps = P->stamps; a.ps = P->ps;
+  a.gramx = P->gramx; a.gramp = P->gramp; a.pstride = P->pstride; a.qpart = P->qpart; a.dgran = P->dgran;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -647,7 +768,7 @@ static int upload(bwgr_panel *P, const void *X, int memloc, int64_t ldx) {
 extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   if (!P) return BWGR_OK;
   (void)hipSetDevice(P->device);
-  hipFree(P->X); hipFree(P->gram); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev); hipFree(P->xpart); hipFree(P->xflags);
+  hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramp); hipFree(P->ps.spec); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev); hipFree(P->xpart); hipFree(P->qpart); hipFree(P->dgran); hipFree(P->xflags);
   hipFree(P->ps.blocks); hipFree(P->stamps);
   delete P;
   return BWGR_OK;
@@ -697,6 +818,36 @@ static int panel_setup(bwgr_panel *P) {
     }
   }
   HIPCHK(hipGetLastError());
+  if (P->nblocks > 1) {   // off-diagonal blocks (blk-1, blk) for the lag-1 pipeline
+    const unsigned nbx = (unsigned)(P->nblocks - 1);
+    if (P->is_f32) {
+      const size_t lds = (size_t)2 * m * 65 * sizeof(float);
+      double *g = (double *)P->gramx; const float *X = (const float *)P->X;
+      switch (TJ) {
+        case 1: hipLaunchKernelGGL(k_gramx_f32<1>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+        case 2: hipLaunchKernelGGL(k_gramx_f32<2>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+        case 3: hipLaunchKernelGGL(k_gramx_f32<3>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+        default: hipLaunchKernelGGL(k_gramx_f32<4>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+      }
+    } else {
+      const size_t lds = (size_t)2 * m * 33 * sizeof(int32_t);
+      int32_t *g = (int32_t *)P->gramx; const int8_t *X = (const int8_t *)P->X;
+      switch (TJ) {
+        case 1: hipLaunchKernelGGL(k_gramx_i8<1>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+        case 2: hipLaunchKernelGGL(k_gramx_i8<2>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+        case 3: hipLaunchKernelGGL(k_gramx_i8<3>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+        case 4: hipLaunchKernelGGL(k_gramx_i8<4>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+        case 5: hipLaunchKernelGGL(k_gramx_i8<5>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+        case 6: hipLaunchKernelGGL(k_gramx_i8<6>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+        case 7: hipLaunchKernelGGL(k_gramx_i8<7>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+        default: hipLaunchKernelGGL(k_gramx_i8<8>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+      }
+    }
+    HIPCHK(hipGetLastError());
+  }
+  if (P->is_f32) hipLaunchKernelGGL(k_gram_pack<double>, dim3((unsigned)P->nblocks), dim3(256), 0, P->stream, (const double *)P->gram, (double *)P->gramp, m, P->pstride, P->nblocks);
+  else hipLaunchKernelGGL(k_gram_pack<int32_t>, dim3((unsigned)P->nblocks), dim3(256), 0, P->stream, (const int32_t *)P->gram, (int32_t *)P->gramp, m, P->pstride, P->nblocks);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(P->stream));
   return BWGR_OK;
 }
@@ -728,18 +879,30 @@ extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int
   P->K = K; P->R = R; P->ld = (int64_t)K * R;
   P->nblocks = (p + m - 1) / m;
   P->lds_bytes = P->is_f32 ? sweep_lds_bytes<float>(m, R) : sweep_lds_bytes<int8_t>(m, R);
+  P->lds2_bytes = P->is_f32 ? sweep2_lds_bytes<float>(m, R) : sweep2_lds_bytes<int8_t>(m, R);
+  {
+    const char *sv = getenv("BWGR_SWEEP");   // A/B switch for tests and profiling
+    P->sweep_version = (sv && sv[0] == '1') ? 1 : 2;
+    if (P->lds2_bytes > (size_t)160 * 1024 || K + 1 > 256) P->sweep_version = 1;
+  }
   P->x_bytes = (size_t)P->ld * (size_t)p * (P->is_f32 ? 4 : 1);
-  P->gram_bytes = (size_t)P->nblocks * m * m * (P->is_f32 ? 8 : 4);
+  P->gram_bytes = (size_t)P->nblocks * m * m * (P->is_f32 ? 8 : 4);   // per Gram array (diagonal blocks; off-diagonal blocks)
   int rc = BWGR_OK;
   auto bail = [&](int code) { bwgr_panel_destroy(P); return code; };
 #define PCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return bail(fail(BWGR_EHIP, "%s failed: %s", #x, hipGetErrorString(e_))); } while (0)
   PCHK(hipMalloc(&P->X, P->x_bytes));
   PCHK(hipMalloc(&P->gram, P->gram_bytes));
+  PCHK(hipMalloc(&P->gramx, P->gram_bytes));
+  P->pstride = ((m * (m - 1) / 2 + 3) / 4) * 4;
+  PCHK(hipMalloc(&P->gramp, (size_t)P->nblocks * std::max(P->pstride, 4) * (P->is_f32 ? 8 : 4)));
+  PCHK(hipMalloc(&P->ps.spec, sizeof(SpecBuf) * (size_t)P->nblocks));
   PCHK(hipMalloc(&P->xx, sizeof(float) * p));
   PCHK(hipMalloc(&P->vx, sizeof(float) * p));
   PCHK(hipMalloc(&P->msx_dev, sizeof(float)));
   PCHK(hipMalloc(&P->xpart, sizeof(double) * 2 * (size_t)K * SW_MAXM));
   PCHK(hipMalloc(&P->xflags, sizeof(uint32_t) * ((size_t)K + 1) * SW_FLAG_STRIDE));
+  PCHK(hipMalloc(&P->qpart, sizeof(double) * S2_NSLOT * (size_t)K * SW_MAXM));
+  PCHK(hipMalloc(&P->dgran, sizeof(unsigned long long) * S2_NSLOT * SW_MAXM));
   PCHK(hipMalloc(&P->ps.blocks, sizeof(StageBuf) * (size_t)P->nblocks));
 #ifdef BWGR_STAMPS
   PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 12));
@@ -749,6 +912,10 @@ extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<int8_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<int8_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<int8_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef PCHK
   if (xtype == BWGR_X_I8) rc = upload<int8_t, int8_t>(P, X, memloc, ldx);
   else if (xtype == BWGR_X_F32) rc = upload<float, float>(P, X, memloc, ldx);
@@ -778,7 +945,7 @@ extern "C" int bwgr_panel_set_stream(bwgr_panel *P, void *hip_stream) {
 extern "C" int bwgr_panel_info(const bwgr_panel *P, int64_t info[8]) {
   if (!P || !info) return fail(BWGR_EINVAL, "null pointer");
   info[0] = P->n; info[1] = P->p; info[2] = P->ld; info[3] = P->m; info[4] = P->K; info[5] = P->R;
-  info[6] = (int64_t)P->x_bytes; info[7] = (int64_t)P->gram_bytes;
+  info[6] = (int64_t)P->x_bytes; info[7] = (int64_t)(2 * P->gram_bytes);
   return BWGR_OK;
 }
 
@@ -905,7 +1072,7 @@ extern "C" int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end
   a.iter = (uint32_t)C->done; a.marker0 = (uint32_t)C->marker0; a.rng = make_rng(C->seed, C->rng_mode);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  if (P->K > 1) HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
+  CHK(reset_exchange(P));
   launch_prestage(P, a);
   HIPCHK(hipEventRecord(e0, P->stream));
   launch_sweep_kernel(P, a);

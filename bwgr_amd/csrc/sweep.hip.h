@@ -55,13 +55,22 @@ struct ChainScalars {
 // per-marker constants of one sweep, produced chip-wide by k_prestage before the sweep kernel starts (they depend on
 // the previous iteration's b and lambda and on the RNG counters only, never on the residual)
 struct StageBuf;
+struct SpecBuf {                // r-independent per-marker terms of one block (k_sweep2), filled by k_spec
+  double spec[128];             // sum_{k<j} G_bb[k][j] * drej[k]        (selection models)
+  double xspec[128];            // sum_k Gx_b[k][j] * drej_{b-1}[k]      (selection models; unused for the first block of a launch)
+  double gjj[128];              // G_bb[j][j]
+};
 struct PreStage {
   StageBuf *blocks;   // one StageBuf per marker block, filled by k_prestage
+  SpecBuf *spec;      // one SpecBuf per marker block, filled by k_spec
 };
 
 struct SweepArgs {
   const void *X; int64_t ld;    // slab-major: element (row i, marker j) at ((i/R)*p + j)*R + i%R; ld = K*R padded rows
-  const void *gram;             // [nblocks][m][m]
+  const void *gram;             // [nblocks][m][m]  diagonal blocks X_b' X_b
+  const void *gramx;            // [nblocks][m][m]  off-diagonal blocks X_{b-1}' X_b (entry 0 unused)
+  const void *gramp;            // [nblocks][pstride] strict upper triangle of the diagonal blocks, row k = entries (k, k+1..m-1)
+  int pstride;
   int n, p, m, K, R;
   int blk_begin, blk_end;
   int flags;
@@ -73,7 +82,9 @@ struct SweepArgs {
   uint32_t marker0;             // global id of local marker 0 (RNG counters use global ids)
   Rng rng;
   PreStage ps;
-  double *xpart;                // [2][K][SW_MAXM]
+  double *xpart;                // k_sweep: [2][K][SW_MAXM]
+  double *qpart;                // k_sweep2: [S2_NSLOT][K][SW_MAXM] streamer slab dots
+  unsigned long long *dgran;    // k_sweep2: [S2_NSLOT][SW_MAXM] {epoch, float delta} granules
   uint32_t *xflags;             // [K*SW_FLAG_STRIDE] epochs, then the abort word
   unsigned long long *stamps;   // diagnostic build only (-DBWGR_STAMPS): per-phase cycle sums of workgroup 0
 };
@@ -114,13 +125,26 @@ __device__ __forceinline__ float readlane_f32(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+// hand-off words are always accessed as GLOBAL (address_space(1)) agent-scope atomics, never through flat_*
+typedef __attribute__((address_space(1))) uint32_t gu32_t;
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+__device__ __forceinline__ uint32_t ld_agent_u32(const uint32_t *p) {
+  return __hip_atomic_load((const gu32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent_u32(uint32_t *p, uint32_t v) {
+  __hip_atomic_store((gu32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent_raw64(const unsigned long long *p) {
+  return __hip_atomic_load((const gu64_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent_raw64(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store((gu64_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void st_agent_u64(double *p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  st_agent_raw64(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v));
 }
 __device__ __forceinline__ double ld_agent_f64(const double *p) {
-  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return __longlong_as_double((long long)ld_agent_raw64(reinterpret_cast<const unsigned long long *>(p)));
 }
 
 // slab-major addressing of the resident panel: workgroup w's rows of marker j are the contiguous run
@@ -168,7 +192,7 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
     if (piece == 0) {
       st.b0[t] = b0;
       st.xxb0[t] = xxj * b0;
-      st.rden[t] = 1.0 / (double)den;   // (float)(a * rden) equals the float quotient a/den except ~1e-8 of the time
+      st.rden[t] = 1.0 / (double)den;
       st.sdz1[t] = (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z1, 0);
     } else if (piece == 1) {
       const float b2 = sel ? (float)((double)0.0f + (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z2, 0)) : 0.0f;
@@ -181,6 +205,33 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
     }
   }
 }
+// k_spec: the r-independent speculative terms of every block of a sweep (one workgroup of 128 threads per block,
+// thread = marker j; Gram rows are read coalesced across j; fixed summation order k ascending)
+template <typename GT>
+__global__ __launch_bounds__(128) void k_spec(const SweepArgs a, int blk_begin, int select) {
+  const int blk = blk_begin + blockIdx.x, j = threadIdx.x, m = a.m;
+  const int mB = min(m, a.p - blk * m);
+  const GT *G = reinterpret_cast<const GT *>(a.gram) + (size_t)blk * m * m;
+  SpecBuf &sp = a.ps.spec[blk];
+  __shared__ float dr[128], drp[128];
+  const StageBuf &st = a.ps.blocks[blk];
+  dr[j] = (j < mB) ? st.drej[j] : 0.0f;
+  drp[j] = (blk > blk_begin) ? a.ps.blocks[blk - 1].drej[j] : 0.0f;   // previous block is always a full block
+  __syncthreads();
+  double s = 0.0, xs = 0.0, gjj = 0.0;
+  if (j < mB) {
+    gjj = (double)G[(size_t)j * m + j];
+    if (select) {
+      for (int k = 0; k < j; ++k) s = fma((double)G[(size_t)k * m + j], (double)dr[k], s);
+      if (blk > blk_begin) {
+        const GT *Gx = reinterpret_cast<const GT *>(a.gramx) + (size_t)blk * m * m;
+        for (int k = 0; k < m; ++k) xs = fma((double)Gx[(size_t)k * m + j], (double)drp[k], xs);
+      }
+    }
+  }
+  sp.spec[j] = s; sp.xspec[j] = xs; sp.gjj[j] = gjj;
+}
+
 // block constants global -> LDS: one StageBuf is sizeof(StageBuf)/16 chunks, at most one per thread
 __device__ inline void stage_block(StageBuf &st, int blk, const SweepArgs &a, int tid0, int nthreads) {
   constexpr int NCH = (int)(sizeof(StageBuf) / 16);
@@ -214,10 +265,10 @@ struct LaneConst {
   float b0, xxb0, b2, drej;
   double rden, sdz1, u, gjj;
 };
+// The conditional mean stays in fp64 (wide contract): 2 dependent fp64 ops instead of the
+// cvt/add/cvt/mul/cvt/cvt/add chain that the reference's float rounding points would force on the serial path.
 __device__ __forceinline__ float lane_b1(double r, const LaneConst &c) {
-  const float a = (float)r + c.xxb0;
-  const float mean = (float)((double)a * c.rden);
-  return (float)((double)mean + c.sdz1);
+  return (float)fma(r + (double)c.xxb0, c.rden, c.sdz1);
 }
 __device__ __forceinline__ bool lane_accept(double r, float b1, const LaneConst &c, int flags, float Cc, float odds,
                                             float one_minus_pi) {
@@ -397,7 +448,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0)
-        __hip_atomic_store(a.xflags + (size_t)wg * SW_FLAG_STRIDE, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_agent_u32(a.xflags + (size_t)wg * SW_FLAG_STRIDE, epoch);
       if (wave == 0) {
         uint32_t *abortw = a.xflags + (size_t)K * SW_FLAG_STRIDE;
         const uint64_t t0 = wall_clock64();
@@ -405,15 +456,14 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
         for (;;) {
           bool all_here = true;
           for (int w = lane; w < K; w += 64) {
-            const uint32_t f = __hip_atomic_load(a.xflags + (size_t)w * SW_FLAG_STRIDE, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t f = ld_agent_u32(a.xflags + (size_t)w * SW_FLAG_STRIDE);
             all_here = all_here && (f >= epoch);
           }
           if (__all(all_here)) { ok = 1; break; }
-          const uint32_t ab = __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t ab = ld_agent_u32(abortw);
           if (__any(ab != 0)) break;
           if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) {
-            if (lane == 0) __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) st_agent_u32(abortw, 1u);
             break;
           }
           __builtin_amdgcn_s_sleep(1);

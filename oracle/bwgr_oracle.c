@@ -18,7 +18,9 @@
  * The file is compiled twice (see Makefile):
  *   -DACC_T=double -DSUF=_w   "wide":     every Eigen reduction accumulates in double, the
  *                                          residual vector e (and the e1/e2 temporaries) is carried
- *                                          in double, and the Bernoulli log-odds uses the un-rounded
+ *                                          in double, the marker's dot product and conditional mean
+ *                                          stay in double (only the drawn effect is rounded to float,
+ *                                          as stored), and the Bernoulli log-odds uses the un-rounded
  *                                          norm difference.  This is the parity target for the GPU:
  *                                          the same algorithm with the float round-off of the
  *                                          n-vector arithmetic removed, so that it is independent
@@ -66,6 +68,28 @@ static float v_dot(const float *x, const E_T *e, int64_t n) {
     for (int l = 0; l < 8; l++) s[l] += (ACC_T)x[i + l] * (ACC_T)e[i + l];
   for (int l = 0; i < n; i++, l++) s[l] += (ACC_T)x[i] * (ACC_T)e[i];
   return (float)red8(s);
+}
+/* the same dot kept in the accumulator type */
+static ACC_T v_dot_acc(const float *x, const E_T *e, int64_t n) {
+  ACC_T s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t i = 0;
+  for (; i + 8 <= n; i += 8)
+    for (int l = 0; l < 8; l++) s[l] += (ACC_T)x[i + l] * (ACC_T)e[i + l];
+  for (int l = 0; i < n; i++, l++) s[l] += (ACC_T)x[i] * (ACC_T)e[i];
+  return red8(s);
+}
+/* b1 = rnorm((X_j.e + xx_j b0)/(xx_j + lambda_j), sd)  -- src/Rcpp20260726ai.cpp:20, :615, :670 ...
+ * faithful: every intermediate is a float, as the reference's types dictate.
+ * wide:     the dot product and the conditional mean stay in double (xx_j*b0, the denominator and sd are the
+ *           reference's floats); only b1 itself is rounded to float, as the reference stores it. */
+static inline float draw_b1(const float *xj, const E_T *e, int64_t n, float xxj, float b0, float den, float sd, double z) {
+#ifdef ACC_WIDE
+  const double mean = (v_dot_acc(xj, e, n) + (double)(xxj * b0)) / (double)den;
+  return (float)(mean + (double)sd * z);
+#else
+  const float mean = ((float)v_dot_acc(xj, e, n) + xxj * b0) / den;
+  return (float)((double)mean + (double)sd * z);
+#endif
 }
 /* v.squaredNorm() kept in the accumulator type (caller rounds) */
 static ACC_T v_sqnorm_acc(const float *v, int64_t n) {
@@ -182,7 +206,7 @@ int FN(oracle_kmup)(const float *X, int64_t n, int64_t p, int64_t ldx, float *b,
     uint32_t mk = marker0 + (uint32_t)j;   /* RNG counters carry global marker ids (0 offset = the reference's single panel) */
     b0 = b[j];                                                                   /* :19 */
     float den = xx[j] + L[j];
-    b1 = draw_norm((v_dot(xj, e, n) + xx[j] * b0) / den, sqrtf(Ve / den), orng_normal(&g, mk, iter, ORNG_Z1, 0)); /* :20 */
+    b1 = draw_b1(xj, e, n, xx[j], b0, den, sqrtf(Ve / den), orng_normal(&g, mk, iter, ORNG_Z1, 0));                /* :20 */
     b2 = draw_norm(0.0f, sqrtf(Ve / den), orng_normal(&g, mk, iter, ORNG_Z2, 0)); /* :21 */
     v_axpy_to(e1, e, xj, b1 - b0, n);                                            /* :22 */
     if (pi > 0) {                                                                /* :23 */
@@ -263,7 +287,7 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
       float lam = per_marker_vb ? Lmbv[j] : Lmb;
       float den = xx[j] + lam;
       b0 = b[j];
-      b1 = draw_norm((v_dot(xj, e, n) + xx[j] * b0) / den, sqrtf(ve / den), orng_normal(&g, mk, itx, ORNG_Z1, 0));
+      b1 = draw_b1(xj, e, n, xx[j], b0, den, sqrtf(ve / den), orng_normal(&g, mk, itx, ORNG_Z1, 0));
       switch (model) {
       case M_BAYESA: case M_BAYESL:                                   /* :613-618, :787-792 */
         b[j] = b1;
