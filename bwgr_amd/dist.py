@@ -155,7 +155,7 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
                    "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": 1, "block": P.block,
                    "slab_workgroups": P.nwg, "sync_rounds_per_sweep": rounds},
         "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                     "kernel": "k_sweep<int8> (rank 0, all launches of one sweep summed)", "kernel_ms": sweep_ms_per_iter,
+                     "kernel": "k_sweep2<int8> (rank 0, all launches of one sweep summed)", "kernel_ms": sweep_ms_per_iter,
                      "launches": launches, "algorithmic_bytes_per_launch": alg},
         "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d_rank0": float(st["d"].mean())},
     }

@@ -218,3 +218,24 @@ def test_geometry_sweep(model, n, p, block, nwg):
     o = O.bayes(model, y, X, it=5, bi=1, pi=0.8, seed=8)["last"]
     assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL, (P.nwg, P.slab_rows)
     ch.close(); P.close()
+
+
+@pytest.mark.parametrize("model", ["BayesRR", "BayesB", "BayesCpi", "BayesDpi"])
+def test_both_sweep_engines_give_the_same_chain(model, monkeypatch):
+    """k_sweep (replicated recurrence behind an all-gather) and k_sweep2 (streamer/sequencer pipeline, the default) are
+    two schedules of the same blocked algebra: same chain to round-off of the fp64 partial-sum order."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = synth_small(900, 700, seed=77)
+    out = {}
+    for v in ("1", "2"):
+        monkeypatch.setenv("BWGR_SWEEP", v)
+        P = bwgr_amd.Panel(X, block=64, nwg=4)
+        ch = bwgr_amd.Chain(P, model, y, it=8, bi=2, pi=0.9, seed=6)
+        ch.run(8)
+        out[v] = ch.state()
+        ch.close(); P.close()
+    o = O.bayes(model, y, X, it=8, bi=2, pi=0.9, seed=6)["last"]
+    for v in ("1", "2"):
+        assert scaled_err(out[v]["b"], o["b"]) < TOL and scaled_err(out[v]["e"], o["e"]) < TOL
+    assert scaled_err(out["1"]["b"], out["2"]["b"]) < 1e-9 and np.array_equal(out["1"]["d"], out["2"]["d"])
