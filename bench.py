@@ -87,7 +87,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = local_rank
 
-    if world > 1:
+    if world > 1 or os.environ.get("BWGR_FORCE_DIST"):   # BWGR_FORCE_DIST=1: rehearse the sharded leg with one rank
         from bwgr_amd import dist as bdist
         out = bdist.bench_sharded(args, n, p, model, pi, K, W, rank, world, dev)
         if rank == 0:

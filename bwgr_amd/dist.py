@@ -113,7 +113,8 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     import bwgr_amd
     from . import synth
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
     block = args.block if args.block > 0 else 128
     lo, hi = shard_bounds(p, world, rank, block)
     X = synth.genotypes(n, hi - lo, col0=lo, device=dev)
