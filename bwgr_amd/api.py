@@ -258,36 +258,74 @@ def KMUP(X, b, d, xx, e, L, Ve, pi, *, seed=None, it=0, rng_mode=0, **panel_kw):
 
 def wgr(y, X, it=1500, bi=500, th=1, bag=1, rp=False, iv=False, de=False, pi=0, df=5, R2=0.5, eigK=None, VarK=0.95,
         verb=False, *, seed=None, rng_mode=0, **panel_kw):
-    """wgr(), R/wgr.R:2-169, device-resident.  bag != 1 (KMUP2) and eigK are SURVEY section 8(f) rows f1/f2 and are
-    not built in this round: they raise instead of silently running something else."""
+    """wgr(), R/wgr.R:2-169, device-resident.  eigK = {"values": ..., "vectors": ...} (R's eigen(K)) adds the
+    polygenic kernel term.  bag != 1 (KMUP2) is not built yet and raises instead of silently running
+    something else.  Returns wgr's list: mu, b, Vb, d, Ve, hat[, u, Vk], cxx (R/wgr.R:155-167)."""
     if bag != 1 or rp:
         raise NotImplementedError("wgr(bag != 1): the KMUP2 bagging path (SURVEY section 8 f1) is not built yet")
-    if eigK is not None:
-        raise NotImplementedError("wgr(eigK=...): the polygenic kernel term (SURVEY section 8 f2) is not built yet")
     y = np.asarray(y, np.float64)
-    if np.isnan(y).any():   # R/wgr.R:34-39: drop rows with missing y
+    U0 = V = None
+    if eigK is not None:                       # R/wgr.R:23-27
+        Vall = np.asarray(eigK["values"], np.float64)
+        pk = int(np.argmax((np.cumsum(Vall) / Vall.size) > VarK)) + 1
+        U0 = np.asfortranarray(np.asarray(eigK["vectors"], np.float64)[:, :pk])
+        V = np.ascontiguousarray(Vall[:pk])
+    gen0 = None
+    keep = None
+    if np.isnan(y).any():   # R/wgr.R:34-39: drop rows with missing y (hat is still returned for every row of gen0)
+        if isinstance(X, Panel) or hasattr(X, "data_ptr"):
+            raise ValueError("missing y with a pre-staged X: drop the rows before staging X")
         keep = ~np.isnan(y)
+        gen0 = np.asarray(X)
         y = y[keep]
-        if isinstance(X, Panel):
-            raise ValueError("missing y with a pre-built Panel: drop the rows before staging X")
-        X = np.asarray(X)[keep]
     if not isinstance(X, Panel) and not hasattr(X, "data_ptr"):
         X = np.asarray(X)
         if np.issubdtype(X.dtype, np.floating) and np.isnan(X).any():   # R/wgr.R:12-18 mean imputation
             X = X.astype(np.float64, copy=True)
             cm = np.nanmean(X, axis=0); cm[np.isnan(cm)] = 0.0
             idx = np.where(np.isnan(X)); X[idx] = cm[idx[1]]
+            if gen0 is not None:
+                gen0 = X
+        if keep is not None:
+            X = X[keep]
+    U = None
+    if U0 is not None:
+        U = np.asfortranarray(U0[keep] if keep is not None else U0)
     P, own = _as_panel(X, **panel_kw)
     try:
         n, p = P.n, P.p
+        assert y.size == n, "length(y) must equal nrow(X)"
         per = bool(iv or de)
-        b = np.zeros(p); d = np.zeros(p); Vb = np.zeros(p if per else 1); hat = np.zeros(n)
-        mu = C.c_double(); Ve = C.c_double(); cxx = C.c_double()
+        b = np.zeros(p); d = np.zeros(p); Vb = np.zeros(p if per else 1); hat = np.zeros(n); u = np.zeros(n)
+        mu = C.c_double(); Ve = C.c_double(); cxx = C.c_double(); Vk = C.c_double()
         yc = np.ascontiguousarray(y, np.float64)
-        check(_lib.lib().bwgr_wgr(P._h, _dp(yc), int(it), int(bi), int(th), int(bool(iv)), int(bool(de)), float(pi), float(df),
-                                   float(R2), C.c_uint64(_seed(seed)), int(rng_mode), C.byref(mu), _dp(b), _dp(Vb), _dp(d),
-                                   C.byref(Ve), _dp(hat), C.byref(cxx)))
-        return {"mu": mu.value, "b": b, "Vb": Vb if per else float(Vb[0]), "d": d, "Ve": Ve.value, "hat": hat, "cxx": cxx.value}
+        if U is None:
+            check(_lib.lib().bwgr_wgr(P._h, _dp(yc), int(it), int(bi), int(th), int(bool(iv)), int(bool(de)), float(pi),
+                                       float(df), float(R2), C.c_uint64(_seed(seed)), int(rng_mode), C.byref(mu), _dp(b), _dp(Vb),
+                                       _dp(d), C.byref(Ve), _dp(hat), C.byref(cxx)))
+        else:
+            assert U.shape[0] == n
+            check(_lib.lib().bwgr_wgr_ex(P._h, _dp(yc), int(it), int(bi), int(th), int(bool(iv)), int(bool(de)), float(pi),
+                                          float(df), float(R2), C.c_uint64(_seed(seed)), int(rng_mode), _dp(U), _dp(V),
+                                          C.c_int64(U.shape[1]), C.byref(mu), _dp(b), _dp(Vb), _dp(d), C.byref(Ve), _dp(hat),
+                                          C.byref(cxx), _dp(u), C.byref(Vk)))
+        if keep is not None:
+            # HAT = B0 + gen0 %*% B (+ U0 %*% H) over ALL rows of gen0 (R/wgr.R:146-152): rows with missing y are predicted.
+            # R-level post-processing in the reference too; the rows that were swept keep the device's values.
+            full = np.empty(keep.size); full[keep] = hat
+            miss = ~keep
+            full[miss] = mu.value + np.asarray(gen0, np.float64)[miss] @ b
+            if U is not None:
+                Hk = np.linalg.lstsq(U, u, rcond=None)[0]      # u = U %*% H on the kept rows; recover H for the others
+                ufull = U0 @ Hk
+                full[miss] += ufull[miss]
+                u = ufull
+            hat = full
+        out = {"mu": mu.value, "b": b, "Vb": Vb if per else float(Vb[0]), "d": d, "Ve": Ve.value, "hat": hat}
+        if U is not None:
+            out["u"] = u; out["Vk"] = Vk.value
+        out["cxx"] = cxx.value
+        return out
     finally:
         if own:
             P.close()

@@ -428,6 +428,7 @@ __global__ void k_hat_finish(const double *part, int64_t ld, int nchunks, int n,
 // ---- wgr(): R-side (double) steps around the KMUP sweep, R/wgr.R:41-168 --------------------------------------------
 struct WgrScalars {
   double mu, Ve, Va, Sb, Se, MSx, vy, bb, B0, VE, VA, sumD, cxx;
+  double Vp, VP, Sk;   // polygenic term (eigK)
 };
 // per-column double statistics as R computes them: xx = crossprod, var = sum((x-mean)^2)/(n-1); one wave per column
 template <typename XT>
@@ -473,6 +474,7 @@ __global__ void k_wgr_init(const double *y, double *eR, int n, int64_t ld, const
     WgrScalars w; memset(&w, 0, sizeof(w));
     w.mu = mu; w.vy = sv / (double)(n - 1); w.MSx = ms; w.Ve = 1.0; w.Va = ms;
     w.Sb = (R2) * df * w.vy / ms; w.Se = (1 - R2) * df * w.vy; w.cxx = sx / (double)p;
+    w.Sk = R2 * w.vy * (df + 2); w.Vp = 1.0;                                       // R/wgr.R:60, :30
     *ws = w;
   }
 }
@@ -551,6 +553,49 @@ __global__ __launch_bounds__(1024) void k_wgr_mu(double *eR, int n, int iv, int 
     ws->mu += mu0;
     if (accumulate) { ws->B0 += ws->mu; ws->VE += ws->Ve; if (!iv) ws->VA += ws->Va; }
   }
+}
+// ---- polygenic term: narrowing for KMUP(U,h,dh,xxK,e,Lk,Ve,0) (R/wgr.R:70-76), widening of its outputs ----
+__global__ void k_wgr_pre_k(const double *hR, const double *Vd, const double *eR, float *hf, float *dhf, float *xxKf, float *Lkf, double *e64,
+                            int pk, int n, int64_t ld, const WgrScalars *ws, ChainScalars *sc) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+  const double Ve = ws->Ve, Vp = ws->Vp;
+  for (int64_t k = gid; k < pk; k += gsz) { hf[k] = (float)hR[k]; dhf[k] = 0.0f; xxKf[k] = 1.0f; Lkf[k] = (float)(Ve / (Vd[k] * Vp)); }
+  for (int64_t i = gid; i < ld; i += gsz) e64[i] = (i < n) ? (double)(float)eR[i] : 0.0;
+  if (gid == 0) {
+    ChainScalars c; memset(&c, 0, sizeof(c));
+    const float Vef = (float)Ve;
+    c.ve = Vef; c.pi = 0.0f; c.C = -0.5f / sqrtf(Vef); c.odds = 0.0f; c.dfp1 = 1.0f;
+    *sc = c;
+  }
+}
+__global__ void k_wgr_post_k(const float *hf, double *hR, const double *e64, double *eR, int pk, int n) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = gid; k < pk; k += gsz) hR[k] = (double)hf[k];
+  for (int64_t i = gid; i < n; i += gsz) eR[i] = (double)(float)e64[i];   // KMUP returns e as float (src/Rcpp20260726ai.cpp:37)
+}
+// Vp = (sum(h^2/V) + Sk)/rchisq(1, df+pk)  (R/wgr.R:117)
+__global__ __launch_bounds__(1024) void k_wgr_vp(const double *hR, const double *Vd, int pk, double dfv, uint32_t iter, Rng rng, WgrScalars *ws) {
+  __shared__ double red[17];
+  double s = 0;
+  for (int k = threadIdx.x; k < pk; k += blockDim.x) s += hR[k] * hR[k] / Vd[k];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) ws->Vp = (s + ws->Sk) / rng_chisq(rng, dfv + (double)pk, RNG_GLOBAL_MARKER, iter, RNG_G_VK);
+}
+// out[i] (+)= sum_k U[i,k] * coef[k] * scale   (U %*% h in double, R/wgr.R:124,148)
+__global__ void k_uh(const double *Ud, const double *coef, int n, int pk, double scale, double *out, int accumulate_into_neg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0;
+  for (int k = 0; k < pk; ++k) s = fma(Ud[(size_t)k * n + i], coef[k] * scale, s);
+  if (accumulate_into_neg) out[i] -= s; else out[i] = s;
+}
+__global__ void k_wgr_accum_k(const double *hR, double *H, int pk, WgrScalars *ws) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < pk; k += gridDim.x * blockDim.x) H[k] += hR[k];
+  if (blockIdx.x == 0 && threadIdx.x == 0) ws->VP += ws->Vp;
+}
+__global__ void k_add_vec(double *a, const double *b, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += b[i];
 }
 // posterior means (R/wgr.R:141-145)
 __global__ void k_wgr_final(double *B, double *D, double *VB, int p, double mc, const double *dpart, int iv, WgrScalars *ws) {
@@ -1288,7 +1333,15 @@ static int gemv_parts(bwgr_panel *P, const CT *coef_dev, double **part_out, int 
 extern "C" int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, int de, double pi, double df, double R2,
                         uint64_t seed, int rng_mode, double *mu, double *b, double *Vb, double *d, double *Ve, double *hat,
                         double *cxx) {
+  return bwgr_wgr_ex(P, y, it, bi, th, iv, de, pi, df, R2, seed, rng_mode, nullptr, nullptr, 0, mu, b, Vb, d, Ve, hat, cxx, nullptr, nullptr);
+}
+
+extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, int de, double pi, double df, double R2,
+                           uint64_t seed, int rng_mode, const double *U, const double *V, int64_t pk, double *mu, double *b,
+                           double *Vb, double *d, double *Ve, double *hat, double *cxx, double *u, double *Vk) {
   if (!P || !y) return fail(BWGR_EINVAL, "wgr: null pointer");
+  if (!U || pk <= 0) { U = nullptr; pk = 0; }
+  if (U && !V) return fail(BWGR_EINVAL, "wgr: eigenvalues missing");
   if (it < 1 || bi < 0 || th < 1) return fail(BWGR_EINVAL, "wgr: need it >= 1, bi >= 0, th >= 1");
   if (de) iv = 1;                                                                  // R/wgr.R:9
   HIPCHK(hipSetDevice(P->device));
@@ -1300,13 +1353,25 @@ extern "C" int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, 
   std::vector<void *> owned;
   auto dalloc = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, bytes) != hipSuccess) return nullptr; owned.push_back(q); return q; };
   auto cleanup = [&]() { for (void *q : owned) hipFree(q); };
-  double *yd = (double *)dalloc(sizeof(double) * n), *eR = (double *)dalloc(sizeof(double) * P->ld), *e64 = (double *)dalloc(sizeof(double) * P->ld);
+  bwgr_panel *PU = nullptr;   // eigenvectors as an fp32 panel (KMUP narrows U to float like any other X)
+  if (U) {
+    int rcu = bwgr_panel_create(&PU, U, BWGR_X_F64, BWGR_HOST, n, pk, n, P->device, 0, 0);
+    if (rcu != BWGR_OK) return rcu;
+    PU->stream = P->stream;
+  }
+  const int64_t ldmax = std::max<int64_t>(P->ld, PU ? PU->ld : 0);
+  const size_t kd = sizeof(double) * (size_t)std::max<int64_t>(pk, 1), kf = sizeof(float) * (size_t)std::max<int64_t>(pk, 1);
+  double *yd = (double *)dalloc(sizeof(double) * n), *eR = (double *)dalloc(sizeof(double) * ldmax), *e64 = (double *)dalloc(sizeof(double) * ldmax);
+  double *Ud = (double *)dalloc(sizeof(double) * (size_t)std::max<int64_t>(n * pk, 1)), *Vd = (double *)dalloc(kd), *hR = (double *)dalloc(kd), *Hk = (double *)dalloc(kd), *uhd = (double *)dalloc(sizeof(double) * n);
+  float *hf = (float *)dalloc(kf), *dhf = (float *)dalloc(kf), *xxKf = (float *)dalloc(kf), *Lkf = (float *)dalloc(kf), *vbk = (float *)dalloc(kf);
+  ChainScalars *sck = (ChainScalars *)dalloc(sizeof(ChainScalars));
   double *xx64 = (double *)dalloc(pd), *vx64 = (double *)dalloc(pd), *bR = (double *)dalloc(pd), *dR = (double *)dalloc(pd);
   double *VbR = (double *)dalloc(pd), *LR = (double *)dalloc(pd), *B = (double *)dalloc(pd), *D = (double *)dalloc(pd), *VB = (double *)dalloc(pd);
   float *bf = (float *)dalloc(pf), *dfl = (float *)dalloc(pf), *Lf = (float *)dalloc(pf), *xxf = (float *)dalloc(pf), *vbf = (float *)dalloc(pf);
   double *part1 = (double *)dalloc(sizeof(double) * 256), *part2 = (double *)dalloc(sizeof(double) * 256), *hatd = (double *)dalloc(sizeof(double) * n);
   WgrScalars *ws = (WgrScalars *)dalloc(sizeof(WgrScalars));
   ChainScalars *sc = (ChainScalars *)dalloc(sizeof(ChainScalars));
+  if (!Ud || !Vd || !hR || !Hk || !uhd || !hf || !dhf || !xxKf || !Lkf || !vbk || !sck) { cleanup(); if (PU) bwgr_panel_destroy(PU); return fail(BWGR_ENOMEM, "wgr: device allocation failed"); }
   if (!yd || !eR || !e64 || !xx64 || !vx64 || !bR || !dR || !VbR || !LR || !B || !D || !VB || !bf || !dfl || !Lf || !xxf || !vbf || !part1 || !part2 || !hatd || !ws || !sc) {
     cleanup(); return fail(BWGR_ENOMEM, "wgr: device allocation failed");
   }
@@ -1315,18 +1380,33 @@ extern "C" int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, 
 #define WCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = fail(BWGR_EHIP, "%s failed: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
   {
     WCHK(hipMemcpyAsync(yd, y, sizeof(double) * n, hipMemcpyHostToDevice, P->stream));
+    if (pk > 0) {
+      WCHK(hipMemcpyAsync(Ud, U, sizeof(double) * (size_t)n * pk, hipMemcpyHostToDevice, P->stream));
+      WCHK(hipMemcpyAsync(Vd, V, kd, hipMemcpyHostToDevice, P->stream));
+      WCHK(hipMemsetAsync(hR, 0, kd, P->stream)); WCHK(hipMemsetAsync(Hk, 0, kd, P->stream));
+    }
     const int wpb = 4;
     if (P->is_f32) hipLaunchKernelGGL(k_stats64<float>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const float *)P->X, P->R, n, p, xx64, vx64);
     else hipLaunchKernelGGL(k_stats64<int8_t>, dim3((p + wpb - 1) / wpb), dim3(64 * wpb), 0, P->stream, (const int8_t *)P->X, P->R, n, p, xx64, vx64);
     hipLaunchKernelGGL(k_dsum_stage1, dim3(256), dim3(256), 0, P->stream, vx64, (int64_t)p, part1, 0);
     hipLaunchKernelGGL(k_dsum_stage1, dim3(256), dim3(256), 0, P->stream, xx64, (int64_t)p, part2, 0);
-    hipLaunchKernelGGL(k_wgr_init, dim3(1), dim3(1024), 0, P->stream, yd, eR, n, P->ld, part1, part2, p, df, R2, ws);
+    hipLaunchKernelGGL(k_wgr_init, dim3(1), dim3(1024), 0, P->stream, yd, eR, n, ldmax, part1, part2, p, df, R2, ws);
     hipLaunchKernelGGL(k_wgr_marker_init, dim3(1024), dim3(256), 0, P->stream, bR, dR, VbR, LR, B, D, VB, p, ws);
     WCHK(hipGetLastError());
     const unsigned pg = (unsigned)std::min<int64_t>(2048, (P->p + 255) / 256);
     for (int i = 1; i <= it; ++i) {                                                // R/wgr.R:66
       const uint32_t itx = (uint32_t)(i - 1);
       const int accumulate = (i >= bi && ((i - bi) % th) == 0) ? 1 : 0;            // i %in% post
+      if (pk > 0) {                                                                // R/wgr.R:70-76
+        hipLaunchKernelGGL(k_wgr_pre_k, dim3(64), dim3(256), 0, P->stream, hR, Vd, eR, hf, dhf, xxKf, Lkf, e64, (int)pk, n, ldmax, ws, sck);
+        SweepArgs ak; memset(&ak, 0, sizeof(ak));
+        fill_panel_args(PU, ak);
+        ak.flags = SWF_LAM_VEC;
+        ak.e = e64; ak.b = hf; ak.d = dhf; ak.vb = vbk; ak.xx = xxKf; ak.lam = Lkf; ak.sc = sck; ak.iter = itx; ak.marker0 = 0x80000000u; ak.rng = rng;
+        rc = launch_sweep(PU, ak);
+        if (rc != BWGR_OK) goto done;
+        hipLaunchKernelGGL(k_wgr_post_k, dim3(64), dim3(256), 0, P->stream, hf, hR, e64, eR, (int)pk, n);
+      }
       hipLaunchKernelGGL(k_wgr_pre, dim3(pg), dim3(256), 0, P->stream, bR, dR, LR, xx64, eR, bf, dfl, Lf, xxf, e64, p, n, P->ld, (float)pi, ws, sc);
       SweepArgs a; memset(&a, 0, sizeof(a));
       fill_panel_args(P, a);
@@ -1336,12 +1416,15 @@ extern "C" int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, 
       if (rc != BWGR_OK) goto done;
       hipLaunchKernelGGL(k_wgr_post, dim3(pg), dim3(256), 0, P->stream, bf, dfl, bR, dR, VbR, p, pi > 0 ? 1 : 0, iv, de, df, itx, rng, ws);
       hipLaunchKernelGGL(k_dsum_stage1, dim3(256), dim3(256), 0, P->stream, bR, (int64_t)p, part1, 1);
+      if (pk > 0) hipLaunchKernelGGL(k_wgr_vp, dim3(1), dim3(1024), 0, P->stream, hR, Vd, (int)pk, df, itx, rng, ws);   // R/wgr.R:116-119
       hipLaunchKernelGGL(k_wgr_scal, dim3(1), dim3(1024), 0, P->stream, e64, n, p, part1, iv, df, itx, rng, ws);
       hipLaunchKernelGGL(k_wgr_L, dim3(pg), dim3(256), 0, P->stream, bR, dR, VbR, LR, B, D, VB, p, iv, accumulate, ws);
       rc = gemv_parts<double>(P, bR, &gpart, &nchunks);
       if (rc != BWGR_OK) goto done;
       hipLaunchKernelGGL(k_wgr_efinish, dim3((n + 255) / 256), dim3(256), 0, P->stream, gpart, P->ld, nchunks, n, yd, eR, ws);
+      if (pk > 0) hipLaunchKernelGGL(k_uh, dim3((n + 255) / 256), dim3(256), 0, P->stream, Ud, hR, n, (int)pk, 1.0, eR, 1);   // - U %*% h
       hipLaunchKernelGGL(k_wgr_mu, dim3(1), dim3(1024), 0, P->stream, eR, n, iv, accumulate, itx, rng, ws);
+      if (pk > 0 && accumulate) hipLaunchKernelGGL(k_wgr_accum_k, dim3(8), dim3(256), 0, P->stream, hR, Hk, (int)pk, ws);
       WCHK(hipGetLastError());
       if ((i & 63) == 0) WCHK(hipStreamSynchronize(P->stream));                    // bound the launch queue
     }
@@ -1356,6 +1439,10 @@ extern "C" int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, 
     rc = gemv_parts<double>(P, B, &gpart, &nchunks);                               // HAT = B0 + gen0 %*% B, R/wgr.R:152
     if (rc != BWGR_OK) goto done;
     hipLaunchKernelGGL(k_hat64_finish, dim3((n + 255) / 256), dim3(256), 0, P->stream, gpart, P->ld, nchunks, n, B0, hatd);
+    if (pk > 0) {                                                                  // poly = U0 %*% H; HAT += poly, R/wgr.R:148-150
+      hipLaunchKernelGGL(k_uh, dim3((n + 255) / 256), dim3(256), 0, P->stream, Ud, Hk, n, (int)pk, 1.0 / (double)mc, uhd, 0);
+      hipLaunchKernelGGL(k_add_vec, dim3((n + 255) / 256), dim3(256), 0, P->stream, hatd, uhd, n);
+    }
     WCHK(hipGetLastError());
     if (mu) *mu = B0;
     if (Ve) *Ve = h.VE / mc;
@@ -1364,12 +1451,15 @@ extern "C" int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, 
     if (d) WCHK(hipMemcpy(d, D, pd, hipMemcpyDeviceToHost));
     if (Vb) { if (iv) WCHK(hipMemcpy(Vb, VB, pd, hipMemcpyDeviceToHost)); else Vb[0] = h.VA / mc; }
     if (hat) WCHK(hipMemcpy(hat, hatd, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (pk > 0 && u) WCHK(hipMemcpy(u, uhd, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (pk > 0 && Vk) *Vk = h.VP / mc;
   }
 done:
 #undef WCHK
   (void)hipStreamSynchronize(P->stream);
   if (gpart) hipFree(gpart);
   cleanup();
+  if (PU) bwgr_panel_destroy(PU);
   return rc;
 }
 

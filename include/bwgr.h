@@ -136,6 +136,13 @@ int bwgr_bayes(bwgr_panel *P, int model, const float *y, float it, float bi, flo
 int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, int de, double pi, double df, double R2,
              uint64_t seed, int rng_mode, double *mu, double *b, double *Vb, double *d, double *Ve, double *hat,
              double *cxx);
+/* wgr() with the polygenic kernel term (eigK, R/wgr.R:23-32,70-78,116-119,148-150): U = the first pk eigenvectors
+ * of the kernel (n x pk doubles, column-major, host), V their eigenvalues (the caller applies VarK: pk =
+ * which.max(cumsum(V)/length(V) > VarK)).  Each iteration first sweeps KMUP(U,h,dh,xxK = 1,e,Lk = Ve/(V*Vk),Ve,0),
+ * then the markers.  Extra outputs as in wgr's list: u[n] = U %*% H, Vk.  U == NULL is bwgr_wgr. */
+int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, int de, double pi, double df, double R2,
+                uint64_t seed, int rng_mode, const double *U, const double *V, int64_t pk, double *mu, double *b,
+                double *Vb, double *d, double *Ve, double *hat, double *cxx, double *u, double *Vk);
 
 /* ---- synthetic panels ----------------------------------------------------------
  * X_ij ~ Binomial(2, f_j), f_j ~ U(0.05,0.5), int8 column-major written to device memory Xdev

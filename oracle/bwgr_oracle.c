@@ -426,26 +426,38 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
   return 0;
 }
 
-/* ---- wgr(): the split shape, /root/reference/R/wgr.R:2-169 (bag = 1, eigK = NULL) ---------------
+/* ---- wgr(): the split shape, /root/reference/R/wgr.R:2-169 (bag = 1) ---------------------------------
  * R arithmetic is double; KMUP is entered through the Rcpp glue that narrows every argument to
  * float (/root/reference/src/RcppExports.cpp:20-27) and widens the returned b, d, e back to double
  * (/root/reference/src/Rcpp20260726ai.cpp:37).  X arrives as an R numeric (double) matrix.
  * o_Vb has p entries when iv (or de) is set, else 1.  Iteration i (1-based in R) uses RNG
- * iteration word i-1. */
+ * iteration word i-1.
+ * Polygenic term (eigK, wgr.R:23-32,70-78,116-119,148-150): U = the first pk eigenvectors (n x pk, column-major,
+ * rows already restricted to non-missing y), V = their eigenvalues; pass U = NULL for eigK = NULL.  The kernel
+ * sweep KMUP(U,h,dh,xxK,e,Lk,Ve,0) draws with marker ids 0x80000000 + k so that its variates are independent of the
+ * marker sweep's.  o_u (n) receives U %*% H, o_Vk the posterior mean of Vp. */
+#define ORNG_KERNEL_MARKER0 0x80000000u
 int FN(oracle_wgr)(const double *y, const double *X, int64_t n, int64_t p, int64_t ldx, int it, int bi, int th,
                    int iv, int de, double pi, double df, double R2, uint64_t seed, int rng_mode, int stable,
-                   double *o_mu, double *o_b, double *o_Vb, double *o_d, double *o_Ve, double *o_hat, double *o_cxx) {
+                   const double *U, const double *V, int64_t pk,
+                   double *o_mu, double *o_b, double *o_Vb, double *o_d, double *o_Ve, double *o_hat, double *o_cxx,
+                   double *o_u, double *o_Vk) {
   orng_t g = { seed, rng_mode };
   const uint32_t GM = ORNG_GLOBAL_MARKER;
   if (de) iv = 1;                                                             /* wgr.R:9 */
+  if (!U) pk = 0;
   float *Xf = (float *)malloc(sizeof(float) * n * p);
   float *bf = (float *)malloc(sizeof(float) * p), *dfl = (float *)malloc(sizeof(float) * p), *xxf = (float *)malloc(sizeof(float) * p);
   float *Lf = (float *)malloc(sizeof(float) * p), *ef = (float *)malloc(sizeof(float) * n);
   double *xx = (double *)malloc(sizeof(double) * p), *b = (double *)calloc(p, sizeof(double)), *d = (double *)malloc(sizeof(double) * p);
   double *Vb = (double *)malloc(sizeof(double) * p), *L = (double *)malloc(sizeof(double) * p), *e = (double *)malloc(sizeof(double) * n);
   double *B = (double *)calloc(p, sizeof(double)), *D = (double *)calloc(p, sizeof(double)), *VB = (double *)calloc(p, sizeof(double));
-  if (!Xf || !bf || !dfl || !xxf || !Lf || !ef || !xx || !b || !d || !Vb || !L || !e || !B || !D || !VB) return 1;
+  float *Uf = (float *)malloc(sizeof(float) * (n * pk + 1)), *hf = (float *)malloc(sizeof(float) * (pk + 1)), *dhf = (float *)malloc(sizeof(float) * (pk + 1));
+  float *xxKf = (float *)malloc(sizeof(float) * (pk + 1)), *Lkf = (float *)malloc(sizeof(float) * (pk + 1));
+  double *h = (double *)calloc(pk + 1, sizeof(double)), *H = (double *)calloc(pk + 1, sizeof(double));
+  if (!Xf || !bf || !dfl || !xxf || !Lf || !ef || !xx || !b || !d || !Vb || !L || !e || !B || !D || !VB || !Uf || !hf || !dhf || !xxKf || !Lkf || !h || !H) return 1;
   for (int64_t j = 0; j < p; j++) for (int64_t i = 0; i < n; i++) Xf[j * n + i] = (float)X[j * ldx + i];
+  for (int64_t k = 0; k < pk; k++) for (int64_t i = 0; i < n; i++) Uf[k * n + i] = (float)U[k * n + i];
   /* post = seq(bi,it,th); mc = length(post)                                   wgr.R:41-42 */
   int mc = 0; for (int q = bi; q <= it; q += th) mc++;
   double MSx = 0, sy = 0;
@@ -464,9 +476,18 @@ int FN(oracle_wgr)(const double *y, const double *X, int64_t n, int64_t p, int64
   double Va = MSx, Ve = 1;                                                    /* wgr.R:52-54 */
   for (int64_t j = 0; j < p; j++) { Vb[j] = Va; L[j] = Vb[j] / Ve; }          /* wgr.R:53,55 (sic) */
   double Sb = (R2)*df * vy / MSx, Se = (1 - R2) * df * vy;                    /* wgr.R:58-59 */
+  double Sk = R2 * vy * (df + 2), Vp = 1, VP = 0;                             /* wgr.R:60; Vk = rep(1,pk) wgr.R:30 */
   double B0 = 0, VA = 0, VE = 0;
   for (int i = 1; i <= it; i++) {                                             /* wgr.R:66 */
     uint32_t itx = (uint32_t)(i - 1);
+    if (pk > 0) {                                                             /* wgr.R:70-78 */
+      for (int64_t k = 0; k < pk; k++) { hf[k] = (float)h[k]; dhf[k] = 0.0f; xxKf[k] = 1.0f; Lkf[k] = (float)(Ve / (V[k] * Vp)); }
+      for (int64_t k = 0; k < n; k++) ef[k] = (float)e[k];
+      int rc = FN(oracle_kmup)(Uf, n, pk, n, hf, dhf, xxKf, ef, Lkf, (float)Ve, 0.0f, seed, itx, rng_mode, stable, ORNG_KERNEL_MARKER0);
+      if (rc) return rc;
+      for (int64_t k = 0; k < pk; k++) h[k] = (double)hf[k];
+      for (int64_t k = 0; k < n; k++) e[k] = (double)ef[k];
+    }
     for (int64_t j = 0; j < p; j++) { bf[j] = (float)b[j]; dfl[j] = (float)d[j]; xxf[j] = (float)xx[j]; Lf[j] = (float)L[j]; }
     for (int64_t k = 0; k < n; k++) ef[k] = (float)e[k];
     int rc = FN(oracle_kmup)(Xf, n, p, n, bf, dfl, xxf, ef, Lf, (float)Ve, (float)pi, seed, itx, rng_mode, stable, 0u);   /* wgr.R:85 */
@@ -482,11 +503,16 @@ int FN(oracle_wgr)(const double *y, const double *X, int64_t n, int64_t p, int64
       Va = (bb + Sb) / orng_chisq(&g, df + (double)p, GM, itx, ORNG_G_VB);
       for (int64_t j = 0; j < p; j++) Vb[j] = Va;
     }
+    if (pk > 0) {                                                             /* wgr.R:116-119 */
+      double hv = 0; for (int64_t k = 0; k < pk; k++) hv += h[k] * h[k] / V[k];
+      Vp = (hv + Sk) / orng_chisq(&g, df + (double)pk, GM, itx, ORNG_G_VK);
+    }
     double ee = 0; for (int64_t k = 0; k < n; k++) ee += e[k] * e[k];
     Ve = (ee + Se) / orng_chisq(&g, (double)n + df, GM, itx, ORNG_G_VE);      /* wgr.R:121 */
     for (int64_t j = 0; j < p; j++) L[j] = Ve / Vb[j];                        /* wgr.R:122 */
     for (int64_t k = 0; k < n; k++) e[k] = y[k] - mu;                         /* wgr.R:124 */
     for (int64_t j = 0; j < p; j++) { const double *xj = X + j * ldx; double bj = b[j]; if (bj != 0) for (int64_t k = 0; k < n; k++) e[k] -= xj[k] * bj; }
+    for (int64_t q = 0; q < pk; q++) { const double *uq = U + q * n; double hq = h[q]; for (int64_t k = 0; k < n; k++) e[k] -= uq[k] * hq; }
     double me = 0; for (int64_t k = 0; k < n; k++) me += e[k]; me /= (double)n;
     double mu0 = me + (Ve / (double)n) * orng_normal(&g, GM, itx, ORNG_G_MU, 0);   /* wgr.R:125 sd = Ve/n (sic) */
     mu += mu0;                                                                /* wgr.R:126 */
@@ -495,6 +521,8 @@ int FN(oracle_wgr)(const double *y, const double *X, int64_t n, int64_t p, int64
       B0 += mu; VE += Ve;
       for (int64_t j = 0; j < p; j++) { B[j] += b[j]; D[j] += d[j]; }
       if (iv) for (int64_t j = 0; j < p; j++) VB[j] += Vb[j]; else VA += Va;
+      for (int64_t k = 0; k < pk; k++) H[k] += h[k];
+      if (pk > 0) VP += Vp;
     }
   }
   B0 /= mc; VE /= mc;                                                         /* wgr.R:141-145 */
@@ -503,9 +531,16 @@ int FN(oracle_wgr)(const double *y, const double *X, int64_t n, int64_t p, int64
   if (iv) { for (int64_t j = 0; j < p; j++) o_Vb[j] = VB[j] / mc; } else o_Vb[0] = VA / mc;
   for (int64_t k = 0; k < n; k++) o_hat[k] = B0;                              /* wgr.R:152 */
   for (int64_t j = 0; j < p; j++) { const double *xj = X + j * ldx; double Bj = B[j]; for (int64_t k = 0; k < n; k++) o_hat[k] += xj[k] * Bj; }
+  if (pk > 0) {                                                               /* wgr.R:146-150 */
+    for (int64_t k = 0; k < n; k++) o_u[k] = 0;
+    for (int64_t q = 0; q < pk; q++) { const double *uq = U + q * n; double Hq = H[q] / mc; for (int64_t k = 0; k < n; k++) o_u[k] += uq[k] * Hq; }
+    for (int64_t k = 0; k < n; k++) o_hat[k] += o_u[k];
+    *o_Vk = VP / mc;
+  }
   double cxx = 0; for (int64_t j = 0; j < p; j++) cxx += xx[j]; cxx /= (double)p;
   *o_mu = B0; *o_Ve = VE; *o_cxx = cxx;
   memcpy(o_b, B, sizeof(double) * p); memcpy(o_d, D, sizeof(double) * p);
   free(Xf); free(bf); free(dfl); free(xxf); free(Lf); free(ef); free(xx); free(b); free(d); free(Vb); free(L); free(e); free(B); free(D); free(VB);
+  free(Uf); free(hf); free(dhf); free(xxKf); free(Lkf); free(h); free(H);
   return 0;
 }

@@ -117,17 +117,35 @@ def bayes(model, y, X, it=1500, bi=500, pi=0.95, df=5.0, R2=0.5, seed=1, rng_mod
     return out
 
 
-def wgr(y, X, it=1500, bi=500, th=1, iv=False, de=False, pi=0.0, df=5.0, R2=0.5, seed=1, rng_mode=0, stable=1, flavour="w"):
-    """Reference wgr(y,X,it,bi,th,bag=1,rp=F,iv,de,pi,df,R2,eigK=NULL), R/wgr.R:2-169."""
+def eigk_truncate(eigK, VarK):
+    """R/wgr.R:23-27: pk = which.max((cumsum(V)/length(V)) > VarK); first pk eigenpairs."""
+    V = np.asarray(eigK["values"], np.float64)
+    U = np.asarray(eigK["vectors"], np.float64)
+    pk = int(np.argmax((np.cumsum(V) / V.size) > VarK)) + 1
+    return np.asfortranarray(U[:, :pk]), np.ascontiguousarray(V[:pk]), pk
+
+
+def wgr(y, X, it=1500, bi=500, th=1, iv=False, de=False, pi=0.0, df=5.0, R2=0.5, eigK=None, VarK=0.95, seed=1, rng_mode=0,
+        stable=1, flavour="w"):
+    """Reference wgr(y,X,it,bi,th,bag=1,rp=F,iv,de,pi,df,R2,eigK,VarK), R/wgr.R:2-169."""
     Xd = np.asfortranarray(np.asarray(X), dtype=np.float64)
     n, p = Xd.shape
     y = np.ascontiguousarray(y, np.float64)
     per = bool(iv or de)
-    b = np.zeros(p); d = np.zeros(p); Vb = np.zeros(p if per else 1); hat = np.zeros(n)
-    mu = C.c_double(); Ve = C.c_double(); cxx = C.c_double()
+    b = np.zeros(p); d = np.zeros(p); Vb = np.zeros(p if per else 1); hat = np.zeros(n); u = np.zeros(n)
+    mu = C.c_double(); Ve = C.c_double(); cxx = C.c_double(); Vk = C.c_double()
+    if eigK is not None:
+        U, V, pk = eigk_truncate(eigK, VarK)
+        Up, Vp = _dp(U), _dp(V)
+    else:
+        U, V, pk, Up, Vp = None, None, 0, None, None
     rc = getattr(lib(), "oracle_wgr_" + flavour)(
         _dp(y), _dp(Xd), C.c_int64(n), C.c_int64(p), C.c_int64(n), C.c_int(it), C.c_int(bi), C.c_int(th),
         C.c_int(int(iv)), C.c_int(int(de)), C.c_double(pi), C.c_double(df), C.c_double(R2), C.c_uint64(seed),
-        C.c_int(rng_mode), C.c_int(stable), C.byref(mu), _dp(b), _dp(Vb), _dp(d), C.byref(Ve), _dp(hat), C.byref(cxx))
+        C.c_int(rng_mode), C.c_int(stable), Up, Vp, C.c_int64(pk),
+        C.byref(mu), _dp(b), _dp(Vb), _dp(d), C.byref(Ve), _dp(hat), C.byref(cxx), _dp(u), C.byref(Vk))
     assert rc == 0
+    if eigK is not None:
+        return {"mu": mu.value, "b": b, "Vb": Vb if per else float(Vb[0]), "d": d, "Ve": Ve.value, "hat": hat, "u": u,
+                "Vk": Vk.value, "cxx": cxx.value}
     return {"mu": mu.value, "b": b, "Vb": Vb if per else float(Vb[0]), "d": d, "Ve": Ve.value, "hat": hat, "cxx": cxx.value}

@@ -137,8 +137,6 @@ def test_wgr_unbuilt_rows_raise(tpod):
     import bwgr_amd
     with pytest.raises(NotImplementedError):
         bwgr_amd.wgr(tpod["y"], tpod["gen"], it=5, bi=1, bag=0.5)
-    with pytest.raises(NotImplementedError):
-        bwgr_amd.wgr(tpod["y"], tpod["gen"], it=5, bi=1, eigK={"values": [1.0], "vectors": [[1.0]]})
 
 
 def test_sharded_entry_points_world1_equals_run(tpod):
@@ -239,3 +237,26 @@ def test_both_sweep_engines_give_the_same_chain(model, monkeypatch):
     for v in ("1", "2"):
         assert scaled_err(out[v]["b"], o["b"]) < TOL and scaled_err(out[v]["e"], o["e"]) < TOL
     assert scaled_err(out["1"]["b"], out["2"]["b"]) < 1e-9 and np.array_equal(out["1"]["d"], out["2"]["d"])
+
+
+def _tpod_eigk(tpod):
+    Z = tpod["gen"].astype(np.float64); Z = Z - Z.mean(0)
+    K = Z @ Z.T; K = K / np.mean(np.diag(K))
+    w, v = np.linalg.eigh(K); o = np.argsort(-w)
+    return {"values": w[o], "vectors": v[:, o]}
+
+
+@pytest.mark.parametrize("kw", [{}, {"iv": True, "pi": 0.5}])
+def test_wgr_polygenic_term_tpod(tpod, kw):
+    """wgr(eigK=eigen(K)): second KMUP sweep over the kernel's eigenvectors each iteration (R/wgr.R:70-78),
+    Vk draw (:116-119), list(mu,b,Vb,d,Ve,hat,u,Vk,cxx)."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = tpod["gen"], tpod["y"]
+    eig = _tpod_eigk(tpod)
+    g = bwgr_amd.wgr(y, X, it=25, bi=5, eigK=eig, VarK=0.9, seed=13, **kw)
+    o = O.wgr(y, X, it=25, bi=5, eigK=eig, VarK=0.9, seed=13, **kw)
+    assert list(g.keys()) == ["mu", "b", "Vb", "d", "Ve", "hat", "u", "Vk", "cxx"] == list(o.keys())
+    assert scaled_err(g["b"], o["b"]) < TOL and scaled_err(g["hat"], o["hat"]) < TOL and scaled_err(g["u"], o["u"]) < 5 * TOL
+    assert _rel(g["Ve"], o["Ve"]) < TOL and _rel(g["Vk"], o["Vk"]) < TOL and _rel(g["mu"], o["mu"]) < TOL
+    assert scaled_err(g["d"], o["d"]) < 1e-12
