@@ -47,7 +47,7 @@ def lib():
     L.bwgr_chain_sweep_ms.argtypes = [vp, c_f, C.POINTER(i32)]
     L.bwgr_bayes.argtypes = [vp, i32, c_f, f32, f32, f32, f32, f32, u64, i32] + [c_f] * 10
     L.bwgr_wgr.argtypes = [vp, c_d, i32, i32, i32, i32, i32, f64, f64, f64, u64, i32] + [c_d] * 7
-    L.bwgr_wgr_ex.argtypes = [vp, c_d, i32, i32, i32, i32, i32, f64, f64, f64, u64, i32, c_d, c_d, i64] + [c_d] * 9
+    L.bwgr_wgr_ex.argtypes = [vp, c_d, i32, i32, i32, i32, i32, f64, f64, f64, u64, i32, c_d, c_d, i64, f64, i32] + [c_d] * 9
     L.bwgr_synth_genotypes.argtypes = [vp, i64, i64, i64, i64, u64, vp, i32, vp]
     L.bwgr_debug_variates.argtypes = [i32, u64, i32, f64, u32, u32, u32, i32, c_d]
     L.bwgr_device_count.argtypes = [C.POINTER(i32)]

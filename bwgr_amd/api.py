@@ -259,10 +259,12 @@ def KMUP(X, b, d, xx, e, L, Ve, pi, *, seed=None, it=0, rng_mode=0, **panel_kw):
 def wgr(y, X, it=1500, bi=500, th=1, bag=1, rp=False, iv=False, de=False, pi=0, df=5, R2=0.5, eigK=None, VarK=0.95,
         verb=False, *, seed=None, rng_mode=0, **panel_kw):
     """wgr(), R/wgr.R:2-169, device-resident.  eigK = {"values": ..., "vectors": ...} (R's eigen(K)) adds the
-    polygenic kernel term.  bag != 1 (KMUP2) is not built yet and raises instead of silently running
-    something else.  Returns wgr's list: mu, b, Vb, d, Ve, hat[, u, Vk], cxx (R/wgr.R:155-167)."""
-    if bag != 1 or rp:
-        raise NotImplementedError("wgr(bag != 1): the KMUP2 bagging path (SURVEY section 8 f1) is not built yet")
+    polygenic kernel term; bag != 1 sweeps KMUP2 on sort(sample(n, n*bag, rp)) rows each iteration.  The two together
+    are refused: the reference itself indexes out of bounds there (R/wgr.R:73-79).
+    Returns wgr's list: mu, b, Vb, d, Ve, hat[, u, Vk], cxx (R/wgr.R:155-167)."""
+    if bag != 1 and eigK is not None:
+        raise NotImplementedError("wgr(bag != 1, eigK=...): undefined in the reference (a subsampled residual is indexed with "
+                                  "full-length row ids, R/wgr.R:73-79)")
     y = np.asarray(y, np.float64)
     U0 = V = None
     if eigK is not None:                       # R/wgr.R:23-27
@@ -299,16 +301,17 @@ def wgr(y, X, it=1500, bi=500, th=1, bag=1, rp=False, iv=False, de=False, pi=0, 
         b = np.zeros(p); d = np.zeros(p); Vb = np.zeros(p if per else 1); hat = np.zeros(n); u = np.zeros(n)
         mu = C.c_double(); Ve = C.c_double(); cxx = C.c_double(); Vk = C.c_double()
         yc = np.ascontiguousarray(y, np.float64)
-        if U is None:
+        if U is None and bag == 1:
             check(_lib.lib().bwgr_wgr(P._h, _dp(yc), int(it), int(bi), int(th), int(bool(iv)), int(bool(de)), float(pi),
                                        float(df), float(R2), C.c_uint64(_seed(seed)), int(rng_mode), C.byref(mu), _dp(b), _dp(Vb),
                                        _dp(d), C.byref(Ve), _dp(hat), C.byref(cxx)))
         else:
-            assert U.shape[0] == n
+            assert U is None or U.shape[0] == n
             check(_lib.lib().bwgr_wgr_ex(P._h, _dp(yc), int(it), int(bi), int(th), int(bool(iv)), int(bool(de)), float(pi),
-                                          float(df), float(R2), C.c_uint64(_seed(seed)), int(rng_mode), _dp(U), _dp(V),
-                                          C.c_int64(U.shape[1]), C.byref(mu), _dp(b), _dp(Vb), _dp(d), C.byref(Ve), _dp(hat),
-                                          C.byref(cxx), _dp(u), C.byref(Vk)))
+                                          float(df), float(R2), C.c_uint64(_seed(seed)), int(rng_mode),
+                                          _dp(U) if U is not None else None, _dp(V) if U is not None else None,
+                                          C.c_int64(U.shape[1] if U is not None else 0), float(bag), int(bool(rp)), C.byref(mu),
+                                          _dp(b), _dp(Vb), _dp(d), C.byref(Ve), _dp(hat), C.byref(cxx), _dp(u), C.byref(Vk)))
         if keep is not None:
             # HAT = B0 + gen0 %*% B (+ U0 %*% H) over ALL rows of gen0 (R/wgr.R:146-152): rows with missing y are predicted.
             # R-level post-processing in the reference too; the rows that were swept keep the device's values.

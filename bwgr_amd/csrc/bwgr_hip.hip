@@ -509,7 +509,7 @@ __global__ void k_wgr_post(const float *bf, const float *df_, double *bR, double
   }
 }
 // Va (common variance) and Ve draws (R/wgr.R:113,121); e64 holds KMUP's residual (float values)
-__global__ __launch_bounds__(1024) void k_wgr_scal(const double *e64, int n, int p, const double *bbpart, int iv, double dfv, uint32_t iter, Rng rng, WgrScalars *ws) {
+__global__ __launch_bounds__(1024) void k_wgr_scal(const double *e64, int n, double n_dof, int p, const double *bbpart, int iv, double dfv, uint32_t iter, Rng rng, WgrScalars *ws) {
   __shared__ double red[17];
   double ee = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) { const double v = (double)(float)e64[i]; ee += v * v; }
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(1024) void k_wgr_scal(const double *e64, int n, int
   bb = block_sum(bb, red);
   if (threadIdx.x == 0) {
     if (!iv) ws->Va = (bb + ws->Sb) / rng_chisq(rng, dfv + (double)p, RNG_GLOBAL_MARKER, iter, RNG_G_VB);
-    ws->Ve = (ee + ws->Se) / rng_chisq(rng, (double)n + dfv, RNG_GLOBAL_MARKER, iter, RNG_G_VE);
+    ws->Ve = (ee + ws->Se) / rng_chisq(rng, n_dof + dfv, RNG_GLOBAL_MARKER, iter, RNG_G_VE);   // n*bag + df, R/wgr.R:121
     ws->bb = bb;
   }
 }
@@ -597,6 +597,26 @@ __global__ void k_add_vec(double *a, const double *b, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] += b[i];
 }
+// ---- bagging (bag != 1): KMUP2 works on a row subsample (src/Rcpp20260726ai.cpp:49-57) ----
+// rows Use[0..nb) of the base panel -> a panel of nb rows (both slab-major, each with its own slab height)
+template <typename XT>
+__global__ void k_gather_rows(const XT *Xb, int Rb, const int *use, int nb, XT *Xo, int Ro, int64_t ldo, int64_t p) {
+  const int64_t total = p * ldo;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = idx / ldo, i = idx - j * ldo;
+    XT v = (XT)0;
+    if (i < nb) v = Xb[xoff(use[i], j, Rb, p)];
+    Xo[xoff(i, j, Ro, p)] = v;
+  }
+}
+__global__ void k_gather_e(const double *eR, const int *use, int nb, int64_t ldo, double *e64) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ldo; i += (int64_t)gridDim.x * blockDim.x)
+    e64[i] = (i < nb) ? (double)(float)eR[use[i]] : 0.0;
+}
+__global__ void k_scale_d(double *v, int64_t n, double s) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] *= s;
+}
+__global__ void k_set_bg(ChainScalars *sc, float bg) { sc->bg = bg; }
 // posterior means (R/wgr.R:141-145)
 __global__ void k_wgr_final(double *B, double *D, double *VB, int p, double mc, const double *dpart, int iv, WgrScalars *ws) {
   __shared__ double red[17];
@@ -819,6 +839,7 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   return BWGR_OK;
 }
 
+static int panel_build_gram(bwgr_panel *P);
 static int panel_setup(bwgr_panel *P) {
   const int p = (int)P->p, n = (int)P->n;
   // a10: xx, vx, MSx
@@ -837,7 +858,12 @@ static int panel_setup(bwgr_panel *P) {
     HIPCHK(hipStreamSynchronize(P->stream));
     HIPCHK(hipFree(part));
   }
-  // block-diagonal Gram
+  return panel_build_gram(P);
+}
+
+// diagonal, off-diagonal and packed Gram blocks of the resident X
+static int panel_build_gram(bwgr_panel *P) {
+  const int p = (int)P->p;
   const int m = P->m, TJ = m / 16;
   if (P->is_f32) {
     const size_t lds = (size_t)m * 65 * sizeof(float);
@@ -897,17 +923,14 @@ static int panel_setup(bwgr_panel *P) {
   return BWGR_OK;
 }
 
-extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int memloc, int64_t n, int64_t p,
-                                 int64_t ldx, int device, int block, int nwg) {
-  if (!out || !X) return fail(BWGR_EINVAL, "panel_create: null pointer");
+// geometry + every device allocation of a panel of n rows x p markers (no data yet)
+static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int device, int block, int nwg) {
   *out = nullptr;
-  if (n < 2 || p < 1 || ldx < n) return fail(BWGR_EINVAL, "panel_create: need n >= 2, p >= 1, ldx >= n (n=%lld p=%lld ldx=%lld)", (long long)n, (long long)p, (long long)ldx);
-  if (n > 0x7FFFFF00ll || p > 0x7FFFFF00ll) return fail(BWGR_EINVAL, "panel_create: n and p must fit 31 bits");
-  if (xtype != BWGR_X_I8 && xtype != BWGR_X_F32 && xtype != BWGR_X_F64) return fail(BWGR_EINVAL, "panel_create: bad xtype %d", xtype);
-  if (memloc != BWGR_HOST && memloc != BWGR_DEVICE) return fail(BWGR_EINVAL, "panel_create: bad memloc %d", memloc);
+  if (n < 2 || p < 1) return fail(BWGR_EINVAL, "panel: need n >= 2, p >= 1 (n=%lld p=%lld)", (long long)n, (long long)p);
+  if (n > 0x7FFFFF00ll || p > 0x7FFFFF00ll) return fail(BWGR_EINVAL, "panel: n and p must fit 31 bits");
   CHK(require_device(device));
   bwgr_panel *P = new bwgr_panel();
-  P->device = device; P->n = n; P->p = p; P->is_f32 = (xtype != BWGR_X_I8);
+  P->device = device; P->n = n; P->p = p; P->is_f32 = is_f32;
   const int mmax = P->is_f32 ? 64 : SW_MAXM;
   int m = block > 0 ? block : mmax;
   if (m > mmax) { delete P; return fail(BWGR_EINVAL, "panel_create: block %d > %d (limit for this genotype type)", m, mmax); }
@@ -962,12 +985,26 @@ extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef PCHK
+  (void)rc;
+  *out = P;
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int memloc, int64_t n, int64_t p,
+                                 int64_t ldx, int device, int block, int nwg) {
+  if (!out || !X) return fail(BWGR_EINVAL, "panel_create: null pointer");
+  *out = nullptr;
+  if (ldx < n) return fail(BWGR_EINVAL, "panel_create: need ldx >= n (n=%lld ldx=%lld)", (long long)n, (long long)ldx);
+  if (xtype != BWGR_X_I8 && xtype != BWGR_X_F32 && xtype != BWGR_X_F64) return fail(BWGR_EINVAL, "panel_create: bad xtype %d", xtype);
+  if (memloc != BWGR_HOST && memloc != BWGR_DEVICE) return fail(BWGR_EINVAL, "panel_create: bad memloc %d", memloc);
+  bwgr_panel *P = nullptr;
+  CHK(panel_alloc(&P, xtype != BWGR_X_I8, n, p, device, block, nwg));
+  int rc;
   if (xtype == BWGR_X_I8) rc = upload<int8_t, int8_t>(P, X, memloc, ldx);
   else if (xtype == BWGR_X_F32) rc = upload<float, float>(P, X, memloc, ldx);
   else rc = upload<double, float>(P, X, memloc, ldx);
-  if (rc != BWGR_OK) return bail(rc);
-  rc = panel_setup(P);
-  if (rc != BWGR_OK) return bail(rc);
+  if (rc == BWGR_OK) rc = panel_setup(P);
+  if (rc != BWGR_OK) { bwgr_panel_destroy(P); return rc; }
   *out = P;
   return BWGR_OK;
 }
@@ -1315,6 +1352,30 @@ extern "C" int bwgr_bayes(bwgr_panel *P, int model, const float *y, float it, fl
   return rc;
 }
 
+// host side of the RNG contract for wgr's row resampling, R/wgr.R:68: Use = sort(sample(n, n*bag, rp)) - 1
+static double host_uniform(uint64_t seed, uint32_t marker, uint32_t iter, uint32_t purpose, uint32_t k) {
+  uint32_t c0 = marker, c1 = iter, c2 = purpose, c3 = k, k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6) + 0.5) / 9007199254740992.0;
+}
+static void bag_rows(uint64_t seed, uint32_t iter, int64_t n, int64_t k, int rp, std::vector<int> &use) {
+  use.resize((size_t)k);
+  if (rp) {
+    for (int64_t t = 0; t < k; ++t) { int r = (int)(host_uniform(seed, (uint32_t)t, iter, RNG_BAG, 1) * (double)n); use[(size_t)t] = r >= n ? (int)n - 1 : r; }
+  } else {
+    std::vector<std::pair<double, int>> kv((size_t)n);
+    for (int64_t i = 0; i < n; ++i) kv[(size_t)i] = std::make_pair(host_uniform(seed, (uint32_t)i, iter, RNG_BAG, 0), (int)i);
+    std::sort(kv.begin(), kv.end());
+    for (int64_t t = 0; t < k; ++t) use[(size_t)t] = kv[(size_t)t].second;
+  }
+  std::sort(use.begin(), use.end());
+}
+
 // X * coef (fp64 partial products per column chunk); caller finishes.  Returns nchunks and the device buffer.
 template <typename CT>
 static int gemv_parts(bwgr_panel *P, const CT *coef_dev, double **part_out, int *nchunks_out) {
@@ -1333,15 +1394,21 @@ static int gemv_parts(bwgr_panel *P, const CT *coef_dev, double **part_out, int 
 extern "C" int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, int de, double pi, double df, double R2,
                         uint64_t seed, int rng_mode, double *mu, double *b, double *Vb, double *d, double *Ve, double *hat,
                         double *cxx) {
-  return bwgr_wgr_ex(P, y, it, bi, th, iv, de, pi, df, R2, seed, rng_mode, nullptr, nullptr, 0, mu, b, Vb, d, Ve, hat, cxx, nullptr, nullptr);
+  return bwgr_wgr_ex(P, y, it, bi, th, iv, de, pi, df, R2, seed, rng_mode, nullptr, nullptr, 0, 1.0, 0, mu, b, Vb, d, Ve, hat, cxx, nullptr, nullptr);
 }
 
 extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, int de, double pi, double df, double R2,
-                           uint64_t seed, int rng_mode, const double *U, const double *V, int64_t pk, double *mu, double *b,
-                           double *Vb, double *d, double *Ve, double *hat, double *cxx, double *u, double *Vk) {
+                           uint64_t seed, int rng_mode, const double *U, const double *V, int64_t pk, double bag, int rp,
+                           double *mu, double *b, double *Vb, double *d, double *Ve, double *hat, double *cxx, double *u, double *Vk) {
   if (!P || !y) return fail(BWGR_EINVAL, "wgr: null pointer");
   if (!U || pk <= 0) { U = nullptr; pk = 0; }
   if (U && !V) return fail(BWGR_EINVAL, "wgr: eigenvalues missing");
+  const bool bagging = (bag != 1.0);
+  if (bagging && U) return fail(BWGR_EINVAL, "wgr: bag != 1 with eigK is undefined in the reference (R/wgr.R:73-79 index a subsampled e with full row ids)");
+  if (bagging && !(bag > 0.0)) return fail(BWGR_EINVAL, "wgr: bag must be > 0");
+  const int64_t nbag = bagging ? (int64_t)((double)P->n * bag) : P->n;
+  if (bagging && nbag < 2) return fail(BWGR_EINVAL, "wgr: n*bag < 2");
+  if (bagging) df = df / (bag * bag);                                              // R/wgr.R:20
   if (it < 1 || bi < 0 || th < 1) return fail(BWGR_EINVAL, "wgr: need it >= 1, bi >= 0, th >= 1");
   if (de) iv = 1;                                                                  // R/wgr.R:9
   HIPCHK(hipSetDevice(P->device));
@@ -1359,7 +1426,16 @@ extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int t
     if (rcu != BWGR_OK) return rcu;
     PU->stream = P->stream;
   }
-  const int64_t ldmax = std::max<int64_t>(P->ld, PU ? PU->ld : 0);
+  bwgr_panel *PB = nullptr;   // the row subsample of this iteration (bag != 1): same markers, nbag rows
+  int *use_d = nullptr;
+  std::vector<int> use_h;
+  if (bagging) {
+    int rcb = panel_alloc(&PB, P->is_f32, nbag, P->p, P->device, P->m, 0);
+    if (rcb != BWGR_OK) return rcb;
+    PB->stream = P->stream;
+    if (hipMalloc(&use_d, sizeof(int) * (size_t)nbag) != hipSuccess) { bwgr_panel_destroy(PB); return fail(BWGR_ENOMEM, "wgr: device allocation failed"); }
+  }
+  const int64_t ldmax = std::max<int64_t>(std::max<int64_t>(P->ld, PU ? PU->ld : 0), PB ? PB->ld : 0);
   const size_t kd = sizeof(double) * (size_t)std::max<int64_t>(pk, 1), kf = sizeof(float) * (size_t)std::max<int64_t>(pk, 1);
   double *yd = (double *)dalloc(sizeof(double) * n), *eR = (double *)dalloc(sizeof(double) * ldmax), *e64 = (double *)dalloc(sizeof(double) * ldmax);
   double *Ud = (double *)dalloc(sizeof(double) * (size_t)std::max<int64_t>(n * pk, 1)), *Vd = (double *)dalloc(kd), *hR = (double *)dalloc(kd), *Hk = (double *)dalloc(kd), *uhd = (double *)dalloc(sizeof(double) * n);
@@ -1392,6 +1468,7 @@ extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int t
     hipLaunchKernelGGL(k_dsum_stage1, dim3(256), dim3(256), 0, P->stream, xx64, (int64_t)p, part2, 0);
     hipLaunchKernelGGL(k_wgr_init, dim3(1), dim3(1024), 0, P->stream, yd, eR, n, ldmax, part1, part2, p, df, R2, ws);
     hipLaunchKernelGGL(k_wgr_marker_init, dim3(1024), dim3(256), 0, P->stream, bR, dR, VbR, LR, B, D, VB, p, ws);
+    if (bagging) hipLaunchKernelGGL(k_scale_d, dim3(256), dim3(256), 0, P->stream, xx64, (int64_t)p, bag);     // xx = crossprod * bag, R/wgr.R:46
     WCHK(hipGetLastError());
     const unsigned pg = (unsigned)std::min<int64_t>(2048, (P->p + 255) / 256);
     for (int i = 1; i <= it; ++i) {                                                // R/wgr.R:66
@@ -1407,17 +1484,28 @@ extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int t
         if (rc != BWGR_OK) goto done;
         hipLaunchKernelGGL(k_wgr_post_k, dim3(64), dim3(256), 0, P->stream, hf, hR, e64, eR, (int)pk, n);
       }
-      hipLaunchKernelGGL(k_wgr_pre, dim3(pg), dim3(256), 0, P->stream, bR, dR, LR, xx64, eR, bf, dfl, Lf, xxf, e64, p, n, P->ld, (float)pi, ws, sc);
+      hipLaunchKernelGGL(k_wgr_pre, dim3(pg), dim3(256), 0, P->stream, bR, dR, LR, xx64, eR, bf, dfl, Lf, xxf, e64, p, n, ldmax, (float)pi, ws, sc);
       SweepArgs a; memset(&a, 0, sizeof(a));
-      fill_panel_args(P, a);
-      a.flags = SWF_LAM_VEC | (pi > 0 ? (SWF_SELECT | SWF_ALT_B2) : 0);
+      bwgr_panel *PS = bagging ? PB : P;                                           // the panel this iteration sweeps
+      if (bagging) {                                                               // R/wgr.R:68 + KMUP2's gathers
+        bag_rows(seed, itx, n, nbag, rp, use_h);
+        WCHK(hipMemcpyAsync(use_d, use_h.data(), sizeof(int) * (size_t)nbag, hipMemcpyHostToDevice, P->stream));
+        if (P->is_f32) hipLaunchKernelGGL(k_gather_rows<float>, dim3(4096), dim3(256), 0, P->stream, (const float *)P->X, P->R, use_d, (int)nbag, (float *)PB->X, PB->R, PB->ld, P->p);
+        else hipLaunchKernelGGL(k_gather_rows<int8_t>, dim3(4096), dim3(256), 0, P->stream, (const int8_t *)P->X, P->R, use_d, (int)nbag, (int8_t *)PB->X, PB->R, PB->ld, P->p);
+        rc = panel_build_gram(PB);                                                  // syncs the stream (use_h stays valid)
+        if (rc != BWGR_OK) goto done;
+        hipLaunchKernelGGL(k_gather_e, dim3(64), dim3(256), 0, P->stream, eR, use_d, (int)nbag, ldmax, e64);
+        hipLaunchKernelGGL(k_set_bg, dim3(1), dim3(1), 0, P->stream, sc, (float)n / (float)nbag);
+      }
+      fill_panel_args(PS, a);
+      a.flags = SWF_LAM_VEC | (pi > 0 ? (SWF_SELECT | SWF_ALT_B2) : 0) | (bagging ? SWF_KMUP2 : 0);
       a.e = e64; a.b = bf; a.d = dfl; a.vb = vbf; a.xx = xxf; a.lam = Lf; a.sc = sc; a.iter = itx; a.rng = rng;
-      rc = launch_sweep(P, a);                                                     // KMUP, R/wgr.R:85
+      rc = launch_sweep(PS, a);                                                    // KMUP / KMUP2, R/wgr.R:85
       if (rc != BWGR_OK) goto done;
       hipLaunchKernelGGL(k_wgr_post, dim3(pg), dim3(256), 0, P->stream, bf, dfl, bR, dR, VbR, p, pi > 0 ? 1 : 0, iv, de, df, itx, rng, ws);
       hipLaunchKernelGGL(k_dsum_stage1, dim3(256), dim3(256), 0, P->stream, bR, (int64_t)p, part1, 1);
       if (pk > 0) hipLaunchKernelGGL(k_wgr_vp, dim3(1), dim3(1024), 0, P->stream, hR, Vd, (int)pk, df, itx, rng, ws);   // R/wgr.R:116-119
-      hipLaunchKernelGGL(k_wgr_scal, dim3(1), dim3(1024), 0, P->stream, e64, n, p, part1, iv, df, itx, rng, ws);
+      hipLaunchKernelGGL(k_wgr_scal, dim3(1), dim3(1024), 0, P->stream, e64, (int)nbag, (double)n * bag, p, part1, iv, df, itx, rng, ws);
       hipLaunchKernelGGL(k_wgr_L, dim3(pg), dim3(256), 0, P->stream, bR, dR, VbR, LR, B, D, VB, p, iv, accumulate, ws);
       rc = gemv_parts<double>(P, bR, &gpart, &nchunks);
       if (rc != BWGR_OK) goto done;
@@ -1446,7 +1534,7 @@ extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int t
     WCHK(hipGetLastError());
     if (mu) *mu = B0;
     if (Ve) *Ve = h.VE / mc;
-    if (cxx) *cxx = h.cxx;
+    if (cxx) *cxx = h.cxx * bag;                                                   // mean(xx), xx = crossprod * bag
     if (b) WCHK(hipMemcpy(b, B, pd, hipMemcpyDeviceToHost));
     if (d) WCHK(hipMemcpy(d, D, pd, hipMemcpyDeviceToHost));
     if (Vb) { if (iv) WCHK(hipMemcpy(Vb, VB, pd, hipMemcpyDeviceToHost)); else Vb[0] = h.VA / mc; }
@@ -1460,6 +1548,8 @@ done:
   if (gpart) hipFree(gpart);
   cleanup();
   if (PU) bwgr_panel_destroy(PU);
+  if (PB) bwgr_panel_destroy(PB);
+  if (use_d) hipFree(use_d);
   return rc;
 }
 

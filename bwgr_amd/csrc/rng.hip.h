@@ -13,7 +13,7 @@ namespace bwgr {
 
 enum : uint32_t {
   RNG_Z1 = 0, RNG_Z2 = 1, RNG_U = 2, RNG_CHI = 3,
-  RNG_G_MU = 16, RNG_G_VE = 17, RNG_G_VB = 18, RNG_G_VK = 19
+  RNG_G_MU = 16, RNG_G_VE = 17, RNG_G_VB = 18, RNG_G_VK = 19, RNG_BAG = 20
 };
 static constexpr uint32_t RNG_GLOBAL_MARKER = 0xFFFFFFFFu;
 

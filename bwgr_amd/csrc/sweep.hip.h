@@ -38,7 +38,8 @@ enum : int {
   SWF_ALT_B2 = 2,     // the alternative residual uses b2 (KMUP, Dpi); otherwise 0 (B, C, Cpi)
   SWF_MH = 4,         // BayesDpi acceptance  min(1,(1-pi) exp(C(|e1|^2-|e2|^2)))
   SWF_LAM_VEC = 8,    // per-marker lambda array (else the common scalar)
-  SWF_VB_VEC = 16     // per-marker variance draw vb_j = (Sb + b_j^2)/chisq(df+1)
+  SWF_VB_VEC = 16,    // per-marker variance draw vb_j = (Sb + b_j^2)/chisq(df+1)
+  SWF_KMUP2 = 32      // KMUP2's conditional mean: numerator + b0 (not xx*b0), denominator xx*bg + L (src/Rcpp20260726ai.cpp:59)
 };
 
 // scalars produced on the device by the per-iteration tail kernel (or filled by the host for KMUP)
@@ -49,7 +50,7 @@ struct ChainScalars {
   float MU, VE, VBs, Pi;        // posterior sums
   double sum_d, sum_b2;         // written by the sweep (marker order, fp64)
   uint32_t error;               // non-zero: an exchange gave up
-  uint32_t pad;
+  float bg;                     // KMUP2: n0/n of the row subsample
 };
 
 // per-marker constants of one sweep, produced chip-wide by k_prestage before the sweep kernel starts (they depend on
@@ -185,13 +186,14 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
     const float b0 = a.b[j];
     const float xxj = a.xx[j];
     const float lamj = (a.flags & SWF_LAM_VEC) ? a.lam[j] : lam_common;
-    const float den = xxj + lamj;
+    const bool k2 = (a.flags & SWF_KMUP2) != 0;
+    const float den = k2 ? (xxj * sc.bg + lamj) : (xxj + lamj);
     const float sd = sqrtf(ve / den);
     const uint32_t mk = a.marker0 + (uint32_t)j;
     const bool sel = (a.flags & SWF_SELECT) != 0;
     if (piece == 0) {
       st.b0[t] = b0;
-      st.xxb0[t] = xxj * b0;
+      st.xxb0[t] = k2 ? b0 : xxj * b0;
       st.rden[t] = 1.0 / (double)den;
       st.sdz1[t] = (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z1, 0);
     } else if (piece == 1) {

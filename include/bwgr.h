@@ -139,10 +139,14 @@ int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, int
 /* wgr() with the polygenic kernel term (eigK, R/wgr.R:23-32,70-78,116-119,148-150): U = the first pk eigenvectors
  * of the kernel (n x pk doubles, column-major, host), V their eigenvalues (the caller applies VarK: pk =
  * which.max(cumsum(V)/length(V) > VarK)).  Each iteration first sweeps KMUP(U,h,dh,xxK = 1,e,Lk = Ve/(V*Vk),Ve,0),
- * then the markers.  Extra outputs as in wgr's list: u[n] = U %*% H, Vk.  U == NULL is bwgr_wgr. */
+ * then the markers.  Extra outputs as in wgr's list: u[n] = U %*% H, Vk.  U == NULL, bag == 1 is bwgr_wgr.
+ * bag != 1 (R/wgr.R:20,46,68,85,121): every iteration sweeps KMUP2 (src/Rcpp20260726ai.cpp:41-77) on
+ * sort(sample(n, n*bag, rp)) rows -- the subsample is drawn from the RNG contract (purpose 20), a panel of those rows
+ * and its Gram blocks are rebuilt on the device per iteration, df is divided by bag^2 and xx multiplied by bag as in R.
+ * bag != 1 together with eigK is refused: the reference indexes the subsampled residual out of bounds there. */
 int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, int de, double pi, double df, double R2,
-                uint64_t seed, int rng_mode, const double *U, const double *V, int64_t pk, double *mu, double *b,
-                double *Vb, double *d, double *Ve, double *hat, double *cxx, double *u, double *Vk);
+                uint64_t seed, int rng_mode, const double *U, const double *V, int64_t pk, double bag, int rp, double *mu,
+                double *b, double *Vb, double *d, double *Ve, double *hat, double *cxx, double *u, double *Vk);
 
 /* ---- synthetic panels ----------------------------------------------------------
  * X_ij ~ Binomial(2, f_j), f_j ~ U(0.05,0.5), int8 column-major written to device memory Xdev

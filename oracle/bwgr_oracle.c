@@ -82,14 +82,17 @@ static ACC_T v_dot_acc(const float *x, const E_T *e, int64_t n) {
  * faithful: every intermediate is a float, as the reference's types dictate.
  * wide:     the dot product and the conditional mean stay in double (xx_j*b0, the denominator and sd are the
  *           reference's floats); only b1 itself is rounded to float, as the reference stores it. */
-static inline float draw_b1(const float *xj, const E_T *e, int64_t n, float xxj, float b0, float den, float sd, double z) {
+static inline float draw_b1_add(const float *xj, const E_T *e, int64_t n, float addend, float den, float sd, double z) {
 #ifdef ACC_WIDE
-  const double mean = (v_dot_acc(xj, e, n) + (double)(xxj * b0)) / (double)den;
+  const double mean = (v_dot_acc(xj, e, n) + (double)addend) / (double)den;
   return (float)(mean + (double)sd * z);
 #else
-  const float mean = ((float)v_dot_acc(xj, e, n) + xxj * b0) / den;
+  const float mean = ((float)v_dot_acc(xj, e, n) + addend) / den;
   return (float)((double)mean + (double)sd * z);
 #endif
+}
+static inline float draw_b1(const float *xj, const E_T *e, int64_t n, float xxj, float b0, float den, float sd, double z) {
+  return draw_b1_add(xj, e, n, xxj * b0, den, sd, z);
 }
 /* v.squaredNorm() kept in the accumulator type (caller rounds) */
 static ACC_T v_sqnorm_acc(const float *v, int64_t n) {
@@ -236,6 +239,78 @@ int FN(oracle_kmup)(const float *X, int64_t n, int64_t p, int64_t ldx, float *b,
   }
   for (int64_t i = 0; i < n; i++) e_io[i] = (float)e[i];                          /* :37 */
   free(e); free(e1); free(e2);
+  return 0;
+}
+
+
+/* ---- wgr's row resampling, R/wgr.R:68: Use = sort(sample(n, n*bag, rp)) - 1 ---------------------------------
+ * R's sample() runs on its serial stream; here the subset is a pure function of (seed, iteration):
+ * without replacement = the rows holding the k smallest of n uniform keys (a uniformly random k-subset);
+ * with replacement = floor(u_t * n) for k uniforms.  Returned sorted ascending.  k = (int)(n*bag). */
+static int cmp_keyidx(const void *a, const void *b) {
+  const double *x = (const double *)a, *y = (const double *)b;
+  return (x[0] < y[0]) ? -1 : (x[0] > y[0]) ? 1 : ((x[1] < y[1]) ? -1 : (x[1] > y[1]));
+}
+static int cmp_int(const void *a, const void *b) { return (*(const int *)a > *(const int *)b) - (*(const int *)a < *(const int *)b); }
+int FN(oracle_bag_rows)(uint64_t seed, uint32_t iter, int64_t n, int64_t k, int rp, int *use) {
+  orng_t g = { seed, ORNG_PHILOX };
+  if (rp) {
+    for (int64_t t = 0; t < k; t++) { int r = (int)(orng_uniform(&g, (uint32_t)t, iter, ORNG_BAG, 1) * (double)n); use[t] = r >= n ? (int)n - 1 : r; }
+  } else {
+    double *kv = (double *)malloc(sizeof(double) * 2 * n);
+    if (!kv) return 1;
+    for (int64_t i = 0; i < n; i++) { kv[2 * i] = orng_uniform(&g, (uint32_t)i, iter, ORNG_BAG, 0); kv[2 * i + 1] = (double)i; }
+    qsort(kv, n, 2 * sizeof(double), cmp_keyidx);
+    for (int64_t t = 0; t < k; t++) use[t] = (int)kv[2 * t + 1];
+    free(kv);
+  }
+  qsort(use, k, sizeof(int), cmp_int);
+  return 0;
+}
+
+/* ---- KMUP2: the sweep on a row subsample, /root/reference/src/Rcpp20260726ai.cpp:41-77 ------------------------
+ * E has n0 entries, Use (0-based, n entries) selects the rows; the returned e has n entries (the gathered
+ * subsample, :76).  Quirks kept: the conditional mean's numerator adds b0, not xx*b0 (:59); the denominator is
+ * xx*bg + L with bg = n0/n (:47,59), where xx is whatever the caller passes (wgr passes colSums(X^2)*bag). */
+int FN(oracle_kmup2)(const float *X, int64_t n0, int64_t p, int64_t ldx, const int *Use, int64_t n, float *b, float *d,
+                     const float *xx, const float *E, float *e_out, const float *L, float Ve, float pi, uint64_t seed,
+                     uint32_t iter, int rng_mode, int stable, uint32_t marker0) {
+  orng_t g = { seed, rng_mode };
+  E_T *e0 = (E_T *)malloc(sizeof(E_T) * n), *e1 = (E_T *)malloc(sizeof(E_T) * n), *e2 = (E_T *)malloc(sizeof(E_T) * n);
+  float *H = (float *)malloc(sizeof(float) * n);
+  if (!e0 || !e1 || !e2 || !H) return 1;
+  float b0, b1, b2, cj, dj, pj;
+  float C = -0.5f / sqrtf(Ve);                                                   /* :46 */
+  float bg = (float)n0 / (float)n;                                               /* :47 */
+  for (int64_t k = 0; k < n; k++) e0[k] = e1[k] = e2[k] = (E_T)E[Use[k]];        /* :49-53 */
+  for (int64_t j = 0; j < p; j++) {                                              /* :54 */
+    for (int64_t x = 0; x < n; x++) H[x] = X[j * ldx + Use[x]];                  /* :55-57 */
+    uint32_t mk = marker0 + (uint32_t)j;
+    b0 = b[j];                                                                   /* :58 */
+    float den = xx[j] * bg + L[j];
+    b1 = draw_b1_add(H, e0, n, b0, den, sqrtf(Ve / den), orng_normal(&g, mk, iter, ORNG_Z1, 0));   /* :59 (sic: + b0) */
+    b2 = draw_norm(0.0f, sqrtf(Ve / den), orng_normal(&g, mk, iter, ORNG_Z2, 0));                 /* :60 */
+    v_axpy_to(e1, e0, H, b1 - b0, n);                                            /* :61 */
+    if (pi > 0) {                                                                /* :62 */
+      v_axpy_to(e2, e0, H, b2 - b0, n);                                          /* :63 */
+      if (stable) {
+#ifdef ACC_WIDE
+        float diff = (float)(e_sqnorm_acc(e2, n) - e_sqnorm_acc(e1, n));
+#else
+        float diff = e_sqnorm(e2, n) - e_sqnorm(e1, n);
+#endif
+        pj = 1.0f / (1.0f + (pi / (1.0f - pi)) * f_exp(C * diff));
+      } else {
+        cj = (1 - pi) * f_exp(C * e_sqnorm(e1, n));                              /* :64 */
+        dj = (pi)*f_exp(C * e_sqnorm(e2, n));                                    /* :65 */
+        pj = cj / (cj + dj);                                                     /* :66 */
+      }
+      if (orng_uniform(&g, mk, iter, ORNG_U, 0) < (double)pj) { b[j] = b1; d[j] = 1; memcpy(e0, e1, sizeof(E_T) * n); }   /* :67-68 */
+      else { b[j] = b2; d[j] = 0; memcpy(e0, e2, sizeof(E_T) * n); }             /* :70 */
+    } else { d[j] = 1; b[j] = b1; memcpy(e0, e1, sizeof(E_T) * n); }             /* :73 */
+  }
+  for (int64_t k = 0; k < n; k++) e_out[k] = (float)e0[k];                       /* :76 */
+  free(e0); free(e1); free(e2); free(H);
   return 0;
 }
 
@@ -439,13 +514,19 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
 #define ORNG_KERNEL_MARKER0 0x80000000u
 int FN(oracle_wgr)(const double *y, const double *X, int64_t n, int64_t p, int64_t ldx, int it, int bi, int th,
                    int iv, int de, double pi, double df, double R2, uint64_t seed, int rng_mode, int stable,
-                   const double *U, const double *V, int64_t pk,
+                   const double *U, const double *V, int64_t pk, double bag, int rp,
                    double *o_mu, double *o_b, double *o_Vb, double *o_d, double *o_Ve, double *o_hat, double *o_cxx,
                    double *o_u, double *o_Vk) {
   orng_t g = { seed, rng_mode };
   const uint32_t GM = ORNG_GLOBAL_MARKER;
   if (de) iv = 1;                                                             /* wgr.R:9 */
   if (!U) pk = 0;
+  if (bag != 1.0 && pk > 0) return 2;   /* the reference indexes a subsampled e with full-length row ids here (wgr.R:73-79): undefined */
+  if (bag != 1.0) df = df / (bag * bag);                                      /* wgr.R:20 */
+  const int64_t nbag = (bag != 1.0) ? (int64_t)((double)n * bag) : n;
+  int *use = (int *)malloc(sizeof(int) * (nbag + 1));
+  float *ebag = (float *)malloc(sizeof(float) * (nbag + 1));
+  if (!use || !ebag) return 1;
   float *Xf = (float *)malloc(sizeof(float) * n * p);
   float *bf = (float *)malloc(sizeof(float) * p), *dfl = (float *)malloc(sizeof(float) * p), *xxf = (float *)malloc(sizeof(float) * p);
   float *Lf = (float *)malloc(sizeof(float) * p), *ef = (float *)malloc(sizeof(float) * n);
@@ -464,7 +545,7 @@ int FN(oracle_wgr)(const double *y, const double *X, int64_t n, int64_t p, int64
   for (int64_t j = 0; j < p; j++) {                                           /* wgr.R:46,51 */
     const double *xj = X + j * ldx; double s2 = 0, s1 = 0;
     for (int64_t i = 0; i < n; i++) { s2 += xj[i] * xj[i]; s1 += xj[i]; }
-    xx[j] = s2; double m = s1 / (double)n, v = 0;
+    xx[j] = s2 * bag; double m = s1 / (double)n, v = 0;                         /* wgr.R:46: crossprod * bag */
     for (int64_t i = 0; i < n; i++) v += (xj[i] - m) * (xj[i] - m);
     MSx += v / (double)(n - 1);
     d[j] = 1;                                                                 /* wgr.R:48 */
@@ -490,11 +571,19 @@ int FN(oracle_wgr)(const double *y, const double *X, int64_t n, int64_t p, int64
     }
     for (int64_t j = 0; j < p; j++) { bf[j] = (float)b[j]; dfl[j] = (float)d[j]; xxf[j] = (float)xx[j]; Lf[j] = (float)L[j]; }
     for (int64_t k = 0; k < n; k++) ef[k] = (float)e[k];
-    int rc = FN(oracle_kmup)(Xf, n, p, n, bf, dfl, xxf, ef, Lf, (float)Ve, (float)pi, seed, itx, rng_mode, stable, 0u);   /* wgr.R:85 */
+    int rc;
+    if (bag != 1.0) {                                                         /* wgr.R:68,85: KMUP2 on the resampled rows */
+      rc = FN(oracle_bag_rows)(seed, itx, n, nbag, rp, use);
+      if (rc) return rc;
+      rc = FN(oracle_kmup2)(Xf, n, p, n, use, nbag, bf, dfl, xxf, ef, ebag, Lf, (float)Ve, (float)pi, seed, itx, rng_mode, stable, 0u);
+    } else {
+      rc = FN(oracle_kmup)(Xf, n, p, n, bf, dfl, xxf, ef, Lf, (float)Ve, (float)pi, seed, itx, rng_mode, stable, 0u);   /* wgr.R:85 */
+    }
     if (rc) return rc;
     if (pi > 0) for (int64_t j = 0; j < p; j++) d[j] = (double)dfl[j];        /* wgr.R:86 */
     for (int64_t j = 0; j < p; j++) b[j] = (double)bf[j];                     /* wgr.R:87 */
-    for (int64_t k = 0; k < n; k++) e[k] = (double)ef[k];                     /* wgr.R:88 */
+    const int64_t ne = (bag != 1.0) ? nbag : n;                               /* e is the subsample after KMUP2 */
+    for (int64_t k = 0; k < ne; k++) e[k] = (double)((bag != 1.0) ? ebag[k] : ef[k]);   /* wgr.R:88 */
     if (iv) {                                                                 /* wgr.R:91-111 */
       if (de) for (int64_t j = 0; j < p; j++) Vb[j] = sqrt(b[j] * b[j] * Ve / MSx);
       else for (int64_t j = 0; j < p; j++) Vb[j] = (Sb + b[j] * b[j]) / orng_chisq(&g, df + 1, (uint32_t)j, itx, ORNG_CHI);
@@ -507,8 +596,8 @@ int FN(oracle_wgr)(const double *y, const double *X, int64_t n, int64_t p, int64
       double hv = 0; for (int64_t k = 0; k < pk; k++) hv += h[k] * h[k] / V[k];
       Vp = (hv + Sk) / orng_chisq(&g, df + (double)pk, GM, itx, ORNG_G_VK);
     }
-    double ee = 0; for (int64_t k = 0; k < n; k++) ee += e[k] * e[k];
-    Ve = (ee + Se) / orng_chisq(&g, (double)n + df, GM, itx, ORNG_G_VE);      /* wgr.R:121 */
+    double ee = 0; for (int64_t k = 0; k < ne; k++) ee += e[k] * e[k];
+    Ve = (ee + Se) / orng_chisq(&g, (double)n * bag + df, GM, itx, ORNG_G_VE);   /* wgr.R:121: n*bag+df */
     for (int64_t j = 0; j < p; j++) L[j] = Ve / Vb[j];                        /* wgr.R:122 */
     for (int64_t k = 0; k < n; k++) e[k] = y[k] - mu;                         /* wgr.R:124 */
     for (int64_t j = 0; j < p; j++) { const double *xj = X + j * ldx; double bj = b[j]; if (bj != 0) for (int64_t k = 0; k < n; k++) e[k] -= xj[k] * bj; }
@@ -541,6 +630,6 @@ int FN(oracle_wgr)(const double *y, const double *X, int64_t n, int64_t p, int64
   *o_mu = B0; *o_Ve = VE; *o_cxx = cxx;
   memcpy(o_b, B, sizeof(double) * p); memcpy(o_d, D, sizeof(double) * p);
   free(Xf); free(bf); free(dfl); free(xxf); free(Lf); free(ef); free(xx); free(b); free(d); free(Vb); free(L); free(e); free(B); free(D); free(VB);
-  free(Uf); free(hf); free(dhf); free(xxKf); free(Lkf); free(h); free(H);
+  free(Uf); free(hf); free(dhf); free(xxKf); free(Lkf); free(h); free(H); free(use); free(ebag);
   return 0;
 }

@@ -31,7 +31,8 @@ enum {
   ORNG_G_MU = 16,   /* N(0,1) behind the intercept draw                */
   ORNG_G_VE = 17,   /* chi-square behind the residual variance         */
   ORNG_G_VB = 18,   /* chi-square behind the common marker variance    */
-  ORNG_G_VK = 19    /* chi-square behind the polygenic variance (wgr)  */
+  ORNG_G_VK = 19,   /* chi-square behind the polygenic variance (wgr)  */
+  ORNG_BAG = 20     /* uniforms behind wgr's row resampling sample(n, n*bag, rp) */
 };
 #define ORNG_GLOBAL_MARKER 0xFFFFFFFFu  /* first counter word of per-iteration scalars */
 

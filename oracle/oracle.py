@@ -117,6 +117,28 @@ def bayes(model, y, X, it=1500, bi=500, pi=0.95, df=5.0, R2=0.5, seed=1, rng_mod
     return out
 
 
+def bag_rows(seed, it, n, k, rp=False):
+    use = np.zeros(k, np.int32)
+    rc = lib().oracle_bag_rows_w(C.c_uint64(seed), C.c_uint32(it), C.c_int64(n), C.c_int64(k), C.c_int(int(rp)), use.ctypes.data_as(C.POINTER(C.c_int)))
+    assert rc == 0
+    return use
+
+
+def kmup2(X, Use, b, d, xx, E, L, Ve, pi, seed=1, it=0, rng_mode=0, stable=1, flavour="w"):
+    """Reference KMUP2(X,Use,b,d,xx,E,L,Ve,pi) -> dict(b,d,e), src/Rcpp20260726ai.cpp:41-77 (Use 0-based)."""
+    Xf = as_f32_colmajor(X)
+    n0, p = Xf.shape
+    use = np.ascontiguousarray(Use, np.int32); n = use.size
+    b = np.array(b, np.float32); d = np.array(d, np.float32); E = np.ascontiguousarray(E, np.float32)
+    xx = np.ascontiguousarray(xx, np.float32); L = np.ascontiguousarray(L, np.float32); e = np.zeros(n, np.float32)
+    rc = getattr(lib(), "oracle_kmup2_" + flavour)(
+        _fp(Xf), C.c_int64(n0), C.c_int64(p), C.c_int64(n0), use.ctypes.data_as(C.POINTER(C.c_int)), C.c_int64(n), _fp(b), _fp(d),
+        _fp(xx), _fp(E), _fp(e), _fp(L), C.c_float(Ve), C.c_float(pi), C.c_uint64(seed), C.c_uint32(it), C.c_int(rng_mode),
+        C.c_int(stable), C.c_uint32(0))
+    assert rc == 0
+    return {"b": b, "d": d, "e": e}
+
+
 def eigk_truncate(eigK, VarK):
     """R/wgr.R:23-27: pk = which.max((cumsum(V)/length(V)) > VarK); first pk eigenpairs."""
     V = np.asarray(eigK["values"], np.float64)
@@ -125,8 +147,8 @@ def eigk_truncate(eigK, VarK):
     return np.asfortranarray(U[:, :pk]), np.ascontiguousarray(V[:pk]), pk
 
 
-def wgr(y, X, it=1500, bi=500, th=1, iv=False, de=False, pi=0.0, df=5.0, R2=0.5, eigK=None, VarK=0.95, seed=1, rng_mode=0,
-        stable=1, flavour="w"):
+def wgr(y, X, it=1500, bi=500, th=1, bag=1.0, rp=False, iv=False, de=False, pi=0.0, df=5.0, R2=0.5, eigK=None, VarK=0.95, seed=1,
+        rng_mode=0, stable=1, flavour="w"):
     """Reference wgr(y,X,it,bi,th,bag=1,rp=F,iv,de,pi,df,R2,eigK,VarK), R/wgr.R:2-169."""
     Xd = np.asfortranarray(np.asarray(X), dtype=np.float64)
     n, p = Xd.shape
@@ -142,7 +164,7 @@ def wgr(y, X, it=1500, bi=500, th=1, iv=False, de=False, pi=0.0, df=5.0, R2=0.5,
     rc = getattr(lib(), "oracle_wgr_" + flavour)(
         _dp(y), _dp(Xd), C.c_int64(n), C.c_int64(p), C.c_int64(n), C.c_int(it), C.c_int(bi), C.c_int(th),
         C.c_int(int(iv)), C.c_int(int(de)), C.c_double(pi), C.c_double(df), C.c_double(R2), C.c_uint64(seed),
-        C.c_int(rng_mode), C.c_int(stable), Up, Vp, C.c_int64(pk),
+        C.c_int(rng_mode), C.c_int(stable), Up, Vp, C.c_int64(pk), C.c_double(bag), C.c_int(int(rp)),
         C.byref(mu), _dp(b), _dp(Vb), _dp(d), C.byref(Ve), _dp(hat), C.byref(cxx), _dp(u), C.byref(Vk))
     assert rc == 0
     if eigK is not None:

@@ -19,12 +19,19 @@ BayesDpi <- function(y, X, it = 1500, bi = 500, df = 5, R2 = 0.5) .bwgr_fused(6L
 
 wgr <- function(y, X, it = 1500, bi = 500, th = 1, bag = 1, rp = FALSE, iv = FALSE, de = FALSE, pi = 0, df = 5, R2 = 0.5,
                 eigK = NULL, VarK = 0.95, verb = FALSE) {
-  if (bag != 1 || !is.null(eigK)) stop("bag != 1 (KMUP2) and eigK are not built in the MI355X engine yet; call bWGR::wgr")
+  if (bag != 1 && !is.null(eigK)) stop("bag != 1 with eigK is undefined in bWGR (R/wgr.R:73-79); not supported")
+  if (bag != 1) df <- df   # df/(bag^2) (R/wgr.R:20) is applied inside the engine
   if (anyNA(X)) {                       # R/wgr.R:12-18
     imp <- function(x) { x[is.na(x)] <- mean(x, na.rm = TRUE); x[is.nan(x)] <- 0; x }
     X <- apply(X, 2, imp)
   }
   if (anyNA(y)) { mis <- which(is.na(y)); y <- y[-mis]; X <- X[-mis, ] }   # R/wgr.R:34-39
+  U <- V <- NULL
+  if (!is.null(eigK)) {                  # R/wgr.R:23-27; rows of missing y were dropped from U above in bWGR too
+    V <- eigK$values; pk <- which.max((cumsum(V) / length(V)) > VarK)
+    U <- eigK$vectors[, 1:pk, drop = FALSE]; V <- V[1:pk]
+    if (exists("mis")) U <- U[-mis, , drop = FALSE]
+  }
   .Call("bwgrhip_wgr", as.double(y), .bwgr_panel(X), as.integer(it), as.integer(bi), as.integer(th), as.logical(iv), as.logical(de),
-        as.double(pi), as.double(df), as.double(R2))
+        as.double(pi), as.double(df), as.double(R2), U, V, as.double(bag), as.logical(rp))
 }

@@ -138,7 +138,7 @@ SEXP bwgrhip_Bayes(SEXP model, SEXP y, SEXP panel, SEXP it, SEXP bi, SEXP pi, SE
 }
 
 /* wgr(y,X,it,bi,th,bag=1,rp=FALSE,iv,de,pi,df,R2,eigK=NULL)    R/wgr.R:2-169 -> list(mu,b,Vb,d,Ve,hat,cxx), :155-168 */
-SEXP bwgrhip_wgr(SEXP y, SEXP panel, SEXP it, SEXP bi, SEXP th, SEXP iv, SEXP de, SEXP pi, SEXP df, SEXP R2) {
+SEXP bwgrhip_wgr(SEXP y, SEXP panel, SEXP it, SEXP bi, SEXP th, SEXP iv, SEXP de, SEXP pi, SEXP df, SEXP R2, SEXP U, SEXP V, SEXP bag, SEXP rp) {
   bwgr_panel *P = panel_of(panel);
   int64_t info[8]; chk(bwgr_panel_info(P, info));
   const R_xlen_t n = info[0], p = info[1];
@@ -146,20 +146,32 @@ SEXP bwgrhip_wgr(SEXP y, SEXP panel, SEXP it, SEXP bi, SEXP th, SEXP iv, SEXP de
   const int per = Rf_asLogical(iv) || Rf_asLogical(de);
   SEXP b = PROTECT(Rf_allocVector(REALSXP, p)), d = PROTECT(Rf_allocVector(REALSXP, p)), Vb = PROTECT(Rf_allocVector(REALSXP, per ? p : 1));
   SEXP hat = PROTECT(Rf_allocMatrix(REALSXP, (int)n, 1));
-  double mu, Ve, cxx;
-  chk(bwgr_wgr(P, REAL(y), Rf_asInteger(it), Rf_asInteger(bi), Rf_asInteger(th), Rf_asLogical(iv), Rf_asLogical(de), Rf_asReal(pi), Rf_asReal(df),
-               Rf_asReal(R2), seed_from_R(), BWGR_RNG_PHILOX, &mu, REAL(b), REAL(Vb), REAL(d), &Ve, REAL(hat), &cxx));
-  const char *nm[] = {"mu", "b", "Vb", "d", "Ve", "hat", "cxx"};
-  SEXP out = PROTECT(named_list(7, nm));
+  double mu, Ve, cxx, Vk = 0;
+  const int has_k = !Rf_isNull(U);
+  const int64_t pk = has_k ? INTEGER(Rf_getAttrib(U, R_DimSymbol))[1] : 0;
+  SEXP u = PROTECT(Rf_allocMatrix(REALSXP, (int)n, 1));
+  chk(bwgr_wgr_ex(P, REAL(y), Rf_asInteger(it), Rf_asInteger(bi), Rf_asInteger(th), Rf_asLogical(iv), Rf_asLogical(de), Rf_asReal(pi),
+                  Rf_asReal(df), Rf_asReal(R2), seed_from_R(), BWGR_RNG_PHILOX, has_k ? REAL(U) : NULL, has_k ? REAL(V) : NULL, pk,
+                  Rf_asReal(bag), Rf_asLogical(rp), &mu, REAL(b), REAL(Vb), REAL(d), &Ve, REAL(hat), &cxx, REAL(u), &Vk));
+  SEXP out;
+  if (has_k) {   /* list(mu,b,Vb,d,Ve,hat,u,Vk,cxx), R/wgr.R:157-160 */
+    const char *nm[] = {"mu", "b", "Vb", "d", "Ve", "hat", "u", "Vk", "cxx"};
+    out = PROTECT(named_list(9, nm));
+    SET_VECTOR_ELT(out, 6, u); SET_VECTOR_ELT(out, 7, Rf_ScalarReal(Vk)); SET_VECTOR_ELT(out, 8, Rf_ScalarReal(cxx));
+  } else {
+    const char *nm[] = {"mu", "b", "Vb", "d", "Ve", "hat", "cxx"};
+    out = PROTECT(named_list(7, nm));
+    SET_VECTOR_ELT(out, 6, Rf_ScalarReal(cxx));
+  }
   SET_VECTOR_ELT(out, 0, Rf_ScalarReal(mu)); SET_VECTOR_ELT(out, 1, b); SET_VECTOR_ELT(out, 2, Vb); SET_VECTOR_ELT(out, 3, d);
-  SET_VECTOR_ELT(out, 4, Rf_ScalarReal(Ve)); SET_VECTOR_ELT(out, 5, hat); SET_VECTOR_ELT(out, 6, Rf_ScalarReal(cxx));
-  UNPROTECT(5);
+  SET_VECTOR_ELT(out, 4, Rf_ScalarReal(Ve)); SET_VECTOR_ELT(out, 5, hat);
+  UNPROTECT(6);
   return out;
 }
 
 static const R_CallMethodDef CallEntries[] = {   /* as src/RcppExports.cpp:1152-1228 registers _bWGR_* */
   {"bwgrhip_panel", (DL_FUNC)&bwgrhip_panel, 2}, {"bwgrhip_KMUP", (DL_FUNC)&bwgrhip_KMUP, 9},
-  {"bwgrhip_Bayes", (DL_FUNC)&bwgrhip_Bayes, 8}, {"bwgrhip_wgr", (DL_FUNC)&bwgrhip_wgr, 10}, {NULL, NULL, 0}};
+  {"bwgrhip_Bayes", (DL_FUNC)&bwgrhip_Bayes, 8}, {"bwgrhip_wgr", (DL_FUNC)&bwgrhip_wgr, 14}, {NULL, NULL, 0}};
 
 void R_init_bwgrhip(DllInfo *dll) {              /* as R_init_bWGR, src/RcppExports.cpp:1230-1233 */
   R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);

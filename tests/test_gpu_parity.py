@@ -133,10 +133,10 @@ def test_wgr_tpod(tpod, name, kw):
     assert scaled_err(g["d"], o["d"]) < 1e-12
 
 
-def test_wgr_unbuilt_rows_raise(tpod):
+def test_wgr_bag_with_eigk_is_refused(tpod):
     import bwgr_amd
     with pytest.raises(NotImplementedError):
-        bwgr_amd.wgr(tpod["y"], tpod["gen"], it=5, bi=1, bag=0.5)
+        bwgr_amd.wgr(tpod["y"], tpod["gen"], it=5, bi=1, bag=0.5, eigK={"values": [1.0], "vectors": [[1.0]]})
 
 
 def test_sharded_entry_points_world1_equals_run(tpod):
@@ -260,3 +260,17 @@ def test_wgr_polygenic_term_tpod(tpod, kw):
     assert scaled_err(g["b"], o["b"]) < TOL and scaled_err(g["hat"], o["hat"]) < TOL and scaled_err(g["u"], o["u"]) < 5 * TOL
     assert _rel(g["Ve"], o["Ve"]) < TOL and _rel(g["Vk"], o["Vk"]) < TOL and _rel(g["mu"], o["mu"]) < TOL
     assert scaled_err(g["d"], o["d"]) < 1e-12
+
+
+@pytest.mark.parametrize("kw", [{"bag": 0.5}, {"bag": 0.8, "rp": True, "iv": True, "pi": 0.5}, {"bag": 0.7, "pi": 0.3}])
+def test_wgr_bagging_tpod(tpod, kw):
+    """wgr(bag != 1): KMUP2 on sort(sample(n, n*bag, rp)) rows each iteration (R/wgr.R:68,85;
+    src/Rcpp20260726ai.cpp:41-77 incl. its '+ b0' numerator and xx*bg + L denominator), df/bag^2, xx*bag."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = tpod["gen"], tpod["y"]
+    g = bwgr_amd.wgr(y, X, it=20, bi=5, seed=17, **kw)
+    o = O.wgr(y, X, it=20, bi=5, seed=17, **kw)
+    assert scaled_err(g["b"], o["b"]) < TOL and scaled_err(g["hat"], o["hat"]) < TOL
+    assert _rel(g["Ve"], o["Ve"]) < TOL and _rel(g["mu"], o["mu"]) < TOL and _rel(g["cxx"], o["cxx"]) < 1e-12
+    assert scaled_err(np.atleast_1d(g["Vb"]), np.atleast_1d(o["Vb"])) < 5 * TOL and scaled_err(g["d"], o["d"]) < 1e-12
