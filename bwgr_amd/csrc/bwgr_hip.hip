@@ -742,6 +742,7 @@ static int reset_exchange(bwgr_panel *P) {
   if (P->sweep_version == 2) {
     HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
     HIPCHK(hipMemsetAsync(P->dgran, 0, sizeof(unsigned long long) * S2_NSLOT * SW_MAXM, P->stream));
+    HIPCHK(hipMemsetAsync(P->qpart, 0, sizeof(double) * S2_NSLOT * (size_t)P->K * SW_MAXM, P->stream));
   } else if (P->K > 1) {
     HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
   }
@@ -973,8 +974,8 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipMalloc(&P->dgran, sizeof(unsigned long long) * S2_NSLOT * SW_MAXM));
   PCHK(hipMalloc(&P->ps.blocks, sizeof(StageBuf) * (size_t)P->nblocks));
 #ifdef BWGR_STAMPS
-  PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 12));
-  PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 12));
+  PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 48));
+  PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 48));
 #endif
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<int8_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<int8_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1011,9 +1012,9 @@ extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int
 
 #ifdef BWGR_STAMPS
 // diagnostic build only: cumulative per-phase s_memtime ticks of workgroup 0 (not part of include/bwgr.h)
-extern "C" int bwgr_debug_stamps(bwgr_panel *P, unsigned long long out[12]) {
-  HIPCHK(hipMemcpy(out, P->stamps, sizeof(unsigned long long) * 12, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 12));
+extern "C" int bwgr_debug_stamps(bwgr_panel *P, unsigned long long out[48]) {
+  HIPCHK(hipMemcpy(out, P->stamps, sizeof(unsigned long long) * 48, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 48));
   return BWGR_OK;
 }
 #endif

@@ -19,24 +19,38 @@
 namespace bwgr {
 
 #ifdef BWGR_STAMPS
+// diagnostic build: per-phase cycle sums of streamer 0 (stamps[0..15]) and of the sequencer (stamps[16..31]), and
+// wall-clock sums for the hand-off latencies (stamps[32..])
+#define S2STAMP_DECL unsigned long long ph2[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}, tl2 = __builtin_amdgcn_s_memtime()
 #define S2STAMP(k) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph2[k] += t_ - tl2; tl2 = t_; } } while (0)
-#define S2STAMP_DECL unsigned long long ph2[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, tl2 = __builtin_amdgcn_s_memtime()
-#define S2STAMP_FLUSH(base, n) do { if (tid == 0 && a.stamps) for (int k_ = 0; k_ < (n); ++k_) a.stamps[(base) + k_] += ph2[k_]; } while (0)
+#define S2STAMP_FLUSH(base) do { if (tid == 0 && a.stamps) for (int k_ = 0; k_ < 16; ++k_) a.stamps[(base) + k_] += ph2[k_]; } while (0)
+#define S2WALL(slot, cond) do { if ((cond) && a.stamps) atomicAdd(&a.stamps[32 + (slot)], (unsigned long long)wall_clock64()); } while (0)
 #else
-#define S2STAMP(k) do { } while (0)
 #define S2STAMP_DECL do { } while (0)
-#define S2STAMP_FLUSH(base, n) do { } while (0)
+#define S2STAMP(k) do { } while (0)
+#define S2STAMP_FLUSH(base) do { } while (0)
+#define S2WALL(slot, cond) do { } while (0)
 #endif
 
 static constexpr int S2_NSLOT = 4;   // ring depth of the q / delta buffers (2 would do; 4 keeps lines apart)
 
 template <typename XT> __host__ __device__ inline size_t s2_seq_lds_bytes(int m);
+__host__ __device__ inline size_t s2i_lds_bytes(int m, int R);
 template <typename XT> __host__ __device__ inline size_t sweep2_lds_bytes(int m, int R) {
   size_t streamer = (size_t)3 * m * tile_rp<XT>(R) * sizeof(XT);
   streamer = (streamer + 15) & ~(size_t)15;
   streamer += (size_t)R * sizeof(double) + SW_MAXM * sizeof(double) + (size_t)(SW_THREADS / 64) * SW_MAXM * sizeof(double) + 64;
+  if (sizeof(XT) == 1) streamer = s2i_lds_bytes(m, R);
   const size_t seq = s2_seq_lds_bytes<XT>(m);
   return streamer > seq ? streamer : seq;
+}
+
+// q hand-off: each slab dot travels as ONE 8-byte word whose low 8 mantissa bits carry the block's tag (1..255; the
+// slots are zeroed before every launch and a slot's consecutive users differ in tag), so a reader needs a single round
+// trip and the writer no payload fence.  The value loses 8 of its 53 mantissa bits (relative 2^-45).
+__device__ __forceinline__ unsigned long long s2_qtag(int b) { return (unsigned long long)(b % 255 + 1); }
+__device__ __forceinline__ void s2_put_q(double *slot, double v, int b) {
+  st_agent_raw64(reinterpret_cast<unsigned long long *>(slot), ((unsigned long long)__double_as_longlong(v) & ~0xFFull) | s2_qtag(b));
 }
 
 // tile macros with an explicit thread numbering (streamers use all 512 threads)
@@ -130,12 +144,9 @@ __device__ __forceinline__ void s2_streamer(const SweepArgs &a) {
     if (tid < mB) {
       double mine = 0.0;
       for (int g = 0; g < ngroups; ++g) mine += part_s[g * SW_MAXM + tid];
-      st_agent_u64(a.qpart + ((size_t)(b % S2_NSLOT) * K + wg) * SW_MAXM + tid, mine);
+      s2_put_q(a.qpart + ((size_t)(b % S2_NSLOT) * K + wg) * SW_MAXM + tid, mine, b);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-      st_agent_u32(a.xflags + (size_t)wg * SW_FLAG_STRIDE, (uint32_t)(b + 1));
+    __syncthreads();   // part_s is free again
   };
   publish(0, S2_TILE(0));
   if (nb > 1) publish(1, S2_TILE(1));
@@ -146,7 +157,6 @@ __device__ __forceinline__ void s2_streamer(const SweepArgs &a) {
     S2STAMP(5);
     // tile(i+2) lands in the buffer tile(i-1) used; its loads were issued one iteration ago
     if (i + 2 < nb) S2_TILE_COMMIT(S2_TILE(i + 2), blk_m(i + 2));
-    if (i + 3 < nb) S2_TILE_ISSUE(blk_j0(i + 3), blk_m(i + 3));
     S2STAMP(0);
     // delta_i: one 8-byte {epoch, float} granule per marker, polled by the thread that needs it
     int bad = 0;
@@ -170,6 +180,7 @@ __device__ __forceinline__ void s2_streamer(const SweepArgs &a) {
     if (bad) fail_s[0] = 1;
     __syncthreads();
     if (fail_s[0]) { if (tid == 0) a.sc->error = 1u; return; }
+    if (i + 3 < nb) S2_TILE_ISSUE(blk_j0(i + 3), blk_m(i + 3));   // after the poll: see s2_streamer_i8
     S2STAMP(1);
     // slab update with tile(i) (fp64, x*delta exact)
     {
@@ -207,7 +218,257 @@ __device__ __forceinline__ void s2_streamer(const SweepArgs &a) {
     if (i + 2 < nb) publish(i + 2, S2_TILE(i + 2));
     S2STAMP(4);
   }
-  if (wg == 0) S2STAMP_FLUSH(0, 6);
+  if (wg == 0) S2STAMP_FLUSH(0);
+  __syncthreads();
+  for (int i = tid; i < R; i += SW_THREADS) a.e[row0 + i] = e_s[i];
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// int8 streamer: both slab phases as exact integer matrix products on v_mfma_i32_16x16x64_i8
+// ------------------------------------------------------------------------------------------------------------------
+// A value v (fp64 residual, or the float delta) is taken relative to a power-of-two scale S above the block maximum,
+// rounded to an integer of < 55 (e) / 47 (delta) bits and split into signed base-256 digits; int8 x times a digit,
+// summed over the slab rows / the block's markers, is exact in the MFMA's int32 accumulators, and sum_n acc_n 256^n / S
+// is formed in fp64.  The only inexact step is the rounding of v to 2^-54 (e) / 2^-46 (delta) of its block maximum.
+//   dots:    M = 16 markers, K = 64 slab rows, N = digit n of e       (A dword = 4 rows of one marker, as stored)
+//   update:  M = 16 rows,    K = 64 markers,   N = digit n of delta   (A dword = 4 markers of one row: 4x4 byte
+//                                                                      transposes of the stored micro-tiles, v_perm)
+// Both operands of a product use the same (lane group, dword, byte) -> k map, so the k order inside the instruction
+// does not matter; the M / N / accumulator maps were checked with exact integer data (tools/mfma_probe.hip).
+typedef int s2_v4i __attribute__((ext_vector_type(4)));
+static constexpr int S2_NDE = 7;     // digits of e:     |q| < 2^54
+static constexpr int S2_NDD = 6;     // digits of delta: |q| < 2^46
+static constexpr int S2_OS = 20;     // dwords per row of the int32 output array (8 used; 20 keeps its b128 reads conflict-free)
+static constexpr int S2_DP = SW_MAXM + 16;   // bytes per digit row of the delta digits
+__host__ __device__ inline size_t s2i_lds_bytes(int m, int R) {
+  const size_t Rp = (size_t)R + 16;
+  return 3 * (size_t)m * Rp + (size_t)R * 8 + 16 * Rp + 16 * S2_DP + 2 * (size_t)(R > SW_MAXM ? R : SW_MAXM) * S2_OS * 4 + 64;
+}
+__device__ __forceinline__ double pow2_field(int field) { return __hiloint2double(field << 20, 0); }   // 2^(field-1023)
+// maximum over the wave (DPP row shifts + row broadcasts, result broadcast from lane 63); v >= 0 as int
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  int x = (int)v;
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true));   // row_shr:1
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true));   // row_shr:2
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true));   // row_shr:4
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true));   // row_shr:8  -> lane 15 of each row holds the row maximum
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true));   // row_bcast:15 into rows 1 and 3
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true));   // row_bcast:31 into rows 2 and 3
+  return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+// signed base-256 digits of q into bytes dst[n*stride], n < ND
+template <int ND> __device__ __forceinline__ void put_digits(long long q, int8_t *dst, int stride) {
+#pragma unroll
+  for (int n = 0; n < ND; ++n) {
+    const int dg = (int)((q + 128) & 255) - 128;
+    dst[n * stride] = (int8_t)dg;
+    q = (q - dg) >> 8;
+  }
+}
+
+__device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // declared here so that LDS accesses stay ds_*
+  using XT = int8_t;
+  constexpr int PER = 16;
+  const int tid = threadIdx.x, wg = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m16 = lane & 15, grp = lane >> 4;   // MFMA lane coordinates
+  const int m = a.m, R = a.R, K = a.K;
+  const int Rp = R + 16;                        // bytes per marker in an LDS tile, and per digit row of e
+  const int row0 = wg * R;
+  const int nb = a.blk_end - a.blk_begin;
+  const size_t tile_b = (size_t)m * Rp;
+#define S2I_TILE(i_) reinterpret_cast<int8_t *>(smem + (size_t)((i_) % 3) * tile_b)
+  size_t off = 3 * tile_b;
+  double *e_s = reinterpret_cast<double *>(smem + off); off += (size_t)R * sizeof(double);
+  int8_t *edig_s = reinterpret_cast<int8_t *>(smem + off); off += (size_t)16 * Rp;        // [n][row]: digit n of e[row]; rows n >= S2_NDE stay 0
+  int8_t *ddig_s = reinterpret_cast<int8_t *>(smem + off); off += 16 * S2_DP;             // [n][marker]: digit n of delta[marker]
+  const size_t out_n = (size_t)(R > SW_MAXM ? R : SW_MAXM) * S2_OS;
+  int *out_s = reinterpret_cast<int *>(smem + off); off += 2 * out_n * 4;   // [half][row or marker][n]
+  uint32_t *ctl_s = reinterpret_cast<uint32_t *>(smem + off);   // [0],[1]: max exponent of delta (by block parity); [2],[3]: of e; [8]: failure
+  const int8_t *X = reinterpret_cast<const int8_t *>(a.X) + (size_t)wg * a.p * R;
+  uint32_t *abortw = a.xflags + (size_t)K * SW_FLAG_STRIDE;
+  auto blk_j0 = [&](int b) { return (a.blk_begin + b) * m; };
+  auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
+
+  uint4 tp0 = make_uint4(0, 0, 0, 0), tp1 = tp0, tp2 = tp0, tp3 = tp0, tp4 = tp0;
+  for (int i = tid; i < 4 * Rp; i += SW_THREADS) reinterpret_cast<uint32_t *>(edig_s)[i] = 0u;
+  for (int i = tid; i < 4 * S2_DP; i += SW_THREADS) reinterpret_cast<uint32_t *>(ddig_s)[i] = 0u;
+  if (tid < 16) ctl_s[tid] = 0u;
+  S2_TILE_ISSUE(blk_j0(0), blk_m(0)); S2_TILE_COMMIT(S2I_TILE(0), blk_m(0));
+  if (nb > 1) { S2_TILE_ISSUE(blk_j0(1), blk_m(1)); S2_TILE_COMMIT(S2I_TILE(1), blk_m(1)); }
+  if (nb > 2) S2_TILE_ISSUE(blk_j0(2), blk_m(2));
+  __syncthreads();
+  S2STAMP_DECL;
+
+  // digits of the e slab relative to the maximum exponent field recorded in ctl_s[2 + epar]; returns 1/S
+  auto e_digits = [&](int epar) -> double {
+    const int E = max((int)ctl_s[2 + epar], 100);            // max|e| < 2^(E-1022);  S = 2^(1076-E): |q| < 2^54
+    const double S = pow2_field(2099 - E);
+    for (int r = tid; r < R; r += SW_THREADS) put_digits<S2_NDE>(__double2ll_rn(e_s[r] * S), edig_s + r, Rp);
+    return pow2_field(E - 53);
+  };
+  // slab dots of block b against the current e digits, payload write-through, then the epoch flag
+  auto publish = [&](int b, const int8_t *tile, double invSe) {
+    const int mB = blk_m(b);
+    __syncthreads();                                          // e digits visible; out_s free
+    if (wave * 16 < mB) {
+      const int8_t *ap = tile + (size_t)(16 * wave + m16) * Rp + 16 * grp;
+      const int8_t *bp = edig_s + (size_t)m16 * Rp + 16 * grp;
+      s2_v4i acc = {0, 0, 0, 0};
+      for (int r = 0; r < R; r += 64)                         // 64 rows per MFMA: lane group grp holds rows r+16grp .. +15
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap + r), *reinterpret_cast<const s2_v4i *>(bp + r), acc, 0, 0, 0);
+      if (m16 < 8) {                                          // lane: digit n = m16 of markers 16 wave + 4 grp + reg
+        int *op = out_s + (size_t)(16 * wave + 4 * grp) * S2_OS + m16;
+        op[0] = acc[0]; op[S2_OS] = acc[1]; op[2 * S2_OS] = acc[2]; op[3 * S2_OS] = acc[3];
+      }
+    }
+    __syncthreads();
+    S2STAMP(7);
+    if (tid < mB) {
+      const int4 o0 = *reinterpret_cast<const int4 *>(out_s + (size_t)tid * S2_OS), o1 = *reinterpret_cast<const int4 *>(out_s + (size_t)tid * S2_OS + 4);
+      double w = invSe, v = (double)o0.x * w;
+      w *= 256.0; v = fma((double)o0.y, w, v); w *= 256.0; v = fma((double)o0.z, w, v); w *= 256.0; v = fma((double)o0.w, w, v);
+      w *= 256.0; v = fma((double)o1.x, w, v); w *= 256.0; v = fma((double)o1.y, w, v); w *= 256.0; v = fma((double)o1.z, w, v);
+      s2_put_q(a.qpart + ((size_t)(b % S2_NSLOT) * K + wg) * SW_MAXM + tid, v, b);
+    }
+    S2WALL(2, wg == 0 && tid == 0 && b >= 2);
+  };
+  static_assert(S2_NDE == 7 && S2_NDD == 6, "the digit recombinations are written out for 7 / 6 digits");
+
+  {
+    uint32_t ex = 0u;
+    for (int r = tid; r < R; r += SW_THREADS) { const double v = a.e[row0 + r]; e_s[r] = v; ex = max(ex, (uint32_t)((__double2hiint(v) & 0x7FFFFFFF) >> 20)); }
+    ex = wave_max_u32(ex);
+    if (lane == 0) atomicMax(&ctl_s[2], ex);
+    __syncthreads();
+    const double invSe = e_digits(0);
+    publish(0, S2I_TILE(0), invSe);
+    if (nb > 1) publish(1, S2I_TILE(1), invSe);
+  }
+
+  for (int i = 0; i < nb; ++i) {
+    const int mB = blk_m(i);
+    const int par = i & 1;
+    // tile(i+2) lands in the buffer tile(i-1) used; its loads were issued one iteration ago
+    if (i + 2 < nb) S2_TILE_COMMIT(S2I_TILE(i + 2), blk_m(i + 2));
+    if (tid == 0) { ctl_s[par ^ 1] = 0u; ctl_s[2 + (par ^ 1)] = 0u; }      // next block's maxima (this block's were reset one iteration ago)
+    S2STAMP(0);
+    // delta_i: one 8-byte {epoch, float} granule per marker, polled by the thread that needs it
+    int bad = 0;
+    uint32_t dbits = 0u;
+    if (tid < SW_MAXM) {
+      if (tid < mB) {
+        const unsigned long long *g = a.dgran + (size_t)(i % S2_NSLOT) * SW_MAXM + tid;
+        const uint32_t epoch = (uint32_t)(i + 1);
+        const uint64_t t0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+          const unsigned long long v = ld_agent_raw64(g);
+          if ((uint32_t)(v >> 32) == epoch) { dbits = (uint32_t)v; break; }
+          if ((++spins & 63u) == 0u) {
+            if (ld_agent_u32(abortw) != 0u) { bad = 1; break; }
+            if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); bad = 1; break; }
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      const uint32_t ex = wave_max_u32((dbits >> 23) & 0xFFu);
+      if (lane == 0) atomicMax(&ctl_s[par], ex);
+    }
+    if (bad) ctl_s[8] = 1u;
+    __syncthreads();
+    S2WALL(1, wg == 0 && tid == 0 && i + 2 < nb);
+    if (ctl_s[8]) { if (tid == 0) a.sc->error = 1u; return; }
+    // the next tile's loads go out only now: a poll queued behind 32 KB of tile loads pays for them (the hand-off's price
+    // sits in the consumer CU's memory queue); they have the whole iteration to land
+    if (i + 3 < nb) S2_TILE_ISSUE(blk_j0(i + 3), blk_m(i + 3));
+    S2STAMP(1);
+    // ---- digits of delta: |delta| < 2^(ex-126) with ex the block's largest exponent field;  S = 2^(172-ex), |q| < 2^46 ----
+    const int dex = (int)ctl_s[par];
+    if (tid < SW_MAXM) put_digits<S2_NDD>(__double2ll_rn((double)__uint_as_float(dbits) * pow2_field(1195 - dex)), ddig_s + tid, S2_DP);
+    const double invSd = pow2_field(851 + dex);
+    __syncthreads();
+    S2STAMP(2);
+    // ---- slab update with tile(i): out_s[row][n] = sum_markers x[row][marker] * digit_n(delta[marker]) ----
+    // lane (m16, grp) of a wave pass owns the row quad r4 = 16 rg + m16; its k slots (dword u, byte q) of MFMA step s are the
+    // markers 64 s + 16 u + 4 grp + q (this interleave keeps the four lane groups on different LDS banks)
+    {
+      const int8_t *tile = S2I_TILE(i);
+      // tasks: (64-row group rg, half of the block's 64-marker steps); the halves' partial sums are added by the reader
+      const int nrg = R / 64;
+      for (int task = wave; task < 2 * nrg; task += SW_THREADS / 64) {
+        const int half = task / nrg, rg = task - half * nrg;
+        const int rowoff = 4 * (16 * rg + m16);
+        s2_v4i acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+        for (int s0 = 64 * half; s0 < mB; s0 += 128) {
+          // c[u][q]: rows rowoff..+3 of marker s0 + 16u + 4grp + q.  For m % 64 != 0 the last step reads up to 48 markers
+          // past the tile: still inside this workgroup's LDS (the arrays behind the tiles are larger), and those k slots
+          // meet zero digits (delta digits are written for all SW_MAXM markers of every block).
+          const int8_t *tp = tile + __mul24(s0 + 4 * grp, Rp) + rowoff;
+          uint32_t c[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              c[u][q] = *reinterpret_cast<const uint32_t *>(tp + (16 * u + q) * Rp);
+          const int8_t *bp = ddig_s + (size_t)m16 * S2_DP + s0 + 4 * grp;
+          const s2_v4i bv = {*reinterpret_cast<const int *>(bp), *reinterpret_cast<const int *>(bp + 16),
+                             *reinterpret_cast<const int *>(bp + 32), *reinterpret_cast<const int *>(bp + 48)};
+          uint32_t rw[4][4];                                               // rw[k][u]: row k, bytes = the 4 markers of chunk u
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t t0 = __builtin_amdgcn_perm(c[u][1], c[u][0], 0x05010400u), t1 = __builtin_amdgcn_perm(c[u][1], c[u][0], 0x07030602u);
+            const uint32_t t2 = __builtin_amdgcn_perm(c[u][3], c[u][2], 0x05010400u), t3 = __builtin_amdgcn_perm(c[u][3], c[u][2], 0x07030602u);
+            rw[0][u] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); rw[1][u] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+            rw[2][u] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); rw[3][u] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+          }
+          acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[0][0], (int)rw[0][1], (int)rw[0][2], (int)rw[0][3]}, bv, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[1][0], (int)rw[1][1], (int)rw[1][2], (int)rw[1][3]}, bv, acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[2][0], (int)rw[2][1], (int)rw[2][2], (int)rw[2][3]}, bv, acc2, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[3][0], (int)rw[3][1], (int)rw[3][2], (int)rw[3][3]}, bv, acc3, 0, 0, 0);
+        }
+        if (m16 < 8) {      // lane: digit n = m16; acc_k[reg] belongs to row 4 (16 rg + 4 grp + reg) + k
+          int *op = out_s + half * out_n + (size_t)(4 * (16 * rg + 4 * grp)) * S2_OS + m16;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            op[(4 * reg + 0) * S2_OS] = acc0[reg]; op[(4 * reg + 1) * S2_OS] = acc1[reg];
+            op[(4 * reg + 2) * S2_OS] = acc2[reg]; op[(4 * reg + 3) * S2_OS] = acc3[reg];
+          }
+        }
+      }
+    }
+    S2STAMP(3);
+    __syncthreads();
+    S2STAMP(4);
+    {
+      uint32_t ex = 0u;
+      for (int r = tid; r < R; r += SW_THREADS) {
+        int4 o0 = *reinterpret_cast<const int4 *>(out_s + (size_t)r * S2_OS);
+        int2 o1 = *reinterpret_cast<const int2 *>(out_s + (size_t)r * S2_OS + 4);
+        const int4 p0 = *reinterpret_cast<const int4 *>(out_s + out_n + (size_t)r * S2_OS);
+        const int2 p1 = *reinterpret_cast<const int2 *>(out_s + out_n + (size_t)r * S2_OS + 4);
+        o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w; o1.x += p1.x; o1.y += p1.y;
+        double w = invSd, v = (double)o0.x * w;
+        w *= 256.0; v = fma((double)o0.y, w, v); w *= 256.0; v = fma((double)o0.z, w, v); w *= 256.0; v = fma((double)o0.w, w, v);
+        w *= 256.0; v = fma((double)o1.x, w, v); w *= 256.0; v = fma((double)o1.y, w, v);
+        const double en = e_s[r] - v;
+        e_s[r] = en;
+        ex = max(ex, (uint32_t)((__double2hiint(en) & 0x7FFFFFFF) >> 20));
+      }
+      ex = wave_max_u32(ex);
+      if (lane == 0) atomicMax(&ctl_s[2 + par], ex);
+    }
+    __syncthreads();
+    S2STAMP(5);
+    if (i + 2 < nb) {
+      const double invSe = e_digits(par);
+      S2STAMP(6);
+      publish(i + 2, S2I_TILE(i + 2), invSe);
+    }
+    S2STAMP(8);
+  }
+  if (wg == 0) S2STAMP_FLUSH(0);
   __syncthreads();
   for (int i = tid; i < R; i += SW_THREADS) a.e[row0 + i] = e_s[i];
 }
@@ -271,38 +532,43 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
   auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
   auto prow = [&](int k) { return k * (m - 1) - k * (k - 1) / 2; };   // offset of packed row k
 
-  auto wait_q = [&](int b) -> int {
-    const uint32_t epoch = (uint32_t)(b + 1);
-    const uint64_t t0 = wall_clock64();
-    for (;;) {
-      bool all_here = true;
-      for (int w = lane; w < K; w += 64)
-        all_here = all_here && (ld_agent_u32(a.xflags + (size_t)w * SW_FLAG_STRIDE) >= epoch);
-      if (__all(all_here)) return 1;
-      if (__any(ld_agent_u32(abortw) != 0u)) return 0;
-      if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) {
-        if (lane == 0) st_agent_u32(abortw, 1u);
-        return 0;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  };
-  // sum over a third of the streamers of q_b[t]; fixed order; result in part_s[part][t]
-  auto gather_q = [&](int b, int part, int t, int mB) {
-    const double *slot = a.qpart + (size_t)(b % S2_NSLOT) * K * SW_MAXM;
+  // sum over a third of the streamers of q_b[t], fixed order, into part_s[part][t]; every word is polled until it
+  // carries block b's tag.  Returns 0 on abort / timeout.
+  auto gather_q = [&](int b, int part, int t, int mB) -> int {
+    const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(a.qpart + (size_t)(b % S2_NSLOT) * K * SW_MAXM);
+    const unsigned long long tag = s2_qtag(b);
     const int wq = (K + 2) / 3;
+    const uint64_t t0 = wall_clock64();
     double r = 0.0;
     for (int wbase = 0; wbase < wq; wbase += 16) {
-      double v[16];
+      unsigned long long v[16];
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int w = part * wq + wbase + u;
+          const bool need = (t < mB && wbase + u < wq && w < K);
+          v[u] = need ? ld_agent_raw64(slot + (size_t)w * SW_MAXM + t) : tag;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) ok = ok && ((v[u] & 0xFFull) == tag);
+        if (ok) break;
+        if ((++spins & 63u) == 0u) {
+          if (ld_agent_u32(abortw) != 0u) return 0;
+          if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int w = part * wq + wbase + u;
-        v[u] = (t < mB && wbase + u < wq && w < K) ? ld_agent_f64(slot + (size_t)w * SW_MAXM + t) : 0.0;
+        const bool need = (t < mB && wbase + u < wq && w < K);
+        r += need ? __longlong_as_double((long long)(v[u] & ~0xFFull)) : 0.0;
       }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) r += v[u];
     }
     part_s[part * SW_MAXM + t] = r;
+    return 1;
   };
   auto copy16 = [&](void *dst, const void *src, int nchunks, int t0, int nth) {
     for (int c = t0; c < nchunks; c += nth) reinterpret_cast<uint4 *>(dst)[c] = reinterpret_cast<const uint4 *>(src)[c];
@@ -317,15 +583,35 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
     if (tid == 0) { ctrl_s[0] = 1; ctrl_s[1] = 0; }
     __syncthreads();
     if (wave >= 1 && wave <= 6) {
-      const int ok = wait_q(0);
-      if (!ok && lane == 0) ctrl_s[0] = 0;
-      if (ok) gather_q(0, (tid - 64) >> 7, (tid - 64) & 127, mB);
+      if (!gather_q(0, (tid - 64) >> 7, (tid - 64) & 127, mB)) ctrl_s[0] = 0;
     }
     __syncthreads();
     if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
     if (tid < mB) r0_s[tid] = (part_s[tid] + part_s[SW_MAXM + tid]) + part_s[2 * SW_MAXM + tid];
   }
   double sum_d = 0.0, sum_b2 = 0.0;
+  // helper threads' prefetch registers (plain named locals: an aggregate would end up in scratch memory)
+  static_assert(PCH <= 5 && XCH <= 10, "named prefetch registers cover 5 + 10 chunks per helper thread");
+  constexpr int NCH = (int)(sizeof(StageBuf) / 16), NSP = (int)(sizeof(SpecBuf) / 16);
+  static_assert(NCH <= NHELP && NSP <= NHELP, "one chunk per helper thread");
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+  uint4 gq0 = z4, gq1 = z4, gq2 = z4, gq3 = z4, gq4 = z4;
+  uint4 xq0 = z4, xq1 = z4, xq2 = z4, xq3 = z4, xq4 = z4, xq5 = z4, xq6 = z4, xq7 = z4, xq8 = z4, xq9 = z4;
+  uint4 spre = z4, cpre = z4;
+#define S2_G_EACH(X) X(0, gq0) X(1, gq1) X(2, gq2) X(3, gq3) X(4, gq4)
+#define S2_X_EACH(X) X(0, xq0) X(1, xq1) X(2, xq2) X(3, xq3) X(4, xq4) X(5, xq5) X(6, xq6) X(7, xq7) X(8, xq8) X(9, xq9)
+#define S2_GLD(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < pchunks) name = gsrc[c_]; }
+#define S2_XLD(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < xchunks) name = xsrc[c_]; }
+#define S2_GST(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < pchunks) gdst[c_] = name; }
+#define S2_XST(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < xchunks) xdst[c_] = name; }
+  if (wave >= 1 && nb > 1) {   // block 1
+    const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(a.blk_begin + 1) * pstride);
+    const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(a.blk_begin + 1) * m * m);
+    S2_G_EACH(S2_GLD)
+    S2_X_EACH(S2_XLD)
+    if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + a.blk_begin + 1)[tid - 64];
+    if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + a.blk_begin + 1)[tid - 64];
+  }
   S2STAMP_DECL;
 
   for (int b = 0; b < nb; ++b) {
@@ -355,6 +641,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
         lc[q].rden = live ? st.rden[t] : 1.0; lc[q].sdz1 = live ? st.sdz1[t] : 0.0;
         lc[q].u = live ? st.u[t] : 2.0; lc[q].gjj = live ? sb.gjj[t] : 0.0;
       }
+      S2STAMP(5);
       // packed row k: entry for marker j (> k) sits at prow(k) + j - k - 1
       auto gat = [&](int k, int j) -> GT { return (j > k && j < m) ? gp[prow(k) + j - k - 1] : (GT)0; };
       unsigned long long accmask[2] = {0ull, 0ull};
@@ -408,6 +695,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
           }
         }
       }
+      S2STAMP(6);
       // outputs; delta_b goes out at once as {epoch, float} granules (one 8-byte write-through store per marker)
       unsigned long long *gslot = a.dgran + (size_t)(b % S2_NSLOT) * SW_MAXM;
       const int nacc0 = __popcll(accmask[0]);
@@ -431,43 +719,31 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
         }
       }
       if (SELECT && lane == 0) ctrl_s[1] = nacc0 + __popcll(accmask[1]);
+      S2WALL(0, lane == 0 && b + 2 < nb);
       S2STAMP(1);
     } else if (have_next) {
-      // ---- helpers: bring in block b+1 (packed G, Gx, constants), then the streamers' q_{b+1} ----
-      static_assert(PCH <= 5 && XCH <= 10, "named prefetch registers cover 5 + 10 chunks per helper thread");
-      const uint4 z4 = make_uint4(0, 0, 0, 0);
-      uint4 gq0 = z4, gq1 = z4, gq2 = z4, gq3 = z4, gq4 = z4;
-      uint4 xq0 = z4, xq1 = z4, xq2 = z4, xq3 = z4, xq4 = z4, xq5 = z4, xq6 = z4, xq7 = z4, xq8 = z4, xq9 = z4;
-      const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(blk + 1) * pstride);
-      const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(blk + 1) * m * m);
-#define S2_G_EACH(X) X(0, gq0) X(1, gq1) X(2, gq2) X(3, gq3) X(4, gq4)
-#define S2_X_EACH(X) X(0, xq0) X(1, xq1) X(2, xq2) X(3, xq3) X(4, xq4) X(5, xq5) X(6, xq6) X(7, xq7) X(8, xq8) X(9, xq9)
-#define S2_GLD(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < pchunks) name = gsrc[c_]; }
-#define S2_XLD(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < xchunks) name = xsrc[c_]; }
-      S2_G_EACH(S2_GLD)
-      S2_X_EACH(S2_XLD)
-      constexpr int NCH = (int)(sizeof(StageBuf) / 16), NSP = (int)(sizeof(SpecBuf) / 16);
-      static_assert(NCH <= NHELP && NSP <= NHELP, "one chunk per helper thread");
-      uint4 spre = make_uint4(0, 0, 0, 0), cpre = spre;
-      if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 1)[tid - 64];
-      if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + blk + 1)[tid - 64];
-      if (wave >= 1 && wave <= 6) {
-        const int ok = wait_q(b + 1);
-        if (!ok && lane == 0) ctrl_s[0] = 0;
-        if (ok) gather_q(b + 1, (tid - 64) >> 7, (tid - 64) & 127, mBn);
-      }
+      // ---- helpers: block b+1's Gram blocks and constants were loaded into registers one iteration ago and go to LDS
+      // now; then the streamers' q_{b+1} is gathered; only then the loads of block b+2 are issued (a poll queued behind
+      // 96 KB of Gram loads would pay for them), and they have a whole iteration to land ----
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): tells the compiler that no prefetch load is in flight
       uint4 *gdst = reinterpret_cast<uint4 *>(S2_GP(b + 1));
       uint4 *xdst = reinterpret_cast<uint4 *>(gx_s);
-#define S2_GST(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < pchunks) gdst[c_] = name; }
-#define S2_XST(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < xchunks) xdst[c_] = name; }
       S2_G_EACH(S2_GST)
       S2_X_EACH(S2_XST)
-#undef S2_GLD
-#undef S2_XLD
-#undef S2_GST
-#undef S2_XST
       if (tid - 64 < NCH) reinterpret_cast<uint4 *>(&stage[(b + 1) & 1])[tid - 64] = spre;
       if (tid - 64 < NSP) reinterpret_cast<uint4 *>(&specb[(b + 1) & 1])[tid - 64] = cpre;
+      if (wave >= 1 && wave <= 6) {
+        if (!gather_q(b + 1, (tid - 64) >> 7, (tid - 64) & 127, mBn)) ctrl_s[0] = 0;
+      }
+      S2WALL(3, tid == 64 && b + 1 >= 2);
+      if (b + 2 < nb) {
+        const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(blk + 2) * pstride);
+        const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(blk + 2) * m * m);
+        S2_G_EACH(S2_GLD)
+        S2_X_EACH(S2_XLD)
+        if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 2)[tid - 64];
+        if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + blk + 2)[tid - 64];
+      }
     }
     __syncthreads();   // A: recurrence done; block b+1's Gram/constants are in LDS; q_{b+1} partial sums in part_s
     S2STAMP(2);
@@ -515,7 +791,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
       S2STAMP(4);
     }
   }
-  S2STAMP_FLUSH(6, 5);
+  S2STAMP_FLUSH(16);
   if (wave == 0) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { sum_d += __shfl_down(sum_d, o, 64); sum_b2 += __shfl_down(sum_b2, o, 64); }
@@ -526,6 +802,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
 template <typename XT, bool SELECT>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep2(const SweepArgs a) {
   if ((int)blockIdx.x == a.K) s2_sequencer<XT, SELECT>(a);
+  else if constexpr (sizeof(XT) == 1) s2_streamer_i8(a);
   else s2_streamer<XT>(a);
 }
 
