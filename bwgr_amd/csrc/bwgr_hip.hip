@@ -154,13 +154,13 @@ __global__ __launch_bounds__(256) void k_gram_i8(const int8_t *X, int64_t ld, in
     for (int c = 0; c < TJ; ++c) g[(size_t)(tj + 16 * a) * m + (tk + 16 * c)] = acc[a][c];
 }
 
-// off-diagonal blocks for the lag-1 pipeline: gramx[blk][k][j] = X_{(blk-1)m+k} . X_{blk*m+j}, blk >= 1
+// off-diagonal blocks for the pipelined sweep: gramx[blk][k][j] = X_{(blk-dist)m+k} . X_{blk*m+j}, blk >= dist (dist = 1, 2)
 template <int TJ>
-__global__ __launch_bounds__(256) void k_gramx_i8(const int8_t *X, int64_t ld, int R, int p, int m, int32_t *gramx) {
+__global__ __launch_bounds__(256) void k_gramx_i8(const int8_t *X, int64_t ld, int R, int p, int m, int32_t *gramx, int dist) {
   constexpr int RC = 128, RW = RC / 4 + 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t *ta = reinterpret_cast<int32_t *>(smem), *tb = ta + (size_t)m * RW;
-  const int blk = blockIdx.x + 1, ja0 = (blk - 1) * m, jb0 = blk * m, mBb = min(m, p - jb0);
+  const int blk = blockIdx.x + dist, ja0 = (blk - dist) * m, jb0 = blk * m, mBb = min(m, p - jb0);
   const int tj = threadIdx.x >> 4, tk = threadIdx.x & 15;
   int32_t acc[TJ][TJ];
 #pragma unroll
@@ -192,11 +192,11 @@ __global__ __launch_bounds__(256) void k_gramx_i8(const int8_t *X, int64_t ld, i
     for (int c = 0; c < TJ; ++c) g[(size_t)(tj + 16 * a) * m + (tk + 16 * c)] = acc[a][c];
 }
 template <int TJ>
-__global__ __launch_bounds__(256) void k_gramx_f32(const float *X, int64_t ld, int R, int p, int m, double *gramx) {
+__global__ __launch_bounds__(256) void k_gramx_f32(const float *X, int64_t ld, int R, int p, int m, double *gramx, int dist) {
   constexpr int RC = 64, RW = RC + 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *ta = reinterpret_cast<float *>(smem), *tb = ta + (size_t)m * RW;
-  const int blk = blockIdx.x + 1, ja0 = (blk - 1) * m, jb0 = blk * m, mBb = min(m, p - jb0);
+  const int blk = blockIdx.x + dist, ja0 = (blk - dist) * m, jb0 = blk * m, mBb = min(m, p - jb0);
   const int tj = threadIdx.x >> 4, tk = threadIdx.x & 15;
   double acc[TJ][TJ];
 #pragma unroll
@@ -683,7 +683,8 @@ struct bwgr_panel {
   int is_f32 = 0;
   int m = 0, K = 0, R = 0;
   int64_t nblocks = 0;
-  void *X = nullptr, *gram = nullptr, *gramx = nullptr, *gramp = nullptr;
+  void *X = nullptr, *gram = nullptr, *gramx = nullptr, *gramx2 = nullptr, *gramp = nullptr;
+  double *xspec2 = nullptr;   // [nblocks][SW_MAXM]: lag-3 speculative cross term (k_spec)
   int pstride = 0;
   size_t x_bytes = 0, gram_bytes = 0;
   float *xx = nullptr, *vx = nullptr, *msx_dev = nullptr;
@@ -784,6 +785,10 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a) {
 }
 
 static int launch_sweep(bwgr_panel *P, SweepArgs &a) {
+  {   // selection models run the deeper pipeline (their cross terms are sparse); BWGR_LAG=2 forces the shallow one (A/B tests)
+    const char *lv = getenv("BWGR_LAG");
+    a.lag = (P->sweep_version == 2 && !P->is_f32 && (a.flags & SWF_SELECT) && P->gramx2 && !(lv && lv[0] == '2')) ? 3 : 2;
+  }
   CHK(reset_exchange(P));
   launch_prestage(P, a);
   launch_sweep_kernel(P, a);
@@ -796,7 +801,7 @@ static void fill_panel_args(const bwgr_panel *P, SweepArgs &a) {
   a.n = (int)P->n; a.p = (int)P->p; a.m = P->m; a.K = P->K; a.R = P->R;
   a.blk_begin = 0; a.blk_end = (int)P->nblocks;
   a.xpart = P->xpart; a.xflags = P->xflags; a.stamps = P->stamps; a.ps = P->ps;
-  a.gramx = P->gramx; a.gramp = P->gramp; a.pstride = P->pstride; a.qpart = P->qpart; a.dgran = P->dgran;
+  a.gramx = P->gramx; a.gramx2 = P->gramx2; a.xspec2 = P->xspec2; a.lag = 2; a.gramp = P->gramp; a.pstride = P->pstride; a.qpart = P->qpart; a.dgran = P->dgran;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -834,7 +839,7 @@ static int upload(bwgr_panel *P, const void *X, int memloc, int64_t ldx) {
 extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   if (!P) return BWGR_OK;
   (void)hipSetDevice(P->device);
-  hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramp); hipFree(P->ps.spec); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev); hipFree(P->xpart); hipFree(P->qpart); hipFree(P->dgran); hipFree(P->xflags);
+  hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->xspec2); hipFree(P->gramp); hipFree(P->ps.spec); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev); hipFree(P->xpart); hipFree(P->qpart); hipFree(P->dgran); hipFree(P->xflags);
   hipFree(P->ps.blocks); hipFree(P->stamps);
   delete P;
   return BWGR_OK;
@@ -890,29 +895,30 @@ static int panel_build_gram(bwgr_panel *P) {
     }
   }
   HIPCHK(hipGetLastError());
-  if (P->nblocks > 1) {   // off-diagonal blocks (blk-1, blk) for the lag-1 pipeline
-    const unsigned nbx = (unsigned)(P->nblocks - 1);
+  for (int dist = 1; dist <= 2; ++dist) {   // off-diagonal blocks (blk-dist, blk): the lag-2 / lag-3 pipelines' cross terms
+    if (P->nblocks <= dist || (dist == 2 && !P->gramx2)) continue;
+    const unsigned nbx = (unsigned)(P->nblocks - dist);
     if (P->is_f32) {
       const size_t lds = (size_t)2 * m * 65 * sizeof(float);
-      double *g = (double *)P->gramx; const float *X = (const float *)P->X;
+      double *g = (double *)(dist == 1 ? P->gramx : P->gramx2); const float *X = (const float *)P->X;
       switch (TJ) {
-        case 1: hipLaunchKernelGGL(k_gramx_f32<1>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
-        case 2: hipLaunchKernelGGL(k_gramx_f32<2>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
-        case 3: hipLaunchKernelGGL(k_gramx_f32<3>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
-        default: hipLaunchKernelGGL(k_gramx_f32<4>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+        case 1: hipLaunchKernelGGL(k_gramx_f32<1>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+        case 2: hipLaunchKernelGGL(k_gramx_f32<2>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+        case 3: hipLaunchKernelGGL(k_gramx_f32<3>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+        default: hipLaunchKernelGGL(k_gramx_f32<4>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
       }
     } else {
       const size_t lds = (size_t)2 * m * 33 * sizeof(int32_t);
-      int32_t *g = (int32_t *)P->gramx; const int8_t *X = (const int8_t *)P->X;
+      int32_t *g = (int32_t *)(dist == 1 ? P->gramx : P->gramx2); const int8_t *X = (const int8_t *)P->X;
       switch (TJ) {
-        case 1: hipLaunchKernelGGL(k_gramx_i8<1>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
-        case 2: hipLaunchKernelGGL(k_gramx_i8<2>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
-        case 3: hipLaunchKernelGGL(k_gramx_i8<3>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
-        case 4: hipLaunchKernelGGL(k_gramx_i8<4>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
-        case 5: hipLaunchKernelGGL(k_gramx_i8<5>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
-        case 6: hipLaunchKernelGGL(k_gramx_i8<6>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
-        case 7: hipLaunchKernelGGL(k_gramx_i8<7>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
-        default: hipLaunchKernelGGL(k_gramx_i8<8>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
+        case 1: hipLaunchKernelGGL(k_gramx_i8<1>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+        case 2: hipLaunchKernelGGL(k_gramx_i8<2>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+        case 3: hipLaunchKernelGGL(k_gramx_i8<3>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+        case 4: hipLaunchKernelGGL(k_gramx_i8<4>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+        case 5: hipLaunchKernelGGL(k_gramx_i8<5>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+        case 6: hipLaunchKernelGGL(k_gramx_i8<6>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+        case 7: hipLaunchKernelGGL(k_gramx_i8<7>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+        default: hipLaunchKernelGGL(k_gramx_i8<8>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
       }
     }
     HIPCHK(hipGetLastError());
@@ -962,6 +968,10 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipMalloc(&P->X, P->x_bytes));
   PCHK(hipMalloc(&P->gram, P->gram_bytes));
   PCHK(hipMalloc(&P->gramx, P->gram_bytes));
+  if (P->sweep_version == 2 && P->nblocks > 2) {   // distance-2 blocks: the selection models' lag-3 pipeline
+    PCHK(hipMalloc(&P->gramx2, P->gram_bytes));
+    PCHK(hipMalloc(&P->xspec2, sizeof(double) * (size_t)P->nblocks * SW_MAXM));
+  }
   P->pstride = ((m * (m - 1) / 2 + 3) / 4) * 4;
   PCHK(hipMalloc(&P->gramp, (size_t)P->nblocks * std::max(P->pstride, 4) * (P->is_f32 ? 8 : 4)));
   PCHK(hipMalloc(&P->ps.spec, sizeof(SpecBuf) * (size_t)P->nblocks));

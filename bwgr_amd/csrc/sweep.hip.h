@@ -70,6 +70,9 @@ struct SweepArgs {
   const void *X; int64_t ld;    // slab-major: element (row i, marker j) at ((i/R)*p + j)*R + i%R; ld = K*R padded rows
   const void *gram;             // [nblocks][m][m]  diagonal blocks X_b' X_b
   const void *gramx;            // [nblocks][m][m]  off-diagonal blocks X_{b-1}' X_b (entry 0 unused)
+  const void *gramx2;           // [nblocks][m][m]  X_{b-2}' X_b (entries 0, 1 unused); null when the panel has < 3 blocks
+  double *xspec2;               // [nblocks][SW_MAXM]  sum_k gramx2_b[k][j] * drej_{b-2}[k] (k_spec, lag 3)
+  int lag;                      // k_sweep2: q_b is taken against e after delta_{b-lag}; 2, or 3 for selection models
   const void *gramp;            // [nblocks][pstride] strict upper triangle of the diagonal blocks, row k = entries (k, k+1..m-1)
   int pstride;
   int n, p, m, K, R;
@@ -232,6 +235,17 @@ __global__ __launch_bounds__(128) void k_spec(const SweepArgs a, int blk_begin, 
     }
   }
   sp.spec[j] = s; sp.xspec[j] = xs; sp.gjj[j] = gjj;
+  if (a.lag == 3) {   // second cross term of the lag-3 pipeline
+    double xs2 = 0.0;
+    __syncthreads();
+    drp[j] = (blk - 2 >= blk_begin) ? a.ps.blocks[blk - 2].drej[j] : 0.0f;
+    __syncthreads();
+    if (j < mB && select && blk - 2 >= blk_begin) {
+      const GT *Gx2 = reinterpret_cast<const GT *>(a.gramx2) + (size_t)blk * m * m;
+      for (int k = 0; k < m; ++k) xs2 = fma((double)Gx2[(size_t)k * m + j], (double)drp[k], xs2);
+    }
+    a.xspec2[(size_t)blk * SW_MAXM + j] = xs2;
+  }
 }
 
 // block constants global -> LDS: one StageBuf is sizeof(StageBuf)/16 chunks, at most one per thread
@@ -321,7 +335,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
   double *delta_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
   float *bnew_s = reinterpret_cast<float *>(smem + off); off += SW_MAXM * sizeof(float);
   float *dnew_s = reinterpret_cast<float *>(smem + off); off += SW_MAXM * sizeof(float);
-  volatile int *ctrl_s = reinterpret_cast<volatile int *>(smem + off);
+  int *ctrl_s = reinterpret_cast<int *>(smem + off);   // (not volatile: a volatile access stays a flat_ one and waits on vmcnt)
 
   const XT *X = reinterpret_cast<const XT *>(a.X) + (size_t)wg * a.p * R;   // this workgroup's slab stream
   const GT *gram = reinterpret_cast<const GT *>(a.gram);

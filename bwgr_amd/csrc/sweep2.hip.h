@@ -55,13 +55,16 @@ __device__ __forceinline__ void s2_put_q(double *slot, double v, int b) {
 
 // tile macros with an explicit thread numbering (streamers use all 512 threads)
 #define S2_ISSUE1(u, name) { const int c_ = tid + (u) * SW_THREADS; if (c_ < tot_) name = src_[c_]; }
-#define S2_TILE_ISSUE(j0_, mB_) do { const int tot_ = (mB_) * (R / PER); \
+// (the vmcnt(0) in front: as for S2_TILE_COMMIT; the previous tile's loads have been committed by then)
+#define S2_TILE_ISSUE(j0_, mB_) do { const int tot_ = (mB_) * (R / PER); __builtin_amdgcn_s_waitcnt(0x0F70); \
     const uint4 *src_ = reinterpret_cast<const uint4 *>(X + (size_t)(j0_) * R); BWGR_TILE_EACH(S2_ISSUE1) } while (0)
 #define S2_COMMIT1(u, name) { const int c_ = tid + (u) * SW_THREADS; if (c_ < tot_) { \
     const int jj_ = (int)(((float)c_ + 0.5f) * rcpr_), ii_ = c_ - jj_ * cpr_; \
     *reinterpret_cast<uint4 *>((dst_) + (size_t)jj_ * Rp + ii_ * PER) = name; } }
+// The unconditional vmcnt(0) in front tells the compiler that none of the (conditionally issued) tile loads is in flight
+// when the registers are written again; without it every load of the next S2_TILE_ISSUE waits for the one before it.
 #define S2_TILE_COMMIT(dstp, mB_) do { XT *dst_ = (dstp); const int cpr_ = R / PER; const int tot_ = (mB_) * cpr_; \
-    const float rcpr_ = 1.0f / (float)cpr_; BWGR_TILE_EACH(S2_COMMIT1) } while (0)
+    const float rcpr_ = 1.0f / (float)cpr_; __builtin_amdgcn_s_waitcnt(0x0F70); BWGR_TILE_EACH(S2_COMMIT1) } while (0)
 
 // ------------------------------------------------------------------------------------------------------------------
 // streamer
@@ -120,7 +123,7 @@ __device__ __forceinline__ void s2_streamer(const SweepArgs &a) {
   double *e_s = reinterpret_cast<double *>(smem + off); off += (size_t)R * sizeof(double);
   double *delta_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
   double *part_s = reinterpret_cast<double *>(smem + off); off += (size_t)(SW_THREADS / 64) * SW_MAXM * sizeof(double);
-  volatile int *fail_s = reinterpret_cast<volatile int *>(smem + off);   // set once, on a failed wait
+  int *fail_s = reinterpret_cast<int *>(smem + off);   // set once, on a failed wait
   const XT *X = reinterpret_cast<const XT *>(a.X) + (size_t)wg * a.p * R;
   uint32_t *abortw = a.xflags + (size_t)K * SW_FLAG_STRIDE;
   const int mpad = (m <= 64) ? 64 : 128;
@@ -295,9 +298,9 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
   for (int i = tid; i < 4 * Rp; i += SW_THREADS) reinterpret_cast<uint32_t *>(edig_s)[i] = 0u;
   for (int i = tid; i < 4 * S2_DP; i += SW_THREADS) reinterpret_cast<uint32_t *>(ddig_s)[i] = 0u;
   if (tid < 16) ctl_s[tid] = 0u;
-  S2_TILE_ISSUE(blk_j0(0), blk_m(0)); S2_TILE_COMMIT(S2I_TILE(0), blk_m(0));
-  if (nb > 1) { S2_TILE_ISSUE(blk_j0(1), blk_m(1)); S2_TILE_COMMIT(S2I_TILE(1), blk_m(1)); }
-  if (nb > 2) S2_TILE_ISSUE(blk_j0(2), blk_m(2));
+  const int L = a.lag;   // q_b is computed after delta_{b-L} has been applied (2 or 3): tiles i .. i+L-1 sit in the ring of 3
+  for (int b = 0; b < L && b < nb; ++b) { S2_TILE_ISSUE(blk_j0(b), blk_m(b)); S2_TILE_COMMIT(S2I_TILE(b), blk_m(b)); }
+  if (nb > L) S2_TILE_ISSUE(blk_j0(L), blk_m(L));
   __syncthreads();
   S2STAMP_DECL;
 
@@ -332,7 +335,7 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
       w *= 256.0; v = fma((double)o1.x, w, v); w *= 256.0; v = fma((double)o1.y, w, v); w *= 256.0; v = fma((double)o1.z, w, v);
       s2_put_q(a.qpart + ((size_t)(b % S2_NSLOT) * K + wg) * SW_MAXM + tid, v, b);
     }
-    S2WALL(2, wg == 0 && tid == 0 && b >= 2);
+    S2WALL(2, wg == 0 && tid == 0 && b >= 3);
   };
   static_assert(S2_NDE == 7 && S2_NDD == 6, "the digit recombinations are written out for 7 / 6 digits");
 
@@ -343,15 +346,12 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     if (lane == 0) atomicMax(&ctl_s[2], ex);
     __syncthreads();
     const double invSe = e_digits(0);
-    publish(0, S2I_TILE(0), invSe);
-    if (nb > 1) publish(1, S2I_TILE(1), invSe);
+    for (int b = 0; b < L && b < nb; ++b) publish(b, S2I_TILE(b), invSe);
   }
 
   for (int i = 0; i < nb; ++i) {
     const int mB = blk_m(i);
     const int par = i & 1;
-    // tile(i+2) lands in the buffer tile(i-1) used; its loads were issued one iteration ago
-    if (i + 2 < nb) S2_TILE_COMMIT(S2I_TILE(i + 2), blk_m(i + 2));
     if (tid == 0) { ctl_s[par ^ 1] = 0u; ctl_s[2 + (par ^ 1)] = 0u; }      // next block's maxima (this block's were reset one iteration ago)
     S2STAMP(0);
     // delta_i: one 8-byte {epoch, float} granule per marker, polled by the thread that needs it
@@ -378,11 +378,8 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     }
     if (bad) ctl_s[8] = 1u;
     __syncthreads();
-    S2WALL(1, wg == 0 && tid == 0 && i + 2 < nb);
+    S2WALL(1, wg == 0 && tid == 0 && i + 3 < nb);
     if (ctl_s[8]) { if (tid == 0) a.sc->error = 1u; return; }
-    // the next tile's loads go out only now: a poll queued behind 32 KB of tile loads pays for them (the hand-off's price
-    // sits in the consumer CU's memory queue); they have the whole iteration to land
-    if (i + 3 < nb) S2_TILE_ISSUE(blk_j0(i + 3), blk_m(i + 3));
     S2STAMP(1);
     // ---- digits of delta: |delta| < 2^(ex-126) with ex the block's largest exponent field;  S = 2^(172-ex), |q| < 2^46 ----
     const int dex = (int)ctl_s[par];
@@ -441,6 +438,13 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     S2STAMP(3);
     __syncthreads();
     S2STAMP(4);
+    // tile(i) is spent: tile(i+L), in registers since the previous iteration, takes a free ring slot (for L = 3 the one of
+    // tile(i)), and the loads of tile(i+L+1) go out (after this iteration's poll: a poll queued behind 32 KB of tile loads
+    // pays for them; they have a whole iteration to land)
+    if (i + L < nb) S2_TILE_COMMIT(S2I_TILE(i + L), blk_m(i + L));
+    S2STAMP(9);
+    if (i + L + 1 < nb) S2_TILE_ISSUE(blk_j0(i + L + 1), blk_m(i + L + 1));
+    S2STAMP(0);
     {
       uint32_t ex = 0u;
       for (int r = tid; r < R; r += SW_THREADS) {
@@ -461,10 +465,10 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     }
     __syncthreads();
     S2STAMP(5);
-    if (i + 2 < nb) {
+    if (i + L < nb) {
       const double invSe = e_digits(par);
       S2STAMP(6);
-      publish(i + 2, S2I_TILE(i + 2), invSe);
+      publish(i + L, S2I_TILE(i + L), invSe);
     }
     S2STAMP(8);
   }
@@ -485,9 +489,9 @@ template <typename XT> __host__ __device__ inline size_t s2_seq_lds_bytes(int m)
   size_t s = ((size_t)2 * ((pstride < 4 ? 4 : pstride) + 256) * sizeof(GT) + 15) & ~(size_t)15;   // 64 + 192 entries of slack per buffer
   s += ((size_t)m * m * sizeof(GT) + 15) & ~(size_t)15;
   s += 2 * sizeof(StageBuf) + 2 * sizeof(SpecBuf);
-  s += 4 * SW_MAXM * sizeof(double);      // r0, r0n, delta, acc_corr
+  s += 5 * SW_MAXM * sizeof(double);      // r0, carry2, delta, acc_corr[2]
   s += 2 * SW_MAXM * sizeof(float);       // bnew, dnew
-  s += SW_MAXM * sizeof(int);             // acc_k
+  s += 2 * SW_MAXM * sizeof(int);         // acc_k[2]
   s += 4 * SW_MAXM * sizeof(double);      // part
   s += 64;
   return s;
@@ -516,14 +520,16 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
   StageBuf *stage = reinterpret_cast<StageBuf *>(smem + off); off += 2 * sizeof(StageBuf);
   SpecBuf *specb = reinterpret_cast<SpecBuf *>(smem + off); off += 2 * sizeof(SpecBuf);
   double *r0_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
-  off += SW_MAXM * sizeof(double);   // (spare)
+  double *carry2_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);   // lag 3: Gx2_{b+1}' delta_{b-1}
   double *delta_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
-  double *acc_corr = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
+  // what the accepted markers of a block changed beyond the speculated step: lists by block parity (block b's list
+  // serves r0_{b+1} right away and, with lag 3, r0_{b+2} one iteration later); counts in ctrl_s[2 + parity]
+  double *acc_corr2 = reinterpret_cast<double *>(smem + off); off += 2 * SW_MAXM * sizeof(double);
   float *bnew_s = reinterpret_cast<float *>(smem + off); off += SW_MAXM * sizeof(float);
   float *dnew_s = reinterpret_cast<float *>(smem + off); off += SW_MAXM * sizeof(float);
-  int *acc_k = reinterpret_cast<int *>(smem + off); off += SW_MAXM * sizeof(int);
+  int *acc_k2 = reinterpret_cast<int *>(smem + off); off += 2 * SW_MAXM * sizeof(int);
   double *part_s = reinterpret_cast<double *>(smem + off); off += 4 * SW_MAXM * sizeof(double);
-  volatile int *ctrl_s = reinterpret_cast<volatile int *>(smem + off);   // [0] ok flag, [1] number of accepted markers
+  int *ctrl_s = reinterpret_cast<int *>(smem + off);   // (not volatile: a volatile access stays a flat_ one and waits on vmcnt)   // [0] ok flag, [2], [3] number of accepted markers (by block parity)
   const GT *gramp = reinterpret_cast<const GT *>(a.gramp);
   const GT *gramx = reinterpret_cast<const GT *>(a.gramx);
   uint32_t *abortw = a.xflags + (size_t)K * SW_FLAG_STRIDE;
@@ -580,7 +586,8 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
     copy16(S2_GP(0), gramp + (size_t)a.blk_begin * pstride, pchunks, tid, SW_THREADS);
     copy16(&stage[0], a.ps.blocks + a.blk_begin, (int)(sizeof(StageBuf) / 16), tid, SW_THREADS);
     copy16(&specb[0], a.ps.spec + a.blk_begin, (int)(sizeof(SpecBuf) / 16), tid, SW_THREADS);
-    if (tid == 0) { ctrl_s[0] = 1; ctrl_s[1] = 0; }
+    if (tid == 0) { ctrl_s[0] = 1; ctrl_s[2] = 0; ctrl_s[3] = 0; }
+    if (tid < SW_MAXM) carry2_s[tid] = 0.0;
     __syncthreads();
     if (wave >= 1 && wave <= 6) {
       if (!gather_q(0, (tid - 64) >> 7, (tid - 64) & 127, mB)) ctrl_s[0] = 0;
@@ -604,11 +611,17 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
 #define S2_XLD(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < xchunks) name = xsrc[c_]; }
 #define S2_GST(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < pchunks) gdst[c_] = name; }
 #define S2_XST(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < xchunks) xdst[c_] = name; }
+  // m == 128 with 4-byte entries: 2032 packed and 4096 cross chunks, so every helper thread's first 4 / 9 chunks exist and
+  // only the last one needs a guard (unguarded accesses spare the exec-mask juggling of 15 conditional loads and stores)
+#define S2_GLD_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < 4 || c_ < pchunks) name = gsrc[c_]; }
+#define S2_XLD_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < 9 || c_ < xchunks) name = xsrc[c_]; }
+#define S2_GST_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < 4 || c_ < pchunks) gdst[c_] = name; }
+#define S2_XST_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < 9 || c_ < xchunks) xdst[c_] = name; }
+  const bool fullm = (m == SW_MAXM) && (sizeof(GT) == 4);
   if (wave >= 1 && nb > 1) {   // block 1
     const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(a.blk_begin + 1) * pstride);
     const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(a.blk_begin + 1) * m * m);
-    S2_G_EACH(S2_GLD)
-    S2_X_EACH(S2_XLD)
+    if (fullm) { S2_G_EACH(S2_GLD_F) S2_X_EACH(S2_XLD_F) } else { S2_G_EACH(S2_GLD) S2_X_EACH(S2_XLD) }
     if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + a.blk_begin + 1)[tid - 64];
     if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + a.blk_begin + 1)[tid - 64];
   }
@@ -623,6 +636,8 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
     const StageBuf &st = stage[b & 1];
     const SpecBuf &sb = specb[b & 1];
     const GT *gp = S2_GP(b);
+    int *acc_k = acc_k2 + (b & 1) * SW_MAXM;
+    double *acc_corr = acc_corr2 + (b & 1) * SW_MAXM;
     __syncthreads();   // r0_s, gp_s[b&1], stage[b&1], specb[b&1] of this block are in place
     S2STAMP(0);
 
@@ -718,32 +733,58 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
           sum_b2 = fma((double)bn, (double)bn, sum_b2);
         }
       }
-      if (SELECT && lane == 0) ctrl_s[1] = nacc0 + __popcll(accmask[1]);
-      S2WALL(0, lane == 0 && b + 2 < nb);
+      if (SELECT && lane == 0) ctrl_s[2 + (b & 1)] = nacc0 + __popcll(accmask[1]);
+      S2WALL(0, lane == 0 && b + 3 < nb);
       S2STAMP(1);
     } else if (have_next) {
-      // ---- helpers: block b+1's Gram blocks and constants were loaded into registers one iteration ago and go to LDS
-      // now; then the streamers' q_{b+1} is gathered; only then the loads of block b+2 are issued (a poll queued behind
-      // 96 KB of Gram loads would pay for them), and they have a whole iteration to land ----
-      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): tells the compiler that no prefetch load is in flight
+      // ---- helpers.  Block b+1's Gram blocks and constants were loaded into registers one iteration ago.  Order:
+      // (1) the registers go to LDS, (2) the loads of block b+2 are issued (they have a whole iteration to land),
+      // (3) q_{b+1} is gathered: its round trip runs under the prefetch traffic instead of in front of it ----
+      const int gpart = (tid - 64) >> 7, gt = (tid - 64) & 127;
+      S2WALL(4, tid == 64);
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no prefetch load is in flight
+      S2WALL(5, tid == 64);
       uint4 *gdst = reinterpret_cast<uint4 *>(S2_GP(b + 1));
       uint4 *xdst = reinterpret_cast<uint4 *>(gx_s);
-      S2_G_EACH(S2_GST)
-      S2_X_EACH(S2_XST)
+      if (fullm) { S2_G_EACH(S2_GST_F) S2_X_EACH(S2_XST_F) } else { S2_G_EACH(S2_GST) S2_X_EACH(S2_XST) }
       if (tid - 64 < NCH) reinterpret_cast<uint4 *>(&stage[(b + 1) & 1])[tid - 64] = spre;
       if (tid - 64 < NSP) reinterpret_cast<uint4 *>(&specb[(b + 1) & 1])[tid - 64] = cpre;
-      if (wave >= 1 && wave <= 6) {
-        if (!gather_q(b + 1, (tid - 64) >> 7, (tid - 64) & 127, mBn)) ctrl_s[0] = 0;
-      }
-      S2WALL(3, tid == 64 && b + 1 >= 2);
+      S2WALL(6, tid == 64);
       if (b + 2 < nb) {
         const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(blk + 2) * pstride);
         const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(blk + 2) * m * m);
-        S2_G_EACH(S2_GLD)
-        S2_X_EACH(S2_XLD)
+        if (fullm) { S2_G_EACH(S2_GLD_F) S2_X_EACH(S2_XLD_F) } else { S2_G_EACH(S2_GLD) S2_X_EACH(S2_XLD) }
         if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 2)[tid - 64];
         if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + blk + 2)[tid - 64];
       }
+      S2WALL(7, tid == 64);
+      if (wave <= 6) {
+        if (!gather_q(b + 1, gpart, gt, mBn)) ctrl_s[0] = 0;
+      } else if (SELECT && a.lag == 3) {
+        // wave 7: r0_{b+1}'s cross term with block b-1 = speculated part (k_spec) + the rows of Gx2_{b+1} that block
+        // b-1's accepted markers touch, straight from global memory (the list has been final since the last barrier A)
+        const int *pk = acc_k2 + ((b + 1) & 1) * SW_MAXM;
+        const double *pc = acc_corr2 + ((b + 1) & 1) * SW_MAXM;
+        const int npre = (b >= 1) ? ctrl_s[2 + ((b + 1) & 1)] : 0;
+        const GT *gx2 = reinterpret_cast<const GT *>(a.gramx2) + (size_t)(blk + 1) * m * m;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = lane + 64 * h;
+          double c = 0.0;
+          if (b >= 1 && j < mBn) {
+            c = a.xspec2[(size_t)(blk + 1) * SW_MAXM + j];
+            for (int i0 = 0; i0 < npre; i0 += 8) {
+              GT gv[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) gv[u] = (i0 + u < npre) ? gx2[(size_t)pk[i0 + u] * m + j] : (GT)0;
+#pragma unroll
+              for (int u = 0; u < 8; ++u) if (i0 + u < npre) c = fma((double)gv[u], pc[i0 + u], c);
+            }
+          }
+          carry2_s[j] = c;
+        }
+      }
+      S2WALL(9, tid == 64);
     }
     __syncthreads();   // A: recurrence done; block b+1's Gram/constants are in LDS; q_{b+1} partial sums in part_s
     S2STAMP(2);
@@ -760,8 +801,9 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
         // r0_{b+1} = sum_w q - Gx' drej_b (precomputed) - sum_{accepted k} Gx[k][.] * (what k changed beyond drej)
         if (tid < mBn) {
           double r = ((part_s[tid] + part_s[SW_MAXM + tid]) + part_s[2 * SW_MAXM + tid]) - specb[(b + 1) & 1].xspec[tid];
-          const int nacc = ctrl_s[1];
+          const int nacc = ctrl_s[2 + (b & 1)];
           for (int i = 0; i < nacc; ++i) r = fma(-(double)gx_s[(size_t)acc_k[i] * m + tid], acc_corr[i], r);
+          if (a.lag == 3) r -= carry2_s[tid];
           r0_s[tid] = r;
         }
         S2STAMP(3);

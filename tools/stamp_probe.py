@@ -12,7 +12,7 @@ import numpy as np, torch
 import bwgr_amd
 from bwgr_amd import synth, _lib
 wl = {"c2": (5000, 50000, "BayesA", 0.0), "c4s": (10000, 100000, "BayesB", 0.99)}
-names2 = {0: "streamer: tile commit", 1: "streamer: wait delta (+ tile issue)", 2: "streamer: delta digits", 3: "streamer: update MFMA (wave 0)", 4: "streamer: update barrier", 5: "streamer: e update + max", 6: "streamer: e digits", 7: "streamer: dots (barrier, MFMA, barrier)", 8: "streamer: q recombine + store",
+names2 = {0: "streamer: loop top + tile issue", 9: "streamer: tile commit (vmcnt(0) + LDS stores)", 1: "streamer: wait delta (+ tile issue)", 2: "streamer: delta digits", 3: "streamer: update MFMA (wave 0)", 4: "streamer: update barrier", 5: "streamer: e update + max", 6: "streamer: e digits", 7: "streamer: dots (barrier, MFMA, barrier)", 8: "streamer: q recombine + store",
           16: "sequencer: top barrier", 21: "sequencer: lane constants", 22: "sequencer: recurrence rounds", 17: "sequencer: outputs + delta store", 18: "sequencer: wait at barrier A (helpers, q_{b+1})", 19: "sequencer: post (state, r0 of next block)", 20: "sequencer: post tail"}
 names = ["top-barrier", "dot", "combine+exchange", "wait for prefetch waves", "outputs+update", "spec matvec", "recurrence (wave 0)", "-", "wave1: prefetch until tile+stage stored", "wave1: residual vmcnt(0)", "wave1: t(gram loads landed)", "wave1: t(+stage landed)"]
 for key in sys.argv[1:] or ["c2", "c4s"]:
@@ -34,5 +34,7 @@ for key in sys.argv[1:] or ["c2", "c4s"]:
         print("   wall clock: delta stored -> seen by streamer 0: %.2f us;  q stored by streamer 0 -> gathered from all: %.2f us" % ((w[1] - w[0]) / (nblk - 6) / 100.0, (w[3] - w[2]) / (nblk - 6) / 100.0))
     else:
         for nm, x in zip(names, v): print("   %-50s %9.0f ticks/block" % (nm, x / nblk))
+    hw = v[32:48] / (nblk - 3) / 100.0
+    print("   sequencer helper wave 1 (us per block, wall clock): wait for prefetch regs %.2f, stores to LDS %.2f, issue next prefetch %.2f, gather q %.2f" % (hw[5] - hw[4], hw[6] - hw[5], hw[7] - hw[6], hw[9] - hw[7]))
     ms, nl = ch.sweep_ms(); print("   sweep ms", ms)
     ch.close(); P.close()
