@@ -277,6 +277,18 @@ __global__ void k_gram_pack(const GT *gram, GT *gramp, int m, int pstride, int64
   for (int e = m * (m - 1) / 2 + threadIdx.x; e < pstride; e += blockDim.x) P[e] = (GT)0;
 }
 
+// 16-bit copies of the packed and the distance-1 cross Gram blocks for the k_sweep2 sequencer (half the bytes through its
+// CU per block); *bad is set when an entry does not fit, and the sequencer then stages the 32-bit arrays
+__global__ void k_gram_narrow(const int32_t *src, uint16_t *dst, int64_t count, int *bad) {
+  int any = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t v = src[i];
+    any |= (v < 0 || v > 65535);
+    dst[i] = (uint16_t)v;
+  }
+  if (any) *bad = 1;
+}
+
 // ---- chain setup (src/Rcpp20260726ai.cpp:599-610 and the identical blocks of the other samplers) ----
 struct InitArgs {
   const float *y; double *e; int n, p; int64_t ld; int model; float pi, df, R2; float MSx; ChainScalars *sc;
@@ -685,6 +697,9 @@ struct bwgr_panel {
   int64_t nblocks = 0;
   void *X = nullptr, *gram = nullptr, *gramx = nullptr, *gramx2 = nullptr, *gramp = nullptr;
   double *xspec2 = nullptr;   // [nblocks][SW_MAXM]: lag-3 speculative cross term (k_spec)
+  uint16_t *gramp16 = nullptr, *gramx16 = nullptr;   // 16-bit copies for the sequencer (int8 panels)
+  int *gram16_bad = nullptr;
+  bool gram16 = false;        // the copies are exact: every entry in 0..65535
   int pstride = 0;
   size_t x_bytes = 0, gram_bytes = 0;
   float *xx = nullptr, *vx = nullptr, *msx_dev = nullptr;
@@ -743,7 +758,7 @@ static int reset_exchange(bwgr_panel *P) {
   if (P->sweep_version == 2) {
     HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
     HIPCHK(hipMemsetAsync(P->dgran, 0, sizeof(unsigned long long) * S2_NSLOT * SW_MAXM, P->stream));
-    HIPCHK(hipMemsetAsync(P->qpart, 0, sizeof(double) * S2_NSLOT * (size_t)P->K * SW_MAXM, P->stream));
+    HIPCHK(hipMemsetAsync(P->qpart, 0, sizeof(double) * S2_NSLOT * ((size_t)P->K + 1) * SW_MAXM, P->stream));   // + the feeder's sums
   } else if (P->K > 1) {
     HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
   }
@@ -770,7 +785,12 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a) {
       if (sel) hipLaunchKernelGGL((k_sweep2<float, true>), grid, blk, P->lds2_bytes, P->stream, a);
       else hipLaunchKernelGGL((k_sweep2<float, false>), grid, blk, P->lds2_bytes, P->stream, a);
     } else {
-      if (sel) hipLaunchKernelGGL((k_sweep2<int8_t, true>), grid, blk, P->lds2_bytes, P->stream, a);
+      if (P->gram16) {
+        SweepArgs a16 = a;
+        a16.gramp = P->gramp16; a16.gramx = P->gramx16;
+        if (sel) hipLaunchKernelGGL((k_sweep2<int8_t, true, uint16_t>), dim3(P->K + 2), blk, P->lds2_bytes, P->stream, a16);   // + the q feeder
+        else hipLaunchKernelGGL((k_sweep2<int8_t, false, uint16_t>), grid, blk, P->lds2_bytes, P->stream, a16);
+      } else if (sel) hipLaunchKernelGGL((k_sweep2<int8_t, true>), grid, blk, P->lds2_bytes, P->stream, a);
       else hipLaunchKernelGGL((k_sweep2<int8_t, false>), grid, blk, P->lds2_bytes, P->stream, a);
     }
     return;
@@ -784,11 +804,13 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a) {
   }
 }
 
+// selection models run the deeper pipeline (their cross terms are sparse); BWGR_LAG=2 forces the shallow one (A/B tests)
+static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
+  const char *lv = getenv("BWGR_LAG");
+  a.lag = (P->sweep_version == 2 && !P->is_f32 && (a.flags & SWF_SELECT) && P->gramx2 && !(lv && lv[0] == '2')) ? 3 : 2;
+}
 static int launch_sweep(bwgr_panel *P, SweepArgs &a) {
-  {   // selection models run the deeper pipeline (their cross terms are sparse); BWGR_LAG=2 forces the shallow one (A/B tests)
-    const char *lv = getenv("BWGR_LAG");
-    a.lag = (P->sweep_version == 2 && !P->is_f32 && (a.flags & SWF_SELECT) && P->gramx2 && !(lv && lv[0] == '2')) ? 3 : 2;
-  }
+  choose_lag(P, a);
   CHK(reset_exchange(P));
   launch_prestage(P, a);
   launch_sweep_kernel(P, a);
@@ -839,7 +861,7 @@ static int upload(bwgr_panel *P, const void *X, int memloc, int64_t ldx) {
 extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   if (!P) return BWGR_OK;
   (void)hipSetDevice(P->device);
-  hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->xspec2); hipFree(P->gramp); hipFree(P->ps.spec); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev); hipFree(P->xpart); hipFree(P->qpart); hipFree(P->dgran); hipFree(P->xflags);
+  hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->xspec2); hipFree(P->gramp16); hipFree(P->gramx16); hipFree(P->gram16_bad); hipFree(P->gramp); hipFree(P->ps.spec); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev); hipFree(P->xpart); hipFree(P->qpart); hipFree(P->dgran); hipFree(P->xflags);
   hipFree(P->ps.blocks); hipFree(P->stamps);
   delete P;
   return BWGR_OK;
@@ -926,6 +948,19 @@ static int panel_build_gram(bwgr_panel *P) {
   if (P->is_f32) hipLaunchKernelGGL(k_gram_pack<double>, dim3((unsigned)P->nblocks), dim3(256), 0, P->stream, (const double *)P->gram, (double *)P->gramp, m, P->pstride, P->nblocks);
   else hipLaunchKernelGGL(k_gram_pack<int32_t>, dim3((unsigned)P->nblocks), dim3(256), 0, P->stream, (const int32_t *)P->gram, (int32_t *)P->gramp, m, P->pstride, P->nblocks);
   HIPCHK(hipGetLastError());
+  P->gram16 = false;
+  if (P->gramp16) {
+    HIPCHK(hipMemsetAsync(P->gram16_bad, 0, sizeof(int), P->stream));
+    hipLaunchKernelGGL(k_gram_narrow, dim3(2048), dim3(256), 0, P->stream, (const int32_t *)P->gramp, P->gramp16, (int64_t)P->nblocks * P->pstride, P->gram16_bad);
+    if (P->nblocks > 1)
+      hipLaunchKernelGGL(k_gram_narrow, dim3(2048), dim3(256), 0, P->stream, (const int32_t *)P->gramx + (size_t)m * m, P->gramx16 + (size_t)m * m, (int64_t)(P->nblocks - 1) * m * m, P->gram16_bad);
+    HIPCHK(hipGetLastError());
+    int bad = 1;
+    HIPCHK(hipMemcpyAsync(&bad, P->gram16_bad, sizeof(int), hipMemcpyDeviceToHost, P->stream));
+    HIPCHK(hipStreamSynchronize(P->stream));
+    const char *gv = getenv("BWGR_GRAM16");   // BWGR_GRAM16=0 forces the 32-bit staging (A/B tests)
+    P->gram16 = (bad == 0) && !(gv && gv[0] == '0');
+  }
   HIPCHK(hipStreamSynchronize(P->stream));
   return BWGR_OK;
 }
@@ -958,7 +993,7 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   {
     const char *sv = getenv("BWGR_SWEEP");   // A/B switch for tests and profiling
     P->sweep_version = (sv && sv[0] == '1') ? 1 : 2;
-    if (P->lds2_bytes > (size_t)160 * 1024 || K + 1 > 256) P->sweep_version = 1;
+    if (P->lds2_bytes > (size_t)160 * 1024 || K + 2 > 256) P->sweep_version = 1;
   }
   P->x_bytes = (size_t)P->ld * (size_t)p * (P->is_f32 ? 4 : 1);
   P->gram_bytes = (size_t)P->nblocks * m * m * (P->is_f32 ? 8 : 4);   // per Gram array (diagonal blocks; off-diagonal blocks)
@@ -972,15 +1007,20 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
     PCHK(hipMalloc(&P->gramx2, P->gram_bytes));
     PCHK(hipMalloc(&P->xspec2, sizeof(double) * (size_t)P->nblocks * SW_MAXM));
   }
-  P->pstride = ((m * (m - 1) / 2 + 3) / 4) * 4;
-  PCHK(hipMalloc(&P->gramp, (size_t)P->nblocks * std::max(P->pstride, 4) * (P->is_f32 ? 8 : 4)));
+  P->pstride = ((m * (m - 1) / 2 + 7) / 8) * 8;
+  PCHK(hipMalloc(&P->gramp, (size_t)P->nblocks * std::max(P->pstride, 8) * (P->is_f32 ? 8 : 4)));
+  if (!P->is_f32 && P->sweep_version == 2) {
+    PCHK(hipMalloc(&P->gramp16, (size_t)P->nblocks * std::max(P->pstride, 8) * 2));
+    PCHK(hipMalloc(&P->gramx16, (size_t)P->nblocks * m * m * 2));
+    PCHK(hipMalloc(&P->gram16_bad, sizeof(int)));
+  }
   PCHK(hipMalloc(&P->ps.spec, sizeof(SpecBuf) * (size_t)P->nblocks));
   PCHK(hipMalloc(&P->xx, sizeof(float) * p));
   PCHK(hipMalloc(&P->vx, sizeof(float) * p));
   PCHK(hipMalloc(&P->msx_dev, sizeof(float)));
   PCHK(hipMalloc(&P->xpart, sizeof(double) * 2 * (size_t)K * SW_MAXM));
   PCHK(hipMalloc(&P->xflags, sizeof(uint32_t) * ((size_t)K + 1) * SW_FLAG_STRIDE));
-  PCHK(hipMalloc(&P->qpart, sizeof(double) * S2_NSLOT * (size_t)K * SW_MAXM));
+  PCHK(hipMalloc(&P->qpart, sizeof(double) * S2_NSLOT * ((size_t)K + 1) * SW_MAXM));
   PCHK(hipMalloc(&P->dgran, sizeof(unsigned long long) * S2_NSLOT * SW_MAXM));
   PCHK(hipMalloc(&P->ps.blocks, sizeof(StageBuf) * (size_t)P->nblocks));
 #ifdef BWGR_STAMPS
@@ -993,6 +1033,8 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<int8_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<int8_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<int8_t, true, uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<int8_t, false, uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef PCHK
@@ -1165,6 +1207,7 @@ extern "C" int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end
   a.iter = (uint32_t)C->done; a.marker0 = (uint32_t)C->marker0; a.rng = make_rng(C->seed, C->rng_mode);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  choose_lag(P, a);
   CHK(reset_exchange(P));
   launch_prestage(P, a);
   HIPCHK(hipEventRecord(e0, P->stream));

@@ -24,12 +24,21 @@ namespace bwgr {
 #define S2STAMP_DECL unsigned long long ph2[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}, tl2 = __builtin_amdgcn_s_memtime()
 #define S2STAMP(k) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph2[k] += t_ - tl2; tl2 = t_; } } while (0)
 #define S2STAMP_FLUSH(base) do { if (tid == 0 && a.stamps) for (int k_ = 0; k_ < 16; ++k_) a.stamps[(base) + k_] += ph2[k_]; } while (0)
-#define S2WALL(slot, cond) do { if ((cond) && a.stamps) atomicAdd(&a.stamps[32 + (slot)], (unsigned long long)wall_clock64()); } while (0)
+// wall-clock sums are kept in registers and flushed once at the end (an atomic per sample would sit in front of the next vmcnt(0))
+#define S2WALL_DECL unsigned long long wl2[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}
+#define S2WALL(slot, cond) do { if (cond) wl2[slot] += (unsigned long long)wall_clock64(); } while (0)
+#define S2WALL_FLUSH do { if (a.stamps) for (int k_ = 0; k_ < 16; ++k_) if (wl2[k_]) atomicAdd(&a.stamps[32 + k_], wl2[k_]); } while (0)
+#define S2ONE(dst, cond) do { if ((cond) && a.stamps) a.stamps[dst] = (unsigned long long)wall_clock64(); } while (0)
+#define S2WALL_FLUSH_AT(base) do { if (a.stamps) for (int k_ = 4; k_ < 8; ++k_) if (wl2[k_]) { atomicAdd(&a.stamps[(base) + k_ - 4], wl2[k_]); wl2[k_] = 0; } } while (0)
 #else
 #define S2STAMP_DECL do { } while (0)
 #define S2STAMP(k) do { } while (0)
 #define S2STAMP_FLUSH(base) do { } while (0)
+#define S2WALL_DECL do { } while (0)
 #define S2WALL(slot, cond) do { } while (0)
+#define S2WALL_FLUSH do { } while (0)
+#define S2ONE(dst, cond) do { } while (0)
+#define S2WALL_FLUSH_AT(base) do { } while (0)
 #endif
 
 static constexpr int S2_NSLOT = 4;   // ring depth of the q / delta buffers (2 would do; 4 keeps lines apart)
@@ -303,6 +312,7 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
   if (nb > L) S2_TILE_ISSUE(blk_j0(L), blk_m(L));
   __syncthreads();
   S2STAMP_DECL;
+  S2WALL_DECL;
 
   // digits of the e slab relative to the maximum exponent field recorded in ctl_s[2 + epar]; returns 1/S
   auto e_digits = [&](int epar) -> double {
@@ -336,6 +346,7 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
       s2_put_q(a.qpart + ((size_t)(b % S2_NSLOT) * K + wg) * SW_MAXM + tid, v, b);
     }
     S2WALL(2, wg == 0 && tid == 0 && b >= 3);
+    S2WALL(6, wg == 0 && tid == 0 && b == 103);
   };
   static_assert(S2_NDE == 7 && S2_NDD == 6, "the digit recombinations are written out for 7 / 6 digits");
 
@@ -379,6 +390,8 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     if (bad) ctl_s[8] = 1u;
     __syncthreads();
     S2WALL(1, wg == 0 && tid == 0 && i + 3 < nb);
+    S2WALL(4, wg == 0 && tid == 0 && i == 100);
+    S2WALL(5, wg == 0 && tid == 0 && i == 101);
     if (ctl_s[8]) { if (tid == 0) a.sc->error = 1u; return; }
     S2STAMP(1);
     // ---- digits of delta: |delta| < 2^(ex-126) with ex the block's largest exponent field;  S = 2^(172-ex), |q| < 2^46 ----
@@ -473,6 +486,7 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     S2STAMP(8);
   }
   if (wg == 0) S2STAMP_FLUSH(0);
+  S2WALL_FLUSH;
   __syncthreads();
   for (int i = tid; i < R; i += SW_THREADS) a.e[row0 + i] = e_s[i];
 }
@@ -484,9 +498,9 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
 // runs the recurrence), the off-diagonal block Gx_{b+1} (single: written during recurrence(b), read right after it),
 // two StageBuf + two SpecBuf, and small vectors.
 template <typename XT> __host__ __device__ inline size_t s2_seq_lds_bytes(int m) {
-  using GT = typename XTraits<XT>::GT;
-  const int pstride = ((m * (m - 1) / 2 + 3) / 4) * 4;
-  size_t s = ((size_t)2 * ((pstride < 4 ? 4 : pstride) + 256) * sizeof(GT) + 15) & ~(size_t)15;   // 64 + 192 entries of slack per buffer
+  using GT = typename XTraits<XT>::GT;   // (the 16-bit staging variant needs less; the launch reserves for the wide one)
+  const int pstride = ((m * (m - 1) / 2 + 7) / 8) * 8;
+  size_t s = ((size_t)2 * ((pstride < 8 ? 8 : pstride) + 256) * sizeof(GT) + 15) & ~(size_t)15;   // 64 + 192 entries of slack per buffer
   s += ((size_t)m * m * sizeof(GT) + 15) & ~(size_t)15;
   s += 2 * sizeof(StageBuf) + 2 * sizeof(SpecBuf);
   s += 5 * SW_MAXM * sizeof(double);      // r0, carry2, delta, acc_corr[2]
@@ -497,15 +511,61 @@ template <typename XT> __host__ __device__ inline size_t s2_seq_lds_bytes(int m)
   return s;
 }
 
-template <typename XT, bool SELECT>
+// sum over a third of the streamers of q_b[t], fixed order, into dst[part][t]; every word is polled until it carries
+// block b's tag.  Returns 0 on abort / timeout.
+__device__ __forceinline__ int s2_gather_q(const SweepArgs &a, int b, int part, int t, int mB, double *dst) {
+  const int K = a.K;
+  uint32_t *abortw = a.xflags + (size_t)K * SW_FLAG_STRIDE;
+  const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(a.qpart + (size_t)(b % S2_NSLOT) * K * SW_MAXM);
+  const unsigned long long tag = s2_qtag(b);
+  const int wq = (K + 2) / 3;
+  const uint64_t t0 = wall_clock64();
+  double r = 0.0;
+  for (int wbase = 0; wbase < wq; wbase += 16) {
+    unsigned long long v[16];
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int w = part * wq + wbase + u;
+        const bool need = (t < mB && wbase + u < wq && w < K);
+        v[u] = need ? ld_agent_raw64(slot + (size_t)w * SW_MAXM + t) : tag;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) ok = ok && ((v[u] & 0xFFull) == tag);
+      if (ok) break;
+      if ((++spins & 63u) == 0u) {
+        if (ld_agent_u32(abortw) != 0u) return 0;
+        if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int w = part * wq + wbase + u;
+      const bool need = (t < mB && wbase + u < wq && w < K);
+      r += need ? __longlong_as_double((long long)(v[u] & ~0xFFull)) : 0.0;
+    }
+  }
+  dst[part * SW_MAXM + t] = r;
+  return 1;
+}
+
+// GT: element type of the packed diagonal and the distance-1 cross Gram blocks as staged through LDS (the panel's Gram
+// type, or uint16_t when every entry of the panel's Gram blocks fits: half the bytes through this CU per block);
+// the distance-2 blocks, read sparsely from global memory, keep the panel's type
+template <typename XT, bool SELECT, typename GT>
 __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using GT = typename XTraits<XT>::GT;
+  using G2T = typename XTraits<XT>::GT;
   constexpr int GPT = 16 / sizeof(GT);
   constexpr int MAXMX = XTraits<XT>::MAXM;
   constexpr int NHELP = SW_THREADS - 64;
   constexpr int XCH = (MAXMX * MAXMX / GPT + NHELP - 1) / NHELP;                    // chunks of Gx per helper thread
-  constexpr int PCH = ((MAXMX * (MAXMX - 1) / 2 + 3) / 4 * 4 / GPT + NHELP - 1) / NHELP;   // chunks of packed G
+  constexpr int PFULLCH = ((MAXMX * (MAXMX - 1) / 2 + 7) / 8 * 8) / GPT, XFULLCH = MAXMX * MAXMX / GPT;   // chunk counts at m = MAXM
+  constexpr int PCH = (PFULLCH + NHELP - 1) / NHELP;   // chunks of packed G per helper thread
+  constexpr int PSURE = PFULLCH / NHELP, XSURE = XFULLCH / NHELP;   // at m = MAXM every helper thread's first PSURE / XSURE chunks exist
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = a.m, K = a.K;
   const int nb = a.blk_end - a.blk_begin;
@@ -513,10 +573,15 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
   size_t off = 0;
   // each packed buffer has 64 entries of slack in front and 192 behind, so the recurrence's row loads need no clamp
   GT *gp_base = reinterpret_cast<GT *>(smem) + 64;
-  const int gp_elems = (pstride < 4 ? 4 : pstride) + 256;
+  const int gp_elems = (pstride < 8 ? 8 : pstride) + 256;
 #define S2_GP(i_) (gp_base + (size_t)((i_) & 1) * gp_elems)
   off = ((size_t)2 * gp_elems * sizeof(GT) + 15) & ~(size_t)15;
-  GT *gx_s = reinterpret_cast<GT *>(smem + off); off += ((size_t)m * m * sizeof(GT) + 15) & ~(size_t)15;
+  // 16-bit staging: Gx is double-buffered too (same LDS as one 32-bit copy) and both blocks arrive by LDS-DMA, see below
+  constexpr bool DMA = (sizeof(GT) == 2);
+  GT *gx_base = reinterpret_cast<GT *>(smem + off);
+  const size_t gx_elems = (((size_t)m * m * sizeof(GT) + 15) & ~(size_t)15) / sizeof(GT);
+  off += (DMA ? 2 : 1) * gx_elems * sizeof(GT);
+#define S2_GX(i_) (gx_base + (DMA ? (size_t)((i_) & 1) * gx_elems : (size_t)0))
   StageBuf *stage = reinterpret_cast<StageBuf *>(smem + off); off += 2 * sizeof(StageBuf);
   SpecBuf *specb = reinterpret_cast<SpecBuf *>(smem + off); off += 2 * sizeof(SpecBuf);
   double *r0_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
@@ -538,44 +603,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
   auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
   auto prow = [&](int k) { return k * (m - 1) - k * (k - 1) / 2; };   // offset of packed row k
 
-  // sum over a third of the streamers of q_b[t], fixed order, into part_s[part][t]; every word is polled until it
-  // carries block b's tag.  Returns 0 on abort / timeout.
-  auto gather_q = [&](int b, int part, int t, int mB) -> int {
-    const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(a.qpart + (size_t)(b % S2_NSLOT) * K * SW_MAXM);
-    const unsigned long long tag = s2_qtag(b);
-    const int wq = (K + 2) / 3;
-    const uint64_t t0 = wall_clock64();
-    double r = 0.0;
-    for (int wbase = 0; wbase < wq; wbase += 16) {
-      unsigned long long v[16];
-      unsigned spins = 0;
-      for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int w = part * wq + wbase + u;
-          const bool need = (t < mB && wbase + u < wq && w < K);
-          v[u] = need ? ld_agent_raw64(slot + (size_t)w * SW_MAXM + t) : tag;
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) ok = ok && ((v[u] & 0xFFull) == tag);
-        if (ok) break;
-        if ((++spins & 63u) == 0u) {
-          if (ld_agent_u32(abortw) != 0u) return 0;
-          if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int w = part * wq + wbase + u;
-        const bool need = (t < mB && wbase + u < wq && w < K);
-        r += need ? __longlong_as_double((long long)(v[u] & ~0xFFull)) : 0.0;
-      }
-    }
-    part_s[part * SW_MAXM + t] = r;
-    return 1;
-  };
+  auto gather_q = [&](int b, int part, int t, int mB) -> int { return s2_gather_q(a, b, part, t, mB, part_s); };
   auto copy16 = [&](void *dst, const void *src, int nchunks, int t0, int nth) {
     for (int c = t0; c < nchunks; c += nth) reinterpret_cast<uint4 *>(dst)[c] = reinterpret_cast<const uint4 *>(src)[c];
   };
@@ -611,21 +639,22 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
 #define S2_XLD(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < xchunks) name = xsrc[c_]; }
 #define S2_GST(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < pchunks) gdst[c_] = name; }
 #define S2_XST(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < xchunks) xdst[c_] = name; }
-  // m == 128 with 4-byte entries: 2032 packed and 4096 cross chunks, so every helper thread's first 4 / 9 chunks exist and
-  // only the last one needs a guard (unguarded accesses spare the exec-mask juggling of 15 conditional loads and stores)
-#define S2_GLD_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < 4 || c_ < pchunks) name = gsrc[c_]; }
-#define S2_XLD_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < 9 || c_ < xchunks) name = xsrc[c_]; }
-#define S2_GST_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < 4 || c_ < pchunks) gdst[c_] = name; }
-#define S2_XST_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < 9 || c_ < xchunks) xdst[c_] = name; }
-  const bool fullm = (m == SW_MAXM) && (sizeof(GT) == 4);
+  // at m == MAXM every helper thread's first PSURE / XSURE chunks exist and only the last one needs a guard (unguarded
+  // accesses spare the exec-mask juggling of up to 15 conditional loads and stores)
+#define S2_GLD_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < PSURE || c_ < pchunks) name = gsrc[c_]; }
+#define S2_XLD_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < XSURE || c_ < xchunks) name = xsrc[c_]; }
+#define S2_GST_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < PSURE || c_ < pchunks) gdst[c_] = name; }
+#define S2_XST_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < XSURE || c_ < xchunks) xdst[c_] = name; }
+  const bool fullm = (m == MAXMX);
   if (wave >= 1 && nb > 1) {   // block 1
     const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(a.blk_begin + 1) * pstride);
     const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(a.blk_begin + 1) * m * m);
-    if (fullm) { S2_G_EACH(S2_GLD_F) S2_X_EACH(S2_XLD_F) } else { S2_G_EACH(S2_GLD) S2_X_EACH(S2_XLD) }
+    if constexpr (!DMA) { if (fullm) { S2_G_EACH(S2_GLD_F) S2_X_EACH(S2_XLD_F) } else { S2_G_EACH(S2_GLD) S2_X_EACH(S2_XLD) } }
     if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + a.blk_begin + 1)[tid - 64];
     if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + a.blk_begin + 1)[tid - 64];
   }
   S2STAMP_DECL;
+  S2WALL_DECL;
 
   for (int b = 0; b < nb; ++b) {
     const int blk = a.blk_begin + b;
@@ -737,36 +766,14 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
       S2WALL(0, lane == 0 && b + 3 < nb);
       S2STAMP(1);
     } else if (have_next) {
-      // ---- helpers.  Block b+1's Gram blocks and constants were loaded into registers one iteration ago.  Order:
-      // (1) the registers go to LDS, (2) the loads of block b+2 are issued (they have a whole iteration to land),
-      // (3) q_{b+1} is gathered: its round trip runs under the prefetch traffic instead of in front of it ----
       const int gpart = (tid - 64) >> 7, gt = (tid - 64) & 127;
-      S2WALL(4, tid == 64);
-      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no prefetch load is in flight
-      S2WALL(5, tid == 64);
-      uint4 *gdst = reinterpret_cast<uint4 *>(S2_GP(b + 1));
-      uint4 *xdst = reinterpret_cast<uint4 *>(gx_s);
-      if (fullm) { S2_G_EACH(S2_GST_F) S2_X_EACH(S2_XST_F) } else { S2_G_EACH(S2_GST) S2_X_EACH(S2_XST) }
-      if (tid - 64 < NCH) reinterpret_cast<uint4 *>(&stage[(b + 1) & 1])[tid - 64] = spre;
-      if (tid - 64 < NSP) reinterpret_cast<uint4 *>(&specb[(b + 1) & 1])[tid - 64] = cpre;
-      S2WALL(6, tid == 64);
-      if (b + 2 < nb) {
-        const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(blk + 2) * pstride);
-        const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(blk + 2) * m * m);
-        if (fullm) { S2_G_EACH(S2_GLD_F) S2_X_EACH(S2_XLD_F) } else { S2_G_EACH(S2_GLD) S2_X_EACH(S2_XLD) }
-        if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 2)[tid - 64];
-        if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + blk + 2)[tid - 64];
-      }
-      S2WALL(7, tid == 64);
-      if (wave <= 6) {
-        if (!gather_q(b + 1, gpart, gt, mBn)) ctrl_s[0] = 0;
-      } else if (SELECT && a.lag == 3) {
+      auto carry2_term = [&]() {
         // wave 7: r0_{b+1}'s cross term with block b-1 = speculated part (k_spec) + the rows of Gx2_{b+1} that block
         // b-1's accepted markers touch, straight from global memory (the list has been final since the last barrier A)
         const int *pk = acc_k2 + ((b + 1) & 1) * SW_MAXM;
         const double *pc = acc_corr2 + ((b + 1) & 1) * SW_MAXM;
         const int npre = (b >= 1) ? ctrl_s[2 + ((b + 1) & 1)] : 0;
-        const GT *gx2 = reinterpret_cast<const GT *>(a.gramx2) + (size_t)(blk + 1) * m * m;
+        const G2T *gx2 = reinterpret_cast<const G2T *>(a.gramx2) + (size_t)(blk + 1) * m * m;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int j = lane + 64 * h;
@@ -774,17 +781,70 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
           if (b >= 1 && j < mBn) {
             c = a.xspec2[(size_t)(blk + 1) * SW_MAXM + j];
             for (int i0 = 0; i0 < npre; i0 += 8) {
-              GT gv[8];
+              G2T gv[8];
 #pragma unroll
-              for (int u = 0; u < 8; ++u) gv[u] = (i0 + u < npre) ? gx2[(size_t)pk[i0 + u] * m + j] : (GT)0;
+              for (int u = 0; u < 8; ++u) gv[u] = (i0 + u < npre) ? gx2[(size_t)pk[i0 + u] * m + j] : (G2T)0;
 #pragma unroll
               for (int u = 0; u < 8; ++u) if (i0 + u < npre) c = fma((double)gv[u], pc[i0 + u], c);
             }
           }
           carry2_s[j] = c;
         }
+      };
+      if constexpr (DMA) {
+        // ---- helpers, 16-bit staging.  Block b+1's packed G and Gx go straight from global memory into LDS by LDS-DMA (no
+        // VGPRs, no store pass; one 1 KiB piece per instruction, ~7 per helper wave: one wave alone sustains only ~25 GB/s).
+        // The pieces land under the recurrence and are drained by the vmcnt(0) that __syncthreads() puts in front of
+        // barrier A; both destination buffers were last read two blocks ago.  Then waves 1-6 gather q_{b+1}, store block
+        // b+1's constants (in registers since the last iteration) and request block b+2's; wave 7 forms the lag-3 cross term. ----
+        S2WALL(4, tid == 64);
+        {   // the 1 KiB pieces of block b+1's packed G (first) and Gx, dealt round-robin to the 7 helper waves
+          const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(blk + 1) * pstride);
+          const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(blk + 1) * m * m);
+          unsigned char *gl = reinterpret_cast<unsigned char *>(S2_GP(b + 1)), *xl = reinterpret_cast<unsigned char *>(S2_GX(b + 1));
+          const int gpieces = (pchunks + 63) >> 6, xpieces = (xchunks + 63) >> 6;
+          for (int pc = wave - 1; pc < gpieces + xpieces; pc += 7) {
+            const bool isg = pc < gpieces;
+            const int c0 = (isg ? pc : pc - gpieces) << 6;
+            const uint4 *src = (isg ? gsrc : xsrc) + c0 + lane;
+            unsigned char *dst = (isg ? gl : xl) + (size_t)c0 * 16;
+            if (c0 + lane < (isg ? pchunks : xchunks))
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+          }
+        }
+        S2WALL(5, tid == 64);
+        if (wave <= 6) {
+          if (!gather_q(b + 1, gpart, gt, mBn)) ctrl_s[0] = 0;
+          S2WALL(6, tid == 64);
+          if (tid - 64 < NCH) reinterpret_cast<uint4 *>(&stage[(b + 1) & 1])[tid - 64] = spre;
+          if (tid - 64 < NSP) reinterpret_cast<uint4 *>(&specb[(b + 1) & 1])[tid - 64] = cpre;
+          if (b + 2 < nb) {
+            if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 2)[tid - 64];
+            if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + blk + 2)[tid - 64];
+          }
+          S2WALL(7, tid == 64);
+        } else if (SELECT && a.lag == 3) carry2_term();
+      } else {
+        // ---- helpers, register staging.  Block b+1's Gram blocks and constants were loaded into registers one iteration
+        // ago.  Order: (1) the registers go to LDS, (2) the loads of block b+2 are issued (they have a whole iteration to
+        // land), (3) q_{b+1} is gathered: its round trip runs under the prefetch traffic instead of in front of it ----
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no prefetch load is in flight
+        uint4 *gdst = reinterpret_cast<uint4 *>(S2_GP(b + 1));
+        uint4 *xdst = reinterpret_cast<uint4 *>(S2_GX(b + 1));
+        if (fullm) { S2_G_EACH(S2_GST_F) S2_X_EACH(S2_XST_F) } else { S2_G_EACH(S2_GST) S2_X_EACH(S2_XST) }
+        if (tid - 64 < NCH) reinterpret_cast<uint4 *>(&stage[(b + 1) & 1])[tid - 64] = spre;
+        if (tid - 64 < NSP) reinterpret_cast<uint4 *>(&specb[(b + 1) & 1])[tid - 64] = cpre;
+        if (b + 2 < nb) {
+          const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(blk + 2) * pstride);
+          const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(blk + 2) * m * m);
+          if (fullm) { S2_G_EACH(S2_GLD_F) S2_X_EACH(S2_XLD_F) } else { S2_G_EACH(S2_GLD) S2_X_EACH(S2_XLD) }
+          if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 2)[tid - 64];
+          if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + blk + 2)[tid - 64];
+        }
+        if (wave <= 6) {
+          if (!gather_q(b + 1, gpart, gt, mBn)) ctrl_s[0] = 0;
+        } else if (SELECT && a.lag == 3) carry2_term();
       }
-      S2WALL(9, tid == 64);
     }
     __syncthreads();   // A: recurrence done; block b+1's Gram/constants are in LDS; q_{b+1} partial sums in part_s
     S2STAMP(2);
@@ -802,7 +862,8 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
         if (tid < mBn) {
           double r = ((part_s[tid] + part_s[SW_MAXM + tid]) + part_s[2 * SW_MAXM + tid]) - specb[(b + 1) & 1].xspec[tid];
           const int nacc = ctrl_s[2 + (b & 1)];
-          for (int i = 0; i < nacc; ++i) r = fma(-(double)gx_s[(size_t)acc_k[i] * m + tid], acc_corr[i], r);
+          const GT *gxn = S2_GX(b + 1);
+          for (int i = 0; i < nacc; ++i) r = fma(-(double)gxn[(size_t)acc_k[i] * m + tid], acc_corr[i], r);
           if (a.lag == 3) r -= carry2_s[tid];
           r0_s[tid] = r;
         }
@@ -810,6 +871,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
       } else {
         // r0_{b+1} = sum_w q - Gx' delta_b  (dense; 4 k-ranges per marker, LDS reads batched)
         const int sp = tid >> 7, j = tid & 127;
+        const GT *gxn = S2_GX(b + 1);
         double xa = 0.0;
         if (j < mBn) {
           const int k0 = sp * 32, kx1 = min(k0 + 32, mB);
@@ -817,11 +879,11 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
           for (; k + 8 <= kx1; k += 8) {
             double gv[8], dv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { gv[u] = (double)gx_s[(size_t)(k + u) * m + j]; dv[u] = delta_s[k + u]; }
+            for (int u = 0; u < 8; ++u) { gv[u] = (double)gxn[(size_t)(k + u) * m + j]; dv[u] = delta_s[k + u]; }
 #pragma unroll
             for (int u = 0; u < 8; ++u) xa = fma(gv[u], dv[u], xa);
           }
-          for (; k < kx1; ++k) xa = fma((double)gx_s[(size_t)k * m + j], delta_s[k], xa);
+          for (; k < kx1; ++k) xa = fma((double)gxn[(size_t)k * m + j], delta_s[k], xa);
         }
         const double q3 = (tid < mBn) ? ((part_s[tid] + part_s[SW_MAXM + tid]) + part_s[2 * SW_MAXM + tid]) : 0.0;
         __syncthreads();   // the q partial sums have been read; part_s is free
@@ -834,6 +896,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
     }
   }
   S2STAMP_FLUSH(16);
+  S2WALL_FLUSH;
   if (wave == 0) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { sum_d += __shfl_down(sum_d, o, 64); sum_b2 += __shfl_down(sum_b2, o, 64); }
@@ -841,9 +904,382 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
   }
 }
 
-template <typename XT, bool SELECT>
+
+
+// q feeder (selection models, 16-bit Gram path): its own workgroup, hence its own CU's memory path.  Gathers the K
+// streamers' slab dots of each block (the 40 KB of write-through words per block that otherwise go through the
+// sequencer's CU, whose ingest is what bounds the chain), sums them in the fixed order and hands the sequencer one
+// tagged word per marker.  Costs one more hop on a path that the lag-3 pipeline keeps off the critical cycle.
+__device__ __forceinline__ void s2_feeder(const SweepArgs &a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int m = a.m, nb = a.blk_end - a.blk_begin;
+  double *part_s = reinterpret_cast<double *>(smem);
+  int *ok_s = reinterpret_cast<int *>(smem + 3 * SW_MAXM * sizeof(double));
+  double *qsum = a.qpart + (size_t)S2_NSLOT * a.K * SW_MAXM;
+  S2WALL_DECL;
+  if (tid == 0) ok_s[0] = 1;
+  __syncthreads();
+  for (int b = 0; b < nb; ++b) {
+    const int mB = min(m, a.p - (a.blk_begin + b) * m);
+    if (wave >= 1 && wave <= 6) {
+      if (!s2_gather_q(a, b, (tid - 64) >> 7, (tid - 64) & 127, mB, part_s)) ok_s[0] = 0;
+    }
+    __syncthreads();
+    if (ok_s[0] == 0) return;   // the abort word is set; the sequencer reports the error
+    if (tid < mB) s2_put_q(qsum + (size_t)(b % S2_NSLOT) * SW_MAXM + tid, (part_s[tid] + part_s[SW_MAXM + tid]) + part_s[2 * SW_MAXM + tid], b);
+    S2WALL(3, tid == 0 && b >= 3);
+    S2WALL(13, tid == 0 && b == 103);
+    __syncthreads();
+  }
+  S2WALL_FLUSH;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// sequencer, selection models on an int8 panel whose Gram blocks fit 16 bits: ONE barrier per block.
+// Wave 0 owns the chain and issues no global memory operation but the delta granules: recurrence of block b, then (after
+// the barrier) r0_{b+1} for its own lanes, then straight into block b+1.  Waves 1-7 run one block ahead: while wave 0 is
+// in block b they bring in block b+1 (the feeder's q sums, packed G, Gx and the constants through registers, the lag-3
+// cross term) and write out block b-1's state; every LDS object they fill is double-buffered by block parity, so they
+// start on block b+2 the moment barrier b has passed.
+// Period = max(recurrence + post, helpers); the generic sequencer pays max(recurrence, helpers) + post + a barrier.
+// ------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t s2_seq16_lds_bytes(int m) {
+  const int pstride = ((m * (m - 1) / 2 + 7) / 8) * 8;
+  size_t s = (size_t)2 * ((pstride < 8 ? 8 : pstride) + 256) * 2;     // packed G, two buffers with 64 + 192 entries of slack
+  s = (s + 15) & ~(size_t)15;
+  s += (size_t)2 * m * m * 2;                                          // Gx, two buffers
+  s += 2 * sizeof(StageBuf) + 2 * sizeof(SpecBuf);
+  s += (size_t)2 * SW_MAXM * sizeof(double);                           // sum_w q [parity]
+  s += (size_t)2 * 3 * SW_MAXM * sizeof(float);                        // state of a block [parity]
+  s += (size_t)2 * SW_MAXM * sizeof(double);                           // lag-3 cross term [parity]
+  s += (size_t)2 * SW_MAXM * (sizeof(double) + sizeof(int));           // accepted lists [parity]
+  return s + 64;
+}
+__device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using GT = uint16_t;
+  constexpr int GPT = 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  S2WALL_DECL;
+  const int m = a.m, nb = a.blk_end - a.blk_begin, pstride = a.pstride;
+  const int gp_elems = (pstride < 8 ? 8 : pstride) + 256;
+  GT *gp_base = reinterpret_cast<GT *>(smem) + 64;
+  size_t off = ((size_t)2 * gp_elems * sizeof(GT) + 15) & ~(size_t)15;
+  GT *gx_base = reinterpret_cast<GT *>(smem + off); off += (size_t)2 * m * m * sizeof(GT);
+  StageBuf *stage = reinterpret_cast<StageBuf *>(smem + off); off += 2 * sizeof(StageBuf);
+  SpecBuf *specb = reinterpret_cast<SpecBuf *>(smem + off); off += 2 * sizeof(SpecBuf);
+  double *qs2 = reinterpret_cast<double *>(smem + off); off += (size_t)2 * SW_MAXM * sizeof(double);       // sum_w q [parity]
+  float *state2 = reinterpret_cast<float *>(smem + off); off += (size_t)2 * 3 * SW_MAXM * sizeof(float);   // b, d, vb of a block [parity]
+  double *carry2 = reinterpret_cast<double *>(smem + off); off += (size_t)2 * SW_MAXM * sizeof(double);
+  double *acc_corr2 = reinterpret_cast<double *>(smem + off); off += (size_t)2 * SW_MAXM * sizeof(double);
+  int *acc_k2 = reinterpret_cast<int *>(smem + off); off += (size_t)2 * SW_MAXM * sizeof(int);
+  int *ctrl_s = reinterpret_cast<int *>(smem + off);   // [0] ok flag, [2], [3] number of accepted markers (by block parity)
+#define Q16_GP(i_) (gp_base + (size_t)((i_) & 1) * gp_elems)
+#define Q16_GX(i_) (gx_base + (size_t)((i_) & 1) * m * m)
+#define Q16_QS(i_) (qs2 + (size_t)((i_) & 1) * SW_MAXM)
+#define Q16_STATE(i_) (state2 + (size_t)((i_) & 1) * 3 * SW_MAXM)
+  const GT *gramp = reinterpret_cast<const GT *>(a.gramp);
+  const GT *gramx = reinterpret_cast<const GT *>(a.gramx);
+  const float Cc = a.sc->C, odds = a.sc->odds, one_minus_pi = 1.0f - a.sc->pi, Sb = a.sc->Sb;
+  const int pchunks = pstride / GPT, xchunks = m * m / GPT;
+  const bool lag3 = (a.lag == 3);
+  auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
+  auto prow = [&](int k) { return k * (m - 1) - k * (k - 1) / 2; };   // offset of packed row k
+  constexpr int NCH = (int)(sizeof(StageBuf) / 16), NSP = (int)(sizeof(SpecBuf) / 16);
+  static_assert(NCH <= 384 && NSP <= 384, "one chunk per thread of waves 1-6");
+  const int gpart = (tid - 64) >> 7, gt = (tid - 64) & 127;
+
+  double *qsum = a.qpart + (size_t)S2_NSLOT * a.K * SW_MAXM;   // the feeder's sums, [S2_NSLOT][SW_MAXM] tagged words
+  uint32_t *abortw = a.xflags + (size_t)a.K * SW_FLAG_STRIDE;
+  auto poll_qsum = [&](int c, int mBc) -> int {   // one wave, two markers per lane
+    const unsigned long long *g = reinterpret_cast<const unsigned long long *>(qsum + (size_t)(c % S2_NSLOT) * SW_MAXM);
+    const unsigned long long tag = s2_qtag(c);
+    const bool n0 = lane < mBc, n1 = 64 + lane < mBc;
+    const uint64_t t0 = wall_clock64();
+    unsigned spins = 0;
+    unsigned long long w0 = tag, w1 = tag;
+    for (;;) {
+      if (n0) w0 = ld_agent_raw64(g + lane);
+      if (n1) w1 = ld_agent_raw64(g + 64 + lane);
+      if ((w0 & 0xFFull) == tag && (w1 & 0xFFull) == tag) break;
+      if ((++spins & 63u) == 0u) {
+        if (ld_agent_u32(abortw) != 0u) return 0;
+        if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    Q16_QS(c)[lane] = n0 ? __longlong_as_double((long long)(w0 & ~0xFFull)) : 0.0;
+    Q16_QS(c)[64 + lane] = n1 ? __longlong_as_double((long long)(w1 & ~0xFFull)) : 0.0;
+    return 1;
+  };
+  auto store_state = [&](int c) {   // one wave
+    const int j0c = (a.blk_begin + c) * m, mBc = blk_m(c);
+    const float *sp = Q16_STATE(c);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int t = lane + 64 * h;
+      if (t < mBc) {
+        a.b[j0c + t] = sp[t];
+        a.d[j0c + t] = sp[SW_MAXM + t];
+        if (a.flags & SWF_VB_VEC) a.vb[j0c + t] = sp[2 * SW_MAXM + t];
+      }
+    }
+  };
+  // the helpers' work for block c (c >= 1): everything block c needs that does not depend on block c-1's recurrence
+  uint4 spre = make_uint4(0, 0, 0, 0), cpre = spre;   // block c's constants, requested one phase earlier
+  // block c's Gram chunks, requested one phase earlier (plain named locals: an aggregate would end up in scratch memory)
+  constexpr int NHELP = SW_THREADS - 128;   // waves 1-6 stage Gram blocks and constants; wave 7 polls (in-order vmcnt: a
+                                            // poll behind a wave's own prefetch loads would wait for them)
+  constexpr int PFULLCH = ((SW_MAXM * (SW_MAXM - 1) / 2 + 7) / 8 * 8) / GPT, XFULLCH = SW_MAXM * SW_MAXM / GPT;
+  constexpr int PSURE = PFULLCH / NHELP, XSURE = XFULLCH / NHELP;   // at m = 128 every helper thread's first PSURE / XSURE chunks exist
+  static_assert((PFULLCH + NHELP - 1) / NHELP <= 3 && (XFULLCH + NHELP - 1) / NHELP <= 6, "named prefetch registers cover 3 + 6 chunks per helper thread");
+  uint4 gq0 = spre, gq1 = spre, gq2 = spre, xq0 = spre, xq1 = spre, xq2 = spre, xq3 = spre, xq4 = spre, xq5 = spre;
+  const bool fullm = (m == SW_MAXM);
+#define S16_G_EACH(X) X(0, gq0) X(1, gq1) X(2, gq2)
+#define S16_X_EACH(X) X(0, xq0) X(1, xq1) X(2, xq2) X(3, xq3) X(4, xq4) X(5, xq5)
+#define S16_GLD(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < pchunks) name = gsrc[c_]; }
+#define S16_XLD(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < xchunks) name = xsrc[c_]; }
+#define S16_GST(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < pchunks) gdst[c_] = name; }
+#define S16_XST(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < xchunks) xdst[c_] = name; }
+#define S16_GLD_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < PSURE || c_ < pchunks) name = gsrc[c_]; }
+#define S16_XLD_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < XSURE || c_ < xchunks) name = xsrc[c_]; }
+#define S16_GST_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < PSURE || c_ < pchunks) gdst[c_] = name; }
+#define S16_XST_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < XSURE || c_ < xchunks) xdst[c_] = name; }
+  auto helper_phase = [&](int c) {
+    const int blk = a.blk_begin + c, mBc = blk_m(c);
+    S2ONE(10, tid == 64 && c == 103); S2ONE(13, tid == 448 && c == 103);
+    if (wave <= 6) {
+      // waves 1-6: block c's packed G, Gx and constants, in registers since the previous phase, go to LDS; block c+1's are
+      // requested and have a whole period to land.  (Register staging moves ~60 GB/s through this CU, LDS-DMA only ~25.)
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): tells the compiler that no prefetch load is in flight
+      uint4 *gdst = reinterpret_cast<uint4 *>(Q16_GP(c));
+      uint4 *xdst = reinterpret_cast<uint4 *>(Q16_GX(c));
+      if (fullm) { S16_G_EACH(S16_GST_F) S16_X_EACH(S16_XST_F) } else { S16_G_EACH(S16_GST) S16_X_EACH(S16_XST) }
+      if (tid - 64 < NCH) reinterpret_cast<uint4 *>(&stage[c & 1])[tid - 64] = spre;
+      if (tid - 64 < NSP) reinterpret_cast<uint4 *>(&specb[c & 1])[tid - 64] = cpre;
+      S2ONE(11, tid == 64 && c == 103);
+      if (c + 1 < nb) {
+        const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(blk + 1) * pstride);
+        const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(blk + 1) * m * m);
+        if (fullm) { S16_G_EACH(S16_GLD_F) S16_X_EACH(S16_XLD_F) } else { S16_G_EACH(S16_GLD) S16_X_EACH(S16_XLD) }
+        if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 1)[tid - 64];
+        if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + blk + 1)[tid - 64];
+      }
+      S2ONE(12, tid == 64 && c == 103);
+    } else {
+      // wave 7 holds no prefetch: the feeder's sums first (nothing of its own in front of the poll)
+      if (!poll_qsum(c, mBc)) ctrl_s[0] = 0;
+      S2WALL(10, tid == 448 && c >= 3);
+      S2WALL(14, tid == 448 && c == 103);
+      S2ONE(14, tid == 448 && c == 103);
+      // wave 7: block c-2's state (left in LDS by wave 0, which issues no global memory operation but the delta granules)
+      // block c's cross term with block c-2 = speculated part (k_spec) + the rows of Gx2_c that block c-2's accepted
+      // markers touch, straight from global memory (that list has been final since the barrier of block c-2)
+      double *dst = carry2 + (size_t)(c & 1) * SW_MAXM;
+      const int *pk = acc_k2 + (size_t)(c & 1) * SW_MAXM;
+      const double *pc2 = acc_corr2 + (size_t)(c & 1) * SW_MAXM;
+      const bool on = lag3 && c >= 2;
+      const int npre = on ? ctrl_s[2 + (c & 1)] : 0;
+      const int32_t *gx2 = reinterpret_cast<const int32_t *>(a.gramx2) + (size_t)blk * m * m;
+      // every load unconditional (clamped indices) and issued before the first use: one round trip per 8 accepted markers
+      const int ja = min(lane, m - 1), jb = min(64 + lane, m - 1);
+      double cva = 0.0, cvb = 0.0;
+      if (on) {
+        cva = a.xspec2[(size_t)blk * SW_MAXM + ja]; cvb = a.xspec2[(size_t)blk * SW_MAXM + jb];
+        for (int i0 = 0; i0 < npre; i0 += 8) {
+          int32_t ga[8], gb[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int32_t *row = gx2 + (size_t)pk[min(i0 + u, npre - 1)] * m;
+            ga[u] = row[ja]; gb[u] = row[jb];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const double cf = (i0 + u < npre) ? pc2[i0 + u] : 0.0;
+            cva = fma((double)ga[u], cf, cva); cvb = fma((double)gb[u], cf, cvb);
+          }
+        }
+      }
+      dst[lane] = (on && lane < mBc) ? cva : 0.0;
+      dst[64 + lane] = (on && 64 + lane < mBc) ? cvb : 0.0;
+      S2ONE(15, tid == 448 && c == 103);
+      if (c >= 2) store_state(c - 2);   // last: the next phase's poll is behind these stores only
+      S2ONE(26, tid == 448 && c == 103);
+    }
+  };
+
+  // ---- prologue: block 0 through registers, block 1's constants requested ----
+  {
+    const int mB0 = blk_m(0);
+    for (int c = tid; c < pchunks; c += SW_THREADS) reinterpret_cast<uint4 *>(Q16_GP(0))[c] = reinterpret_cast<const uint4 *>(gramp + (size_t)a.blk_begin * pstride)[c];
+    for (int c = tid; c < NCH; c += SW_THREADS) reinterpret_cast<uint4 *>(&stage[0])[c] = reinterpret_cast<const uint4 *>(a.ps.blocks + a.blk_begin)[c];
+    for (int c = tid; c < NSP; c += SW_THREADS) reinterpret_cast<uint4 *>(&specb[0])[c] = reinterpret_cast<const uint4 *>(a.ps.spec + a.blk_begin)[c];
+    if (tid == 0) { ctrl_s[0] = 1; ctrl_s[2] = 0; ctrl_s[3] = 0; }
+    __syncthreads();
+    if (wave >= 1 && wave <= 6) {
+      if (nb > 1) {
+        if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + a.blk_begin + 1)[tid - 64];
+        if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + a.blk_begin + 1)[tid - 64];
+      }
+    }
+    if (wave == 7) { if (!poll_qsum(0, mB0)) ctrl_s[0] = 0; }
+    if (wave >= 1 && wave <= 6 && nb > 1) {
+      const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(a.blk_begin + 1) * pstride);
+      const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(a.blk_begin + 1) * m * m);
+      if (fullm) { S16_G_EACH(S16_GLD_F) S16_X_EACH(S16_XLD_F) } else { S16_G_EACH(S16_GLD) S16_X_EACH(S16_XLD) }
+    }
+    __syncthreads();
+    if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
+  }
+  double sum_d = 0.0, sum_b2 = 0.0;
+  double rnext[2] = {0.0, 0.0};
+  if (wave == 0) {
+    const double *ps = Q16_QS(0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) rnext[q] = ps[64 * q + lane];
+  }
+  S2STAMP_DECL;
+
+  for (int b = 0; b < nb; ++b) {
+    const int blk = a.blk_begin + b, j0 = blk * m, mB = blk_m(b);
+    const bool have_next = (b + 1 < nb);
+    const int mBn = have_next ? blk_m(b + 1) : 0;
+    float bn[2] = {0.0f, 0.0f}, dn[2] = {0.0f, 0.0f}, corr_own[2] = {0.0f, 0.0f}, drej_own[2] = {0.0f, 0.0f};
+    double chi[2] = {1.0, 1.0};
+    unsigned long long am0 = 0ull, am1 = 0ull;
+    int nacc = 0;
+    if (wave == 0) {
+      const StageBuf &st = stage[b & 1];
+      const SpecBuf &sb = specb[b & 1];
+      const GT *gp = Q16_GP(b);
+      int *acc_k = acc_k2 + (size_t)(b & 1) * SW_MAXM;
+      double *acc_corr = acc_corr2 + (size_t)(b & 1) * SW_MAXM;
+      const int ngrp = (mB + 63) >> 6;
+      double r[2];
+      LaneConst lc[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = 64 * q + lane;
+        const bool live = t < mB;
+        r[q] = live ? (rnext[q] - sb.spec[t]) : 0.0;
+        lc[q].b0 = live ? st.b0[t] : 0.0f; lc[q].xxb0 = live ? st.xxb0[t] : 0.0f;
+        lc[q].b2 = live ? st.b2[t] : 0.0f; lc[q].drej = live ? st.drej[t] : 0.0f;
+        lc[q].rden = live ? st.rden[t] : 1.0; lc[q].sdz1 = live ? st.sdz1[t] : 0.0;
+        lc[q].u = live ? st.u[t] : 2.0; lc[q].gjj = live ? sb.gjj[t] : 0.0;
+        chi[q] = live ? st.chi[t] : 1.0;
+      }
+      S2STAMP(5);
+      // packed row k: entry for marker j (> k) sits at prow(k) + j - k - 1
+      auto gat = [&](int k, int j) -> GT { return (j > k && j < m) ? gp[prow(k) + j - k - 1] : (GT)0; };
+      unsigned long long accmask[2] = {0ull, 0ull};
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q < ngrp) {
+          const int base = 64 * q, cnt = min(64, mB - base);
+          int front = 0;
+          while (front < cnt) {   // exact speculative rounds: all lanes assume "nobody before me is accepted"
+            const float b1 = lane_b1(r[q], lc[q]);
+            const bool acc = lane_accept(r[q], b1, lc[q], a.flags, Cc, odds, one_minus_pi);
+            const unsigned long long bal = __ballot(acc && lane >= front && lane < cnt);
+            if (bal == 0ull) break;
+            const int js = __ffsll((long long)bal) - 1;
+            const float corr_f1 = b1 - lc[q].b0;
+            const double corr = (double)readlane_f32(corr_f1, js) - (double)readlane_f32(lc[q].drej, js);
+            r[q] = fma(-(double)gat(base + js, base + lane), corr, r[q]);
+            if (q == 0 && ngrp > 1) r[1] = fma(-(double)gat(base + js, 64 + lane), corr, r[1]);
+            accmask[q] |= (1ull << js);
+            front = js + 1;
+          }
+        }
+      }
+      S2STAMP(6);
+      // outputs; delta_b goes out at once as {epoch, float} granules (one 8-byte write-through store per marker)
+      unsigned long long *gslot = a.dgran + (size_t)(b % S2_NSLOT) * SW_MAXM;
+      const int nacc0 = __popcll(accmask[0]);
+      nacc = nacc0 + __popcll(accmask[1]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = 64 * q + lane;
+        if (t < mB) {
+          const float b1 = lane_b1(r[q], lc[q]);
+          const bool inc = ((accmask[q] >> lane) & 1ull) != 0ull;
+          bn[q] = inc ? b1 : lc[q].b2;
+          dn[q] = inc ? 1.0f : 0.0f;
+          const float dl = bn[q] - lc[q].b0;
+          st_agent_raw64(gslot + t, ((unsigned long long)(uint32_t)(b + 1) << 32) | (unsigned long long)__float_as_uint(dl));
+          if (inc) {   // what this marker changed relative to the speculated step
+            const int idx = (q ? nacc0 : 0) + __popcll(accmask[q] & ((1ull << lane) - 1ull));
+            acc_k[idx] = t; acc_corr[idx] = (double)(b1 - lc[q].b0) - (double)lc[q].drej;
+          }
+          float *sp = Q16_STATE(b);
+          sp[t] = bn[q]; sp[SW_MAXM + t] = dn[q];
+          if (a.flags & SWF_VB_VEC) sp[2 * SW_MAXM + t] = (float)((double)(Sb + bn[q] * bn[q]) / chi[q]);
+          corr_own[q] = (b1 - lc[q].b0);
+          drej_own[q] = lc[q].drej;
+          sum_d += (double)dn[q];
+          sum_b2 = fma((double)bn[q], (double)bn[q], sum_b2);
+        }
+      }
+      am0 = accmask[0]; am1 = accmask[1];
+      if (lane == 0) ctrl_s[2 + (b & 1)] = nacc;
+      S2WALL(0, lane == 0 && b + 3 < nb);
+      S2WALL(7, lane == 0 && b == 100); S2WALL(9, lane == 0 && b == 101); S2WALL(11, lane == 0 && b == 102); S2WALL(12, lane == 0 && b == 103);
+      S2STAMP(1);
+    } else if (have_next) {
+      helper_phase(b + 1);
+    }
+    __syncthreads();   // block b's recurrence is done; everything block b+1 needs is in LDS (parity (b+1)&1)
+    S2ONE(27, tid == 0 && b == 102);
+    S2STAMP(2);
+    if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
+    if (wave == 0 && have_next) {
+      // r0_{b+1} = sum_w q - Gx' drej_b (precomputed) - what block b's accepted markers changed beyond drej - lag-3 term,
+      // for this lane's two markers; the accepted markers come from the masks (no list reads), their Gx rows from LDS
+      const double *ps = Q16_QS(b + 1);
+      const double *cr = carry2 + (size_t)((b + 1) & 1) * SW_MAXM;
+      const GT *gxn = Q16_GX(b + 1);
+      const SpecBuf &sn = specb[(b + 1) & 1];
+      const bool l0 = lane < mBn, l1 = 64 + lane < mBn;
+      double r0 = l0 ? ps[lane] - sn.xspec[lane] : 0.0, r1 = l1 ? ps[64 + lane] - sn.xspec[64 + lane] : 0.0;
+      if (lag3) { r0 -= l0 ? cr[lane] : 0.0; r1 -= l1 ? cr[64 + lane] : 0.0; }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        unsigned long long mk = q ? am1 : am0;
+        while (mk) {
+          const int js = __ffsll((long long)mk) - 1;
+          mk &= mk - 1ull;
+          const double corr = (double)readlane_f32(corr_own[q], js) - (double)readlane_f32(drej_own[q], js);
+          const GT *row = gxn + (size_t)(64 * q + js) * m;
+          r0 = fma(-(double)row[lane], corr, r0);
+          r1 = fma(-(double)row[64 + lane], corr, r1);
+        }
+      }
+      rnext[0] = l0 ? r0 : 0.0; rnext[1] = l1 ? r1 : 0.0;
+      S2STAMP(3);
+    }
+  }
+  S2STAMP_FLUSH(16);
+  S2WALL_FLUSH;
+  if (wave == 7) {   // the state of the last two blocks is still in LDS
+    if (nb >= 2) store_state(nb - 2);
+    store_state(nb - 1);
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum_d += __shfl_down(sum_d, o, 64); sum_b2 += __shfl_down(sum_b2, o, 64); }
+    if (lane == 0) { a.sc->sum_d += sum_d; a.sc->sum_b2 += sum_b2; }
+  }
+}
+
+template <typename XT, bool SELECT, typename GT = typename XTraits<XT>::GT>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep2(const SweepArgs a) {
-  if ((int)blockIdx.x == a.K) s2_sequencer<XT, SELECT>(a);
+  if ((int)blockIdx.x == a.K + 1) {
+    if constexpr (SELECT && sizeof(XT) == 1 && sizeof(GT) == 2) s2_feeder(a);
+  } else if ((int)blockIdx.x == a.K) {
+    if constexpr (SELECT && sizeof(XT) == 1 && sizeof(GT) == 2) s2_sequencer_sel16(a);
+    else s2_sequencer<XT, SELECT, GT>(a);
+  }
   else if constexpr (sizeof(XT) == 1) s2_streamer_i8(a);
   else s2_streamer<XT>(a);
 }
