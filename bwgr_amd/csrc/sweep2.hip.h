@@ -452,8 +452,9 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     __syncthreads();
     S2STAMP(4);
     // tile(i) is spent: tile(i+L), in registers since the previous iteration, takes a free ring slot (for L = 3 the one of
-    // tile(i)), and the loads of tile(i+L+1) go out (after this iteration's poll: a poll queued behind 32 KB of tile loads
-    // pays for them; they have a whole iteration to land)
+    // tile(i)), and the loads of tile(i+L+1) go out at once: they must have landed before the next iteration's poll (the
+    // vmcnt counter is in order, so a poll behind 32 KB of tile loads pays for them; issued after the publish they cost
+    // 10 % of the sweep)
     if (i + L < nb) S2_TILE_COMMIT(S2I_TILE(i + L), blk_m(i + L));
     S2STAMP(9);
     if (i + L + 1 < nb) S2_TILE_ISSUE(blk_j0(i + L + 1), blk_m(i + L + 1));
@@ -1158,16 +1159,26 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       const int ngrp = (mB + 63) >> 6;
       double r[2];
       LaneConst lc[2];
+      {   // all loads unconditional (the buffers hold SW_MAXM entries) and issued before the first use; dead lanes masked after
+        double spc[2], rd[2], sz[2], uu[2], gj[2], ch[2];
+        float fb0[2], fxx[2], fb2[2], fdr[2];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int t = 64 * q + lane;
-        const bool live = t < mB;
-        r[q] = live ? (rnext[q] - sb.spec[t]) : 0.0;
-        lc[q].b0 = live ? st.b0[t] : 0.0f; lc[q].xxb0 = live ? st.xxb0[t] : 0.0f;
-        lc[q].b2 = live ? st.b2[t] : 0.0f; lc[q].drej = live ? st.drej[t] : 0.0f;
-        lc[q].rden = live ? st.rden[t] : 1.0; lc[q].sdz1 = live ? st.sdz1[t] : 0.0;
-        lc[q].u = live ? st.u[t] : 2.0; lc[q].gjj = live ? sb.gjj[t] : 0.0;
-        chi[q] = live ? st.chi[t] : 1.0;
+        for (int q = 0; q < 2; ++q) {
+          const int t = 64 * q + lane;
+          spc[q] = sb.spec[t]; gj[q] = sb.gjj[t];
+          fb0[q] = st.b0[t]; fxx[q] = st.xxb0[t]; fb2[q] = st.b2[t]; fdr[q] = st.drej[t];
+          rd[q] = st.rden[t]; sz[q] = st.sdz1[t]; uu[q] = st.u[t]; ch[q] = st.chi[t];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const bool live = 64 * q + lane < mB;
+          r[q] = live ? (rnext[q] - spc[q]) : 0.0;
+          lc[q].b0 = live ? fb0[q] : 0.0f; lc[q].xxb0 = live ? fxx[q] : 0.0f;
+          lc[q].b2 = live ? fb2[q] : 0.0f; lc[q].drej = live ? fdr[q] : 0.0f;
+          lc[q].rden = live ? rd[q] : 1.0; lc[q].sdz1 = live ? sz[q] : 0.0;
+          lc[q].u = live ? uu[q] : 2.0; lc[q].gjj = live ? gj[q] : 0.0;
+          chi[q] = live ? ch[q] : 1.0;
+        }
       }
       S2STAMP(5);
       // packed row k: entry for marker j (> k) sits at prow(k) + j - k - 1
@@ -1186,8 +1197,12 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
             const int js = __ffsll((long long)bal) - 1;
             const float corr_f1 = b1 - lc[q].b0;
             const double corr = (double)readlane_f32(corr_f1, js) - (double)readlane_f32(lc[q].drej, js);
-            r[q] = fma(-(double)gat(base + js, base + lane), corr, r[q]);
-            if (q == 0 && ngrp > 1) r[1] = fma(-(double)gat(base + js, 64 + lane), corr, r[1]);
+            // packed row k = base+js: own-group entry of this lane at prow(k) + lane - js - 1 (used for lane > js), the other
+            // group's (q == 0: marker 64+lane) 64 entries further; both loads unconditional (the buffers carry slack)
+            const int o0 = prow(base + js) + lane - js - 1;
+            const GT g0 = gp[o0], g1 = gp[o0 + 64];
+            r[q] = fma(-(double)((lane > js) ? g0 : (GT)0), corr, r[q]);
+            if (q == 0 && ngrp > 1) r[1] = fma(-(double)((64 + lane < m) ? g1 : (GT)0), corr, r[1]);
             accmask[q] |= (1ull << js);
             front = js + 1;
           }
@@ -1251,8 +1266,9 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
           mk &= mk - 1ull;
           const double corr = (double)readlane_f32(corr_own[q], js) - (double)readlane_f32(drej_own[q], js);
           const GT *row = gxn + (size_t)(64 * q + js) * m;
-          r0 = fma(-(double)row[lane], corr, r0);
-          r1 = fma(-(double)row[64 + lane], corr, r1);
+          const GT ga = row[lane], gb = row[min(64 + lane, m - 1)];
+          r0 = fma(-(double)ga, corr, r0);
+          r1 = fma(-(double)gb, corr, r1);
         }
       }
       rnext[0] = l0 ? r0 : 0.0; rnext[1] = l1 ? r1 : 0.0;
