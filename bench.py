@@ -136,8 +136,9 @@ def main():
         "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32 scalars, f64 residual/accumulation, int8 genotypes", "data": "synthetic",
         "config": {"workload": "%s: synthetic n=%d x p=%d int8, %s%s, exact chain (blocked sweep, block=%d, %d slab "
-                               "workgroups x %d rows + 1 sequencer)" % (args.workload, n, p, model,
-                                                          " pi=%.2f (1%% in model)" % pi if pi else "", P.block, P.nwg, P.slab_rows),
+                               "workgroups x %d rows + 1 sequencer%s)" % (args.workload, n, p, model,
+                                                          " pi=%.2f (1%% in model)" % pi if pi else "", P.block, P.nwg, P.slab_rows,
+                                                          " + 1 q feeder, lag-3 pipeline" if pi else ", lag-2 pipeline"),
                    "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_sweep2<int8>" if os.environ.get("BWGR_SWEEP", "2") != "1" else "k_sweep<int8>",

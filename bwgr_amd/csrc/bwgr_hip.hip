@@ -785,11 +785,11 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a) {
       if (sel) hipLaunchKernelGGL((k_sweep2<float, true>), grid, blk, P->lds2_bytes, P->stream, a);
       else hipLaunchKernelGGL((k_sweep2<float, false>), grid, blk, P->lds2_bytes, P->stream, a);
     } else {
-      if (P->gram16) {
+      if (P->gram16 && sel) {   // selection models: 16-bit staging, single-barrier sequencer, q feeder (the affine recurrence is
+                                // compute-bound and measured faster on the 32-bit blocks: no conversion in its inner loop)
         SweepArgs a16 = a;
         a16.gramp = P->gramp16; a16.gramx = P->gramx16;
-        if (sel) hipLaunchKernelGGL((k_sweep2<int8_t, true, uint16_t>), dim3(P->K + 2), blk, P->lds2_bytes, P->stream, a16);   // + the q feeder
-        else hipLaunchKernelGGL((k_sweep2<int8_t, false, uint16_t>), grid, blk, P->lds2_bytes, P->stream, a16);
+        hipLaunchKernelGGL((k_sweep2<int8_t, true, uint16_t>), dim3(P->K + 2), blk, P->lds2_bytes, P->stream, a16);
       } else if (sel) hipLaunchKernelGGL((k_sweep2<int8_t, true>), grid, blk, P->lds2_bytes, P->stream, a);
       else hipLaunchKernelGGL((k_sweep2<int8_t, false>), grid, blk, P->lds2_bytes, P->stream, a);
     }
@@ -1034,7 +1034,6 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<int8_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<int8_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<int8_t, true, uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<int8_t, false, uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef PCHK

@@ -595,10 +595,10 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
   float *dnew_s = reinterpret_cast<float *>(smem + off); off += SW_MAXM * sizeof(float);
   int *acc_k2 = reinterpret_cast<int *>(smem + off); off += 2 * SW_MAXM * sizeof(int);
   double *part_s = reinterpret_cast<double *>(smem + off); off += 4 * SW_MAXM * sizeof(double);
-  int *ctrl_s = reinterpret_cast<int *>(smem + off);   // (not volatile: a volatile access stays a flat_ one and waits on vmcnt)   // [0] ok flag, [2], [3] number of accepted markers (by block parity)
+  // [0] ok flag, [2], [3] number of accepted markers (by block parity); not volatile: a volatile access stays a flat_ one and waits on vmcnt
+  int *ctrl_s = reinterpret_cast<int *>(smem + off);
   const GT *gramp = reinterpret_cast<const GT *>(a.gramp);
   const GT *gramx = reinterpret_cast<const GT *>(a.gramx);
-  uint32_t *abortw = a.xflags + (size_t)K * SW_FLAG_STRIDE;
   const float Cc = a.sc->C, odds = a.sc->odds, one_minus_pi = 1.0f - a.sc->pi, Sb = a.sc->Sb;
   const int pchunks = pstride / GPT, xchunks = m * m / GPT;
   auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
@@ -989,7 +989,6 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
   auto prow = [&](int k) { return k * (m - 1) - k * (k - 1) / 2; };   // offset of packed row k
   constexpr int NCH = (int)(sizeof(StageBuf) / 16), NSP = (int)(sizeof(SpecBuf) / 16);
   static_assert(NCH <= 384 && NSP <= 384, "one chunk per thread of waves 1-6");
-  const int gpart = (tid - 64) >> 7, gt = (tid - 64) & 127;
 
   double *qsum = a.qpart + (size_t)S2_NSLOT * a.K * SW_MAXM;   // the feeder's sums, [S2_NSLOT][SW_MAXM] tagged words
   uint32_t *abortw = a.xflags + (size_t)a.K * SW_FLAG_STRIDE;
@@ -1143,7 +1142,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
   S2STAMP_DECL;
 
   for (int b = 0; b < nb; ++b) {
-    const int blk = a.blk_begin + b, j0 = blk * m, mB = blk_m(b);
+    const int mB = blk_m(b);
     const bool have_next = (b + 1 < nb);
     const int mBn = have_next ? blk_m(b + 1) : 0;
     float bn[2] = {0.0f, 0.0f}, dn[2] = {0.0f, 0.0f}, corr_own[2] = {0.0f, 0.0f}, drej_own[2] = {0.0f, 0.0f};
@@ -1181,8 +1180,6 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
         }
       }
       S2STAMP(5);
-      // packed row k: entry for marker j (> k) sits at prow(k) + j - k - 1
-      auto gat = [&](int k, int j) -> GT { return (j > k && j < m) ? gp[prow(k) + j - k - 1] : (GT)0; };
       unsigned long long accmask[2] = {0ull, 0ull};
 #pragma unroll
       for (int q = 0; q < 2; ++q) {

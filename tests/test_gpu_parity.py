@@ -239,6 +239,28 @@ def test_both_sweep_engines_give_the_same_chain(model, monkeypatch):
     assert scaled_err(out["1"]["b"], out["2"]["b"]) < 1e-9 and np.array_equal(out["1"]["d"], out["2"]["d"])
 
 
+@pytest.mark.parametrize("model", ["BayesB", "BayesDpi", "BayesC"])
+@pytest.mark.parametrize("env", [{}, {"BWGR_LAG": "2"}, {"BWGR_GRAM16": "0"}, {"BWGR_GRAM16": "0", "BWGR_LAG": "2"}])
+def test_selection_pipeline_variants_give_the_same_chain(model, env, monkeypatch):
+    """Selection models run k_sweep2 in one of four schedules: 16-bit Gram staging with the single-barrier sequencer and
+    the q feeder (default when every Gram entry fits 16 bits) or 32-bit staging with the generic sequencer, each at lag 3
+    (default) or lag 2.  All are the same blocked algebra; several blocks and a ragged last one so that the distance-1
+    and distance-2 cross terms, the first blocks of a launch and the tail are all exercised."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = synth_small(700, 1100, seed=91)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    P = bwgr_amd.Panel(X, block=128, nwg=3)
+    ch = bwgr_amd.Chain(P, model, y, it=6, bi=1, pi=0.8, seed=12)
+    ch.run(6)
+    st = ch.state()
+    ch.close(); P.close()
+    o = O.bayes(model, y, X, it=6, bi=1, pi=0.8, seed=12)["last"]
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL
+    assert np.array_equal(st["d"], o["d"])
+
+
 def _tpod_eigk(tpod):
     Z = tpod["gen"].astype(np.float64); Z = Z - Z.mean(0)
     K = Z @ Z.T; K = K / np.mean(np.diag(K))

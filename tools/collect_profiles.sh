@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round profile set for the headline workload (run on the GPU box from the repo root):
+#   bash tools/collect_profiles.sh r01
+# writes gpurun_out/<tag>_* ; copy what is to be judged into profiles/ afterwards.
+set -e
+TAG=${1:-r01}
+OUT=$PWD/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+python3 bench.py > $OUT/${TAG}_bench_c4.json 2> $OUT/${TAG}_bench_c4.err
+echo "bench done"
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o ${TAG} --output-format csv -- python3 $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu > $OUT/${TAG}_bench_c4_under_rocprof.json 2> $OUT/${TAG}_rocprof.err
+echo "stats done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_fetch -o ${TAG} --output-format csv -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu > $OUT/${TAG}_pmc_fetch.log 2>&1
+echo "fetch done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write -o ${TAG} --output-format csv -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu > $OUT/${TAG}_pmc_write.log 2>&1
+echo "write done"
+cd $OLDPWD
+python3 tools/pmc_summary.py $OUT/prof_fetch $OUT/prof_write $OUT/${TAG}_pmc_c4.json c4 10000 1000000 > /dev/null
+find $OUT/prof_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_bench_c4_kernel_stats.csv \;
+# the raw per-dispatch counter files are large: keep the summaries only
+rm -rf $OUT/prof_fetch $OUT/prof_write
+find $OUT/prof_stats -name "*kernel_trace.csv" -delete
+ls -la $OUT | head -30

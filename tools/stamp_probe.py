@@ -24,23 +24,26 @@ for key in sys.argv[1:] or ["c2", "c4s"]:
     out = (C.c_ulonglong * 48)(); _lib.lib().bwgr_debug_stamps(P._h, out)
     ch.run(3); ch.sync()
     _lib.lib().bwgr_debug_stamps(P._h, out)
-    one = (C.c_ulonglong * 48)(); ch2 = bwgr_amd.Chain(P, model, y, it=2, bi=0, pi=pi, seed=2); ch2.run(1); ch2.sync(); _lib.lib().bwgr_debug_stamps(P._h, one); ch2.run(1); ch2.sync(); _lib.lib().bwgr_debug_stamps(P._h, one); ch2.close()
-    o = [int(x) for x in list(one)[32:48]]; t0 = o[7]
-    oo = [int(x) for x in list(one)]
-    print('   helper phase of block 103 (us after the barrier of block 101 ... tid 64 start): waves 1-6: stores done %.2f, next loads issued %.2f;  wave 7: start %.2f, poll done %.2f, cross term %.2f, state stores %.2f;  barrier of block 102 at %.2f;  delta_102 stored at %.2f' % tuple((x - oo[10]) / 100.0 for x in (oo[11], oo[12], oo[13], oo[14], oo[15], oo[26], oo[27], o[11])))
-    print('   one sweep, block 100 (us after the sequencer stores delta_100): streamer 0 sees delta_100 %.2f, stores q_103 %.2f, sees delta_101 %.2f; feeder puts qsum_103 %.2f; wave 7 has qsum_103 %.2f; sequencer stores delta_101 %.2f, delta_102 %.2f, delta_103 %.2f' % tuple((x - t0) / 100.0 for x in (o[4], o[6], o[5], o[13], o[14], o[9], o[11], o[12])))
     v = np.array(list(out), float); nblk = 3 * ((p + P.block - 1) // P.block)
     print(key, model, "n=%d p=%d K=%d m=%d" % (n, p, P.nwg, P.block), "cycles/block (s_memtime):")
     use2 = os.environ.get('BWGR_SWEEP', '2') != '1'
     if use2:
         for k in sorted(names2): print("   %-55s %9.0f" % (names2[k], v[k] / nblk))
-        print("   streamer 0 total %.0f   sequencer total %.0f" % (v[:16].sum() / nblk, v[16:32].sum() / nblk))
-        w = v[32:36]
-        print("   wall clock: delta stored -> seen by streamer 0: %.2f us;  q stored by streamer 0 -> gathered from all: %.2f us" % ((w[1] - w[0]) / (nblk - 6) / 100.0, (w[3] - w[2]) / (nblk - 6) / 100.0))
+        print("   streamer 0 total %.0f   sequencer total %.0f" % (sum(v[k] for k in names2 if k < 16) / nblk, sum(v[k] for k in names2 if k >= 16) / nblk))
+        hw = v[32:48] / (nblk - 9) / 100.0
+        if pi:   # selection models: lag-3 pipeline with the q feeder (wall clock, 100 MHz)
+            print("   means (us): delta_i stored -> seen by streamer 0 %.2f -> streamer 0 stores q_{i+3} %.2f -> feeder puts the sum %.2f -> sequencer has it %.2f"
+                  % (hw[1] - hw[0], hw[2] - hw[0], hw[3] - hw[0], hw[10] - hw[0]))
+            one = (C.c_ulonglong * 48)(); ch2 = bwgr_amd.Chain(P, model, y, it=2, bi=0, pi=pi, seed=2)
+            ch2.run(1); ch2.sync(); _lib.lib().bwgr_debug_stamps(P._h, one); ch2.run(1); ch2.sync(); _lib.lib().bwgr_debug_stamps(P._h, one); ch2.close()
+            oo = [int(x) for x in list(one)]; o = oo[32:48]; t0 = o[7]
+            print("   one sweep, around block 100 (us after the sequencer stores delta_100): streamer 0 sees delta_100 %.2f, stores q_103 %.2f, sees delta_101 %.2f; "
+                  "feeder puts the sum of q_103 %.2f; sequencer wave 7 has it %.2f; sequencer stores delta_101 %.2f, delta_102 %.2f, delta_103 %.2f"
+                  % tuple((x - t0) / 100.0 for x in (o[4], o[6], o[5], o[13], o[14], o[9], o[11], o[12])))
+            print("   sequencer helper phase for block 103 (us after it starts, i.e. after the barrier of block 101): waves 1-6: Gram/constant stores done %.2f, next "
+                  "loads issued %.2f;  wave 7: sum of q_103 polled %.2f, lag-3 cross term %.2f, state of block 101 stored %.2f;  barrier of block 102 at %.2f (wave 0 "
+                  "stored delta_102 at %.2f)" % tuple((x - oo[10]) / 100.0 for x in (oo[11], oo[12], oo[14], oo[15], oo[26], oo[27], o[11])))
     else:
         for nm, x in zip(names, v): print("   %-50s %9.0f ticks/block" % (nm, x / nblk))
-    hw = v[32:48] / (nblk - 3) / 100.0
-    print("   sel16 (us, wall clock): wave 1: Gram + constants stores %.2f, next loads issue %.2f;  wave 7: poll qsum %.2f;  feeder put -> seen by wave 7: %.2f;  streamer 0 q store -> feeder put %.2f" % (hw[6]-hw[4], hw[7]-hw[6], hw[10]-hw[9], hw[10]-hw[3], hw[3]-hw[2]))
-    print("   chain: delta_{c-3} stored -> qsum_c seen by the sequencer: %.2f us;  delta_{c-3} stored -> streamer 0 stores q_c: %.2f us; streamer 0 sees delta_i -> stores q_{i+3}: %.2f us; raw %s" % (hw[10]-hw[0], hw[2]-hw[0], hw[2]-hw[1], [int(x) for x in v[32:44]]))
     ms, nl = ch.sweep_ms(); print("   sweep ms", ms)
     ch.close(); P.close()
