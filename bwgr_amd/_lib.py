@@ -46,11 +46,13 @@ def lib():
     L.bwgr_chain_state.argtypes = [vp] + [c_f] * 5
     L.bwgr_chain_sweep_ms.argtypes = [vp, c_f, C.POINTER(i32)]
     L.bwgr_bayes.argtypes = [vp, i32, c_f, f32, f32, f32, f32, f32, u64, i32] + [c_f] * 10
+    L.bwgr_bayes2.argtypes = [vp, vp, i32, c_f, f32, f32, f32, f32, f32, u64, i32] + [c_f] * 10
     L.bwgr_wgr.argtypes = [vp, c_d, i32, i32, i32, i32, i32, f64, f64, f64, u64, i32] + [c_d] * 7
     L.bwgr_wgr_ex.argtypes = [vp, c_d, i32, i32, i32, i32, i32, f64, f64, f64, u64, i32, c_d, c_d, i64, f64, i32] + [c_d] * 9
     L.bwgr_synth_genotypes.argtypes = [vp, i64, i64, i64, i64, u64, vp, i32, vp]
     L.bwgr_debug_variates.argtypes = [i32, u64, i32, f64, u32, u32, u32, i32, c_d]
     L.bwgr_device_count.argtypes = [C.POINTER(i32)]
+    L.bwgr_sample_rows.argtypes = [u64, u32, i64, i64, i32, C.POINTER(i32)]
     _lib = L
     return L
 
@@ -70,5 +72,5 @@ EXPORTS = ["bwgr_abi_version", "bwgr_last_error", "bwgr_device_count", "bwgr_pan
            "bwgr_panel_set_stream", "bwgr_panel_info", "bwgr_panel_stats", "bwgr_kmup", "bwgr_chain_create",
            "bwgr_chain_create_sharded", "bwgr_chain_sweep_blocks", "bwgr_chain_get_sums", "bwgr_chain_end_iteration",
            "bwgr_chain_destroy", "bwgr_chain_run", "bwgr_chain_sync", "bwgr_chain_iterations", "bwgr_chain_result",
-           "bwgr_chain_state", "bwgr_chain_sweep_ms", "bwgr_bayes", "bwgr_wgr", "bwgr_wgr_ex", "bwgr_synth_genotypes",
-           "bwgr_debug_variates"]
+           "bwgr_chain_state", "bwgr_chain_sweep_ms", "bwgr_bayes", "bwgr_bayes2", "bwgr_wgr", "bwgr_wgr_ex", "bwgr_synth_genotypes",
+           "bwgr_debug_variates", "bwgr_sample_rows"]

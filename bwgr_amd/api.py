@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import c_f, c_d, check
+from ._lib import BwgrError, c_f, c_d, check
 
 MODELS = {"BayesA": 0, "BayesB": 1, "BayesC": 2, "BayesL": 3, "BayesRR": 4, "BayesCpi": 5, "BayesDpi": 6}
 _PER_MARKER_VB = {"BayesA", "BayesB", "BayesL", "BayesDpi"}
@@ -239,6 +239,131 @@ def BayesCpi(y, X, it=1500, bi=500, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw
 
 def BayesDpi(y, X, it=1500, bi=500, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw):
     return _fused("BayesDpi", y, X, it, bi, 0.0, df, R2, seed, rng_mode, **kw)
+
+
+def _fused2(base, y, X1, X2, it, bi, pi, df, R2, seed, rng_mode, **panel_kw):
+    """BayesA2 / BayesB2 / BayesRR2(y, X1, X2, ...), src/Rcpp20260726ai.cpp:990-1218: two panels, one residual."""
+    P1, own1 = _as_panel(X1, **panel_kw)
+    own2 = not isinstance(X2, Panel)
+    if not own2:
+        P2 = X2
+    else:
+        # the two panels share the residual, hence the slab geometry: try X1's workgroup count for X2, else X2's for X1
+        # (an fp32 panel takes fewer rows per slab than an int8 one)
+        kw2 = dict(panel_kw); kw2.setdefault("nwg", P1.nwg)
+        try:
+            P2 = Panel(X2, **kw2)
+        except BwgrError:
+            if not own1:
+                raise
+            P2 = Panel(X2, **panel_kw)
+            P1.close()
+            kw1 = dict(panel_kw); kw1["nwg"] = P2.nwg
+            P1 = Panel(X1, **kw1)
+    try:
+        assert P1.n == P2.n, "X1 and X2 must have the same rows"
+        y = np.ascontiguousarray(y, np.float32)
+        assert y.size == P1.n
+        per = base != "BayesRR"
+        b1 = np.zeros(P1.p, np.float32); d1 = np.zeros(P1.p, np.float32); vb1 = np.zeros(P1.p if per else 1, np.float32)
+        b2 = np.zeros(P2.p, np.float32); d2 = np.zeros(P2.p, np.float32); vb2 = np.zeros(P2.p if per else 1, np.float32)
+        hat = np.zeros(P1.n, np.float32)
+        mu = np.zeros(1, np.float32); ve = np.zeros(1, np.float32); h2 = np.zeros(1, np.float32)
+        check(_lib.lib().bwgr_bayes2(P1._h, P2._h, MODELS[base], _fp(y), float(it), float(bi), float(pi), float(df), float(R2),
+                                      C.c_uint64(_seed(seed)), int(rng_mode), _fp(mu), _fp(b1), _fp(d1), _fp(vb1), _fp(b2), _fp(d2),
+                                      _fp(vb2), _fp(ve), _fp(hat), _fp(h2)))
+        out = {"hat": hat, "mu": float(mu[0]), "b1": b1, "b2": b2, "vb1": vb1 if per else float(vb1[0]),
+               "vb2": vb2 if per else float(vb2[0]), "ve": float(ve[0]), "h2": float(h2[0])}
+        if base == "BayesB":   # list order of :1146-1149
+            out = {"mu": out["mu"], "b1": b1, "d1": d1, "vb1": vb1, "b2": b2, "d2": d2, "vb2": vb2, "ve": out["ve"], "hat": hat, "h2": out["h2"]}
+        return out
+    finally:
+        if own2:
+            P2.close()
+        if own1:
+            P1.close()
+
+
+def BayesA2(y, X1, X2, it=1500, bi=500, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw):
+    return _fused2("BayesA", y, X1, X2, it, bi, 0.0, df, R2, seed, rng_mode, **kw)
+
+
+def BayesB2(y, X1, X2, it=1500, bi=500, pi=0.95, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw):
+    return _fused2("BayesB", y, X1, X2, it, bi, pi, df, R2, seed, rng_mode, **kw)
+
+
+def BayesRR2(y, X1, X2, it=1500, bi=500, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw):
+    return _fused2("BayesRR", y, X1, X2, it, bi, 0.0, df, R2, seed, rng_mode, **kw)
+
+
+def sample_rows(seed, it, n, k, rp=False):
+    """sort(sample(n, k, rp)) - 1 under the RNG contract (host only)."""
+    out = np.zeros(int(k), np.int32)
+    check(_lib.lib().bwgr_sample_rows(C.c_uint64(_seed(seed)), C.c_uint32(int(it)), int(n), int(k), int(bool(rp)),
+                                       out.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out
+
+
+def _cor_last(dta):
+    """cor(dta, use = 'p')[-m, m]: Pearson correlation of every column with the last one over pairwise complete rows."""
+    m = dta.shape[1]
+    out = np.full(m - 1, np.nan)
+    for i in range(m - 1):
+        ok = np.isfinite(dta[:, i]) & np.isfinite(dta[:, m - 1])
+        if ok.sum() > 1:
+            out[i] = np.corrcoef(dta[ok, i], dta[ok, m - 1])[0, 1]
+    return out
+
+
+_CV_FITS = ("BayesA", "BayesB", "BayesC", "BayesL", "BayesRR", "BayesCpi", "BayesDpi")          # f1 .. f7, R/cv.R:124-130
+_CV_NAMES = ("BayesA", "BayesB", "BayesC", "BayesL", "BayesCpi", "BayesDpi", "BayesRR")         # column labels, R/cv.R:132-133
+
+
+def mcmcCV(y, gen, k=5, n=5, it=1500, bi=500, pi=0.95, df=5, R2=0.5, avg=True, llo=None, tbv=None, ReturnGebv=False, *,
+           seed=None, **panel_kw):
+    """mcmcCV(), R/cv.R:113-216: n random k-fold (or leave-level-out) cross-validation cycles of the seven fused samplers;
+    every cycle stages its training rows once and runs the seven chains on that panel.  Returns the predictive
+    correlations like the reference (`avg`: one vector sorted decreasingly, else one row per cycle), rounded to 4
+    digits, or list(cv, hat, beta) with ReturnGebv.  As in the reference, column i holds the predictions of fit f_i =
+    (A, B, C, L, RR, Cpi, Dpi) but is *labelled* (A, B, C, L, Cpi, Dpi, RR) (R/cv.R:124-133).  Fold rows come from the
+    RNG contract (iteration word = cycle number) instead of set.seed(cycle); sample()."""
+    y = np.asarray(y, np.float64); gen = np.asarray(gen)
+    N, p = gen.shape
+    base = _seed(seed)
+    if llo is None:
+        Nk = int(round(N / k))
+        cycles = [sample_rows(base, c + 1, N, Nk) for c in range(int(n))]
+    else:
+        llo = np.asarray(llo).astype(str)
+        cycles = [np.nonzero(llo == lev)[0] for lev in dict.fromkeys(llo.tolist())]
+    obs = y if tbv is None else np.asarray(tbv, np.float64)
+    Ms, Bs = [], []
+    for c, w in enumerate(cycles):
+        keep = np.ones(N, bool); keep[w] = False
+        P = Panel(np.ascontiguousarray(gen[keep]), **panel_kw)
+        try:
+            B = np.zeros((p, 7))
+            for i, model in enumerate(_CV_FITS):
+                kw = {"pi": pi} if model in ("BayesB", "BayesC") else {}
+                fit = globals()[model](y[keep].astype(np.float32), P, it=it, bi=bi, df=df, R2=R2, seed=(base + 1000003 * (c + 1) + i) & 0x7FFFFFFFFFFFFFFF, **kw)
+                B[:, i] = fit["b"]
+        finally:
+            P.close()
+        M = np.empty((len(w), 8))
+        M[:, :7] = np.asarray(gen[w], np.float64) @ B
+        M[:, 7] = obs[w]
+        Ms.append(M); Bs.append(B)
+    if avg:
+        pa = _cor_last(np.vstack(Ms))
+        order = np.argsort(-pa, kind="stable")
+        cv = {_CV_NAMES[i]: round(float(pa[i]), 4) for i in order}
+    else:
+        cv = {"CV_%d" % (c + 1): {_CV_NAMES[i]: round(float(v), 4) for i, v in enumerate(_cor_last(M))} for c, M in enumerate(Ms)}
+    if not ReturnGebv:
+        return cv
+    beta = sum(Bs) / len(Bs)
+    hat = np.asarray(gen, np.float64) @ beta + np.nanmean(y)
+    return {"cv": cv, "hat": hat, "beta": beta}
 
 
 def KMUP(X, b, d, xx, e, L, Ve, pi, *, seed=None, it=0, rng_mode=0, **panel_kw):

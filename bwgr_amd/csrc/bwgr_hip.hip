@@ -394,6 +394,49 @@ __global__ void k_marker_tail(const float *b, const float *d, const float *vb, f
   }
 }
 
+// ---- tail of the two-effect samplers (src/Rcpp20260726ai.cpp:1042-1047, :1138-1143, :1204-1210): one intercept and one
+// residual variance from the shared residual; RR2 also draws the two common marker variances (second chi-square with
+// the marker word RNG_GLOBAL_MARKER - 1).  Scalars are written to both chains' blocks; MU / VE accumulate in the first.
+struct Tail2Args {
+  double *e; int n, p1, p2; int rr; float df; int accumulate; uint32_t iter; Rng rng; ChainScalars *sc1, *sc2;
+};
+__global__ __launch_bounds__(1024) void k_tail2(const Tail2Args a) {
+  __shared__ double red[17];
+  ChainScalars &s1 = *a.sc1, &s2 = *a.sc2;
+  const float ve0 = s1.ve;
+  double s = 0;
+  for (int i = threadIdx.x; i < a.n; i += blockDim.x) s += a.e[i];
+  s = block_sum(s, red);
+  const float me = (float)(s / (double)a.n);
+  const double z = rng_normal(a.rng, RNG_GLOBAL_MARKER, a.iter, RNG_G_MU, 0);
+  const float eM = (float)((double)me + (double)sqrtf(ve0 / a.n) * z);
+  double ss = 0;
+  for (int i = threadIdx.x; i < a.n; i += blockDim.x) { const double v = a.e[i] - (double)eM; a.e[i] = v; ss = fma(v, v, ss); }
+  ss = block_sum(ss, red);
+  if (threadIdx.x == 0) {
+    const float ssf = (float)ss;
+    const float mu = s1.mu + eM;
+    const double chi_e = rng_chisq(a.rng, (double)(a.n + a.df), RNG_GLOBAL_MARKER, a.iter, RNG_G_VE);
+    const float ve = (float)((double)(ssf + s1.Se) / chi_e);
+    if (a.rr) {
+      const double c1 = rng_chisq(a.rng, (double)(a.df + a.p1), RNG_GLOBAL_MARKER, a.iter, RNG_G_VB);
+      const double c2 = rng_chisq(a.rng, (double)(a.df + a.p2), RNG_GLOBAL_MARKER - 1u, a.iter, RNG_G_VB);
+      s1.vb = (float)((double)(s1.Sb + (float)s1.sum_b2) / c1);
+      s2.vb = (float)((double)(s2.Sb + (float)s2.sum_b2) / c2);
+      s1.lam = ve / s1.vb; s2.lam = ve / s2.vb;
+    }
+    const float Cn = -0.5f / sqrtf(ve);
+    s1.ve = ve; s2.ve = ve; s1.mu = mu; s2.mu = mu; s1.C = Cn; s2.C = Cn;
+    s1.sum_d = 0.0; s1.sum_b2 = 0.0; s2.sum_d = 0.0; s2.sum_b2 = 0.0;
+    if (a.accumulate) { s1.MU += mu; s1.VE += ve; s1.VBs += s1.vb; s2.VBs += s2.vb; }
+  }
+}
+__global__ void k_set_rr2_start(ChainScalars *sc) { sc->lam = sc->MSx; }   // BayesRR2 starts with Lmb = MSx (:1190)
+__global__ void k_hat2(const float *h1, const float *h2, float MU, float *hat, int n) {   // fit = X1*B1 + X2*B2; fit += MU
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float f = h1[i] + h2[i]; hat[i] = f + MU; }
+}
+
 // ---- finalisation ----
 __global__ void k_final_markers(float *B, float *D, float *VB, float *pval, int p, float MCMC, int per) {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < p; j += gridDim.x * blockDim.x) {
@@ -725,6 +768,7 @@ struct bwgr_chain {
   int64_t marker0 = 0, p_total = 0;   // sharding: global id of local marker 0, markers over all ranks
   float MSx_eff = 0;                  // MSx over all ranks
   bool e_owned = true;
+  int flags_extra = 0;                // two-effect BayesB2: SWF_ALT_B2 (the likelihood comparison uses the drawn alternative)
   std::vector<hipEvent_t> ev;  // pairs around each sweep launch since the last query
   float ms_acc = 0; int launch_acc = 0;
   bool finalized = false;
@@ -1201,7 +1245,7 @@ extern "C" int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end
   if (has_d(model)) fl |= SWF_SELECT;
   if (model == BWGR_BAYESDPI) fl |= SWF_ALT_B2 | SWF_MH;
   if (per_marker_vb(model)) fl |= SWF_LAM_VEC | SWF_VB_VEC;
-  a.flags = fl;
+  a.flags = fl | C->flags_extra;
   a.e = C->e; a.b = C->b; a.d = C->d; a.vb = C->vb; a.xx = P->xx; a.lam = C->lam; a.sc = C->sc;
   a.iter = (uint32_t)C->done; a.marker0 = (uint32_t)C->marker0; a.rng = make_rng(C->seed, C->rng_mode);
   hipEvent_t e0, e1;
@@ -1405,6 +1449,102 @@ extern "C" int bwgr_bayes(bwgr_panel *P, int model, const float *y, float it, fl
   return rc;
 }
 
+// BayesA2 / BayesB2 / BayesRR2, src/Rcpp20260726ai.cpp:990-1218: two chains over two panels sharing the residual
+extern "C" int bwgr_bayes2(bwgr_panel *P1, bwgr_panel *P2, int base_model, const float *y, float it, float bi, float pi, float df,
+                           float R2, uint64_t seed, int rng_mode, float *mu, float *b1, float *d1, float *vb1, float *b2,
+                           float *d2, float *vb2, float *ve, float *hat, float *h2) {
+  if (!P1 || !P2 || !y) return fail(BWGR_EINVAL, "bayes2: null pointer");
+  if (base_model != BWGR_BAYESA && base_model != BWGR_BAYESB && base_model != BWGR_BAYESRR)
+    return fail(BWGR_EINVAL, "bayes2: base model must be BayesA, BayesB or BayesRR (got %d)", base_model);
+  if (P1->device != P2->device || P1->n != P2->n || P1->ld != P2->ld || P1->K != P2->K || P1->R != P2->R)
+    return fail(BWGR_EINVAL, "bayes2: the two panels must share device, rows and slab geometry (n %lld/%lld, %d x %d vs %d x %d rows)",
+                (long long)P1->n, (long long)P2->n, P1->K, P1->R, P2->K, P2->R);
+  const int64_t p1 = P1->p, p2 = P2->p, n = P1->n;
+  if (p1 + p2 > 0xFFFFFFF0ll - 2) return fail(BWGR_EINVAL, "bayes2: p1 + p2 too large");
+  HIPCHK(hipSetDevice(P1->device));
+  hipStream_t s2_saved = P2->stream;
+  P2->stream = P1->stream;   // one stream orders the two chains' kernels
+  bwgr_chain *C1 = nullptr, *C2 = nullptr;
+  float *h1d = nullptr, *h2d = nullptr, *hatd = nullptr, *sdev = nullptr; double *part = nullptr;
+  int rc = bwgr_chain_create_sharded(&C1, P1, base_model, y, BWGR_HOST, it, bi, pi, df, R2, seed, rng_mode, 0, p1 + p2, P1->MSx, nullptr);
+  if (rc == BWGR_OK) rc = bwgr_chain_create_sharded(&C2, P2, base_model, y, BWGR_HOST, it, bi, pi, df, R2, seed, rng_mode, p1, p1 + p2, P2->MSx, C1->e);
+  auto done = [&](int code) {
+    if (C2) bwgr_chain_destroy(C2);
+    if (C1) bwgr_chain_destroy(C1);
+    hipFree(h1d); hipFree(h2d); hipFree(hatd); hipFree(sdev); hipFree(part);
+    P2->stream = s2_saved;
+    return code;
+  };
+  if (rc != BWGR_OK) return done(rc);
+#define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return done(fail(BWGR_EHIP, "%s failed: %s", #x, hipGetErrorString(e_))); } while (0)
+  const bool rr = (base_model == BWGR_BAYESRR), per = !rr;
+  if (base_model == BWGR_BAYESB) { C1->flags_extra = SWF_ALT_B2; C2->flags_extra = SWF_ALT_B2; }
+  if (rr) {
+    hipLaunchKernelGGL(k_set_rr2_start, dim3(1), dim3(1), 0, P1->stream, C1->sc);
+    hipLaunchKernelGGL(k_set_rr2_start, dim3(1), dim3(1), 0, P1->stream, C2->sc);
+  }
+  const int iit = (int)it, ibi = (int)bi;
+  for (int i = 0; i < iit; ++i) {
+    rc = bwgr_chain_sweep_blocks(C1, 0, (int)P1->nblocks);
+    if (rc == BWGR_OK) rc = bwgr_chain_sweep_blocks(C2, 0, (int)P2->nblocks);
+    if (rc != BWGR_OK) return done(rc);
+    const int accumulate = (i > ibi) ? 1 : 0;                                        // if(i>ibi), :1047
+    Tail2Args t; t.e = C1->e; t.n = (int)n; t.p1 = (int)p1; t.p2 = (int)p2; t.rr = rr ? 1 : 0; t.df = df;
+    t.accumulate = accumulate; t.iter = (uint32_t)i; t.rng = make_rng(seed, rng_mode); t.sc1 = C1->sc; t.sc2 = C2->sc;
+    hipLaunchKernelGGL(k_tail2, dim3(1), dim3(1024), 0, P1->stream, t);
+    hipLaunchKernelGGL(k_marker_tail, dim3((unsigned)std::min<int64_t>(2048, (p1 + 255) / 256)), dim3(256), 0, P1->stream,
+                       C1->b, C1->d, C1->vb, C1->lam, C1->B, C1->D, C1->VB, (int)p1, base_model, 0.0f, accumulate, C1->sc);
+    hipLaunchKernelGGL(k_marker_tail, dim3((unsigned)std::min<int64_t>(2048, (p2 + 255) / 256)), dim3(256), 0, P1->stream,
+                       C2->b, C2->d, C2->vb, C2->lam, C2->B, C2->D, C2->VB, (int)p2, base_model, 0.0f, accumulate, C2->sc);
+    BCHK(hipGetLastError());
+    C1->done++; C2->done++;
+  }
+  rc = bwgr_chain_sync(C1);
+  if (rc == BWGR_OK) rc = bwgr_chain_sync(C2);
+  if (rc != BWGR_OK) return done(rc);
+  const float MCMC = it - bi;                                                        // :1049
+  hipLaunchKernelGGL(k_final_markers, dim3(1024), dim3(256), 0, P1->stream, C1->B, C1->D, C1->VB, (float *)nullptr, (int)p1, MCMC, per ? 1 : 0);
+  hipLaunchKernelGGL(k_final_markers, dim3(1024), dim3(256), 0, P1->stream, C2->B, C2->D, C2->VB, (float *)nullptr, (int)p2, MCMC, per ? 1 : 0);
+  BCHK(hipGetLastError());
+  ChainScalars g1, g2;
+  BCHK(hipMemcpyAsync(&g1, C1->sc, sizeof(g1), hipMemcpyDeviceToHost, P1->stream));
+  BCHK(hipMemcpyAsync(&g2, C2->sc, sizeof(g2), hipMemcpyDeviceToHost, P1->stream));
+  BCHK(hipStreamSynchronize(P1->stream));
+  const float MU = g1.MU / MCMC, VE = g1.VE / MCMC, VB1s = g1.VBs / MCMC, VB2s = g2.VBs / MCMC;
+  float vg;
+  if (per) {                                                                         // vg = VB1.sum() + VB2.sum(), :1051
+    float v1 = 0, v2 = 0;
+    BCHK(hipMalloc(&part, sizeof(double) * 256)); BCHK(hipMalloc(&sdev, sizeof(float)));
+    hipLaunchKernelGGL(k_sum_stage1, dim3(256), dim3(256), 0, P1->stream, C1->VB, (int64_t)p1, part);
+    hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, P1->stream, part, 256, sdev);
+    BCHK(hipMemcpy(&v1, sdev, sizeof(float), hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(k_sum_stage1, dim3(256), dim3(256), 0, P1->stream, C2->VB, (int64_t)p2, part);
+    hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, P1->stream, part, 256, sdev);
+    BCHK(hipMemcpy(&v2, sdev, sizeof(float), hipMemcpyDeviceToHost));
+    vg = v1 + v2;
+  } else vg = VB1s * P1->MSx + VB2s * P2->MSx;                                       // :1213
+  if (mu) *mu = MU;
+  if (ve) *ve = VE;
+  if (h2) *h2 = vg / (vg + VE);
+  if (b1) BCHK(hipMemcpy(b1, C1->B, sizeof(float) * p1, hipMemcpyDeviceToHost));
+  if (b2) BCHK(hipMemcpy(b2, C2->B, sizeof(float) * p2, hipMemcpyDeviceToHost));
+  if (d1) BCHK(hipMemcpy(d1, C1->D, sizeof(float) * p1, hipMemcpyDeviceToHost));
+  if (d2) BCHK(hipMemcpy(d2, C2->D, sizeof(float) * p2, hipMemcpyDeviceToHost));
+  if (vb1) { if (per) BCHK(hipMemcpy(vb1, C1->VB, sizeof(float) * p1, hipMemcpyDeviceToHost)); else vb1[0] = VB1s; }
+  if (vb2) { if (per) BCHK(hipMemcpy(vb2, C2->VB, sizeof(float) * p2, hipMemcpyDeviceToHost)); else vb2[0] = VB2s; }
+  if (hat) {                                                                         // fit = X1*B1 + X2*B2; fit += MU, :1052-1053
+    BCHK(hipMalloc(&h1d, sizeof(float) * n)); BCHK(hipMalloc(&h2d, sizeof(float) * n)); BCHK(hipMalloc(&hatd, sizeof(float) * n));
+    rc = gemv_hat<float>(P1, C1->B, 0.0f, h1d);
+    if (rc == BWGR_OK) rc = gemv_hat<float>(P2, C2->B, 0.0f, h2d);
+    if (rc != BWGR_OK) return done(rc);
+    hipLaunchKernelGGL(k_hat2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, P1->stream, h1d, h2d, MU, hatd, (int)n);
+    BCHK(hipGetLastError());
+    BCHK(hipMemcpy(hat, hatd, sizeof(float) * n, hipMemcpyDeviceToHost));
+  }
+#undef BCHK
+  return done(BWGR_OK);
+}
+
 // host side of the RNG contract for wgr's row resampling, R/wgr.R:68: Use = sort(sample(n, n*bag, rp)) - 1
 static double host_uniform(uint64_t seed, uint32_t marker, uint32_t iter, uint32_t purpose, uint32_t k) {
   uint32_t c0 = marker, c1 = iter, c2 = purpose, c3 = k, k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -1427,6 +1567,14 @@ static void bag_rows(uint64_t seed, uint32_t iter, int64_t n, int64_t k, int rp,
     for (int64_t t = 0; t < k; ++t) use[(size_t)t] = kv[(size_t)t].second;
   }
   std::sort(use.begin(), use.end());
+}
+
+extern "C" int bwgr_sample_rows(uint64_t seed, uint32_t iter, int64_t n, int64_t k, int rp, int *rows) {
+  if (!rows || n < 1 || k < 0 || (!rp && k > n) || n > 0x7FFFFFFFll) return fail(BWGR_EINVAL, "sample_rows: bad arguments (n=%lld, k=%lld, rp=%d)", (long long)n, (long long)k, rp);
+  std::vector<int> use;
+  bag_rows(seed, iter, n, k, rp, use);
+  for (int64_t t = 0; t < k; ++t) rows[t] = use[(size_t)t];
+  return BWGR_OK;
 }
 
 // X * coef (fp64 partial products per column chunk); caller finishes.  Returns nchunks and the device buffer.

@@ -568,7 +568,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
   constexpr int PCH = (PFULLCH + NHELP - 1) / NHELP;   // chunks of packed G per helper thread
   constexpr int PSURE = PFULLCH / NHELP, XSURE = XFULLCH / NHELP;   // at m = MAXM every helper thread's first PSURE / XSURE chunks exist
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = a.m, K = a.K;
+  const int m = a.m;
   const int nb = a.blk_end - a.blk_begin;
   const int pstride = a.pstride;
   size_t off = 0;

@@ -129,6 +129,22 @@ int bwgr_bayes(bwgr_panel *P, int model, const float *y, float it, float bi, flo
                uint64_t seed, int rng_mode, float *mu, float *b, float *d, float *hat, float *vb, float *ve,
                float *h2, float *MSx, float *pi_out, float *pval);
 
+/* ---- two-effect samplers ---------------------------------------------------------------------------
+ * Replaces BayesA2 / BayesB2 / BayesRR2(y, X1, X2, it, bi, [pi,] df, R2), src/Rcpp20260726ai.cpp:990-1218: one
+ * residual, two resident panels with the same rows swept one after the other in every iteration, each with its own
+ * prior scale and variance(s).  base_model = BWGR_BAYESA, BWGR_BAYESB or BWGR_BAYESRR.  Both panels must have been
+ * created on the same device with the same slab geometry (same n, block and nwg).  Panel-2 markers carry the RNG ids
+ * p1 .. p1+p2-1.  Outputs as the reference's return lists: mu, b1[p1], b2[p2], vb1 / vb2 (p_k entries for A2 and B2,
+ * one for RR2), d1[p1], d2[p2] (B2 only; may be NULL otherwise), ve, hat[n], h2. */
+int bwgr_bayes2(bwgr_panel *P1, bwgr_panel *P2, int base_model, const float *y, float it, float bi, float pi, float df,
+                float R2, uint64_t seed, int rng_mode, float *mu, float *b1, float *d1, float *vb1, float *b2, float *d2,
+                float *vb2, float *ve, float *hat, float *h2);
+
+/* Host-only helper of the RNG contract: the k row indices (0-based, ascending) that `sort(sample(n, k, rp))` selects
+ * for (seed, iter) -- what wgr's bagging (R/wgr.R:68) and the cross-validation folds of mcmcCV (R/cv.R:118-121) draw
+ * from R's stream in the reference.  Does not touch the GPU. */
+int bwgr_sample_rows(uint64_t seed, uint32_t iter, int64_t n, int64_t k, int rp, int *rows);
+
 /* ---- wgr(): the R-level driver, device-resident ---------------------------------------------------
  * Replaces the iteration body and setup/teardown of wgr(), R/wgr.R:41-168 (bag = 1, eigK = NULL in
  * this round).  y is the R numeric vector (double).  Outputs as wgr's return list: mu, b[p],

@@ -501,6 +501,134 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
   return 0;
 }
 
+/* ---- two-effect samplers BayesA2 / BayesB2 / BayesRR2, /root/reference/src/Rcpp20260726ai.cpp:990-1218 --------------
+ * One residual, two marker panels X1 (p1) and X2 (p2) swept one after the other in every iteration, each with its own
+ * prior scale (Sb_k from MSx_k) and variance(s); one intercept and one residual variance.  model2: 0 = A2, 1 = B2, 2 = RR2.
+ * Variates: panel-2 markers carry the global ids p1 .. p1+p2-1; RR2's second common-variance chi-square is drawn with the
+ * marker word ORNG_GLOBAL_MARKER - 1.  BayesB2's inclusion probability cj/(cj+dj) (:1111-1113) is evaluated in the
+ * stable form 1/(1 + pi/(1-pi) exp(C(|e2|^2-|e1|^2))), like BayesB's own (:673-674) -- the literal form is 0/0 once
+ * 0.5|e|^2/sqrt(ve) exceeds ~103 (see oracle_kmup's `stable`).  Note the alternative state of B2 is the drawn b_t2 in
+ * BOTH the likelihood comparison and the update (:1108-1109), unlike BayesB whose comparison uses 0 (:672).
+ * VB1 / VB2: p_k entries for A2 and B2, one entry for RR2.  last_* (optional): b1, b2, e, {mu, ve} after the final iteration. */
+#define ORNG_GLOBAL_MARKER2 (ORNG_GLOBAL_MARKER - 1u)
+int FN(oracle_bayes2)(int model2, const float *y, const float *X1, int64_t p1, const float *X2, int64_t p2, int64_t n,
+                      float it, float bi, float pi, float df, float R2, uint64_t seed, int rng_mode,
+                      float *o_mu, float *o_B1, float *o_D1, float *o_VB1, float *o_B2, float *o_D2, float *o_VB2,
+                      float *o_ve, float *o_hat, float *o_h2, float *last_b1, float *last_b2, float *last_e, float *last_scal) {
+  orng_t g = { seed, rng_mode };
+  const uint32_t GM = ORNG_GLOBAL_MARKER;
+  const int iit = (int)it, ibi = (int)bi;
+  const float *Xs[2] = { X1, X2 };
+  const int64_t ps[2] = { p1, p2 };
+  float *xx[2], *vx[2], *b[2], *d[2], *B[2], *D[2], *VBv[2], *vbv[2], *Lmbv[2];
+  float MSx[2], Sb[2], vbc[2], VBs[2] = { 0, 0 }, Lmb[2];
+  for (int k = 0; k < 2; k++) {
+    const int64_t p = ps[k];
+    xx[k] = (float *)malloc(sizeof(float) * p); vx[k] = (float *)malloc(sizeof(float) * p);
+    b[k] = (float *)calloc(p, sizeof(float)); d[k] = (float *)calloc(p, sizeof(float));
+    B[k] = (float *)calloc(p, sizeof(float)); D[k] = (float *)calloc(p, sizeof(float));
+    VBv[k] = (float *)calloc(p, sizeof(float)); vbv[k] = (float *)malloc(sizeof(float) * p); Lmbv[k] = (float *)malloc(sizeof(float) * p);
+    if (!xx[k] || !vx[k] || !b[k] || !d[k] || !B[k] || !D[k] || !VBv[k] || !vbv[k] || !Lmbv[k]) return 1;
+    FN(oracle_stats)(Xs[k], n, p, n, xx[k], vx[k], &MSx[k]);            /* :997-1008 */
+  }
+  E_T *e = (E_T *)malloc(sizeof(E_T) * n), *e1 = (E_T *)malloc(sizeof(E_T) * n), *e2 = (E_T *)malloc(sizeof(E_T) * n);
+  if (!e || !e1 || !e2) return 1;
+  const float vy = v_fvar(y, n);                                        /* :1009 */
+  for (int k = 0; k < 2; k++) Sb[k] = (R2)*df * vy / MSx[k];            /* :1010-1011 */
+  const float Se = (1 - R2) * df * vy;                                  /* :1012 */
+  float mu = v_mean(y, n), ve = vy, MU = 0, VE = 0, eM, C = 0;
+  for (int k = 0; k < 2; k++) {
+    for (int64_t j = 0; j < ps[k]; j++) { vbv[k][j] = Sb[k]; Lmbv[k][j] = ve * (1.0f / Sb[k]); }   /* :1021-1024 */
+    Lmb[k] = MSx[k]; vbc[k] = 0;                                        /* RR2 starts with Lmb = MSx, :1190 */
+  }
+  for (int64_t i = 0; i < n; i++) { float t = y[i] - mu; e[i] = t; }    /* :1025 */
+  const float Pi0 = pi / (1.0f - pi);
+  for (int i = 0; i < iit; i++) {
+    const uint32_t itx = (uint32_t)i;
+    C = -0.5f / sqrtf(ve);                                              /* :1103 */
+    for (int k = 0; k < 2; k++) {
+      const uint32_t mk0 = (uint32_t)(k ? p1 : 0);
+      for (int64_t j = 0; j < ps[k]; j++) {
+        const float *xj = Xs[k] + j * n;
+        const uint32_t mk = mk0 + (uint32_t)j;
+        const float lam = (model2 == 2) ? Lmb[k] : Lmbv[k][j];
+        const float den = xx[k][j] + lam;
+        const float b0 = b[k][j];
+        const float b1 = draw_b1(xj, e, n, xx[k][j], b0, den, sqrtf(ve / den), orng_normal(&g, mk, itx, ORNG_Z1, 0));
+        if (model2 == 1) {                                              /* :1104-1121 */
+          const float b2 = draw_norm(0.0f, sqrtf(ve / den), orng_normal(&g, mk, itx, ORNG_Z2, 0));
+          v_axpy_to(e1, e, xj, b1 - b0, n);
+          v_axpy_to(e2, e, xj, b2 - b0, n);
+#ifdef ACC_WIDE
+          const float diff = (float)(e_sqnorm_acc(e2, n) - e_sqnorm_acc(e1, n));
+#else
+          const float diff = e_sqnorm(e2, n) - e_sqnorm(e1, n);
+#endif
+          const float pj = 1.0f / (1.0f + Pi0 * f_exp(C * diff));
+          if (orng_uniform(&g, mk, itx, ORNG_U, 0) < (double)pj) { b[k][j] = b1; d[k][j] = 1; }
+          else { b[k][j] = b2; d[k][j] = 0; }
+        } else {
+          b[k][j] = b1;                                                 /* :1031, :1196 */
+        }
+        if (model2 != 2)                                                /* :1032, :1119 */
+          vbv[k][j] = (float)((double)(Sb[k] + b[k][j] * b[k][j]) / orng_chisq(&g, (double)(df + 1), mk, itx, ORNG_CHI));
+        v_axpy(e, xj, b[k][j] - b0, n);
+      }
+    }
+    eM = draw_norm(e_mean(e, n), sqrtf(ve / n), orng_normal(&g, GM, itx, ORNG_G_MU, 0));   /* :1042 */
+    mu += eM;
+    for (int64_t q = 0; q < n; q++) e[q] = e[q] - eM;
+    ve = (float)((double)(e_sqnorm(e, n) + Se) / orng_chisq(&g, (double)(n + df), GM, itx, ORNG_G_VE));   /* :1044 */
+    if (model2 == 2) {                                                  /* :1207-1209 */
+      vbc[0] = (float)((double)(Sb[0] + v_sqnorm(b[0], p1)) / orng_chisq(&g, (double)(df + p1), GM, itx, ORNG_G_VB));
+      vbc[1] = (float)((double)(Sb[1] + v_sqnorm(b[1], p2)) / orng_chisq(&g, (double)(df + p2), ORNG_GLOBAL_MARKER2, itx, ORNG_G_VB));
+      Lmb[0] = ve / vbc[0]; Lmb[1] = ve / vbc[1];
+    } else {
+      for (int k = 0; k < 2; k++) for (int64_t j = 0; j < ps[k]; j++) Lmbv[k][j] = ve * (1.0f / vbv[k][j]);   /* :1045-1046 */
+    }
+    if (i > ibi) {                                                      /* :1047 */
+      MU += mu; VE += ve;
+      for (int k = 0; k < 2; k++) {
+        for (int64_t j = 0; j < ps[k]; j++) { B[k][j] += b[k][j]; D[k][j] += d[k][j]; }
+        if (model2 == 2) VBs[k] += vbc[k]; else for (int64_t j = 0; j < ps[k]; j++) VBv[k][j] += vbv[k][j];
+      }
+    }
+  }
+  const float MCMC = it - bi;                                           /* :1049 */
+  MU /= MCMC; VE /= MCMC;
+  float vg;
+  for (int k = 0; k < 2; k++) {
+    for (int64_t j = 0; j < ps[k]; j++) { B[k][j] /= MCMC; D[k][j] /= MCMC; VBv[k][j] /= MCMC; }
+    VBs[k] /= MCMC;
+  }
+  if (model2 == 2) vg = VBs[0] * MSx[0] + VBs[1] * MSx[1];              /* :1213 */
+  else vg = (float)v_sum_acc(VBv[0], p1) + (float)v_sum_acc(VBv[1], p2);   /* :1051 */
+  /* fit = X1*B1 + X2*B2; fit += MU  (:1052-1053): two float products added, then the intercept */
+  {
+    ACC_T *acc = (ACC_T *)malloc(sizeof(ACC_T) * n);
+    float *f1 = (float *)malloc(sizeof(float) * n);
+    for (int k = 0; k < 2; k++) {
+      for (int64_t q = 0; q < n; q++) acc[q] = 0;
+      for (int64_t j = 0; j < ps[k]; j++) { const float *xj = Xs[k] + j * n; const ACC_T Bj = (ACC_T)B[k][j]; for (int64_t q = 0; q < n; q++) acc[q] += (ACC_T)xj[q] * Bj; }
+      if (k == 0) for (int64_t q = 0; q < n; q++) f1[q] = (float)acc[q];
+      else for (int64_t q = 0; q < n; q++) { const float f = f1[q] + (float)acc[q]; o_hat[q] = f + MU; }
+    }
+    free(acc); free(f1);
+  }
+  *o_mu = MU; *o_ve = VE; *o_h2 = vg / (vg + VE);
+  memcpy(o_B1, B[0], sizeof(float) * p1); memcpy(o_B2, B[1], sizeof(float) * p2);
+  memcpy(o_D1, D[0], sizeof(float) * p1); memcpy(o_D2, D[1], sizeof(float) * p2);
+  if (model2 == 2) { o_VB1[0] = VBs[0]; o_VB2[0] = VBs[1]; }
+  else { memcpy(o_VB1, VBv[0], sizeof(float) * p1); memcpy(o_VB2, VBv[1], sizeof(float) * p2); }
+  if (last_b1) memcpy(last_b1, b[0], sizeof(float) * p1);
+  if (last_b2) memcpy(last_b2, b[1], sizeof(float) * p2);
+  if (last_e) for (int64_t q = 0; q < n; q++) last_e[q] = (float)e[q];
+  if (last_scal) { last_scal[0] = mu; last_scal[1] = ve; }
+  for (int k = 0; k < 2; k++) { free(xx[k]); free(vx[k]); free(b[k]); free(d[k]); free(B[k]); free(D[k]); free(VBv[k]); free(vbv[k]); free(Lmbv[k]); }
+  free(e); free(e1); free(e2);
+  return 0;
+}
+
 /* ---- wgr(): the split shape, /root/reference/R/wgr.R:2-169 (bag = 1) ---------------------------------
  * R arithmetic is double; KMUP is entered through the Rcpp glue that narrows every argument to
  * float (/root/reference/src/RcppExports.cpp:20-27) and widens the returned b, d, e back to double

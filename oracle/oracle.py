@@ -117,6 +117,34 @@ def bayes(model, y, X, it=1500, bi=500, pi=0.95, df=5.0, R2=0.5, seed=1, rng_mod
     return out
 
 
+def bayes2(model, y, X1, X2, it=1500, bi=500, pi=0.95, df=5.0, R2=0.5, seed=1, rng_mode=0, flavour="w", fast=False):
+    """Reference BayesA2 / BayesB2 / BayesRR2(y,X1,X2,it,bi,[pi,]df,R2), src/Rcpp20260726ai.cpp:990-1218.
+    Returns the reference's list as a dict plus 'last' (b1, b2, e after the final iteration)."""
+    m2 = {"BayesA2": 0, "BayesB2": 1, "BayesRR2": 2}[model]
+    X1f, X2f = as_f32_colmajor(X1), as_f32_colmajor(X2)
+    n, p1 = X1f.shape; p2 = X2f.shape[1]
+    assert X2f.shape[0] == n
+    y = np.ascontiguousarray(y, np.float32)
+    per = m2 != 2
+    B1 = np.zeros(p1, np.float32); D1 = np.zeros(p1, np.float32); VB1 = np.zeros(p1 if per else 1, np.float32)
+    B2 = np.zeros(p2, np.float32); D2 = np.zeros(p2, np.float32); VB2 = np.zeros(p2 if per else 1, np.float32)
+    hat = np.zeros(n, np.float32); mu = C.c_float(); ve = C.c_float(); h2 = C.c_float()
+    lb1 = np.zeros(p1, np.float32); lb2 = np.zeros(p2, np.float32); le = np.zeros(n, np.float32); ls = np.zeros(2, np.float32)
+    rc = getattr(lib(fast), "oracle_bayes2_" + flavour)(
+        C.c_int(m2), _fp(y), _fp(X1f), C.c_int64(p1), _fp(X2f), C.c_int64(p2), C.c_int64(n),
+        C.c_float(it), C.c_float(bi), C.c_float(pi), C.c_float(df), C.c_float(R2), C.c_uint64(seed), C.c_int(rng_mode),
+        C.byref(mu), _fp(B1), _fp(D1), _fp(VB1), _fp(B2), _fp(D2), _fp(VB2), C.byref(ve), _fp(hat), C.byref(h2),
+        _fp(lb1), _fp(lb2), _fp(le), _fp(ls))
+    assert rc == 0
+    vb1 = VB1 if per else float(VB1[0]); vb2 = VB2 if per else float(VB2[0])
+    if m2 == 1:   # list order of :1146-1149
+        out = {"mu": mu.value, "b1": B1, "d1": D1, "vb1": vb1, "b2": B2, "d2": D2, "vb2": vb2, "ve": ve.value, "hat": hat, "h2": h2.value}
+    else:         # :1054-1057, :1216-1219
+        out = {"hat": hat, "mu": mu.value, "b1": B1, "b2": B2, "vb1": vb1, "vb2": vb2, "ve": ve.value, "h2": h2.value}
+    out["last"] = {"b1": lb1, "b2": lb2, "e": le, "mu": float(ls[0]), "ve": float(ls[1])}
+    return out
+
+
 def bag_rows(seed, it, n, k, rp=False):
     use = np.zeros(k, np.int32)
     rc = lib().oracle_bag_rows_w(C.c_uint64(seed), C.c_uint32(it), C.c_int64(n), C.c_int64(k), C.c_int(int(rp)), use.ctypes.data_as(C.POINTER(C.c_int)))

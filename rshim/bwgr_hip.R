@@ -16,6 +16,12 @@ BayesL   <- function(y, X, it = 1500, bi = 500, df = 5, R2 = 0.5) .bwgr_fused(3L
 BayesRR  <- function(y, X, it = 1500, bi = 500, df = 5, R2 = 0.5) .bwgr_fused(4L, y, X, it, bi, 0, df, R2)
 BayesCpi <- function(y, X, it = 1500, bi = 500, df = 5, R2 = 0.5) .bwgr_fused(5L, y, X, it, bi, 0, df, R2)
 BayesDpi <- function(y, X, it = 1500, bi = 500, df = 5, R2 = 0.5) .bwgr_fused(6L, y, X, it, bi, 0, df, R2)
+# two-effect samplers, R/RcppExports.R (BayesA2, BayesB2, BayesRR2): the two panels must share the slab geometry, so the
+# second is staged with the first one's workgroup count
+.bwgr_fused2 <- function(model, y, X1, X2, it, bi, pi, df, R2) .Call("bwgrhip_Bayes2", as.integer(model), as.double(y), .bwgr_panel(X1), .bwgr_panel(X2), as.double(it), as.double(bi), as.double(pi), as.double(df), as.double(R2))
+BayesA2  <- function(y, X1, X2, it = 1500, bi = 500, df = 5, R2 = 0.5) .bwgr_fused2(0L, y, X1, X2, it, bi, 0, df, R2)
+BayesB2  <- function(y, X1, X2, it = 1500, bi = 500, pi = 0.95, df = 5, R2 = 0.5) .bwgr_fused2(1L, y, X1, X2, it, bi, pi, df, R2)
+BayesRR2 <- function(y, X1, X2, it = 1500, bi = 500, df = 5, R2 = 0.5) .bwgr_fused2(4L, y, X1, X2, it, bi, 0, df, R2)
 
 wgr <- function(y, X, it = 1500, bi = 500, th = 1, bag = 1, rp = FALSE, iv = FALSE, de = FALSE, pi = 0, df = 5, R2 = 0.5,
                 eigK = NULL, VarK = 0.95, verb = FALSE) {

@@ -137,6 +137,40 @@ SEXP bwgrhip_Bayes(SEXP model, SEXP y, SEXP panel, SEXP it, SEXP bi, SEXP pi, SE
   return out;
 }
 
+/* BayesA2 / BayesB2 / BayesRR2(y,X1,X2,it,bi,[pi,]df,R2)  src/Rcpp20260726ai.cpp:990-1218; return lists :1054-1057,
+ * :1146-1149, :1216-1219 (names and order kept) */
+SEXP bwgrhip_Bayes2(SEXP model, SEXP y, SEXP panel1, SEXP panel2, SEXP it, SEXP bi, SEXP pi, SEXP df, SEXP R2) {
+  bwgr_panel *P1 = panel_of(panel1), *P2 = panel_of(panel2);
+  int64_t i1[8], i2[8]; chk(bwgr_panel_info(P1, i1)); chk(bwgr_panel_info(P2, i2));
+  const R_xlen_t n = i1[0], p1 = i1[1], p2 = i2[1];
+  const int m = Rf_asInteger(model);
+  if (XLENGTH(y) != n || i2[0] != i1[0]) Rf_error("length(y), nrow(X1) and nrow(X2) must agree");
+  const int per = (m != BWGR_BAYESRR);
+  float *fy = to_float(y, n);
+  float *B1 = (float *)R_alloc(p1, 4), *D1 = (float *)R_alloc(p1, 4), *V1 = (float *)R_alloc(per ? p1 : 1, 4);
+  float *B2 = (float *)R_alloc(p2, 4), *D2 = (float *)R_alloc(p2, 4), *V2 = (float *)R_alloc(per ? p2 : 1, 4), *hat = (float *)R_alloc(n, 4);
+  float mu, ve, h2;
+  chk(bwgr_bayes2(P1, P2, m, fy, (float)Rf_asReal(it), (float)Rf_asReal(bi), (float)Rf_asReal(pi), (float)Rf_asReal(df), (float)Rf_asReal(R2),
+                  seed_from_R(), BWGR_RNG_PHILOX, &mu, B1, D1, V1, B2, D2, V2, &ve, hat, &h2));
+  SEXP out;
+  if (m == BWGR_BAYESB) {
+    const char *nm[] = {"mu", "b1", "d1", "vb1", "b2", "d2", "vb2", "ve", "hat", "h2"};
+    out = PROTECT(named_list(10, nm));
+    SET_VECTOR_ELT(out, 0, Rf_ScalarReal(mu)); SET_VECTOR_ELT(out, 1, from_float(B1, p1)); SET_VECTOR_ELT(out, 2, from_float(D1, p1));
+    SET_VECTOR_ELT(out, 3, from_float(V1, p1)); SET_VECTOR_ELT(out, 4, from_float(B2, p2)); SET_VECTOR_ELT(out, 5, from_float(D2, p2));
+    SET_VECTOR_ELT(out, 6, from_float(V2, p2)); SET_VECTOR_ELT(out, 7, Rf_ScalarReal(ve)); SET_VECTOR_ELT(out, 8, from_float(hat, n));
+    SET_VECTOR_ELT(out, 9, Rf_ScalarReal(h2));
+  } else {
+    const char *nm[] = {"hat", "mu", "b1", "b2", "vb1", "vb2", "ve", "h2"};
+    out = PROTECT(named_list(8, nm));
+    SET_VECTOR_ELT(out, 0, from_float(hat, n)); SET_VECTOR_ELT(out, 1, Rf_ScalarReal(mu)); SET_VECTOR_ELT(out, 2, from_float(B1, p1));
+    SET_VECTOR_ELT(out, 3, from_float(B2, p2)); SET_VECTOR_ELT(out, 4, from_float(V1, per ? p1 : 1)); SET_VECTOR_ELT(out, 5, from_float(V2, per ? p2 : 1));
+    SET_VECTOR_ELT(out, 6, Rf_ScalarReal(ve)); SET_VECTOR_ELT(out, 7, Rf_ScalarReal(h2));
+  }
+  UNPROTECT(1);
+  return out;
+}
+
 /* wgr(y,X,it,bi,th,bag=1,rp=FALSE,iv,de,pi,df,R2,eigK=NULL)    R/wgr.R:2-169 -> list(mu,b,Vb,d,Ve,hat,cxx), :155-168 */
 SEXP bwgrhip_wgr(SEXP y, SEXP panel, SEXP it, SEXP bi, SEXP th, SEXP iv, SEXP de, SEXP pi, SEXP df, SEXP R2, SEXP U, SEXP V, SEXP bag, SEXP rp) {
   bwgr_panel *P = panel_of(panel);
@@ -171,7 +205,8 @@ SEXP bwgrhip_wgr(SEXP y, SEXP panel, SEXP it, SEXP bi, SEXP th, SEXP iv, SEXP de
 
 static const R_CallMethodDef CallEntries[] = {   /* as src/RcppExports.cpp:1152-1228 registers _bWGR_* */
   {"bwgrhip_panel", (DL_FUNC)&bwgrhip_panel, 2}, {"bwgrhip_KMUP", (DL_FUNC)&bwgrhip_KMUP, 9},
-  {"bwgrhip_Bayes", (DL_FUNC)&bwgrhip_Bayes, 8}, {"bwgrhip_wgr", (DL_FUNC)&bwgrhip_wgr, 14}, {NULL, NULL, 0}};
+  {"bwgrhip_Bayes", (DL_FUNC)&bwgrhip_Bayes, 8}, {"bwgrhip_Bayes2", (DL_FUNC)&bwgrhip_Bayes2, 9},
+  {"bwgrhip_wgr", (DL_FUNC)&bwgrhip_wgr, 14}, {NULL, NULL, 0}};
 
 void R_init_bwgrhip(DllInfo *dll) {              /* as R_init_bWGR, src/RcppExports.cpp:1230-1233 */
   R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);

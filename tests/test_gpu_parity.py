@@ -296,3 +296,62 @@ def test_wgr_bagging_tpod(tpod, kw):
     assert scaled_err(g["b"], o["b"]) < TOL and scaled_err(g["hat"], o["hat"]) < TOL
     assert _rel(g["Ve"], o["Ve"]) < TOL and _rel(g["mu"], o["mu"]) < TOL and _rel(g["cxx"], o["cxx"]) < 1e-12
     assert scaled_err(np.atleast_1d(g["Vb"]), np.atleast_1d(o["Vb"])) < 5 * TOL and scaled_err(g["d"], o["d"]) < 1e-12
+
+
+@pytest.mark.parametrize("model", ["BayesA2", "BayesB2", "BayesRR2"])
+def test_two_effect_samplers(model):
+    """BayesA2 / BayesB2 / BayesRR2 (src/Rcpp20260726ai.cpp:990-1218): two resident panels sharing one residual, swept one
+    after the other each iteration; an int8 panel and an fp32 panel, several blocks each."""
+    import bwgr_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    n, p1, p2 = 600, 300, 90
+    X1 = rng.binomial(2, 0.3, size=(n, p1)).astype(np.float32)
+    X2 = rng.normal(size=(n, p2)).astype(np.float32)
+    y = (X1[:, :5] @ np.array([1.0, -0.8, 0.6, 0.5, -0.4]) + 0.7 * X2[:, 0] + rng.normal(size=n)).astype(np.float32)
+    kw = dict(it=30, bi=5, seed=21)
+    if model == "BayesB2":
+        kw["pi"] = 0.7
+    g = getattr(bwgr_amd, model)(y, X1, X2, block=64, **kw)
+    o = O.bayes2(model, y, X1, X2, **kw)
+    assert list(g.keys()) == [k for k in o.keys() if k != "last"]
+    for k in ("b1", "b2", "hat"):
+        assert scaled_err(g[k], o[k]) < TOL, k
+    for k in ("mu", "ve", "h2"):
+        assert abs(g[k] - o[k]) <= TOL * max(1.0, abs(o[k])), k
+    if model == "BayesRR2":
+        assert abs(g["vb1"] - o["vb1"]) <= TOL * abs(o["vb1"]) and abs(g["vb2"] - o["vb2"]) <= TOL * abs(o["vb2"])
+    else:
+        assert scaled_err(g["vb1"], o["vb1"]) < TOL and scaled_err(g["vb2"], o["vb2"]) < TOL
+    if model == "BayesB2":
+        assert scaled_err(g["d1"], o["d1"]) < TOL and scaled_err(g["d2"], o["d2"]) < TOL
+
+
+def test_mcmccv_matches_a_checker_built_on_the_oracle(tpod):
+    """mcmcCV (R/cv.R:113-216): same folds, same seven fits per fold, same correlations as a checker that runs the CPU
+    restatement of every sampler on the fold's training rows."""
+    import bwgr_amd
+    from oracle import oracle as O
+    from bwgr_amd.api import _CV_FITS, _CV_NAMES, _cor_last
+    gen, y = tpod["gen"].astype(np.float32), tpod["y"].astype(np.float64)
+    kw = dict(k=4, n=2, it=25, bi=5, pi=0.8, seed=77)
+    g = bwgr_amd.mcmcCV(y, gen, ReturnGebv=True, **kw)
+    N, p = gen.shape
+    Ms, Bs = [], []
+    for c in range(2):
+        w = O.bag_rows(77, c + 1, N, int(round(N / 4)))
+        assert np.array_equal(w, bwgr_amd.sample_rows(77, c + 1, N, int(round(N / 4))))
+        keep = np.ones(N, bool); keep[w] = False
+        B = np.zeros((p, 7))
+        for i, model in enumerate(_CV_FITS):
+            mk = {"pi": 0.8} if model in ("BayesB", "BayesC") else {}
+            B[:, i] = O.bayes(model, y[keep].astype(np.float32), gen[keep], it=25, bi=5, seed=77 + 1000003 * (c + 1) + i, **mk)["b"]
+        M = np.empty((len(w), 8)); M[:, :7] = gen[w].astype(np.float64) @ B; M[:, 7] = y[w]
+        Ms.append(M); Bs.append(B)
+    beta = sum(Bs) / 2
+    assert scaled_err(g["beta"], beta) < TOL
+    assert scaled_err(g["hat"], gen.astype(np.float64) @ beta + y.mean()) < TOL
+    pa = _cor_last(np.vstack(Ms))
+    assert list(g["cv"].values()) == sorted(g["cv"].values(), reverse=True)
+    for i, nm in enumerate(_CV_NAMES):
+        assert abs(g["cv"][nm] - round(float(pa[i]), 4)) <= 1.01e-4

@@ -128,3 +128,21 @@ def test_wgr_oracle_fits_tpod(tpod):
     assert abs(r["cxx"] - 379.128) < 1e-3 and np.all(r["d"] == 1)
     rb = O.wgr(y, X, it=300, bi=100, iv=True, pi=0.5, seed=2)
     assert 0.2 < rb["d"].mean() < 0.9 and np.corrcoef(y, rb["hat"])[0, 1] > 0.5
+
+
+@pytest.mark.parametrize("model", ["BayesA2", "BayesB2", "BayesRR2"])
+def test_two_effect_residual_identity_and_flavours(tpod, model):
+    """e == y - mu - X1 b1 - X2 b2 after the last iteration (src/Rcpp20260726ai.cpp:1025-1043), and the float-faithful
+    and wide restatements agree to float round-off."""
+    X, y = tpod["gen"].astype(np.float32), tpod["y"].astype(np.float32)
+    X1, X2 = X[:, :250], X[:, 250:]
+    kw = dict(it=12, bi=3, seed=4)
+    if model == "BayesB2":
+        kw["pi"] = 0.8
+    w = O.bayes2(model, y, X1, X2, **kw)
+    f = O.bayes2(model, y, X1, X2, flavour="f", **kw)
+    L = w["last"]
+    e = y.astype(np.float64) - L["mu"] - X1.astype(np.float64) @ L["b1"] - X2.astype(np.float64) @ L["b2"]
+    assert np.abs(e - L["e"]).max() < 2e-4 * np.abs(y).max()
+    assert np.abs(w["b1"] - f["b1"]).max() < 1e-3 * np.abs(w["b1"]).max() + 1e-6
+    assert 0.0 < w["h2"] < 1.0 and w["ve"] > 0
