@@ -738,8 +738,9 @@ struct bwgr_panel {
   int is_f32 = 0;
   int m = 0, K = 0, R = 0;
   int64_t nblocks = 0;
-  void *X = nullptr, *gram = nullptr, *gramx = nullptr, *gramx2 = nullptr, *gramp = nullptr;
-  double *xspec2 = nullptr;   // [nblocks][SW_MAXM]: lag-3 speculative cross term (k_spec)
+  void *X = nullptr, *gram = nullptr, *gramx = nullptr, *gramx2 = nullptr, *gramx3 = nullptr, *gramp = nullptr;
+  double *xspec2 = nullptr, *xspec3 = nullptr;   // [nblocks][SW_MAXM]: speculative cross terms of the lag-3 / lag-4 pipelines (k_spec)
+  bool lag4_ok = false;       // the lag-4 streamer (ring of four tiles) fits the LDS at this geometry
   uint16_t *gramp16 = nullptr, *gramx16 = nullptr;   // 16-bit copies for the sequencer (int8 panels)
   int *gram16_bad = nullptr;
   bool gram16 = false;        // the copies are exact: every entry in 0..65535
@@ -833,7 +834,7 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a) {
                                 // compute-bound and measured faster on the 32-bit blocks: no conversion in its inner loop)
         SweepArgs a16 = a;
         a16.gramp = P->gramp16; a16.gramx = P->gramx16;
-        hipLaunchKernelGGL((k_sweep2<int8_t, true, uint16_t>), dim3(P->K + 2), blk, P->lds2_bytes, P->stream, a16);
+        hipLaunchKernelGGL((k_sweep2<int8_t, true, uint16_t>), dim3(P->K + 1 + S2_NFEED), blk, P->lds2_bytes, P->stream, a16);   // + the q feeders
       } else if (sel) hipLaunchKernelGGL((k_sweep2<int8_t, true>), grid, blk, P->lds2_bytes, P->stream, a);
       else hipLaunchKernelGGL((k_sweep2<int8_t, false>), grid, blk, P->lds2_bytes, P->stream, a);
     }
@@ -848,10 +849,18 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a) {
   }
 }
 
-// selection models run the deeper pipeline (their cross terms are sparse); BWGR_LAG=2 forces the shallow one (A/B tests)
+// selection models run the deeper pipelines (their cross terms are sparse); BWGR_LAG=2|3 caps the depth (A/B tests)
 static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
   const char *lv = getenv("BWGR_LAG");
-  a.lag = (P->sweep_version == 2 && !P->is_f32 && (a.flags & SWF_SELECT) && P->gramx2 && !(lv && lv[0] == '2')) ? 3 : 2;
+  // depth 3 by default: at depth 4 (BWGR_LAG=4 when the panel is created and run; one more 4*p*m-byte Gram array, one
+  // output array instead of two in the streamers) the three stages are balanced and nothing is gained (measured: 40.4 vs 42.1 iter/s at C4)
+  const int cap = (lv && lv[0] >= '2' && lv[0] <= '4') ? lv[0] - '0' : 3;
+  int lag = 2;
+  if (P->sweep_version == 2 && !P->is_f32 && (a.flags & SWF_SELECT)) {
+    if (P->gramx2) lag = 3;
+    if (P->gramx3 && P->gram16 && P->lag4_ok) lag = 4;   // only the 16-bit / single-barrier sequencer knows the third cross term
+  }
+  a.lag = lag < cap ? lag : cap;
 }
 static int launch_sweep(bwgr_panel *P, SweepArgs &a) {
   choose_lag(P, a);
@@ -867,7 +876,7 @@ static void fill_panel_args(const bwgr_panel *P, SweepArgs &a) {
   a.n = (int)P->n; a.p = (int)P->p; a.m = P->m; a.K = P->K; a.R = P->R;
   a.blk_begin = 0; a.blk_end = (int)P->nblocks;
   a.xpart = P->xpart; a.xflags = P->xflags; a.stamps = P->stamps; a.ps = P->ps;
-  a.gramx = P->gramx; a.gramx2 = P->gramx2; a.xspec2 = P->xspec2; a.lag = 2; a.gramp = P->gramp; a.pstride = P->pstride; a.qpart = P->qpart; a.dgran = P->dgran;
+  a.gramx = P->gramx; a.gramx2 = P->gramx2; a.xspec2 = P->xspec2; a.gramx3 = P->gramx3; a.xspec3 = P->xspec3; a.lag = 2; a.gramp = P->gramp; a.pstride = P->pstride; a.qpart = P->qpart; a.dgran = P->dgran;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -905,7 +914,7 @@ static int upload(bwgr_panel *P, const void *X, int memloc, int64_t ldx) {
 extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   if (!P) return BWGR_OK;
   (void)hipSetDevice(P->device);
-  hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->xspec2); hipFree(P->gramp16); hipFree(P->gramx16); hipFree(P->gram16_bad); hipFree(P->gramp); hipFree(P->ps.spec); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev); hipFree(P->xpart); hipFree(P->qpart); hipFree(P->dgran); hipFree(P->xflags);
+  hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->xspec2); hipFree(P->gramx3); hipFree(P->xspec3); hipFree(P->gramp16); hipFree(P->gramx16); hipFree(P->gram16_bad); hipFree(P->gramp); hipFree(P->ps.spec); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev); hipFree(P->xpart); hipFree(P->qpart); hipFree(P->dgran); hipFree(P->xflags);
   hipFree(P->ps.blocks); hipFree(P->stamps);
   delete P;
   return BWGR_OK;
@@ -961,12 +970,12 @@ static int panel_build_gram(bwgr_panel *P) {
     }
   }
   HIPCHK(hipGetLastError());
-  for (int dist = 1; dist <= 2; ++dist) {   // off-diagonal blocks (blk-dist, blk): the lag-2 / lag-3 pipelines' cross terms
-    if (P->nblocks <= dist || (dist == 2 && !P->gramx2)) continue;
+  for (int dist = 1; dist <= 3; ++dist) {   // off-diagonal blocks (blk-dist, blk): the cross terms of the lag-2 / 3 / 4 pipelines
+    if (P->nblocks <= dist || (dist == 2 && !P->gramx2) || (dist == 3 && !P->gramx3)) continue;
     const unsigned nbx = (unsigned)(P->nblocks - dist);
     if (P->is_f32) {
       const size_t lds = (size_t)2 * m * 65 * sizeof(float);
-      double *g = (double *)(dist == 1 ? P->gramx : P->gramx2); const float *X = (const float *)P->X;
+      double *g = (double *)(dist == 1 ? P->gramx : dist == 2 ? P->gramx2 : P->gramx3); const float *X = (const float *)P->X;
       switch (TJ) {
         case 1: hipLaunchKernelGGL(k_gramx_f32<1>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
         case 2: hipLaunchKernelGGL(k_gramx_f32<2>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
@@ -975,7 +984,7 @@ static int panel_build_gram(bwgr_panel *P) {
       }
     } else {
       const size_t lds = (size_t)2 * m * 33 * sizeof(int32_t);
-      int32_t *g = (int32_t *)(dist == 1 ? P->gramx : P->gramx2); const int8_t *X = (const int8_t *)P->X;
+      int32_t *g = (int32_t *)(dist == 1 ? P->gramx : dist == 2 ? P->gramx2 : P->gramx3); const int8_t *X = (const int8_t *)P->X;
       switch (TJ) {
         case 1: hipLaunchKernelGGL(k_gramx_i8<1>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
         case 2: hipLaunchKernelGGL(k_gramx_i8<2>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
@@ -1034,10 +1043,14 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   P->nblocks = (p + m - 1) / m;
   P->lds_bytes = P->is_f32 ? sweep_lds_bytes<float>(m, R) : sweep_lds_bytes<int8_t>(m, R);
   P->lds2_bytes = P->is_f32 ? sweep2_lds_bytes<float>(m, R) : sweep2_lds_bytes<int8_t>(m, R);
+  if (!P->is_f32 && s2i_lds_bytes(m, R, 4) <= (size_t)160 * 1024) {
+    P->lag4_ok = true;
+    P->lds2_bytes = std::max(P->lds2_bytes, s2i_lds_bytes(m, R, 4));
+  }
   {
     const char *sv = getenv("BWGR_SWEEP");   // A/B switch for tests and profiling
     P->sweep_version = (sv && sv[0] == '1') ? 1 : 2;
-    if (P->lds2_bytes > (size_t)160 * 1024 || K + 2 > 256) P->sweep_version = 1;
+    if (P->lds2_bytes > (size_t)160 * 1024 || K + 1 + S2_NFEED > 256) P->sweep_version = 1;
   }
   P->x_bytes = (size_t)P->ld * (size_t)p * (P->is_f32 ? 4 : 1);
   P->gram_bytes = (size_t)P->nblocks * m * m * (P->is_f32 ? 8 : 4);   // per Gram array (diagonal blocks; off-diagonal blocks)
@@ -1050,6 +1063,11 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   if (P->sweep_version == 2 && P->nblocks > 2) {   // distance-2 blocks: the selection models' lag-3 pipeline
     PCHK(hipMalloc(&P->gramx2, P->gram_bytes));
     PCHK(hipMalloc(&P->xspec2, sizeof(double) * (size_t)P->nblocks * SW_MAXM));
+  }
+  const char *lagenv = getenv("BWGR_LAG");
+  if (P->sweep_version == 2 && !P->is_f32 && P->nblocks > 3 && P->lag4_ok && lagenv && lagenv[0] == '4') {   // distance-3 blocks: the (opt-in) lag-4 pipeline
+    PCHK(hipMalloc(&P->gramx3, P->gram_bytes));
+    PCHK(hipMalloc(&P->xspec3, sizeof(double) * (size_t)P->nblocks * SW_MAXM));
   }
   P->pstride = ((m * (m - 1) / 2 + 7) / 8) * 8;
   PCHK(hipMalloc(&P->gramp, (size_t)P->nblocks * std::max(P->pstride, 8) * (P->is_f32 ? 8 : 4)));

@@ -71,8 +71,10 @@ struct SweepArgs {
   const void *gram;             // [nblocks][m][m]  diagonal blocks X_b' X_b
   const void *gramx;            // [nblocks][m][m]  off-diagonal blocks X_{b-1}' X_b (entry 0 unused)
   const void *gramx2;           // [nblocks][m][m]  X_{b-2}' X_b (entries 0, 1 unused); null when the panel has < 3 blocks
-  double *xspec2;               // [nblocks][SW_MAXM]  sum_k gramx2_b[k][j] * drej_{b-2}[k] (k_spec, lag 3)
-  int lag;                      // k_sweep2: q_b is taken against e after delta_{b-lag}; 2, or 3 for selection models
+  double *xspec2;               // [nblocks][SW_MAXM]  sum_k gramx2_b[k][j] * drej_{b-2}[k] (k_spec, lag >= 3)
+  const void *gramx3;           // [nblocks][m][m]  X_{b-3}' X_b (lag 4; null otherwise)
+  double *xspec3;               // [nblocks][SW_MAXM]  sum_k gramx3_b[k][j] * drej_{b-3}[k] (k_spec, lag 4)
+  int lag;                      // k_sweep2: q_b is taken against e after delta_{b-lag}; 2, or 3 / 4 for selection models
   const void *gramp;            // [nblocks][pstride] strict upper triangle of the diagonal blocks, row k = entries (k, k+1..m-1)
   int pstride;
   int n, p, m, K, R;
@@ -235,16 +237,16 @@ __global__ __launch_bounds__(128) void k_spec(const SweepArgs a, int blk_begin, 
     }
   }
   sp.spec[j] = s; sp.xspec[j] = xs; sp.gjj[j] = gjj;
-  if (a.lag == 3) {   // second cross term of the lag-3 pipeline
+  for (int dist = 2; dist < a.lag; ++dist) {   // further cross terms of the deeper pipelines
     double xs2 = 0.0;
     __syncthreads();
-    drp[j] = (blk - 2 >= blk_begin) ? a.ps.blocks[blk - 2].drej[j] : 0.0f;
+    drp[j] = (blk - dist >= blk_begin) ? a.ps.blocks[blk - dist].drej[j] : 0.0f;
     __syncthreads();
-    if (j < mB && select && blk - 2 >= blk_begin) {
-      const GT *Gx2 = reinterpret_cast<const GT *>(a.gramx2) + (size_t)blk * m * m;
-      for (int k = 0; k < m; ++k) xs2 = fma((double)Gx2[(size_t)k * m + j], (double)drp[k], xs2);
+    if (j < mB && select && blk - dist >= blk_begin) {
+      const GT *Gxd = reinterpret_cast<const GT *>(dist == 2 ? a.gramx2 : a.gramx3) + (size_t)blk * m * m;
+      for (int k = 0; k < m; ++k) xs2 = fma((double)Gxd[(size_t)k * m + j], (double)drp[k], xs2);
     }
-    a.xspec2[(size_t)blk * SW_MAXM + j] = xs2;
+    (dist == 2 ? a.xspec2 : a.xspec3)[(size_t)blk * SW_MAXM + j] = xs2;
   }
 }
 

@@ -41,15 +41,16 @@ namespace bwgr {
 #define S2WALL_FLUSH_AT(base) do { } while (0)
 #endif
 
+static constexpr int S2_NFEED = 2;   // q feeder workgroups (selection / 16-bit path); feeder f serves the blocks b = f mod S2_NFEED
 static constexpr int S2_NSLOT = 4;   // ring depth of the q / delta buffers (2 would do; 4 keeps lines apart)
 
 template <typename XT> __host__ __device__ inline size_t s2_seq_lds_bytes(int m);
-__host__ __device__ inline size_t s2i_lds_bytes(int m, int R);
+__host__ __device__ inline size_t s2i_lds_bytes(int m, int R, int lag = 3);
 template <typename XT> __host__ __device__ inline size_t sweep2_lds_bytes(int m, int R) {
   size_t streamer = (size_t)3 * m * tile_rp<XT>(R) * sizeof(XT);
   streamer = (streamer + 15) & ~(size_t)15;
   streamer += (size_t)R * sizeof(double) + SW_MAXM * sizeof(double) + (size_t)(SW_THREADS / 64) * SW_MAXM * sizeof(double) + 64;
-  if (sizeof(XT) == 1) streamer = s2i_lds_bytes(m, R);
+  if (sizeof(XT) == 1) streamer = s2i_lds_bytes(m, R, 3);
   const size_t seq = s2_seq_lds_bytes<XT>(m);
   return streamer > seq ? streamer : seq;
 }
@@ -251,11 +252,11 @@ __device__ __forceinline__ void s2_streamer(const SweepArgs &a) {
 typedef int s2_v4i __attribute__((ext_vector_type(4)));
 static constexpr int S2_NDE = 7;     // digits of e:     |q| < 2^54
 static constexpr int S2_NDD = 6;     // digits of delta: |q| < 2^46
-static constexpr int S2_OS = 20;     // dwords per row of the int32 output array (8 used; 20 keeps its b128 reads conflict-free)
+static constexpr int S2_OS = 12;     // dwords per row of the int32 output array (8 used; 12 keeps its b128 reads conflict-free)
 static constexpr int S2_DP = SW_MAXM + 16;   // bytes per digit row of the delta digits
-__host__ __device__ inline size_t s2i_lds_bytes(int m, int R) {
+__host__ __device__ inline size_t s2i_lds_bytes(int m, int R, int lag) {   // ring of max(3, lag) tiles; lag 4 has room for one output array only
   const size_t Rp = (size_t)R + 16;
-  return 3 * (size_t)m * Rp + (size_t)R * 8 + 16 * Rp + 16 * S2_DP + 2 * (size_t)(R > SW_MAXM ? R : SW_MAXM) * S2_OS * 4 + 64;
+  return (size_t)(lag > 3 ? lag : 3) * m * Rp + (size_t)R * 8 + 16 * Rp + 16 * S2_DP + (size_t)(lag > 3 ? 1 : 2) * (R > SW_MAXM ? R : SW_MAXM) * S2_OS * 4 + 64;
 }
 __device__ __forceinline__ double pow2_field(int field) { return __hiloint2double(field << 20, 0); }   // 2^(field-1023)
 // maximum over the wave (DPP row shifts + row broadcasts, result broadcast from lane 63); v >= 0 as int
@@ -289,14 +290,17 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
   const int Rp = R + 16;                        // bytes per marker in an LDS tile, and per digit row of e
   const int row0 = wg * R;
   const int nb = a.blk_end - a.blk_begin;
+  const int L = a.lag;   // q_b is computed after delta_{b-L} has been applied (2..4): tiles i .. i+L-1 sit in a ring of max(3, L)
+  const int NR = L > 3 ? L : 3;
   const size_t tile_b = (size_t)m * Rp;
-#define S2I_TILE(i_) reinterpret_cast<int8_t *>(smem + (size_t)((i_) % 3) * tile_b)
-  size_t off = 3 * tile_b;
+#define S2I_TILE(i_) reinterpret_cast<int8_t *>(smem + (size_t)((i_) % NR) * tile_b)
+  size_t off = (size_t)NR * tile_b;
   double *e_s = reinterpret_cast<double *>(smem + off); off += (size_t)R * sizeof(double);
   int8_t *edig_s = reinterpret_cast<int8_t *>(smem + off); off += (size_t)16 * Rp;        // [n][row]: digit n of e[row]; rows n >= S2_NDE stay 0
   int8_t *ddig_s = reinterpret_cast<int8_t *>(smem + off); off += 16 * S2_DP;             // [n][marker]: digit n of delta[marker]
+  const bool ksplit = (L < 4);   // two output arrays: the update's 64-marker steps are split over two waves per 64-row group
   const size_t out_n = (size_t)(R > SW_MAXM ? R : SW_MAXM) * S2_OS;
-  int *out_s = reinterpret_cast<int *>(smem + off); off += 2 * out_n * 4;   // [half][row or marker][n]
+  int *out_s = reinterpret_cast<int *>(smem + off); off += (ksplit ? 2 : 1) * out_n * 4;   // [half][row or marker][n]
   uint32_t *ctl_s = reinterpret_cast<uint32_t *>(smem + off);   // [0],[1]: max exponent of delta (by block parity); [2],[3]: of e; [8]: failure
   const int8_t *X = reinterpret_cast<const int8_t *>(a.X) + (size_t)wg * a.p * R;
   uint32_t *abortw = a.xflags + (size_t)K * SW_FLAG_STRIDE;
@@ -307,7 +311,6 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
   for (int i = tid; i < 4 * Rp; i += SW_THREADS) reinterpret_cast<uint32_t *>(edig_s)[i] = 0u;
   for (int i = tid; i < 4 * S2_DP; i += SW_THREADS) reinterpret_cast<uint32_t *>(ddig_s)[i] = 0u;
   if (tid < 16) ctl_s[tid] = 0u;
-  const int L = a.lag;   // q_b is computed after delta_{b-L} has been applied (2 or 3): tiles i .. i+L-1 sit in the ring of 3
   for (int b = 0; b < L && b < nb; ++b) { S2_TILE_ISSUE(blk_j0(b), blk_m(b)); S2_TILE_COMMIT(S2I_TILE(b), blk_m(b)); }
   if (nb > L) S2_TILE_ISSUE(blk_j0(L), blk_m(L));
   __syncthreads();
@@ -345,8 +348,8 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
       w *= 256.0; v = fma((double)o1.x, w, v); w *= 256.0; v = fma((double)o1.y, w, v); w *= 256.0; v = fma((double)o1.z, w, v);
       s2_put_q(a.qpart + ((size_t)(b % S2_NSLOT) * K + wg) * SW_MAXM + tid, v, b);
     }
-    S2WALL(2, wg == 0 && tid == 0 && b >= 3);
-    S2WALL(6, wg == 0 && tid == 0 && b == 103);
+    S2WALL(2, wg == 0 && tid == 0 && b >= a.lag);
+    S2WALL(6, wg == 0 && tid == 0 && b == 100 + a.lag);
   };
   static_assert(S2_NDE == 7 && S2_NDD == 6, "the digit recombinations are written out for 7 / 6 digits");
 
@@ -389,7 +392,7 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     }
     if (bad) ctl_s[8] = 1u;
     __syncthreads();
-    S2WALL(1, wg == 0 && tid == 0 && i + 3 < nb);
+    S2WALL(1, wg == 0 && tid == 0 && i + L < nb);
     S2WALL(4, wg == 0 && tid == 0 && i == 100);
     S2WALL(5, wg == 0 && tid == 0 && i == 101);
     if (ctl_s[8]) { if (tid == 0) a.sc->error = 1u; return; }
@@ -405,13 +408,14 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     // markers 64 s + 16 u + 4 grp + q (this interleave keeps the four lane groups on different LDS banks)
     {
       const int8_t *tile = S2I_TILE(i);
-      // tasks: (64-row group rg, half of the block's 64-marker steps); the halves' partial sums are added by the reader
-      const int nrg = R / 64;
-      for (int task = wave; task < 2 * nrg; task += SW_THREADS / 64) {
+      // tasks: (64-row group rg, half): with two output arrays the block's 64-marker steps are dealt to two waves and the
+      // reader adds the halves; with one array (lag 4) a wave runs all steps of its row group
+      const int nrg = R / 64, nhalf = ksplit ? 2 : 1;
+      for (int task = wave; task < nhalf * nrg; task += SW_THREADS / 64) {
         const int half = task / nrg, rg = task - half * nrg;
         const int rowoff = 4 * (16 * rg + m16);
         s2_v4i acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-        for (int s0 = 64 * half; s0 < mB; s0 += 128) {
+        for (int s0 = 64 * half; s0 < mB; s0 += 64 * nhalf) {
           // c[u][q]: rows rowoff..+3 of marker s0 + 16u + 4grp + q.  For m % 64 != 0 the last step reads up to 48 markers
           // past the tile: still inside this workgroup's LDS (the arrays behind the tiles are larger), and those k slots
           // meet zero digits (delta digits are written for all SW_MAXM markers of every block).
@@ -464,9 +468,11 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
       for (int r = tid; r < R; r += SW_THREADS) {
         int4 o0 = *reinterpret_cast<const int4 *>(out_s + (size_t)r * S2_OS);
         int2 o1 = *reinterpret_cast<const int2 *>(out_s + (size_t)r * S2_OS + 4);
-        const int4 p0 = *reinterpret_cast<const int4 *>(out_s + out_n + (size_t)r * S2_OS);
-        const int2 p1 = *reinterpret_cast<const int2 *>(out_s + out_n + (size_t)r * S2_OS + 4);
-        o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w; o1.x += p1.x; o1.y += p1.y;
+        if (ksplit) {
+          const int4 p0 = *reinterpret_cast<const int4 *>(out_s + out_n + (size_t)r * S2_OS);
+          const int2 p1 = *reinterpret_cast<const int2 *>(out_s + out_n + (size_t)r * S2_OS + 4);
+          o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w; o1.x += p1.x; o1.y += p1.y;
+        }
         double w = invSd, v = (double)o0.x * w;
         w *= 256.0; v = fma((double)o0.y, w, v); w *= 256.0; v = fma((double)o0.z, w, v); w *= 256.0; v = fma((double)o0.w, w, v);
         w *= 256.0; v = fma((double)o1.x, w, v); w *= 256.0; v = fma((double)o1.y, w, v);
@@ -907,11 +913,11 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
 
 
 
-// q feeder (selection models, 16-bit Gram path): its own workgroup, hence its own CU's memory path.  Gathers the K
+// q feeders (selection models, 16-bit Gram path): S2_NFEED workgroups of their own, hence their own CUs' memory paths.  Gathers the K
 // streamers' slab dots of each block (the 40 KB of write-through words per block that otherwise go through the
 // sequencer's CU, whose ingest is what bounds the chain), sums them in the fixed order and hands the sequencer one
 // tagged word per marker.  Costs one more hop on a path that the lag-3 pipeline keeps off the critical cycle.
-__device__ __forceinline__ void s2_feeder(const SweepArgs &a) {
+__device__ __forceinline__ void s2_feeder(const SweepArgs &a, int f) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6;
   const int m = a.m, nb = a.blk_end - a.blk_begin;
@@ -921,7 +927,7 @@ __device__ __forceinline__ void s2_feeder(const SweepArgs &a) {
   S2WALL_DECL;
   if (tid == 0) ok_s[0] = 1;
   __syncthreads();
-  for (int b = 0; b < nb; ++b) {
+  for (int b = f; b < nb; b += S2_NFEED) {   // one gather + sum takes about a block period: the feeders take turns
     const int mB = min(m, a.p - (a.blk_begin + b) * m);
     if (wave >= 1 && wave <= 6) {
       if (!s2_gather_q(a, b, (tid - 64) >> 7, (tid - 64) & 127, mB, part_s)) ok_s[0] = 0;
@@ -929,8 +935,8 @@ __device__ __forceinline__ void s2_feeder(const SweepArgs &a) {
     __syncthreads();
     if (ok_s[0] == 0) return;   // the abort word is set; the sequencer reports the error
     if (tid < mB) s2_put_q(qsum + (size_t)(b % S2_NSLOT) * SW_MAXM + tid, (part_s[tid] + part_s[SW_MAXM + tid]) + part_s[2 * SW_MAXM + tid], b);
-    S2WALL(3, tid == 0 && b >= 3);
-    S2WALL(13, tid == 0 && b == 103);
+    S2WALL(3, tid == 0 && b >= a.lag);
+    S2WALL(13, tid == 0 && b == 100 + a.lag);
     __syncthreads();
   }
   S2WALL_FLUSH;
@@ -954,7 +960,7 @@ __host__ __device__ inline size_t s2_seq16_lds_bytes(int m) {
   s += (size_t)2 * SW_MAXM * sizeof(double);                           // sum_w q [parity]
   s += (size_t)2 * 3 * SW_MAXM * sizeof(float);                        // state of a block [parity]
   s += (size_t)2 * SW_MAXM * sizeof(double);                           // lag-3 cross term [parity]
-  s += (size_t)2 * SW_MAXM * (sizeof(double) + sizeof(int));           // accepted lists [parity]
+  s += (size_t)4 * SW_MAXM * (sizeof(double) + sizeof(int));           // accepted lists, ring of four blocks
   return s + 64;
 }
 __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
@@ -973,9 +979,11 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
   double *qs2 = reinterpret_cast<double *>(smem + off); off += (size_t)2 * SW_MAXM * sizeof(double);       // sum_w q [parity]
   float *state2 = reinterpret_cast<float *>(smem + off); off += (size_t)2 * 3 * SW_MAXM * sizeof(float);   // b, d, vb of a block [parity]
   double *carry2 = reinterpret_cast<double *>(smem + off); off += (size_t)2 * SW_MAXM * sizeof(double);
-  double *acc_corr2 = reinterpret_cast<double *>(smem + off); off += (size_t)2 * SW_MAXM * sizeof(double);
-  int *acc_k2 = reinterpret_cast<int *>(smem + off); off += (size_t)2 * SW_MAXM * sizeof(int);
-  int *ctrl_s = reinterpret_cast<int *>(smem + off);   // [0] ok flag, [2], [3] number of accepted markers (by block parity)
+  // what the accepted markers of a block changed beyond the speculated step: ring of four blocks (block b's list serves
+  // r0_{b+1} from wave 0's registers and, through these lists, the cross terms of blocks b+2 and b+3)
+  double *acc_corr2 = reinterpret_cast<double *>(smem + off); off += (size_t)4 * SW_MAXM * sizeof(double);
+  int *acc_k2 = reinterpret_cast<int *>(smem + off); off += (size_t)4 * SW_MAXM * sizeof(int);
+  int *ctrl_s = reinterpret_cast<int *>(smem + off);   // [0] ok flag, [4 + (b & 3)] number of accepted markers of block b
 #define Q16_GP(i_) (gp_base + (size_t)((i_) & 1) * gp_elems)
 #define Q16_GX(i_) (gx_base + (size_t)((i_) & 1) * m * m)
 #define Q16_QS(i_) (qs2 + (size_t)((i_) & 1) * SW_MAXM)
@@ -984,7 +992,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
   const GT *gramx = reinterpret_cast<const GT *>(a.gramx);
   const float Cc = a.sc->C, odds = a.sc->odds, one_minus_pi = 1.0f - a.sc->pi, Sb = a.sc->Sb;
   const int pchunks = pstride / GPT, xchunks = m * m / GPT;
-  const bool lag3 = (a.lag == 3);
+  const int L = a.lag;
   auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
   auto prow = [&](int k) { return k * (m - 1) - k * (k - 1) / 2; };   // offset of packed row k
   constexpr int NCH = (int)(sizeof(StageBuf) / 16), NSP = (int)(sizeof(SpecBuf) / 16);
@@ -1048,7 +1056,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
 #define S16_XST_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < XSURE || c_ < xchunks) xdst[c_] = name; }
   auto helper_phase = [&](int c) {
     const int blk = a.blk_begin + c, mBc = blk_m(c);
-    S2ONE(10, tid == 64 && c == 103); S2ONE(13, tid == 448 && c == 103);
+    S2ONE(10, tid == 64 && c == 100 + L); S2ONE(13, tid == 448 && c == 100 + L);
     if (wave <= 6) {
       // waves 1-6: block c's packed G, Gx and constants, in registers since the previous phase, go to LDS; block c+1's are
       // requested and have a whole period to land.  (Register staging moves ~60 GB/s through this CU, LDS-DMA only ~25.)
@@ -1058,7 +1066,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       if (fullm) { S16_G_EACH(S16_GST_F) S16_X_EACH(S16_XST_F) } else { S16_G_EACH(S16_GST) S16_X_EACH(S16_XST) }
       if (tid - 64 < NCH) reinterpret_cast<uint4 *>(&stage[c & 1])[tid - 64] = spre;
       if (tid - 64 < NSP) reinterpret_cast<uint4 *>(&specb[c & 1])[tid - 64] = cpre;
-      S2ONE(11, tid == 64 && c == 103);
+      S2ONE(11, tid == 64 && c == 100 + L);
       if (c + 1 < nb) {
         const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(blk + 1) * pstride);
         const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(blk + 1) * m * m);
@@ -1066,46 +1074,57 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
         if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 1)[tid - 64];
         if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + blk + 1)[tid - 64];
       }
-      S2ONE(12, tid == 64 && c == 103);
+      S2ONE(12, tid == 64 && c == 100 + L);
     } else {
-      // wave 7 holds no prefetch: the feeder's sums first (nothing of its own in front of the poll)
-      if (!poll_qsum(c, mBc)) ctrl_s[0] = 0;
-      S2WALL(10, tid == 448 && c >= 3);
-      S2WALL(14, tid == 448 && c == 103);
-      S2ONE(14, tid == 448 && c == 103);
+      // wave 7 holds no prefetch.  Its cross-term loads go out first (they depend on nothing of this phase and are ahead of
+      // waves 1-6's prefetch in this CU's queue), then the feeder's sums are polled, then the cross term is finished.
       // wave 7: block c-2's state (left in LDS by wave 0, which issues no global memory operation but the delta granules)
-      // block c's cross term with block c-2 = speculated part (k_spec) + the rows of Gx2_c that block c-2's accepted
-      // markers touch, straight from global memory (that list has been final since the barrier of block c-2)
+      // block c's cross terms with blocks c-2 .. c-L+1 = speculated parts (k_spec) + the rows of Gx2_c / Gx3_c that those
+      // blocks' accepted markers touch, straight from global memory (the lists have been final since their barriers).
+      // Every load unconditional (clamped indices) and issued before the first use: one round trip per 8 accepted markers.
       double *dst = carry2 + (size_t)(c & 1) * SW_MAXM;
-      const int *pk = acc_k2 + (size_t)(c & 1) * SW_MAXM;
-      const double *pc2 = acc_corr2 + (size_t)(c & 1) * SW_MAXM;
-      const bool on = lag3 && c >= 2;
-      const int npre = on ? ctrl_s[2 + (c & 1)] : 0;
-      const int32_t *gx2 = reinterpret_cast<const int32_t *>(a.gramx2) + (size_t)blk * m * m;
-      // every load unconditional (clamped indices) and issued before the first use: one round trip per 8 accepted markers
       const int ja = min(lane, m - 1), jb = min(64 + lane, m - 1);
+      const bool on2 = (L > 2 && c >= 2), on3 = (L > 3 && c >= 3);
+      const int n2 = on2 ? ctrl_s[4 + ((c - 2) & 3)] : 0, n3 = on3 ? ctrl_s[4 + ((c - 3) & 3)] : 0, ntot = n2 + n3;
+      const int *pk2 = acc_k2 + (size_t)((c - 2) & 3) * SW_MAXM, *pk3 = acc_k2 + (size_t)((c - 3) & 3) * SW_MAXM;
+      const double *pc2 = acc_corr2 + (size_t)((c - 2) & 3) * SW_MAXM, *pc3 = acc_corr2 + (size_t)((c - 3) & 3) * SW_MAXM;
+      const int32_t *gx2 = reinterpret_cast<const int32_t *>(a.gramx2) + (size_t)blk * m * m;
+      const int32_t *gx3 = reinterpret_cast<const int32_t *>(a.gramx3) + (size_t)blk * m * m;
+      // the speculated parts: four loads in flight together with the first batch of rows
+      const double x2a = on2 ? a.xspec2[(size_t)blk * SW_MAXM + ja] : 0.0, x2b = on2 ? a.xspec2[(size_t)blk * SW_MAXM + jb] : 0.0;
+      const double x3a = on3 ? a.xspec3[(size_t)blk * SW_MAXM + ja] : 0.0, x3b = on3 ? a.xspec3[(size_t)blk * SW_MAXM + jb] : 0.0;
       double cva = 0.0, cvb = 0.0;
-      if (on) {
-        cva = a.xspec2[(size_t)blk * SW_MAXM + ja]; cvb = a.xspec2[(size_t)blk * SW_MAXM + jb];
-        for (int i0 = 0; i0 < npre; i0 += 8) {
-          int32_t ga[8], gb[8];
+      int32_t ga[8], gb[8];
+      double cf[8];
+      auto batch_load = [&](int i0) {   // the two blocks' accepted markers as one list, eight rows per batch
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int32_t *row = gx2 + (size_t)pk[min(i0 + u, npre - 1)] * m;
-            ga[u] = row[ja]; gb[u] = row[jb];
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const double cf = (i0 + u < npre) ? pc2[i0 + u] : 0.0;
-            cva = fma((double)ga[u], cf, cva); cvb = fma((double)gb[u], cf, cvb);
-          }
+        for (int u = 0; u < 8; ++u) {
+          const int idx = max(0, min(i0 + u, ntot - 1));
+          const bool live = idx < ntot, from2 = idx < n2;              // ntot == 0: one harmless in-bounds load of Gx2's row 0
+          const int k = live ? (from2 ? pk2[idx] : pk3[idx - n2]) : 0;
+          const int32_t *row = ((from2 || !live) ? gx2 : gx3) + (size_t)k * m;
+          ga[u] = row[ja]; gb[u] = row[jb];
+          cf[u] = (i0 + u < ntot) ? (from2 ? pc2[idx] : pc3[idx - n2]) : 0.0;
         }
-      }
-      dst[lane] = (on && lane < mBc) ? cva : 0.0;
-      dst[64 + lane] = (on && 64 + lane < mBc) ? cvb : 0.0;
-      S2ONE(15, tid == 448 && c == 103);
+      };
+      auto batch_use = [&]() {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { cva = fma((double)ga[u], cf[u], cva); cvb = fma((double)gb[u], cf[u], cvb); }
+      };
+      if (on2) batch_load(0);   // (gx3 is only dereferenced for list entries of block c-3, i.e. when on3)
+      else { for (int u = 0; u < 8; ++u) { ga[u] = 0; gb[u] = 0; cf[u] = 0.0; } }
+      if (!poll_qsum(c, mBc)) ctrl_s[0] = 0;   // (the first batch of rows and the speculated parts are in flight)
+      S2WALL(10, tid == 448 && c >= L);
+      S2WALL(14, tid == 448 && c == 100 + L);
+      S2ONE(14, tid == 448 && c == 100 + L);
+      batch_use();
+      for (int i0 = 8; i0 < ntot; i0 += 8) { batch_load(i0); batch_use(); }
+      cva += x2a; cvb += x2b; cva += x3a; cvb += x3b;
+      dst[lane] = (lane < mBc) ? cva : 0.0;
+      dst[64 + lane] = (64 + lane < mBc) ? cvb : 0.0;
+      S2ONE(15, tid == 448 && c == 100 + L);
       if (c >= 2) store_state(c - 2);   // last: the next phase's poll is behind these stores only
-      S2ONE(26, tid == 448 && c == 103);
+      S2ONE(26, tid == 448 && c == 100 + L);
     }
   };
 
@@ -1115,7 +1134,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
     for (int c = tid; c < pchunks; c += SW_THREADS) reinterpret_cast<uint4 *>(Q16_GP(0))[c] = reinterpret_cast<const uint4 *>(gramp + (size_t)a.blk_begin * pstride)[c];
     for (int c = tid; c < NCH; c += SW_THREADS) reinterpret_cast<uint4 *>(&stage[0])[c] = reinterpret_cast<const uint4 *>(a.ps.blocks + a.blk_begin)[c];
     for (int c = tid; c < NSP; c += SW_THREADS) reinterpret_cast<uint4 *>(&specb[0])[c] = reinterpret_cast<const uint4 *>(a.ps.spec + a.blk_begin)[c];
-    if (tid == 0) { ctrl_s[0] = 1; ctrl_s[2] = 0; ctrl_s[3] = 0; }
+    if (tid < 16) ctrl_s[tid] = (tid == 0) ? 1 : 0;
     __syncthreads();
     if (wave >= 1 && wave <= 6) {
       if (nb > 1) {
@@ -1153,8 +1172,8 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       const StageBuf &st = stage[b & 1];
       const SpecBuf &sb = specb[b & 1];
       const GT *gp = Q16_GP(b);
-      int *acc_k = acc_k2 + (size_t)(b & 1) * SW_MAXM;
-      double *acc_corr = acc_corr2 + (size_t)(b & 1) * SW_MAXM;
+      int *acc_k = acc_k2 + (size_t)(b & 3) * SW_MAXM;
+      double *acc_corr = acc_corr2 + (size_t)(b & 3) * SW_MAXM;
       const int ngrp = (mB + 63) >> 6;
       double r[2];
       LaneConst lc[2];
@@ -1234,15 +1253,15 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
         }
       }
       am0 = accmask[0]; am1 = accmask[1];
-      if (lane == 0) ctrl_s[2 + (b & 1)] = nacc;
-      S2WALL(0, lane == 0 && b + 3 < nb);
+      if (lane == 0) ctrl_s[4 + (b & 3)] = nacc;
+      S2WALL(0, lane == 0 && b + L < nb);
       S2WALL(7, lane == 0 && b == 100); S2WALL(9, lane == 0 && b == 101); S2WALL(11, lane == 0 && b == 102); S2WALL(12, lane == 0 && b == 103);
       S2STAMP(1);
     } else if (have_next) {
       helper_phase(b + 1);
     }
     __syncthreads();   // block b's recurrence is done; everything block b+1 needs is in LDS (parity (b+1)&1)
-    S2ONE(27, tid == 0 && b == 102);
+    S2ONE(27, tid == 0 && b == 99 + L);
     S2STAMP(2);
     if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
     if (wave == 0 && have_next) {
@@ -1254,7 +1273,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       const SpecBuf &sn = specb[(b + 1) & 1];
       const bool l0 = lane < mBn, l1 = 64 + lane < mBn;
       double r0 = l0 ? ps[lane] - sn.xspec[lane] : 0.0, r1 = l1 ? ps[64 + lane] - sn.xspec[64 + lane] : 0.0;
-      if (lag3) { r0 -= l0 ? cr[lane] : 0.0; r1 -= l1 ? cr[64 + lane] : 0.0; }
+      if (L > 2) { r0 -= l0 ? cr[lane] : 0.0; r1 -= l1 ? cr[64 + lane] : 0.0; }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         unsigned long long mk = q ? am1 : am0;
@@ -1287,8 +1306,8 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
 
 template <typename XT, bool SELECT, typename GT = typename XTraits<XT>::GT>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep2(const SweepArgs a) {
-  if ((int)blockIdx.x == a.K + 1) {
-    if constexpr (SELECT && sizeof(XT) == 1 && sizeof(GT) == 2) s2_feeder(a);
+  if ((int)blockIdx.x > a.K) {
+    if constexpr (SELECT && sizeof(XT) == 1 && sizeof(GT) == 2) s2_feeder(a, (int)blockIdx.x - a.K - 1);
   } else if ((int)blockIdx.x == a.K) {
     if constexpr (SELECT && sizeof(XT) == 1 && sizeof(GT) == 2) s2_sequencer_sel16(a);
     else s2_sequencer<XT, SELECT, GT>(a);

@@ -30,19 +30,18 @@ for key in sys.argv[1:] or ["c2", "c4s"]:
     if use2:
         for k in sorted(names2): print("   %-55s %9.0f" % (names2[k], v[k] / nblk))
         print("   streamer 0 total %.0f   sequencer total %.0f" % (sum(v[k] for k in names2 if k < 16) / nblk, sum(v[k] for k in names2 if k >= 16) / nblk))
-        hw = v[32:48] / (nblk - 9) / 100.0
+        lag = int(os.environ.get('BWGR_LAG', '4')); hw = v[32:48] / (nblk - 3 * lag) / 100.0
         if pi:   # selection models: lag-3 pipeline with the q feeder (wall clock, 100 MHz)
-            print("   means (us): delta_i stored -> seen by streamer 0 %.2f -> streamer 0 stores q_{i+3} %.2f -> feeder puts the sum %.2f -> sequencer has it %.2f"
+            print("   means (us): delta_i stored -> seen by streamer 0 %.2f -> streamer 0 stores q_{i+lag} %.2f -> feeder puts the sum %.2f -> sequencer has it %.2f"
                   % (hw[1] - hw[0], hw[2] - hw[0], hw[3] - hw[0], hw[10] - hw[0]))
             one = (C.c_ulonglong * 48)(); ch2 = bwgr_amd.Chain(P, model, y, it=2, bi=0, pi=pi, seed=2)
             ch2.run(1); ch2.sync(); _lib.lib().bwgr_debug_stamps(P._h, one); ch2.run(1); ch2.sync(); _lib.lib().bwgr_debug_stamps(P._h, one); ch2.close()
             oo = [int(x) for x in list(one)]; o = oo[32:48]; t0 = o[7]
-            print("   one sweep, around block 100 (us after the sequencer stores delta_100): streamer 0 sees delta_100 %.2f, stores q_103 %.2f, sees delta_101 %.2f; "
-                  "feeder puts the sum of q_103 %.2f; sequencer wave 7 has it %.2f; sequencer stores delta_101 %.2f, delta_102 %.2f, delta_103 %.2f"
+            print("   one sweep, around block 100 (us after the sequencer stores delta_100): streamer 0 sees delta_100 %.2f, stores q_{100+lag} %.2f, sees delta_101 %.2f; "
+                  "feeder puts the sum of q_{100+lag} %.2f; sequencer wave 7 has it %.2f; sequencer stores delta_101 %.2f, delta_102 %.2f, delta_103 %.2f"
                   % tuple((x - t0) / 100.0 for x in (o[4], o[6], o[5], o[13], o[14], o[9], o[11], o[12])))
-            print("   sequencer helper phase for block 103 (us after it starts, i.e. after the barrier of block 101): waves 1-6: Gram/constant stores done %.2f, next "
-                  "loads issued %.2f;  wave 7: sum of q_103 polled %.2f, lag-3 cross term %.2f, state of block 101 stored %.2f;  barrier of block 102 at %.2f (wave 0 "
-                  "stored delta_102 at %.2f)" % tuple((x - oo[10]) / 100.0 for x in (oo[11], oo[12], oo[14], oo[15], oo[26], oo[27], o[11])))
+            print("   sequencer helper phase for block 100+lag (us after it starts, i.e. after the barrier of block 98+lag): waves 1-6: Gram/constant stores done %.2f, next "
+                  "loads issued %.2f;  wave 7: sum of q polled %.2f, lag-3 cross term %.2f, state of block 98+lag stored %.2f;  barrier of block 99+lag at %.2f)" % tuple((x - oo[10]) / 100.0 for x in (oo[11], oo[12], oo[14], oo[15], oo[26], oo[27])))
     else:
         for nm, x in zip(names, v): print("   %-50s %9.0f ticks/block" % (nm, x / nblk))
     ms, nl = ch.sweep_ms(); print("   sweep ms", ms)
