@@ -1648,11 +1648,12 @@ extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int t
   bwgr_panel *PB = nullptr;   // the row subsample of this iteration (bag != 1): same markers, nbag rows
   int *use_d = nullptr;
   std::vector<int> use_h;
+  auto drop_panels = [&]() { if (PU) bwgr_panel_destroy(PU); if (PB) bwgr_panel_destroy(PB); hipFree(use_d); PU = PB = nullptr; use_d = nullptr; };
   if (bagging) {
     int rcb = panel_alloc(&PB, P->is_f32, nbag, P->p, P->device, P->m, 0);
-    if (rcb != BWGR_OK) return rcb;
+    if (rcb != BWGR_OK) { drop_panels(); return rcb; }
     PB->stream = P->stream;
-    if (hipMalloc(&use_d, sizeof(int) * (size_t)nbag) != hipSuccess) { bwgr_panel_destroy(PB); return fail(BWGR_ENOMEM, "wgr: device allocation failed"); }
+    if (hipMalloc(&use_d, sizeof(int) * (size_t)nbag) != hipSuccess) { drop_panels(); return fail(BWGR_ENOMEM, "wgr: device allocation failed"); }
   }
   const int64_t ldmax = std::max<int64_t>(std::max<int64_t>(P->ld, PU ? PU->ld : 0), PB ? PB->ld : 0);
   const size_t kd = sizeof(double) * (size_t)std::max<int64_t>(pk, 1), kf = sizeof(float) * (size_t)std::max<int64_t>(pk, 1);
@@ -1666,9 +1667,9 @@ extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int t
   double *part1 = (double *)dalloc(sizeof(double) * 256), *part2 = (double *)dalloc(sizeof(double) * 256), *hatd = (double *)dalloc(sizeof(double) * n);
   WgrScalars *ws = (WgrScalars *)dalloc(sizeof(WgrScalars));
   ChainScalars *sc = (ChainScalars *)dalloc(sizeof(ChainScalars));
-  if (!Ud || !Vd || !hR || !Hk || !uhd || !hf || !dhf || !xxKf || !Lkf || !vbk || !sck) { cleanup(); if (PU) bwgr_panel_destroy(PU); return fail(BWGR_ENOMEM, "wgr: device allocation failed"); }
-  if (!yd || !eR || !e64 || !xx64 || !vx64 || !bR || !dR || !VbR || !LR || !B || !D || !VB || !bf || !dfl || !Lf || !xxf || !vbf || !part1 || !part2 || !hatd || !ws || !sc) {
-    cleanup(); return fail(BWGR_ENOMEM, "wgr: device allocation failed");
+  if (!Ud || !Vd || !hR || !Hk || !uhd || !hf || !dhf || !xxKf || !Lkf || !vbk || !sck ||
+      !yd || !eR || !e64 || !xx64 || !vx64 || !bR || !dR || !VbR || !LR || !B || !D || !VB || !bf || !dfl || !Lf || !xxf || !vbf || !part1 || !part2 || !hatd || !ws || !sc) {
+    cleanup(); drop_panels(); return fail(BWGR_ENOMEM, "wgr: device allocation failed");
   }
   int rc = BWGR_OK;
   double *gpart = nullptr; int nchunks = 0;

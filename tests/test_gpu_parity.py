@@ -355,3 +355,22 @@ def test_mcmccv_matches_a_checker_built_on_the_oracle(tpod):
     assert list(g["cv"].values()) == sorted(g["cv"].values(), reverse=True)
     for i, nm in enumerate(_CV_NAMES):
         assert abs(g["cv"][nm] - round(float(pa[i]), 4)) <= 1.01e-4
+
+
+def test_wgr_missing_phenotypes_are_dropped_and_predicted(tpod):
+    """R/wgr.R:34-39, 146-152: rows with missing y are left out of the chain and still get a fitted value
+    HAT = B0 + gen0 %*% B; missing genotypes are mean-imputed first (R/wgr.R:12-18)."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = tpod["gen"].astype(np.float64).copy(), tpod["y"].astype(np.float64).copy()
+    miss = np.array([3, 50, 121, 190])
+    y[miss] = np.nan
+    X[7, 11] = np.nan; X[100, 200] = np.nan
+    g = bwgr_amd.wgr(y, X, it=30, bi=5, seed=9)
+    Xi = X.copy(); cm = np.nanmean(Xi, axis=0); idx = np.where(np.isnan(Xi)); Xi[idx] = cm[idx[1]]
+    keep = ~np.isnan(y)
+    o = O.wgr(y[keep], Xi[keep], it=30, bi=5, seed=9)
+    assert scaled_err(g["b"], o["b"]) < TOL and abs(g["mu"] - o["mu"]) <= TOL * max(1.0, abs(o["mu"]))
+    assert g["hat"].shape == (y.size,)
+    assert scaled_err(g["hat"][keep], o["hat"]) < TOL
+    assert scaled_err(g["hat"][~keep], o["mu"] + Xi[~keep] @ o["b"]) < TOL
