@@ -374,3 +374,37 @@ def test_wgr_missing_phenotypes_are_dropped_and_predicted(tpod):
     assert g["hat"].shape == (y.size,)
     assert scaled_err(g["hat"][keep], o["hat"]) < TOL
     assert scaled_err(g["hat"][~keep], o["mu"] + Xi[~keep] @ o["b"]) < TOL
+
+
+def test_full_size_properties_c4(monkeypatch):
+    """BASELINE config 4 (n = 10 000 x p = 1 000 000 int8, BayesB pi = 0.99; 40 streamers, 7 813 blocks, ragged last block) is
+    far too large for the oracle; checked through size-independent properties instead:
+    (1) residual identity  e == y - mu - X b  after three iterations, X b formed by an independent fp64 torch product;
+    (2) the two sweep engines (pipelined k_sweep2 with MFMA streamers / lag 3 / feeders vs the replicated-recurrence
+        k_sweep with fp64-FMA slab loops) give the same chain: inclusion indicators bit-equal, effects to 1e-9;
+    (3) the inclusion rate sits near 1 - pi."""
+    import torch
+    import bwgr_amd
+    from bwgr_amd import synth
+    n, p = 10000, 1000000
+    X = synth.genotypes(n, p)                     # (p, ld) int8 on the GPU, marker-major
+    y = synth.scale_phenotype(synth.phenotype(X, n))
+    out = {}
+    for v in ("2", "1"):
+        monkeypatch.setenv("BWGR_SWEEP", v)
+        P = bwgr_amd.Panel(X, n=n)
+        ch = bwgr_amd.Chain(P, "BayesB", y, it=3, bi=0, pi=0.99, seed=synth.SEED)
+        ch.run(3)
+        out[v] = ch.state()
+        ch.close(); P.close()
+    st = out["2"]
+    b = torch.from_numpy(st["b"]).to(X.device).double()
+    xb = torch.zeros(n, dtype=torch.float64, device=X.device)
+    step = 50000
+    for j0 in range(0, p, step):
+        xb += X[j0:j0 + step, :n].double().T @ b[j0:j0 + step]
+    e_ref = (y.double() - st["mu"] - xb).cpu().numpy()
+    assert np.abs(e_ref - st["e"]).max() < 2e-5 * np.abs(e_ref).max()      # st["e"] is the fp64 residual narrowed to float
+    assert np.array_equal(out["1"]["d"], out["2"]["d"])
+    assert scaled_err(out["1"]["b"], out["2"]["b"]) < 1e-9
+    assert 0.003 < st["d"].mean() < 0.05
