@@ -1033,7 +1033,17 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   m = ((m + 15) / 16) * 16;
   P->m = m;
   const int Rmax = P->is_f32 ? max_slab_rows<float>(m) : max_slab_rows<int8_t>(m);
-  int K = nwg > 0 ? nwg : (int)((n + Rmax - 1) / Rmax);
+  // the pipelined engine keeps three tiles per streamer, so it takes fewer rows per slab than k_sweep at small blocks:
+  // prefer the largest slab it fits (unless that needs more workgroups than the chip has CUs, or k_sweep is forced)
+  int Rpick = Rmax;
+  {
+    const char *sv = getenv("BWGR_SWEEP");
+    int R2 = 0;
+    for (int Rt = 128; Rt <= Rmax; Rt += 128)
+      if ((P->is_f32 ? sweep2_lds_bytes<float>(m, Rt) : sweep2_lds_bytes<int8_t>(m, Rt)) <= (size_t)160 * 1024) R2 = Rt;
+    if (!(sv && sv[0] == '1') && R2 > 0 && (n + R2 - 1) / R2 + 1 + S2_NFEED <= 256) Rpick = R2;
+  }
+  int K = nwg > 0 ? nwg : (int)((n + Rpick - 1) / Rpick);
   int R = (int)((((n + K - 1) / K) + 127) / 128) * 128;
   if (K > 256 || R > Rmax) {
     delete P;
