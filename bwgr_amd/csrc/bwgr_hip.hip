@@ -852,9 +852,8 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a) {
 // selection models run the deeper pipelines (their cross terms are sparse); BWGR_LAG=2|3 caps the depth (A/B tests)
 static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
   const char *lv = getenv("BWGR_LAG");
-  // depth 3 by default: at depth 4 (BWGR_LAG=4 when the panel is created and run; one more 4*p*m-byte Gram array, one
-  // output array instead of two in the streamers) the three stages are balanced and nothing is gained (measured: 40.4 vs 42.1 iter/s at C4)
-  const int cap = (lv && lv[0] >= '2' && lv[0] <= '4') ? lv[0] - '0' : 3;
+  // depth 4 where the panel has the third cross Gram array (int8, 16-bit staging), else 3; BWGR_LAG=2|3 caps it (A/B tests)
+  const int cap = (lv && lv[0] >= '2' && lv[0] <= '4') ? lv[0] - '0' : 4;
   int lag = 2;
   if (P->sweep_version == 2 && !P->is_f32 && (a.flags & SWF_SELECT)) {
     if (P->gramx2) lag = 3;
@@ -1075,7 +1074,7 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
     PCHK(hipMalloc(&P->xspec2, sizeof(double) * (size_t)P->nblocks * SW_MAXM));
   }
   const char *lagenv = getenv("BWGR_LAG");
-  if (P->sweep_version == 2 && !P->is_f32 && P->nblocks > 3 && P->lag4_ok && lagenv && lagenv[0] == '4') {   // distance-3 blocks: the (opt-in) lag-4 pipeline
+  if (P->sweep_version == 2 && !P->is_f32 && P->nblocks > 3 && P->lag4_ok && !(lagenv && (lagenv[0] == '2' || lagenv[0] == '3'))) {   // distance-3 blocks: the lag-4 pipeline
     PCHK(hipMalloc(&P->gramx3, P->gram_bytes));
     PCHK(hipMalloc(&P->xspec3, sizeof(double) * (size_t)P->nblocks * SW_MAXM));
   }

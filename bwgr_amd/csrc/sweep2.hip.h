@@ -76,6 +76,18 @@ __device__ __forceinline__ void s2_put_q(double *slot, double v, int b) {
 #define S2_TILE_COMMIT(dstp, mB_) do { XT *dst_ = (dstp); const int cpr_ = R / PER; const int tot_ = (mB_) * cpr_; \
     const float rcpr_ = 1.0f / (float)cpr_; __builtin_amdgcn_s_waitcnt(0x0F70); BWGR_TILE_EACH(S2_COMMIT1) } while (0)
 
+// int8 streamer: the tile moves belong to waves 2-7 (384 threads, six chunks each) so that waves 0-1, which poll the delta
+// granules, never have a tile load in flight: the vmcnt counter is in order, and a poll behind tile loads waits for them
+#define S2I_TILE_EACH(X) X(0, tp0) X(1, tp1) X(2, tp2) X(3, tp3) X(4, tp4) X(5, tp5)
+#define S2I_ISSUE1(u, name) { const int c_ = (tid - 128) + (u) * (SW_THREADS - 128); if (c_ < tot_) name = src_[c_]; }
+#define S2I_TILE_ISSUE(j0_, mB_) do { if (tid >= 128) { const int tot_ = (mB_) * (R / PER); __builtin_amdgcn_s_waitcnt(0x0F70); \
+    const uint4 *src_ = reinterpret_cast<const uint4 *>(X + (size_t)(j0_) * R); S2I_TILE_EACH(S2I_ISSUE1) } } while (0)
+#define S2I_COMMIT1(u, name) { const int c_ = (tid - 128) + (u) * (SW_THREADS - 128); if (c_ < tot_) { \
+    const int jj_ = (int)(((float)c_ + 0.5f) * rcpr_), ii_ = c_ - jj_ * cpr_; \
+    *reinterpret_cast<uint4 *>((dst_) + (size_t)jj_ * Rp + ii_ * PER) = name; } }
+#define S2I_TILE_COMMIT(dstp, mB_) do { if (tid >= 128) { XT *dst_ = (dstp); const int cpr_ = R / PER; const int tot_ = (mB_) * cpr_; \
+    const float rcpr_ = 1.0f / (float)cpr_; __builtin_amdgcn_s_waitcnt(0x0F70); S2I_TILE_EACH(S2I_COMMIT1) } } while (0)
+
 // ------------------------------------------------------------------------------------------------------------------
 // streamer
 // ------------------------------------------------------------------------------------------------------------------
@@ -307,12 +319,12 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
   auto blk_j0 = [&](int b) { return (a.blk_begin + b) * m; };
   auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
 
-  uint4 tp0 = make_uint4(0, 0, 0, 0), tp1 = tp0, tp2 = tp0, tp3 = tp0, tp4 = tp0;
+  uint4 tp0 = make_uint4(0, 0, 0, 0), tp1 = tp0, tp2 = tp0, tp3 = tp0, tp4 = tp0, tp5 = tp0;
   for (int i = tid; i < 4 * Rp; i += SW_THREADS) reinterpret_cast<uint32_t *>(edig_s)[i] = 0u;
   for (int i = tid; i < 4 * S2_DP; i += SW_THREADS) reinterpret_cast<uint32_t *>(ddig_s)[i] = 0u;
   if (tid < 16) ctl_s[tid] = 0u;
-  for (int b = 0; b < L && b < nb; ++b) { S2_TILE_ISSUE(blk_j0(b), blk_m(b)); S2_TILE_COMMIT(S2I_TILE(b), blk_m(b)); }
-  if (nb > L) S2_TILE_ISSUE(blk_j0(L), blk_m(L));
+  for (int b = 0; b < L && b < nb; ++b) { S2I_TILE_ISSUE(blk_j0(b), blk_m(b)); S2I_TILE_COMMIT(S2I_TILE(b), blk_m(b)); }
+  if (nb > L) S2I_TILE_ISSUE(blk_j0(L), blk_m(L));
   __syncthreads();
   S2STAMP_DECL;
   S2WALL_DECL;
@@ -341,12 +353,13 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     }
     __syncthreads();
     S2STAMP(7);
-    if (tid < mB) {
-      const int4 o0 = *reinterpret_cast<const int4 *>(out_s + (size_t)tid * S2_OS), o1 = *reinterpret_cast<const int4 *>(out_s + (size_t)tid * S2_OS + 4);
+    const int tq = tid - 128;   // waves 2-3 store q: waves 0-1 keep nothing but polls on their memory counter
+    if (tq >= 0 && tq < mB) {
+      const int4 o0 = *reinterpret_cast<const int4 *>(out_s + (size_t)tq * S2_OS), o1 = *reinterpret_cast<const int4 *>(out_s + (size_t)tq * S2_OS + 4);
       double w = invSe, v = (double)o0.x * w;
       w *= 256.0; v = fma((double)o0.y, w, v); w *= 256.0; v = fma((double)o0.z, w, v); w *= 256.0; v = fma((double)o0.w, w, v);
       w *= 256.0; v = fma((double)o1.x, w, v); w *= 256.0; v = fma((double)o1.y, w, v); w *= 256.0; v = fma((double)o1.z, w, v);
-      s2_put_q(a.qpart + ((size_t)(b % S2_NSLOT) * K + wg) * SW_MAXM + tid, v, b);
+      s2_put_q(a.qpart + ((size_t)(b % S2_NSLOT) * K + wg) * SW_MAXM + tq, v, b);
     }
     S2WALL(2, wg == 0 && tid == 0 && b >= a.lag);
     S2WALL(6, wg == 0 && tid == 0 && b == 100 + a.lag);
@@ -363,6 +376,7 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     for (int b = 0; b < L && b < nb; ++b) publish(b, S2I_TILE(b), invSe);
   }
 
+  unsigned long long pre = 0ull;   // early-requested granule of the next block's delta (tid < SW_MAXM)
   for (int i = 0; i < nb; ++i) {
     const int mB = blk_m(i);
     const int par = i & 1;
@@ -377,8 +391,11 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
         const uint32_t epoch = (uint32_t)(i + 1);
         const uint64_t t0 = wall_clock64();
         unsigned spins = 0;
+        unsigned long long v = pre;   // requested during the previous iteration: when this streamer runs behind, delta_i is
+                                      // already there and the poll's round trip (~0.6 us) is off its iteration
         for (;;) {
-          const unsigned long long v = ld_agent_raw64(g);
+          if ((uint32_t)(v >> 32) == epoch) { dbits = (uint32_t)v; break; }
+          v = ld_agent_raw64(g);
           if ((uint32_t)(v >> 32) == epoch) { dbits = (uint32_t)v; break; }
           if ((++spins & 63u) == 0u) {
             if (ld_agent_u32(abortw) != 0u) { bad = 1; break; }
@@ -459,9 +476,11 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     // tile(i)), and the loads of tile(i+L+1) go out at once: they must have landed before the next iteration's poll (the
     // vmcnt counter is in order, so a poll behind 32 KB of tile loads pays for them; issued after the publish they cost
     // 10 % of the sweep)
-    if (i + L < nb) S2_TILE_COMMIT(S2I_TILE(i + L), blk_m(i + L));
+    if (i + L < nb) S2I_TILE_COMMIT(S2I_TILE(i + L), blk_m(i + L));
+    // early request for delta_{i+1} (older than the tile loads below, so the in-order vmcnt lets it be consumed first)
+    if (tid < SW_MAXM && i + 1 < nb) pre = (tid < blk_m(i + 1)) ? ld_agent_raw64(a.dgran + (size_t)((i + 1) % S2_NSLOT) * SW_MAXM + tid) : 0ull;
     S2STAMP(9);
-    if (i + L + 1 < nb) S2_TILE_ISSUE(blk_j0(i + L + 1), blk_m(i + L + 1));
+    if (i + L + 1 < nb) S2I_TILE_ISSUE(blk_j0(i + L + 1), blk_m(i + L + 1));
     S2STAMP(0);
     {
       uint32_t ex = 0u;

@@ -240,11 +240,11 @@ def test_both_sweep_engines_give_the_same_chain(model, monkeypatch):
 
 
 @pytest.mark.parametrize("model", ["BayesB", "BayesDpi", "BayesC"])
-@pytest.mark.parametrize("env", [{}, {"BWGR_LAG": "4"}, {"BWGR_LAG": "2"}, {"BWGR_GRAM16": "0"}, {"BWGR_GRAM16": "0", "BWGR_LAG": "2"}])
+@pytest.mark.parametrize("env", [{}, {"BWGR_LAG": "3"}, {"BWGR_LAG": "2"}, {"BWGR_GRAM16": "0"}, {"BWGR_GRAM16": "0", "BWGR_LAG": "2"}])
 def test_selection_pipeline_variants_give_the_same_chain(model, env, monkeypatch):
     """Selection models run k_sweep2 in one of five schedules: 16-bit Gram staging with the single-barrier sequencer and
-    the q feeders (default when every Gram entry fits 16 bits) at lag 3 (default), 4 (opt-in) or 2, or 32-bit staging with
-    the generic sequencer at lag 3 or 2.  All are the same blocked algebra; several blocks and a ragged last one so that the distance-1
+    the q feeders (default when every Gram entry fits 16 bits) at lag 4 (default), 3 or 2, or 32-bit staging with the
+    generic sequencer at lag 3 or 2.  All are the same blocked algebra; several blocks and a ragged last one so that the distance-1
     and distance-2 cross terms, the first blocks of a launch and the tail are all exercised."""
     import bwgr_amd
     from oracle import oracle as O

@@ -30,7 +30,7 @@ for key in sys.argv[1:] or ["c2", "c4s"]:
     if use2:
         for k in sorted(names2): print("   %-55s %9.0f" % (names2[k], v[k] / nblk))
         print("   streamer 0 total %.0f   sequencer total %.0f" % (sum(v[k] for k in names2 if k < 16) / nblk, sum(v[k] for k in names2 if k >= 16) / nblk))
-        lag = int(os.environ.get('BWGR_LAG', '3')); hw = v[32:48] / (nblk - 3 * lag) / 100.0
+        lag = int(os.environ.get('BWGR_LAG', '4')); hw = v[32:48] / (nblk - 3 * lag) / 100.0
         if pi:   # selection models: lag-3 pipeline with the q feeder (wall clock, 100 MHz)
             print("   means (us): delta_i stored -> seen by streamer 0 %.2f -> streamer 0 stores q_{i+lag} %.2f -> feeder puts the sum %.2f -> sequencer has it %.2f"
                   % (hw[1] - hw[0], hw[2] - hw[0], hw[3] - hw[0], hw[10] - hw[0]))
