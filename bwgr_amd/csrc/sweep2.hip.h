@@ -29,6 +29,7 @@ namespace bwgr {
 #define S2WALL(slot, cond) do { if (cond) wl2[slot] += (unsigned long long)wall_clock64(); } while (0)
 #define S2WALL_FLUSH do { if (a.stamps) for (int k_ = 0; k_ < 16; ++k_) if (wl2[k_]) atomicAdd(&a.stamps[32 + k_], wl2[k_]); } while (0)
 #define S2ONE(dst, cond) do { if ((cond) && a.stamps) a.stamps[dst] = (unsigned long long)wall_clock64(); } while (0)
+#define S2MINMAX(dmin, dmax, cond) do { if ((cond) && a.stamps) { const unsigned long long t_ = (unsigned long long)wall_clock64(); atomicMax(&a.stamps[dmax], t_); atomicMax(&a.stamps[dmin], ~t_); } } while (0)
 #define S2WALL_FLUSH_AT(base) do { if (a.stamps) for (int k_ = 4; k_ < 8; ++k_) if (wl2[k_]) { atomicAdd(&a.stamps[(base) + k_ - 4], wl2[k_]); wl2[k_] = 0; } } while (0)
 #else
 #define S2STAMP_DECL do { } while (0)
@@ -38,6 +39,7 @@ namespace bwgr {
 #define S2WALL(slot, cond) do { } while (0)
 #define S2WALL_FLUSH do { } while (0)
 #define S2ONE(dst, cond) do { } while (0)
+#define S2MINMAX(dmin, dmax, cond) do { } while (0)
 #define S2WALL_FLUSH_AT(base) do { } while (0)
 #endif
 
@@ -363,6 +365,7 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     }
     S2WALL(2, wg == 0 && tid == 0 && b >= a.lag);
     S2WALL(6, wg == 0 && tid == 0 && b == 100 + a.lag);
+    S2MINMAX(28, 29, tid == 128 && b == 100 + a.lag);
   };
   static_assert(S2_NDE == 7 && S2_NDD == 6, "the digit recombinations are written out for 7 / 6 digits");
 
@@ -411,6 +414,7 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     __syncthreads();
     S2WALL(1, wg == 0 && tid == 0 && i + L < nb);
     S2WALL(4, wg == 0 && tid == 0 && i == 100);
+    S2MINMAX(30, 31, tid == 0 && i == 100);
     S2WALL(5, wg == 0 && tid == 0 && i == 101);
     if (ctl_s[8]) { if (tid == 0) a.sc->error = 1u; return; }
     S2STAMP(1);

@@ -40,6 +40,9 @@ for key in sys.argv[1:] or ["c2", "c4s"]:
             print("   one sweep, around block 100 (us after the sequencer stores delta_100): streamer 0 sees delta_100 %.2f, stores q_{100+lag} %.2f, sees delta_101 %.2f; "
                   "feeder puts the sum of q_{100+lag} %.2f; sequencer wave 7 has it %.2f; sequencer stores delta_101 %.2f, delta_102 %.2f, delta_103 %.2f"
                   % tuple((x - t0) / 100.0 for x in (o[4], o[6], o[5], o[13], o[14], o[9], o[11], o[12])))
+            mm = lambda k: ((~oo[k]) & 0xFFFFFFFFFFFFFFFF)
+            print("   over all streamers (us after delta_100 stored): delta_100 seen first %.2f / last %.2f;  q_{100+lag} stored first %.2f / last %.2f"
+                  % ((mm(30) - t0) / 100.0, (oo[31] - t0) / 100.0, (mm(28) - t0) / 100.0, (oo[29] - t0) / 100.0))
             print("   sequencer helper phase for block 100+lag (us after it starts, i.e. after the barrier of block 98+lag): waves 1-6: Gram/constant stores done %.2f, next "
                   "loads issued %.2f;  wave 7: sum of q polled %.2f, lag-3 cross term %.2f, state of block 98+lag stored %.2f;  barrier of block 99+lag at %.2f)" % tuple((x - oo[10]) / 100.0 for x in (oo[11], oo[12], oo[14], oo[15], oo[26], oo[27])))
     else:
