@@ -741,6 +741,7 @@ struct bwgr_panel {
   void *X = nullptr, *gram = nullptr, *gramx = nullptr, *gramx2 = nullptr, *gramx3 = nullptr, *gramp = nullptr;
   double *xspec2 = nullptr, *xspec3 = nullptr;   // [nblocks][SW_MAXM]: speculative cross terms of the lag-3 / lag-4 pipelines (k_spec)
   bool lag4_ok = false;       // the lag-4 streamer (ring of four tiles) fits the LDS at this geometry
+  int nfeed = 2;              // q feeder workgroups of k_sweep2 (one gather + sum of K KB takes about a block period at K = 40)
   uint16_t *gramp16 = nullptr, *gramx16 = nullptr;   // 16-bit copies for the sequencer (int8 panels)
   int *gram16_bad = nullptr;
   bool gram16 = false;        // the copies are exact: every entry in 0..65535
@@ -822,19 +823,23 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a) {
   }
 }
 
-static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a) {
+static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
+  SweepArgs a = a_in;
   const bool sel = (a.flags & SWF_SELECT) != 0;
+  // streamers, sequencer, and for the selection models the q feeders (the affine recurrence is compute-bound: its
+  // sequencer gathers q itself under the recurrence, and a feeder hop in its lag-2 chain measured 15 % slower)
+  a.nfeed = (P->sweep_version == 2 && sel) ? P->nfeed : 0;
   if (P->sweep_version == 2) {
-    const dim3 grid(P->K + 1), blk(SW_THREADS);
+    const dim3 grid(P->K + 1 + a.nfeed), blk(SW_THREADS);
     if (P->is_f32) {
       if (sel) hipLaunchKernelGGL((k_sweep2<float, true>), grid, blk, P->lds2_bytes, P->stream, a);
       else hipLaunchKernelGGL((k_sweep2<float, false>), grid, blk, P->lds2_bytes, P->stream, a);
     } else {
-      if (P->gram16 && sel) {   // selection models: 16-bit staging, single-barrier sequencer, q feeder (the affine recurrence is
+      if (P->gram16 && sel) {   // selection models: 16-bit staging and the single-barrier sequencer (the affine recurrence is
                                 // compute-bound and measured faster on the 32-bit blocks: no conversion in its inner loop)
         SweepArgs a16 = a;
         a16.gramp = P->gramp16; a16.gramx = P->gramx16;
-        hipLaunchKernelGGL((k_sweep2<int8_t, true, uint16_t>), dim3(P->K + 1 + S2_NFEED), blk, P->lds2_bytes, P->stream, a16);   // + the q feeders
+        hipLaunchKernelGGL((k_sweep2<int8_t, true, uint16_t>), grid, blk, P->lds2_bytes, P->stream, a16);
       } else if (sel) hipLaunchKernelGGL((k_sweep2<int8_t, true>), grid, blk, P->lds2_bytes, P->stream, a);
       else hipLaunchKernelGGL((k_sweep2<int8_t, false>), grid, blk, P->lds2_bytes, P->stream, a);
     }
@@ -855,9 +860,9 @@ static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
   // depth 4 where the panel has the third cross Gram array (int8, 16-bit staging), else 3; BWGR_LAG=2|3 caps it (A/B tests)
   const int cap = (lv && lv[0] >= '2' && lv[0] <= '4') ? lv[0] - '0' : 4;
   int lag = 2;
-  if (P->sweep_version == 2 && !P->is_f32 && (a.flags & SWF_SELECT)) {
-    if (P->gramx2) lag = 3;
-    if (P->gramx3 && P->gram16 && P->lag4_ok) lag = 4;   // only the 16-bit / single-barrier sequencer knows the third cross term
+  if (P->sweep_version == 2 && (a.flags & SWF_SELECT)) {
+    if (P->gramx2) lag = 3;   // fp32 panels too (generic streamer and sequencer)
+    if (!P->is_f32 && P->gramx3 && P->gram16 && P->lag4_ok) lag = 4;   // only the 16-bit / single-barrier sequencer knows the third cross term
   }
   a.lag = lag < cap ? lag : cap;
 }
@@ -875,7 +880,7 @@ static void fill_panel_args(const bwgr_panel *P, SweepArgs &a) {
   a.n = (int)P->n; a.p = (int)P->p; a.m = P->m; a.K = P->K; a.R = P->R;
   a.blk_begin = 0; a.blk_end = (int)P->nblocks;
   a.xpart = P->xpart; a.xflags = P->xflags; a.stamps = P->stamps; a.ps = P->ps;
-  a.gramx = P->gramx; a.gramx2 = P->gramx2; a.xspec2 = P->xspec2; a.gramx3 = P->gramx3; a.xspec3 = P->xspec3; a.lag = 2; a.gramp = P->gramp; a.pstride = P->pstride; a.qpart = P->qpart; a.dgran = P->dgran;
+  a.gramx = P->gramx; a.gramx2 = P->gramx2; a.xspec2 = P->xspec2; a.gramx3 = P->gramx3; a.xspec3 = P->xspec3; a.lag = 2; a.nfeed = P->nfeed; a.gramp = P->gramp; a.pstride = P->pstride; a.qpart = P->qpart; a.dgran = P->dgran;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1040,7 +1045,7 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
     int R2 = 0;
     for (int Rt = 128; Rt <= Rmax; Rt += 128)
       if ((P->is_f32 ? sweep2_lds_bytes<float>(m, Rt) : sweep2_lds_bytes<int8_t>(m, Rt)) <= (size_t)160 * 1024) R2 = Rt;
-    if (!(sv && sv[0] == '1') && R2 > 0 && (n + R2 - 1) / R2 + 1 + S2_NFEED <= 256) Rpick = R2;
+    if (!(sv && sv[0] == '1') && R2 > 0 && (n + R2 - 1) / R2 + 1 + 6 <= 256) Rpick = R2;
   }
   int K = nwg > 0 ? nwg : (int)((n + Rpick - 1) / Rpick);
   int R = (int)((((n + K - 1) / K) + 127) / 128) * 128;
@@ -1059,7 +1064,8 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   {
     const char *sv = getenv("BWGR_SWEEP");   // A/B switch for tests and profiling
     P->sweep_version = (sv && sv[0] == '1') ? 1 : 2;
-    if (P->lds2_bytes > (size_t)160 * 1024 || K + 1 + S2_NFEED > 256) P->sweep_version = 1;
+    P->nfeed = std::min(6, std::max(2, (K + 39) / 40 + 1));   // K = 40: 2, K = 79: 3, K >= 161: 6
+    if (P->lds2_bytes > (size_t)160 * 1024 || K + 1 + P->nfeed > 256) P->sweep_version = 1;
   }
   P->x_bytes = (size_t)P->ld * (size_t)p * (P->is_f32 ? 4 : 1);
   P->gram_bytes = (size_t)P->nblocks * m * m * (P->is_f32 ? 8 : 4);   // per Gram array (diagonal blocks; off-diagonal blocks)

@@ -75,6 +75,7 @@ struct SweepArgs {
   const void *gramx3;           // [nblocks][m][m]  X_{b-3}' X_b (lag 4; null otherwise)
   double *xspec3;               // [nblocks][SW_MAXM]  sum_k gramx3_b[k][j] * drej_{b-3}[k] (k_spec, lag 4)
   int lag;                      // k_sweep2: q_b is taken against e after delta_{b-lag}; 2, or 3 / 4 for selection models
+  int nfeed;                    // k_sweep2: number of q feeder workgroups behind the sequencer (feeder f serves blocks b = f mod nfeed)
   const void *gramp;            // [nblocks][pstride] strict upper triangle of the diagonal blocks, row k = entries (k, k+1..m-1)
   int pstride;
   int n, p, m, K, R;

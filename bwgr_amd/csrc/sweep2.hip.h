@@ -43,7 +43,6 @@ namespace bwgr {
 #define S2WALL_FLUSH_AT(base) do { } while (0)
 #endif
 
-static constexpr int S2_NFEED = 2;   // q feeder workgroups (selection / 16-bit path); feeder f serves the blocks b = f mod S2_NFEED
 static constexpr int S2_NSLOT = 4;   // ring depth of the q / delta buffers (2 would do; 4 keeps lines apart)
 
 template <typename XT> __host__ __device__ inline size_t s2_seq_lds_bytes(int m);
@@ -158,9 +157,9 @@ __device__ __forceinline__ void s2_streamer(const SweepArgs &a) {
   uint4 tp0 = make_uint4(0, 0, 0, 0), tp1 = tp0, tp2 = tp0, tp3 = tp0, tp4 = tp0;
   for (int i = tid; i < R; i += SW_THREADS) e_s[i] = a.e[row0 + i];
   if (tid == 0) fail_s[0] = 0;
-  S2_TILE_ISSUE(blk_j0(0), blk_m(0)); S2_TILE_COMMIT(S2_TILE(0), blk_m(0));
-  if (nb > 1) { S2_TILE_ISSUE(blk_j0(1), blk_m(1)); S2_TILE_COMMIT(S2_TILE(1), blk_m(1)); }
-  if (nb > 2) S2_TILE_ISSUE(blk_j0(2), blk_m(2));
+  const int L = a.lag < 3 ? a.lag : 3;   // q_b is computed after delta_{b-L}: tiles i .. i+L-1 sit in the ring of three
+  for (int b = 0; b < L && b < nb; ++b) { S2_TILE_ISSUE(blk_j0(b), blk_m(b)); S2_TILE_COMMIT(S2_TILE(b), blk_m(b)); }
+  if (nb > L) S2_TILE_ISSUE(blk_j0(L), blk_m(L));
   __syncthreads();
 
   // publish the slab dots of block b (computed against the current e_s): payload write-through, then the epoch flag
@@ -175,15 +174,11 @@ __device__ __forceinline__ void s2_streamer(const SweepArgs &a) {
     }
     __syncthreads();   // part_s is free again
   };
-  publish(0, S2_TILE(0));
-  if (nb > 1) publish(1, S2_TILE(1));
+  for (int b = 0; b < L && b < nb; ++b) publish(b, S2_TILE(b));
   S2STAMP_DECL;
 
   for (int i = 0; i < nb; ++i) {
     const int mB = blk_m(i);
-    S2STAMP(5);
-    // tile(i+2) lands in the buffer tile(i-1) used; its loads were issued one iteration ago
-    if (i + 2 < nb) S2_TILE_COMMIT(S2_TILE(i + 2), blk_m(i + 2));
     S2STAMP(0);
     // delta_i: one 8-byte {epoch, float} granule per marker, polled by the thread that needs it
     int bad = 0;
@@ -207,7 +202,6 @@ __device__ __forceinline__ void s2_streamer(const SweepArgs &a) {
     if (bad) fail_s[0] = 1;
     __syncthreads();
     if (fail_s[0]) { if (tid == 0) a.sc->error = 1u; return; }
-    if (i + 3 < nb) S2_TILE_ISSUE(blk_j0(i + 3), blk_m(i + 3));   // after the poll: see s2_streamer_i8
     S2STAMP(1);
     // slab update with tile(i) (fp64, x*delta exact)
     {
@@ -242,7 +236,12 @@ __device__ __forceinline__ void s2_streamer(const SweepArgs &a) {
     }
     __syncthreads();
     S2STAMP(2);
-    if (i + 2 < nb) publish(i + 2, S2_TILE(i + 2));
+    // tile(i) is spent: tile(i+L), in registers since the previous iteration, takes a free ring slot (for L = 3 the one of
+    // tile(i)), and the loads of tile(i+L+1) go out (see s2_streamer_i8)
+    if (i + L < nb) S2_TILE_COMMIT(S2_TILE(i + L), blk_m(i + L));
+    if (i + L + 1 < nb) S2_TILE_ISSUE(blk_j0(i + L + 1), blk_m(i + L + 1));
+    __syncthreads();
+    if (i + L < nb) publish(i + L, S2_TILE(i + L));
     S2STAMP(4);
   }
   if (wg == 0) S2STAMP_FLUSH(0);
@@ -633,7 +632,30 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
   auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
   auto prow = [&](int k) { return k * (m - 1) - k * (k - 1) / 2; };   // offset of packed row k
 
-  auto gather_q = [&](int b, int part, int t, int mB) -> int { return s2_gather_q(a, b, part, t, mB, part_s); };
+  // q_b summed over the streamers into part_s[0..2][t] (added up by the reader): from the feeders' tagged sums (one word
+  // per marker, polled by the threads of part 0) or, without feeders, gathered here from the streamers' words
+  auto gather_q = [&](int b, int part, int t, int mB) -> int {
+    if (a.nfeed <= 0) return s2_gather_q(a, b, part, t, mB, part_s);
+    double v = 0.0;
+    if (part == 0 && t < mB) {
+      const unsigned long long *g = reinterpret_cast<const unsigned long long *>(a.qpart + (size_t)S2_NSLOT * a.K * SW_MAXM + (size_t)(b % S2_NSLOT) * SW_MAXM + t);
+      const unsigned long long tag = s2_qtag(b);
+      uint32_t *abortw = a.xflags + (size_t)a.K * SW_FLAG_STRIDE;
+      const uint64_t t0 = wall_clock64();
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned long long w = ld_agent_raw64(g);
+        if ((w & 0xFFull) == tag) { v = __longlong_as_double((long long)(w & ~0xFFull)); break; }
+        if ((++spins & 63u) == 0u) {
+          if (ld_agent_u32(abortw) != 0u) return 0;
+          if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    part_s[part * SW_MAXM + t] = v;
+    return 1;
+  };
   auto copy16 = [&](void *dst, const void *src, int nchunks, int t0, int nth) {
     for (int c = t0; c < nchunks; c += nth) reinterpret_cast<uint4 *>(dst)[c] = reinterpret_cast<const uint4 *>(src)[c];
   };
@@ -936,7 +958,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
 
 
 
-// q feeders (selection models, 16-bit Gram path): S2_NFEED workgroups of their own, hence their own CUs' memory paths.  Gathers the K
+// q feeders: a.nfeed workgroups of their own, hence their own CUs' memory paths.  Gathers the K
 // streamers' slab dots of each block (the 40 KB of write-through words per block that otherwise go through the
 // sequencer's CU, whose ingest is what bounds the chain), sums them in the fixed order and hands the sequencer one
 // tagged word per marker.  Costs one more hop on a path that the lag-3 pipeline keeps off the critical cycle.
@@ -948,9 +970,10 @@ __device__ __forceinline__ void s2_feeder(const SweepArgs &a, int f) {
   int *ok_s = reinterpret_cast<int *>(smem + 3 * SW_MAXM * sizeof(double));
   double *qsum = a.qpart + (size_t)S2_NSLOT * a.K * SW_MAXM;
   S2WALL_DECL;
+  if (a.nfeed <= 0 || f >= a.nfeed) return;
   if (tid == 0) ok_s[0] = 1;
   __syncthreads();
-  for (int b = f; b < nb; b += S2_NFEED) {   // one gather + sum takes about a block period: the feeders take turns
+  for (int b = f; b < nb; b += a.nfeed) {   // one gather + sum takes about a block period: the feeders take turns
     const int mB = min(m, a.p - (a.blk_begin + b) * m);
     if (wave >= 1 && wave <= 6) {
       if (!s2_gather_q(a, b, (tid - 64) >> 7, (tid - 64) & 127, mB, part_s)) ok_s[0] = 0;
@@ -1330,7 +1353,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
 template <typename XT, bool SELECT, typename GT = typename XTraits<XT>::GT>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep2(const SweepArgs a) {
   if ((int)blockIdx.x > a.K) {
-    if constexpr (SELECT && sizeof(XT) == 1 && sizeof(GT) == 2) s2_feeder(a, (int)blockIdx.x - a.K - 1);
+    s2_feeder(a, (int)blockIdx.x - a.K - 1);
   } else if ((int)blockIdx.x == a.K) {
     if constexpr (SELECT && sizeof(XT) == 1 && sizeof(GT) == 2) s2_sequencer_sel16(a);
     else s2_sequencer<XT, SELECT, GT>(a);

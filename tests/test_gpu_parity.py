@@ -115,6 +115,25 @@ def test_float_panel_centered():
     assert scaled_err(g["hat"], o["hat"]) < TOL
 
 
+@pytest.mark.parametrize("model", ["BayesB", "BayesCpi", "BayesA"])
+def test_float_panel_chains(model):
+    """fp32 panels (block <= 64, fp64 Gram blocks, fp64-FMA slab loops) through the generic streamer / sequencer and the q
+    feeders: selection models at lag 3 (sparse cross terms from the fp64 distance-2 blocks), affine at lag 2; several
+    blocks with a ragged last one and several slab workgroups."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = synth_small(500, 330, seed=19)
+    Xc = ((X - X.mean(0)) / (X.std(0) + 0.5)).astype(np.float32)
+    kw = dict(it=8, bi=2, seed=14)
+    if model == "BayesB":
+        kw["pi"] = 0.8
+    g = getattr(bwgr_amd, model)(y, Xc, block=48, **kw)
+    o = O.bayes(model, y, Xc, **kw)
+    assert scaled_err(g["b"], o["b"]) < TOL and scaled_err(g["hat"], o["hat"]) < TOL
+    if "d" in o:
+        assert scaled_err(g["d"], o["d"]) < TOL
+
+
 # wgr() settings of man/wgr.Rd:82: BRR (defaults), BayesA (iv), BayesB (iv, pi>0), BayesC (pi>0), BayesL (de)
 @pytest.mark.parametrize("name,kw", [("BRR", {}), ("BayesA", {"iv": True}), ("BayesB", {"iv": True, "pi": 0.5}),
                                      ("BayesC", {"pi": 0.5}), ("BayesL", {"de": True}), ("thin", {"th": 3, "bi": 4})])
