@@ -635,7 +635,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
   // q_b summed over the streamers into part_s[0..2][t] (added up by the reader): from the feeders' tagged sums (one word
   // per marker, polled by the threads of part 0) or, without feeders, gathered here from the streamers' words
   auto gather_q = [&](int b, int part, int t, int mB) -> int {
-    if (a.nfeed <= 0) return s2_gather_q(a, b, part, t, mB, part_s);
+    if (!SELECT || a.nfeed <= 0) return s2_gather_q(a, b, part, t, mB, part_s);
     double v = 0.0;
     if (part == 0 && t < mB) {
       const unsigned long long *g = reinterpret_cast<const unsigned long long *>(a.qpart + (size_t)S2_NSLOT * a.K * SW_MAXM + (size_t)(b % S2_NSLOT) * SW_MAXM + t);
@@ -1353,7 +1353,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
 template <typename XT, bool SELECT, typename GT = typename XTraits<XT>::GT>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep2(const SweepArgs a) {
   if ((int)blockIdx.x > a.K) {
-    s2_feeder(a, (int)blockIdx.x - a.K - 1);
+    if constexpr (SELECT) s2_feeder(a, (int)blockIdx.x - a.K - 1);   // (the affine variants are launched without feeders)
   } else if ((int)blockIdx.x == a.K) {
     if constexpr (SELECT && sizeof(XT) == 1 && sizeof(GT) == 2) s2_sequencer_sel16(a);
     else s2_sequencer<XT, SELECT, GT>(a);
