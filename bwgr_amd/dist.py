@@ -127,7 +127,10 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     msx = torch.tensor([P.stats()[2]], dtype=torch.float64, device="cuda:%d" % dev)
     dist.all_reduce(msx)
     eng = HipShardEngine(P, model, y, W + K, W, pi, 5.0, 0.5, synth.SEED, lo, p, float(msx.item()))
-    markers_per_sync = args.sync_every if args.sync_every > 0 else 16384
+    # default: one residual all-reduce per 131 072 markers swept over ALL ranks, so the staleness window of the partitioned
+    # sampler -- how many markers are updated against a residual that has not seen the other ranks' updates yet -- does not
+    # depend on the number of GPUs (8 GPUs: every 16 384 markers per rank)
+    markers_per_sync = args.sync_every if args.sync_every > 0 else max(P.block, 131072 // world)
     bps = max(1, markers_per_sync // P.block)
     rounds = sync_rounds(eng.nblocks, bps, world)
     run_iterations(eng, W, bps, world, rounds)
