@@ -219,12 +219,12 @@ def test_two_shards_on_one_gpu_match_cpu_checker():
         P.close()
 
 
-@pytest.mark.parametrize("n,p,block,nwg", [(130, 70, 16, 0), (300, 200, 16, 0), (300, 200, 128, 0), (500, 150, 64, 0),
+@pytest.mark.parametrize("n,p,block,nwg", [(130, 9, 16, 0), (130, 20, 16, 0), (130, 40, 16, 0), (130, 70, 16, 0), (300, 200, 16, 0), (300, 200, 128, 0), (500, 150, 64, 0),
                                            (700, 260, 128, 0), (700, 100, 48, 2), (1100, 300, 128, 0), (1100, 130, 32, 9)])
 @pytest.mark.parametrize("model", ["BayesA", "BayesB"])
 def test_geometry_sweep(model, n, p, block, nwg):
-    """Slab rows R in {128, 256, 384, 512}, 1..9 workgroups, ragged last block: every launch geometry the panel
-    heuristics can pick must give the oracle's chain."""
+    """Slab rows R in {128, 256, 384, 512}, 1..9 workgroups, ragged last block, panels of one, two and three blocks (fewer
+    than the pipeline is deep): every launch geometry the panel heuristics can pick must give the oracle's chain."""
     import bwgr_amd
     from oracle import oracle as O
     X, y = synth_small(n, p, seed=n + p)
