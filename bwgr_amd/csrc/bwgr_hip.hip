@@ -1101,8 +1101,8 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipMalloc(&P->dgran, sizeof(unsigned long long) * S2_NSLOT * SW_MAXM));
   PCHK(hipMalloc(&P->ps.blocks, sizeof(StageBuf) * (size_t)P->nblocks));
 #ifdef BWGR_STAMPS
-  PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 48));
-  PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 48));
+  PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 64));
+  PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 64));
 #endif
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<int8_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<int8_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1140,9 +1140,9 @@ extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int
 
 #ifdef BWGR_STAMPS
 // diagnostic build only: cumulative per-phase s_memtime ticks of workgroup 0 (not part of include/bwgr.h)
-extern "C" int bwgr_debug_stamps(bwgr_panel *P, unsigned long long out[48]) {
-  HIPCHK(hipMemcpy(out, P->stamps, sizeof(unsigned long long) * 48, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 48));
+extern "C" int bwgr_debug_stamps(bwgr_panel *P, unsigned long long out[64]) {
+  HIPCHK(hipMemcpy(out, P->stamps, sizeof(unsigned long long) * 64, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 64));
   return BWGR_OK;
 }
 #endif

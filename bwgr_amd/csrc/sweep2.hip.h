@@ -267,9 +267,9 @@ static constexpr int S2_NDE = 7;     // digits of e:     |q| < 2^54
 static constexpr int S2_NDD = 6;     // digits of delta: |q| < 2^46
 static constexpr int S2_OS = 12;     // dwords per row of the int32 output array (8 used; 12 keeps its b128 reads conflict-free)
 static constexpr int S2_DP = SW_MAXM + 16;   // bytes per digit row of the delta digits
-__host__ __device__ inline size_t s2i_lds_bytes(int m, int R, int lag) {   // ring of max(3, lag) tiles; lag 4 has room for one output array only
+__host__ __device__ inline size_t s2i_lds_bytes(int m, int R, int lag) {   // ring of max(3, lag) tiles
   const size_t Rp = (size_t)R + 16;
-  return (size_t)(lag > 3 ? lag : 3) * m * Rp + (size_t)R * 8 + 16 * Rp + 16 * S2_DP + (size_t)(lag > 3 ? 1 : 2) * (R > SW_MAXM ? R : SW_MAXM) * S2_OS * 4 + 64;
+  return (size_t)(lag > 3 ? lag : 3) * m * Rp + (size_t)R * 8 + 16 * Rp + 16 * S2_DP + (size_t)(R > SW_MAXM ? R : SW_MAXM) * S2_OS * 4 + 64;
 }
 __device__ __forceinline__ double pow2_field(int field) { return __hiloint2double(field << 20, 0); }   // 2^(field-1023)
 // maximum over the wave (DPP row shifts + row broadcasts, result broadcast from lane 63); v >= 0 as int
@@ -311,9 +311,8 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
   double *e_s = reinterpret_cast<double *>(smem + off); off += (size_t)R * sizeof(double);
   int8_t *edig_s = reinterpret_cast<int8_t *>(smem + off); off += (size_t)16 * Rp;        // [n][row]: digit n of e[row]; rows n >= S2_NDE stay 0
   int8_t *ddig_s = reinterpret_cast<int8_t *>(smem + off); off += 16 * S2_DP;             // [n][marker]: digit n of delta[marker]
-  const bool ksplit = (L < 4);   // two output arrays: the update's 64-marker steps are split over two waves per 64-row group
   const size_t out_n = (size_t)(R > SW_MAXM ? R : SW_MAXM) * S2_OS;
-  int *out_s = reinterpret_cast<int *>(smem + off); off += (ksplit ? 2 : 1) * out_n * 4;   // [half][row or marker][n]
+  int *out_s = reinterpret_cast<int *>(smem + off); off += out_n * 4;   // [row or marker][n]
   uint32_t *ctl_s = reinterpret_cast<uint32_t *>(smem + off);   // [0],[1]: max exponent of delta (by block parity); [2],[3]: of e; [8]: failure
   const int8_t *X = reinterpret_cast<const int8_t *>(a.X) + (size_t)wg * a.p * R;
   uint32_t *abortw = a.xflags + (size_t)K * SW_FLAG_STRIDE;
@@ -364,7 +363,7 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     }
     S2WALL(2, wg == 0 && tid == 0 && b >= a.lag);
     S2WALL(6, wg == 0 && tid == 0 && b == 100 + a.lag);
-    S2MINMAX(28, 29, tid == 128 && b == 100 + a.lag);
+    S2MINMAX(56, 57, tid == 128 && b == 100 + a.lag);
   };
   static_assert(S2_NDE == 7 && S2_NDD == 6, "the digit recombinations are written out for 7 / 6 digits");
 
@@ -406,14 +405,16 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
           __builtin_amdgcn_s_sleep(1);
         }
       }
+      S2STAMP(10);
       const uint32_t ex = wave_max_u32((dbits >> 23) & 0xFFu);
       if (lane == 0) atomicMax(&ctl_s[par], ex);
     }
     if (bad) ctl_s[8] = 1u;
+    S2STAMP(11);
     __syncthreads();
     S2WALL(1, wg == 0 && tid == 0 && i + L < nb);
     S2WALL(4, wg == 0 && tid == 0 && i == 100);
-    S2MINMAX(30, 31, tid == 0 && i == 100);
+    S2MINMAX(58, 59, tid == 0 && i == 100);
     S2WALL(5, wg == 0 && tid == 0 && i == 101);
     if (ctl_s[8]) { if (tid == 0) a.sc->error = 1u; return; }
     S2STAMP(1);
@@ -421,6 +422,9 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     const int dex = (int)ctl_s[par];
     if (tid < SW_MAXM) put_digits<S2_NDD>(__double2ll_rn((double)__uint_as_float(dbits) * pow2_field(1195 - dex)), ddig_s + tid, S2_DP);
     const double invSd = pow2_field(851 + dex);
+    // the update's partial products are accumulated with LDS atomics (its 64-marker steps are dealt to two waves per row
+    // group): clear the rows first -- the last reader of out_s (the previous q recombination) is behind the poll's barrier
+    for (int c = tid; c < R * S2_OS / 4; c += SW_THREADS) reinterpret_cast<uint4 *>(out_s)[c] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     S2STAMP(2);
     // ---- slab update with tile(i): out_s[row][n] = sum_markers x[row][marker] * digit_n(delta[marker]) ----
@@ -428,9 +432,8 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     // markers 64 s + 16 u + 4 grp + q (this interleave keeps the four lane groups on different LDS banks)
     {
       const int8_t *tile = S2I_TILE(i);
-      // tasks: (64-row group rg, half): with two output arrays the block's 64-marker steps are dealt to two waves and the
-      // reader adds the halves; with one array (lag 4) a wave runs all steps of its row group
-      const int nrg = R / 64, nhalf = ksplit ? 2 : 1;
+      // tasks: (64-row group rg, half of the block's 64-marker steps); the two halves add into the same int32 entries
+      const int nrg = R / 64, nhalf = 2;
       for (int task = wave; task < nhalf * nrg; task += SW_THREADS / 64) {
         const int half = task / nrg, rg = task - half * nrg;
         const int rowoff = 4 * (16 * rg + m16);
@@ -463,11 +466,11 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
           acc3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[3][0], (int)rw[3][1], (int)rw[3][2], (int)rw[3][3]}, bv, acc3, 0, 0, 0);
         }
         if (m16 < 8) {      // lane: digit n = m16; acc_k[reg] belongs to row 4 (16 rg + 4 grp + reg) + k
-          int *op = out_s + half * out_n + (size_t)(4 * (16 * rg + 4 * grp)) * S2_OS + m16;
+          int *op = out_s + (size_t)(4 * (16 * rg + 4 * grp)) * S2_OS + m16;
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
-            op[(4 * reg + 0) * S2_OS] = acc0[reg]; op[(4 * reg + 1) * S2_OS] = acc1[reg];
-            op[(4 * reg + 2) * S2_OS] = acc2[reg]; op[(4 * reg + 3) * S2_OS] = acc3[reg];
+            atomicAdd(&op[(4 * reg + 0) * S2_OS], acc0[reg]); atomicAdd(&op[(4 * reg + 1) * S2_OS], acc1[reg]);
+            atomicAdd(&op[(4 * reg + 2) * S2_OS], acc2[reg]); atomicAdd(&op[(4 * reg + 3) * S2_OS], acc3[reg]);
           }
         }
       }
@@ -488,13 +491,8 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     {
       uint32_t ex = 0u;
       for (int r = tid; r < R; r += SW_THREADS) {
-        int4 o0 = *reinterpret_cast<const int4 *>(out_s + (size_t)r * S2_OS);
-        int2 o1 = *reinterpret_cast<const int2 *>(out_s + (size_t)r * S2_OS + 4);
-        if (ksplit) {
-          const int4 p0 = *reinterpret_cast<const int4 *>(out_s + out_n + (size_t)r * S2_OS);
-          const int2 p1 = *reinterpret_cast<const int2 *>(out_s + out_n + (size_t)r * S2_OS + 4);
-          o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w; o1.x += p1.x; o1.y += p1.y;
-        }
+        const int4 o0 = *reinterpret_cast<const int4 *>(out_s + (size_t)r * S2_OS);
+        const int2 o1 = *reinterpret_cast<const int2 *>(out_s + (size_t)r * S2_OS + 4);
         double w = invSd, v = (double)o0.x * w;
         w *= 256.0; v = fma((double)o0.y, w, v); w *= 256.0; v = fma((double)o0.z, w, v); w *= 256.0; v = fma((double)o0.w, w, v);
         w *= 256.0; v = fma((double)o1.x, w, v); w *= 256.0; v = fma((double)o1.y, w, v);
@@ -1102,7 +1100,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
 #define S16_XST_F(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if ((u) < XSURE || c_ < xchunks) xdst[c_] = name; }
   auto helper_phase = [&](int c) {
     const int blk = a.blk_begin + c, mBc = blk_m(c);
-    S2ONE(10, tid == 64 && c == 100 + L); S2ONE(13, tid == 448 && c == 100 + L);
+    S2ONE(48, tid == 64 && c == 100 + L); S2ONE(51, tid == 448 && c == 100 + L);
     if (wave <= 6) {
       // waves 1-6: block c's packed G, Gx and constants, in registers since the previous phase, go to LDS; block c+1's are
       // requested and have a whole period to land.  (Register staging moves ~60 GB/s through this CU, LDS-DMA only ~25.)
@@ -1112,7 +1110,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       if (fullm) { S16_G_EACH(S16_GST_F) S16_X_EACH(S16_XST_F) } else { S16_G_EACH(S16_GST) S16_X_EACH(S16_XST) }
       if (tid - 64 < NCH) reinterpret_cast<uint4 *>(&stage[c & 1])[tid - 64] = spre;
       if (tid - 64 < NSP) reinterpret_cast<uint4 *>(&specb[c & 1])[tid - 64] = cpre;
-      S2ONE(11, tid == 64 && c == 100 + L);
+      S2ONE(49, tid == 64 && c == 100 + L);
       if (c + 1 < nb) {
         const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(blk + 1) * pstride);
         const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(blk + 1) * m * m);
@@ -1120,7 +1118,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
         if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 1)[tid - 64];
         if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + blk + 1)[tid - 64];
       }
-      S2ONE(12, tid == 64 && c == 100 + L);
+      S2ONE(50, tid == 64 && c == 100 + L);
     } else {
       // wave 7 holds no prefetch.  Its cross-term loads go out first (they depend on nothing of this phase and are ahead of
       // waves 1-6's prefetch in this CU's queue), then the feeder's sums are polled, then the cross term is finished.
@@ -1162,15 +1160,15 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       if (!poll_qsum(c, mBc)) ctrl_s[0] = 0;   // (the first batch of rows and the speculated parts are in flight)
       S2WALL(10, tid == 448 && c >= L);
       S2WALL(14, tid == 448 && c == 100 + L);
-      S2ONE(14, tid == 448 && c == 100 + L);
+      S2ONE(52, tid == 448 && c == 100 + L);
       batch_use();
       for (int i0 = 8; i0 < ntot; i0 += 8) { batch_load(i0); batch_use(); }
       cva += x2a; cvb += x2b; cva += x3a; cvb += x3b;
       dst[lane] = (lane < mBc) ? cva : 0.0;
       dst[64 + lane] = (64 + lane < mBc) ? cvb : 0.0;
-      S2ONE(15, tid == 448 && c == 100 + L);
+      S2ONE(53, tid == 448 && c == 100 + L);
       if (c >= 2) store_state(c - 2);   // last: the next phase's poll is behind these stores only
-      S2ONE(26, tid == 448 && c == 100 + L);
+      S2ONE(54, tid == 448 && c == 100 + L);
     }
   };
 
@@ -1307,7 +1305,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       helper_phase(b + 1);
     }
     __syncthreads();   // block b's recurrence is done; everything block b+1 needs is in LDS (parity (b+1)&1)
-    S2ONE(27, tid == 0 && b == 99 + L);
+    S2ONE(55, tid == 0 && b == 99 + L);
     S2STAMP(2);
     if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
     if (wave == 0 && have_next) {

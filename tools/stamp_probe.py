@@ -12,7 +12,7 @@ import numpy as np, torch
 import bwgr_amd
 from bwgr_amd import synth, _lib
 wl = {"c2": (5000, 50000, "BayesA", 0.0), "c4s": (10000, 100000, "BayesB", 0.99)}
-names2 = {0: "streamer: loop top + tile issue", 9: "streamer: tile commit (vmcnt(0) + LDS stores)", 1: "streamer: wait delta (+ tile issue)", 2: "streamer: delta digits", 3: "streamer: update MFMA (wave 0)", 4: "streamer: update barrier", 5: "streamer: e update + max", 6: "streamer: e digits", 7: "streamer: dots (barrier, MFMA, barrier)", 8: "streamer: q recombine + store",
+names2 = {0: "streamer: loop top + tile issue", 9: "streamer: tile commit (vmcnt(0) + LDS stores)", 10: "streamer: delta poll (early request or loop)", 11: "streamer: wave max + LDS atomic", 1: "streamer: barrier after the poll", 2: "streamer: delta digits", 3: "streamer: update MFMA (wave 0)", 4: "streamer: update barrier", 5: "streamer: e update + max", 6: "streamer: e digits", 7: "streamer: dots (barrier, MFMA, barrier)", 8: "streamer: q recombine + store",
           16: "sequencer: top barrier", 21: "sequencer: lane constants", 22: "sequencer: recurrence rounds", 17: "sequencer: outputs + delta store", 18: "sequencer: wait at barrier A (helpers, q_{b+1})", 19: "sequencer: post (state, r0 of next block)", 20: "sequencer: post tail"}
 names = ["top-barrier", "dot", "combine+exchange", "wait for prefetch waves", "outputs+update", "spec matvec", "recurrence (wave 0)", "-", "wave1: prefetch until tile+stage stored", "wave1: residual vmcnt(0)", "wave1: t(gram loads landed)", "wave1: t(+stage landed)"]
 for key in sys.argv[1:] or ["c2", "c4s"]:
@@ -21,7 +21,7 @@ for key in sys.argv[1:] or ["c2", "c4s"]:
     P = bwgr_amd.Panel(X, n=n); del X
     ch = bwgr_amd.Chain(P, model, y, it=4, bi=0, pi=pi, seed=1)
     ch.run(1); ch.sync()
-    out = (C.c_ulonglong * 48)(); _lib.lib().bwgr_debug_stamps(P._h, out)
+    out = (C.c_ulonglong * 64)(); _lib.lib().bwgr_debug_stamps(P._h, out)
     ch.run(3); ch.sync()
     _lib.lib().bwgr_debug_stamps(P._h, out)
     v = np.array(list(out), float); nblk = 3 * ((p + P.block - 1) // P.block)
@@ -34,7 +34,7 @@ for key in sys.argv[1:] or ["c2", "c4s"]:
         if pi:   # selection models: lag-3 pipeline with the q feeder (wall clock, 100 MHz)
             print("   means (us): delta_i stored -> seen by streamer 0 %.2f -> streamer 0 stores q_{i+lag} %.2f -> feeder puts the sum %.2f -> sequencer has it %.2f"
                   % (hw[1] - hw[0], hw[2] - hw[0], hw[3] - hw[0], hw[10] - hw[0]))
-            one = (C.c_ulonglong * 48)(); ch2 = bwgr_amd.Chain(P, model, y, it=2, bi=0, pi=pi, seed=2)
+            one = (C.c_ulonglong * 64)(); ch2 = bwgr_amd.Chain(P, model, y, it=2, bi=0, pi=pi, seed=2)
             ch2.run(1); ch2.sync(); _lib.lib().bwgr_debug_stamps(P._h, one); ch2.run(1); ch2.sync(); _lib.lib().bwgr_debug_stamps(P._h, one); ch2.close()
             oo = [int(x) for x in list(one)]; o = oo[32:48]; t0 = o[7]
             print("   one sweep, around block 100 (us after the sequencer stores delta_100): streamer 0 sees delta_100 %.2f, stores q_{100+lag} %.2f, sees delta_101 %.2f; "
@@ -42,9 +42,9 @@ for key in sys.argv[1:] or ["c2", "c4s"]:
                   % tuple((x - t0) / 100.0 for x in (o[4], o[6], o[5], o[13], o[14], o[9], o[11], o[12])))
             mm = lambda k: ((~oo[k]) & 0xFFFFFFFFFFFFFFFF)
             print("   over all streamers (us after delta_100 stored): delta_100 seen first %.2f / last %.2f;  q_{100+lag} stored first %.2f / last %.2f"
-                  % ((mm(30) - t0) / 100.0, (oo[31] - t0) / 100.0, (mm(28) - t0) / 100.0, (oo[29] - t0) / 100.0))
+                  % ((mm(58) - t0) / 100.0, (oo[59] - t0) / 100.0, (mm(56) - t0) / 100.0, (oo[57] - t0) / 100.0))
             print("   sequencer helper phase for block 100+lag (us after it starts, i.e. after the barrier of block 98+lag): waves 1-6: Gram/constant stores done %.2f, next "
-                  "loads issued %.2f;  wave 7: sum of q polled %.2f, lag-3 cross term %.2f, state of block 98+lag stored %.2f;  barrier of block 99+lag at %.2f)" % tuple((x - oo[10]) / 100.0 for x in (oo[11], oo[12], oo[14], oo[15], oo[26], oo[27])))
+                  "loads issued %.2f;  wave 7: sum of q polled %.2f, lag-3 cross term %.2f, state of block 98+lag stored %.2f;  barrier of block 99+lag at %.2f)" % tuple((x - oo[48]) / 100.0 for x in (oo[49], oo[50], oo[52], oo[53], oo[54], oo[55])))
     else:
         for nm, x in zip(names, v): print("   %-50s %9.0f ticks/block" % (nm, x / nblk))
     ms, nl = ch.sweep_ms(); print("   sweep ms", ms)
