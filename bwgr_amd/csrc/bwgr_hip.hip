@@ -1055,6 +1055,7 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   }
   P->K = K; P->R = R; P->ld = (int64_t)K * R;
   P->nblocks = (p + m - 1) / m;
+  if (P->nblocks >= (1ll << 24)) { delete P; return fail(BWGR_EINVAL, "panel_create: %lld marker blocks; the delta granules carry a 24-bit block epoch", (long long)P->nblocks); }
   P->lds_bytes = P->is_f32 ? sweep_lds_bytes<float>(m, R) : sweep_lds_bytes<int8_t>(m, R);
   P->lds2_bytes = P->is_f32 ? sweep2_lds_bytes<float>(m, R) : sweep2_lds_bytes<int8_t>(m, R);
   if (!P->is_f32 && s2i_lds_bytes(m, R, 4) <= (size_t)160 * 1024) {

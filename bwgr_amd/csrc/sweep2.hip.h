@@ -56,6 +56,14 @@ template <typename XT> __host__ __device__ inline size_t sweep2_lds_bytes(int m,
   return streamer > seq ? streamer : seq;
 }
 
+// delta hand-off: one 8-byte granule per marker, {hi: block epoch (24 bits) | largest float exponent field of the
+// block's deltas (8 bits), lo: the float delta}: the datum is the flag, and the int8 streamers get the scale of their
+// fixed-point digits without a reduction of their own
+__device__ __forceinline__ unsigned long long s2_dgranule(int b, uint32_t exmax, float dl) {
+  return ((unsigned long long)((((uint32_t)(b + 1)) & 0xFFFFFFu) | (exmax << 24)) << 32) | (unsigned long long)__float_as_uint(dl);
+}
+__device__ __forceinline__ bool s2_dgranule_is(unsigned long long v, int b) { return (((uint32_t)(v >> 32)) & 0xFFFFFFu) == (((uint32_t)(b + 1)) & 0xFFFFFFu); }
+
 // q hand-off: each slab dot travels as ONE 8-byte word whose low 8 mantissa bits carry the block's tag (1..255; the
 // slots are zeroed before every launch and a slot's consecutive users differ in tag), so a reader needs a single round
 // trip and the writer no payload fence.  The value loses 8 of its 53 mantissa bits (relative 2^-45).
@@ -184,12 +192,11 @@ __device__ __forceinline__ void s2_streamer(const SweepArgs &a) {
     int bad = 0;
     if (tid < mB) {
       const unsigned long long *g = a.dgran + (size_t)(i % S2_NSLOT) * SW_MAXM + tid;
-      const uint32_t epoch = (uint32_t)(i + 1);
       const uint64_t t0 = wall_clock64();
       unsigned spins = 0;
       for (;;) {
         const unsigned long long v = ld_agent_raw64(g);
-        if ((uint32_t)(v >> 32) == epoch) { delta_s[tid] = (double)__uint_as_float((uint32_t)v); break; }
+        if (s2_dgranule_is(v, i)) { delta_s[tid] = (double)__uint_as_float((uint32_t)v); break; }
         if ((++spins & 63u) == 0u) {
           if (ld_agent_u32(abortw) != 0u) { bad = 1; break; }
           if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) {
@@ -353,6 +360,9 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     }
     __syncthreads();
     S2STAMP(7);
+    // out_s must be all zero when the next update starts (its partial products are added with LDS atomics): the threads that
+    // recombine a marker's row clear it behind them, waves 4-7 clear the rows past the markers (last read by the e update)
+    if (tid >= 256) for (int c = tid - 256; c < (R - SW_MAXM) * S2_OS / 4; c += 256) reinterpret_cast<uint4 *>(out_s + (size_t)SW_MAXM * S2_OS)[c] = make_uint4(0, 0, 0, 0);
     const int tq = tid - 128;   // waves 2-3 store q: waves 0-1 keep nothing but polls on their memory counter
     if (tq >= 0 && tq < mB) {
       const int4 o0 = *reinterpret_cast<const int4 *>(out_s + (size_t)tq * S2_OS), o1 = *reinterpret_cast<const int4 *>(out_s + (size_t)tq * S2_OS + 4);
@@ -360,6 +370,10 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
       w *= 256.0; v = fma((double)o0.y, w, v); w *= 256.0; v = fma((double)o0.z, w, v); w *= 256.0; v = fma((double)o0.w, w, v);
       w *= 256.0; v = fma((double)o1.x, w, v); w *= 256.0; v = fma((double)o1.y, w, v); w *= 256.0; v = fma((double)o1.z, w, v);
       s2_put_q(a.qpart + ((size_t)(b % S2_NSLOT) * K + wg) * SW_MAXM + tq, v, b);
+    }
+    if (tq >= 0 && tq < SW_MAXM) {
+      uint4 *rowp = reinterpret_cast<uint4 *>(out_s + (size_t)tq * S2_OS);
+      rowp[0] = make_uint4(0, 0, 0, 0); rowp[1] = make_uint4(0, 0, 0, 0); rowp[2] = make_uint4(0, 0, 0, 0);
     }
     S2WALL(2, wg == 0 && tid == 0 && b >= a.lag);
     S2WALL(6, wg == 0 && tid == 0 && b == 100 + a.lag);
@@ -381,33 +395,34 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
   for (int i = 0; i < nb; ++i) {
     const int mB = blk_m(i);
     const int par = i & 1;
-    if (tid == 0) { ctl_s[par ^ 1] = 0u; ctl_s[2 + (par ^ 1)] = 0u; }      // next block's maxima (this block's were reset one iteration ago)
+    if (tid == 0) ctl_s[2 + (par ^ 1)] = 0u;      // next block's e maximum (this block's was reset one iteration ago)
     S2STAMP(0);
-    // delta_i: one 8-byte {epoch, float} granule per marker, polled by the thread that needs it
+    // delta_i: one granule per marker, polled by the thread that needs it; it also carries the block's largest exponent
+    // field ex: |delta| < 2^(ex-126), so S = 2^(172-ex) gives |q| < 2^46 and the digits follow at once
     int bad = 0;
-    uint32_t dbits = 0u;
     if (tid < SW_MAXM) {
+      uint32_t dbits = 0u, dex = 0u;
       if (tid < mB) {
         const unsigned long long *g = a.dgran + (size_t)(i % S2_NSLOT) * SW_MAXM + tid;
-        const uint32_t epoch = (uint32_t)(i + 1);
         const uint64_t t0 = wall_clock64();
         unsigned spins = 0;
         unsigned long long v = pre;   // requested during the previous iteration: when this streamer runs behind, delta_i is
                                       // already there and the poll's round trip (~0.6 us) is off its iteration
         for (;;) {
-          if ((uint32_t)(v >> 32) == epoch) { dbits = (uint32_t)v; break; }
+          if (s2_dgranule_is(v, i)) break;
           v = ld_agent_raw64(g);
-          if ((uint32_t)(v >> 32) == epoch) { dbits = (uint32_t)v; break; }
+          if (s2_dgranule_is(v, i)) break;
           if ((++spins & 63u) == 0u) {
             if (ld_agent_u32(abortw) != 0u) { bad = 1; break; }
             if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); bad = 1; break; }
           }
           __builtin_amdgcn_s_sleep(1);
         }
+        if (!bad) { dbits = (uint32_t)v; dex = (uint32_t)(v >> 56); }
       }
       S2STAMP(10);
-      const uint32_t ex = wave_max_u32((dbits >> 23) & 0xFFu);
-      if (lane == 0) atomicMax(&ctl_s[par], ex);
+      put_digits<S2_NDD>(__double2ll_rn((double)__uint_as_float(dbits) * pow2_field(1195 - (int)dex)), ddig_s + tid, S2_DP);
+      if (tid == 0) ctl_s[par] = dex;
     }
     if (bad) ctl_s[8] = 1u;
     S2STAMP(11);
@@ -417,15 +432,8 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     S2MINMAX(58, 59, tid == 0 && i == 100);
     S2WALL(5, wg == 0 && tid == 0 && i == 101);
     if (ctl_s[8]) { if (tid == 0) a.sc->error = 1u; return; }
+    const double invSd = pow2_field(851 + (int)ctl_s[par]);
     S2STAMP(1);
-    // ---- digits of delta: |delta| < 2^(ex-126) with ex the block's largest exponent field;  S = 2^(172-ex), |q| < 2^46 ----
-    const int dex = (int)ctl_s[par];
-    if (tid < SW_MAXM) put_digits<S2_NDD>(__double2ll_rn((double)__uint_as_float(dbits) * pow2_field(1195 - dex)), ddig_s + tid, S2_DP);
-    const double invSd = pow2_field(851 + dex);
-    // the update's partial products are accumulated with LDS atomics (its 64-marker steps are dealt to two waves per row
-    // group): clear the rows first -- the last reader of out_s (the previous q recombination) is behind the poll's barrier
-    for (int c = tid; c < R * S2_OS / 4; c += SW_THREADS) reinterpret_cast<uint4 *>(out_s)[c] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
     S2STAMP(2);
     // ---- slab update with tile(i): out_s[row][n] = sum_markers x[row][marker] * digit_n(delta[marker]) ----
     // lane (m16, grp) of a wave pass owns the row quad r4 = 16 rg + m16; its k slots (dword u, byte q) of MFMA step s are the
@@ -509,6 +517,8 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
       const double invSe = e_digits(par);
       S2STAMP(6);
       publish(i + L, S2I_TILE(i + L), invSe);
+    } else {   // no publish to clear out_s behind it
+      for (int c = tid; c < R * S2_OS / 4; c += SW_THREADS) reinterpret_cast<uint4 *>(out_s)[c] = make_uint4(0, 0, 0, 0);
     }
     S2STAMP(8);
   }
@@ -751,25 +761,33 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
             int oA = prow(base) - 1, oB = prow(base) + 63;   // + lane, at l = 0
             if (q == 0 && ngrp > 1) {
               GT gn0 = gp[oA + lane], gn1 = gp[oB + lane];
-              for (int l = 0; l < cnt; ++l) {
-                const GT g0 = (lane > l) ? gn0 : (GT)0, g1 = gn1;
-                oA += m - 2 - (base + l); oB += m - 2 - (base + l);
-                gn0 = gp[oA + lane]; gn1 = gp[oB + lane];          // next row (slack makes the last one harmless)
-                const float dl = lane_b1(r[0], lc[0]) - lc[0].b0;
-                const double dd = (double)readlane_f32(dl, l);
-                r[0] = fma(-(double)g0, dd, r[0]);
-                r[1] = fma(-(double)g1, dd, r[1]);
-              }
+              // eight markers per trip (cnt = 64 except in the last block): the serial chain is ~24 instructions per marker on
+              // one wave, and with one marker per trip its speed followed the loop's placement in the instruction-fetch lines
+#define S2_AFFINE_STEP2(l_) { \
+                const GT g0 = (lane > (l_)) ? gn0 : (GT)0, g1 = gn1; \
+                oA += m - 2 - (base + (l_)); oB += m - 2 - (base + (l_)); \
+                gn0 = gp[oA + lane]; gn1 = gp[oB + lane];          /* next row (slack makes the last one harmless) */ \
+                const float dl = lane_b1(r[0], lc[0]) - lc[0].b0; \
+                const double dd = (double)readlane_f32(dl, (l_)); \
+                r[0] = fma(-(double)g0, dd, r[0]); \
+                r[1] = fma(-(double)g1, dd, r[1]); }
+              int l = 0;
+              for (; l + 8 <= cnt; l += 8) { S2_AFFINE_STEP2(l) S2_AFFINE_STEP2(l + 1) S2_AFFINE_STEP2(l + 2) S2_AFFINE_STEP2(l + 3) S2_AFFINE_STEP2(l + 4) S2_AFFINE_STEP2(l + 5) S2_AFFINE_STEP2(l + 6) S2_AFFINE_STEP2(l + 7) }
+              for (; l < cnt; ++l) S2_AFFINE_STEP2(l)
+#undef S2_AFFINE_STEP2
             } else {
               GT gn0 = gp[oA + lane];
-              for (int l = 0; l < cnt; ++l) {
-                const GT g0 = (lane > l) ? gn0 : (GT)0;
-                oA += m - 2 - (base + l);
-                gn0 = gp[oA + lane];
-                const float dl = lane_b1(r[q], lc[q]) - lc[q].b0;
-                const double dd = (double)readlane_f32(dl, l);
-                r[q] = fma(-(double)g0, dd, r[q]);
-              }
+#define S2_AFFINE_STEP1(l_) { \
+                const GT g0 = (lane > (l_)) ? gn0 : (GT)0; \
+                oA += m - 2 - (base + (l_)); \
+                gn0 = gp[oA + lane]; \
+                const float dl = lane_b1(r[q], lc[q]) - lc[q].b0; \
+                const double dd = (double)readlane_f32(dl, (l_)); \
+                r[q] = fma(-(double)g0, dd, r[q]); }
+              int l = 0;
+              for (; l + 8 <= cnt; l += 8) { S2_AFFINE_STEP1(l) S2_AFFINE_STEP1(l + 1) S2_AFFINE_STEP1(l + 2) S2_AFFINE_STEP1(l + 3) S2_AFFINE_STEP1(l + 4) S2_AFFINE_STEP1(l + 5) S2_AFFINE_STEP1(l + 6) S2_AFFINE_STEP1(l + 7) }
+              for (; l < cnt; ++l) S2_AFFINE_STEP1(l)
+#undef S2_AFFINE_STEP1
             }
           } else {
             int front = 0;
@@ -793,6 +811,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
       // outputs; delta_b goes out at once as {epoch, float} granules (one 8-byte write-through store per marker)
       unsigned long long *gslot = a.dgran + (size_t)(b % S2_NSLOT) * SW_MAXM;
       const int nacc0 = __popcll(accmask[0]);
+      float dl_own[2] = {0.0f, 0.0f};
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int t = 64 * q + lane;
@@ -802,7 +821,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
           const float bn = inc ? b1 : lc[q].b2;
           const float dn = inc ? 1.0f : 0.0f;
           const float dl = bn - lc[q].b0;
-          st_agent_raw64(gslot + t, ((unsigned long long)(uint32_t)(b + 1) << 32) | (unsigned long long)__float_as_uint(dl));
+          dl_own[q] = dl;
           delta_s[t] = (double)dl; bnew_s[t] = bn; dnew_s[t] = dn;
           if (SELECT && inc) {   // what this marker changed relative to the speculated step
             const int idx = (q ? nacc0 : 0) + __popcll(accmask[q] & ((1ull << lane) - 1ull));
@@ -811,6 +830,11 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
           sum_d += (double)dn;
           sum_b2 = fma((double)bn, (double)bn, sum_b2);
         }
+      }
+      {   // the granules: every delta of the block is known here, so is their largest exponent
+        const uint32_t exmax = wave_max_u32(max((__float_as_uint(dl_own[0]) >> 23) & 0xFFu, (__float_as_uint(dl_own[1]) >> 23) & 0xFFu));
+        if (lane < mB) st_agent_raw64(gslot + lane, s2_dgranule(b, exmax, dl_own[0]));
+        if (64 + lane < mB) st_agent_raw64(gslot + 64 + lane, s2_dgranule(b, exmax, dl_own[1]));
       }
       if (SELECT && lane == 0) ctrl_s[2 + (b & 1)] = nacc0 + __popcll(accmask[1]);
       S2WALL(0, lane == 0 && b + 3 < nb);
@@ -1273,6 +1297,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       unsigned long long *gslot = a.dgran + (size_t)(b % S2_NSLOT) * SW_MAXM;
       const int nacc0 = __popcll(accmask[0]);
       nacc = nacc0 + __popcll(accmask[1]);
+      float dl_own[2] = {0.0f, 0.0f};
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int t = 64 * q + lane;
@@ -1281,8 +1306,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
           const bool inc = ((accmask[q] >> lane) & 1ull) != 0ull;
           bn[q] = inc ? b1 : lc[q].b2;
           dn[q] = inc ? 1.0f : 0.0f;
-          const float dl = bn[q] - lc[q].b0;
-          st_agent_raw64(gslot + t, ((unsigned long long)(uint32_t)(b + 1) << 32) | (unsigned long long)__float_as_uint(dl));
+          dl_own[q] = bn[q] - lc[q].b0;
           if (inc) {   // what this marker changed relative to the speculated step
             const int idx = (q ? nacc0 : 0) + __popcll(accmask[q] & ((1ull << lane) - 1ull));
             acc_k[idx] = t; acc_corr[idx] = (double)(b1 - lc[q].b0) - (double)lc[q].drej;
@@ -1295,6 +1319,11 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
           sum_d += (double)dn[q];
           sum_b2 = fma((double)bn[q], (double)bn[q], sum_b2);
         }
+      }
+      {   // the granules: every delta of the block is known here, so is their largest exponent
+        const uint32_t exmax = wave_max_u32(max((__float_as_uint(dl_own[0]) >> 23) & 0xFFu, (__float_as_uint(dl_own[1]) >> 23) & 0xFFu));
+        if (lane < mB) st_agent_raw64(gslot + lane, s2_dgranule(b, exmax, dl_own[0]));
+        if (64 + lane < mB) st_agent_raw64(gslot + 64 + lane, s2_dgranule(b, exmax, dl_own[1]));
       }
       am0 = accmask[0]; am1 = accmask[1];
       if (lane == 0) ctrl_s[4 + (b & 3)] = nacc;
