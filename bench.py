@@ -131,6 +131,7 @@ def main():
     except Exception:
         pass
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+    pl = P.pipeline(bool(pi))
     out = {
         "metric": "MCMC iter/sec (full marker sweep)", "value": K / elapsed, "unit": "iter/s", "n_gpus": 1,
         "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong",
@@ -138,7 +139,7 @@ def main():
         "config": {"workload": "%s: synthetic n=%d x p=%d int8, %s%s, exact chain (blocked sweep, block=%d, %d slab "
                                "workgroups x %d rows + 1 sequencer%s)" % (args.workload, n, p, model,
                                                           " pi=%.2f (1%% in model)" % pi if pi else "", P.block, P.nwg, P.slab_rows,
-                                                          " + 1 q feeder, lag-3 pipeline" if pi else ", lag-2 pipeline"),
+                                                          (" + %d q feeders" % pl["feeders"] if pl["feeders"] else "") + ", lag-%d pipeline" % pl["lag"]),
                    "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_sweep2<int8>" if os.environ.get("BWGR_SWEEP", "2") != "1" else "k_sweep<int8>",

@@ -81,6 +81,12 @@ class Panel:
     def set_stream(self, stream_ptr):
         check(_lib.lib().bwgr_panel_set_stream(self._h, C.c_void_p(stream_ptr)))
 
+    def pipeline(self, selection):
+        """How a sweep over this panel is pipelined: dict(generation, lag, feeders, gram_bits) (bwgr_panel_pipeline)."""
+        info = (C.c_int * 4)()
+        check(_lib.lib().bwgr_panel_pipeline(self._h, int(bool(selection)), info))
+        return dict(zip(("generation", "lag", "feeders", "gram_bits"), (int(v) for v in info)))
+
     def stats(self):
         xx = np.empty(self.p, np.float32); vx = np.empty(self.p, np.float32); msx = C.c_float()
         check(_lib.lib().bwgr_panel_stats(self._h, _fp(xx), _fp(vx), C.byref(msx)))

@@ -1161,6 +1161,18 @@ extern "C" int bwgr_panel_info(const bwgr_panel *P, int64_t info[8]) {
   return BWGR_OK;
 }
 
+extern "C" int bwgr_panel_pipeline(const bwgr_panel *P, int selection, int info[4]) {
+  if (!P || !info) return fail(BWGR_EINVAL, "null pointer");
+  SweepArgs a{};
+  a.flags = selection ? SWF_SELECT : 0u;
+  choose_lag(P, a);
+  info[0] = P->sweep_version;
+  info[1] = a.lag;
+  info[2] = (P->sweep_version == 2 && selection) ? P->nfeed : 0;
+  info[3] = P->is_f32 ? 0 : (P->gram16 ? 16 : 32);
+  return BWGR_OK;
+}
+
 extern "C" int bwgr_panel_stats(bwgr_panel *P, float *xx, float *vx, float *MSx) {
   if (!P) return fail(BWGR_EINVAL, "null panel");
   HIPCHK(hipSetDevice(P->device));

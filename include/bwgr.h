@@ -69,6 +69,11 @@ int bwgr_panel_set_stream(bwgr_panel *P, void *hip_stream); /* NULL = the defaul
 /* geometry actually chosen: info[0]=n, [1]=p, [2]=ld (padded rows), [3]=block, [4]=nwg, [5]=slab rows,
  * [6]=bytes of X resident, [7]=bytes of Gram resident */
 int bwgr_panel_info(const bwgr_panel *P, int64_t info[8]);
+/* how a sweep over this panel is pipelined (no reference counterpart; reporting only): info[0]=kernel generation (1|2),
+ * [1]=pipeline depth in blocks (a block's dots lag the chain by this many blocks), [2]=q feeder workgroups,
+ * [3]=bits of the Gram entries the sequencer stages (16|32; 0 for float panels).  selection != 0: BayesB/C/Cpi/Dpi-type
+ * sweeps (inclusion indicators), else the affine ones (BayesA/L/RR). */
+int bwgr_panel_pipeline(const bwgr_panel *P, int selection, int info[4]);
 /* xx[j] = |X_j|^2, vx[j] = fvar(X_j), MSx = sum vx   (host outputs; any may be NULL) */
 int bwgr_panel_stats(bwgr_panel *P, float *xx, float *vx, float *MSx);
 
