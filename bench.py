@@ -56,6 +56,44 @@ def cpu_baseline(Xs_host, y_host, model, pi, p_total, budget_s=20.0):
                       % (ps, p_total, n, per_sweep, os.cpu_count())}
 
 
+def concurrent_leg(P, model, y, pi, nch, K, W, n, p):
+    """nch independent chains (seeds SEED, SEED+1, ...) of the same model on the one resident panel, each on its own
+    clone (private sweep scratch + stream, shared genotypes): K iterations of every chain, timed like the main leg.
+    This is the throughput shape of the reference's multi-fit callers (mcmcCV, replicate chains); every chain is
+    bit-identical to the one it would be alone (tests/test_gpu_parity.py)."""
+    import torch
+    import bwgr_amd
+    from bwgr_amd import synth
+    handles = [P] + [P.clone() for _ in range(nch - 1)]
+    chains = [bwgr_amd.Chain(h, model, y, it=W + K, bi=W, pi=pi, df=5, R2=0.5, seed=synth.SEED + i) for i, h in enumerate(handles)]
+    try:
+        for _ in range(W):
+            for c in chains:
+                c.run(1)
+        for c in chains:
+            c.sync(); c.sweep_ms()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            for c in chains:
+                c.run(1)
+        for c in chains:
+            c.sync()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        kms = [c.sweep_ms()[0] for c in chains]
+        rate = nch * K / el
+        return {"chains": nch, "value": rate, "unit": "chain-iter/s", "ms_per_step_all_chains": 1e3 * el / K,
+                "sweep_kernel_ms_per_chain": kms, "genotype_GBps": rate * float(n) * float(p) / 1e9,
+                "frac_of_hbm_peak": rate * float(n) * float(p) / 1e9 / HBM_PEAK_GBS,
+                "note": "each chain reads X itself: bytes moved = chains x n x p per step"}
+    finally:
+        for c in chains:
+            c.close()
+        for h in handles[1:]:
+            h.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +103,8 @@ def main():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--nwg", type=int, default=0)
     ap.add_argument("--sync-every", type=int, default=0, help="markers per rank between residual all-reduces (N>1)")
+    ap.add_argument("--chains", type=int, default=0, help="extra leg at N=1: this many chains side by side on the one "
+                    "resident panel (0 = as many as fit the chip, 1 = skip the leg); reported as concurrent_chains")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-slice", type=int, default=20000)
     args = ap.parse_args()
@@ -147,10 +187,18 @@ def main():
         "setup_s": setup_s,
         "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d": float(st["d"].mean())},
     }
+    ch.close()
+    nch = args.chains if args.chains > 0 else P.max_concurrent(bool(pi))
+    nch = min(nch, P.max_concurrent(bool(pi)))
+    if nch > 1:
+        try:
+            out["concurrent_chains"] = concurrent_leg(P, model, y, pi, nch, K, W, n, p)
+        except Exception as ex:   # the headline leg above stands on its own
+            out["concurrent_chains"] = {"chains": nch, "error": str(ex)}
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(Xs_host, y.cpu().numpy(), model, pi, p)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-    ch.close(); P.close()
+    P.close()
     print(json.dumps(out))
 
 

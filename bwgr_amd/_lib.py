@@ -31,6 +31,8 @@ def lib():
     L.bwgr_panel_destroy.argtypes = [vp]
     L.bwgr_panel_set_stream.argtypes = [vp, vp]
     L.bwgr_panel_info.argtypes = [vp, C.POINTER(i64)]
+    L.bwgr_panel_clone.argtypes = [C.POINTER(vp), vp]
+    L.bwgr_panel_max_concurrent.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.bwgr_panel_pipeline.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.bwgr_panel_stats.argtypes = [vp, c_f, c_f, c_f]
     L.bwgr_kmup.argtypes = [vp, c_f, c_f, c_f, c_f, c_f, f32, f32, u64, u32, i32]
@@ -70,7 +72,7 @@ def device_count():
 
 
 EXPORTS = ["bwgr_abi_version", "bwgr_last_error", "bwgr_device_count", "bwgr_panel_create", "bwgr_panel_destroy",
-           "bwgr_panel_set_stream", "bwgr_panel_info", "bwgr_panel_pipeline", "bwgr_panel_stats", "bwgr_kmup", "bwgr_chain_create",
+           "bwgr_panel_set_stream", "bwgr_panel_info", "bwgr_panel_pipeline", "bwgr_panel_clone", "bwgr_panel_max_concurrent", "bwgr_panel_stats", "bwgr_kmup", "bwgr_chain_create",
            "bwgr_chain_create_sharded", "bwgr_chain_sweep_blocks", "bwgr_chain_get_sums", "bwgr_chain_end_iteration",
            "bwgr_chain_destroy", "bwgr_chain_run", "bwgr_chain_sync", "bwgr_chain_iterations", "bwgr_chain_result",
            "bwgr_chain_state", "bwgr_chain_sweep_ms", "bwgr_bayes", "bwgr_bayes2", "bwgr_wgr", "bwgr_wgr_ex", "bwgr_synth_genotypes",

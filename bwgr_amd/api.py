@@ -81,6 +81,28 @@ class Panel:
     def set_stream(self, stream_ptr):
         check(_lib.lib().bwgr_panel_set_stream(self._h, C.c_void_p(stream_ptr)))
 
+    def clone(self):
+        """A second handle on the same resident genotypes with its own sweep scratch and stream (bwgr_panel_clone):
+        chains on a panel and on its clones run side by side on the GPU.  Closed with (or before) the parent."""
+        import weakref
+        q = Panel.__new__(Panel)
+        q._h = C.c_void_p(); q._keep = None
+        root = getattr(self, "_parent", None) or self
+        check(_lib.lib().bwgr_panel_clone(C.byref(q._h), root._h))
+        q._parent = root
+        for k in ("n", "p", "ld", "block", "nwg", "slab_rows", "x_bytes", "gram_bytes", "device"):
+            setattr(q, k, getattr(root, k))
+        if not hasattr(root, "_clones"):
+            root._clones = weakref.WeakSet()
+        root._clones.add(q)
+        return q
+
+    def max_concurrent(self, selection):
+        """How many sweeps of this geometry fit the chip at once (bwgr_panel_max_concurrent)."""
+        c = C.c_int()
+        check(_lib.lib().bwgr_panel_max_concurrent(self._h, int(bool(selection)), C.byref(c)))
+        return int(c.value)
+
     def pipeline(self, selection):
         """How a sweep over this panel is pipelined: dict(generation, lag, feeders, gram_bits) (bwgr_panel_pipeline)."""
         info = (C.c_int * 4)()
@@ -94,6 +116,8 @@ class Panel:
 
     def close(self):
         if self._h:
+            for q in list(getattr(self, "_clones", ())):
+                q.close()
             _lib.lib().bwgr_panel_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -247,6 +271,63 @@ def BayesDpi(y, X, it=1500, bi=500, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw
     return _fused("BayesDpi", y, X, it, bi, 0.0, df, R2, seed, rng_mode, **kw)
 
 
+_SELECTION = ("BayesB", "BayesC", "BayesCpi", "BayesDpi")
+_DEFAULT_PI = {"BayesB": 0.95, "BayesC": 0.95}
+
+
+def fit_many(X, jobs, concurrent=None, chunk=4, **panel_kw):
+    """Several fused-sampler fits on ONE resident X, run side by side: jobs = [dict(model=, y=, it=, bi=, pi=, df=,
+    R2=, seed=, rng_mode=), ...] (same defaults as the BayesX functions); returns the BayesX return lists in job order.
+    Every job's chain is the one BayesX(y, X, ...) alone would run -- bit for bit -- because a chain's arithmetic does
+    not depend on what else is on the chip: the panel is cloned (bwgr_panel_clone: shared genotypes and Gram, private
+    sweep scratch and stream) once per slot, a sweep occupies nwg + 1 + feeders compute units, and up to
+    Panel.max_concurrent() of them fit.  This is the shape of the reference's multi-fit callers (mcmcCV runs seven
+    samplers per fold on the same training matrix, R/cv.R:124-130), which it runs one after the other."""
+    P, own = _as_panel(X, **panel_kw)
+    handles, active, results = [], {}, [None] * len(jobs)   # active: slot -> [job index, chain, iterations left]
+    try:
+        norm = []
+        for j in jobs:
+            j = dict(j)
+            model = j.pop("model"); y = j.pop("y")
+            norm.append((model, y, int(j.pop("it", 1500)), int(j.pop("bi", 500)), float(j.pop("pi", _DEFAULT_PI.get(model, 0.0))),
+                         float(j.pop("df", 5)), float(j.pop("R2", 0.5)), j.pop("seed", None), int(j.pop("rng_mode", 0))))
+            if j:
+                raise TypeError("fit_many: unknown job keys %s" % sorted(j))
+        cap = P.max_concurrent(any(m in _SELECTION for m, *_ in norm))
+        nslot = max(1, min(len(norm), cap if concurrent is None else min(int(concurrent), cap)))
+        handles = [P] + [P.clone() for _ in range(nslot - 1)]
+        queue = list(range(len(norm)))
+        while queue or active:
+            for slot in range(nslot):
+                if slot not in active and queue:
+                    i = queue.pop(0)
+                    model, y, it, bi, pi, df, R2, seed, rng_mode = norm[i]
+                    active[slot] = [i, Chain(handles[slot], model, y, it, bi, pi, df, R2, seed, rng_mode), it]
+            # a few iterations per chain per turn keeps every stream's launch queue fed without one chain hogging the host
+            for slot in list(active):
+                i, ch, left = active[slot]
+                step = min(int(chunk), left)
+                ch.run(step)
+                active[slot][2] = left - step
+            for slot in list(active):
+                i, ch, left = active[slot]
+                if left == 0:
+                    try:
+                        results[i] = ch.result()
+                    finally:
+                        ch.close()
+                    del active[slot]
+        return results
+    finally:
+        for rec in active.values():
+            rec[1].close()
+        for h in handles[1:]:
+            h.close()
+        if own:
+            P.close()
+
+
 def _fused2(base, y, X1, X2, it, bi, pi, df, R2, seed, rng_mode, **panel_kw):
     """BayesA2 / BayesB2 / BayesRR2(y, X1, X2, ...), src/Rcpp20260726ai.cpp:990-1218: two panels, one residual."""
     P1, own1 = _as_panel(X1, **panel_kw)
@@ -328,7 +409,7 @@ _CV_NAMES = ("BayesA", "BayesB", "BayesC", "BayesL", "BayesCpi", "BayesDpi", "Ba
 def mcmcCV(y, gen, k=5, n=5, it=1500, bi=500, pi=0.95, df=5, R2=0.5, avg=True, llo=None, tbv=None, ReturnGebv=False, *,
            seed=None, **panel_kw):
     """mcmcCV(), R/cv.R:113-216: n random k-fold (or leave-level-out) cross-validation cycles of the seven fused samplers;
-    every cycle stages its training rows once and runs the seven chains on that panel.  Returns the predictive
+    every cycle stages its training rows once and runs the seven chains on that panel, side by side (fit_many).  Returns the predictive
     correlations like the reference (`avg`: one vector sorted decreasingly, else one row per cycle), rounded to 4
     digits, or list(cv, hat, beta) with ReturnGebv.  As in the reference, column i holds the predictions of fit f_i =
     (A, B, C, L, RR, Cpi, Dpi) but is *labelled* (A, B, C, L, Cpi, Dpi, RR) (R/cv.R:124-133).  Fold rows come from the
@@ -349,9 +430,10 @@ def mcmcCV(y, gen, k=5, n=5, it=1500, bi=500, pi=0.95, df=5, R2=0.5, avg=True, l
         P = Panel(np.ascontiguousarray(gen[keep]), **panel_kw)
         try:
             B = np.zeros((p, 7))
-            for i, model in enumerate(_CV_FITS):
-                kw = {"pi": pi} if model in ("BayesB", "BayesC") else {}
-                fit = globals()[model](y[keep].astype(np.float32), P, it=it, bi=bi, df=df, R2=R2, seed=(base + 1000003 * (c + 1) + i) & 0x7FFFFFFFFFFFFFFF, **kw)
+            ytr = y[keep].astype(np.float32)
+            jobs = [dict(model=model, y=ytr, it=it, bi=bi, df=df, R2=R2, seed=(base + 1000003 * (c + 1) + i) & 0x7FFFFFFFFFFFFFFF,
+                         **({"pi": pi} if model in ("BayesB", "BayesC") else {})) for i, model in enumerate(_CV_FITS)]
+            for i, fit in enumerate(fit_many(P, jobs)):   # the seven chains side by side on the fold's training panel
                 B[:, i] = fit["b"]
         finally:
             P.close()

@@ -756,6 +756,9 @@ struct bwgr_panel {
   int sweep_version = 2;   // 2: streamer/sequencer pipeline (k_sweep2); 1: replicated recurrence (k_sweep)
   unsigned long long *stamps = nullptr;   // diagnostic build only
   PreStage ps = {};
+  bwgr_panel *parent = nullptr;   // a clone shares the parent's read-only arrays (X, Gram, xx, vx) and owns only the scratch
+  int nclones = 0;
+  hipStream_t own_stream = nullptr;
 };
 
 struct bwgr_chain {
@@ -775,6 +778,16 @@ struct bwgr_chain {
   float ms_acc = 0; int launch_acc = 0;
   bool finalized = false;
 };
+
+// Concurrent chains (bwgr_panel_clone) want one hardware queue per stream; the runtime's default is four.  Set before the
+// first HIP call of the process unless the user chose a value.
+__attribute__((constructor)) static void bwgr_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
+// device -> host copy ordered on the panel's stream (which may be a non-blocking one: the null stream does not wait for it)
+static hipError_t d2h(hipStream_t st, void *dst, const void *src, size_t bytes) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+  return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
 
 static Rng make_rng(uint64_t seed, int mode) {
   Rng g; g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.degenerate = (mode == BWGR_RNG_DEGENERATE); return g;
@@ -917,9 +930,16 @@ static int upload(bwgr_panel *P, const void *X, int memloc, int64_t ldx) {
 
 extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   if (!P) return BWGR_OK;
+  if (P->nclones > 0) return fail(BWGR_EINVAL, "panel_destroy: %d clone(s) of this panel are still alive", P->nclones);
   (void)hipSetDevice(P->device);
-  hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->xspec2); hipFree(P->gramx3); hipFree(P->xspec3); hipFree(P->gramp16); hipFree(P->gramx16); hipFree(P->gram16_bad); hipFree(P->gramp); hipFree(P->ps.spec); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev); hipFree(P->xpart); hipFree(P->qpart); hipFree(P->dgran); hipFree(P->xflags);
-  hipFree(P->ps.blocks); hipFree(P->stamps);
+  if (!P->parent) {
+    hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->gramx3); hipFree(P->gramp16); hipFree(P->gramx16); hipFree(P->gram16_bad); hipFree(P->gramp); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev);
+  } else {
+    P->parent->nclones--;
+  }
+  // the scratch a sweep writes: speculative cross terms, pre-staged constants, exchange words
+  hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->xpart); hipFree(P->qpart); hipFree(P->dgran); hipFree(P->xflags); hipFree(P->stamps);
+  if (P->own_stream) hipStreamDestroy(P->own_stream);
   delete P;
   return BWGR_OK;
 }
@@ -1142,11 +1162,55 @@ extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int
 #ifdef BWGR_STAMPS
 // diagnostic build only: cumulative per-phase s_memtime ticks of workgroup 0 (not part of include/bwgr.h)
 extern "C" int bwgr_debug_stamps(bwgr_panel *P, unsigned long long out[64]) {
-  HIPCHK(hipMemcpy(out, P->stamps, sizeof(unsigned long long) * 64, hipMemcpyDeviceToHost));
+  HIPCHK(d2h(P->stream, out, P->stamps, sizeof(unsigned long long) * 64));
   HIPCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 64));
   return BWGR_OK;
 }
 #endif
+
+// A clone: the same genotypes and Gram arrays (shared, read-only during sweeps), its own sweep scratch and its own
+// stream, so that chains on the parent and on its clones run concurrently on disjoint CUs.
+extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
+  if (!out || !src) return fail(BWGR_EINVAL, "panel_clone: null pointer");
+  *out = nullptr;
+  bwgr_panel *root = src->parent ? src->parent : src;
+  HIPCHK(hipSetDevice(root->device));
+  HIPCHK(hipStreamSynchronize(root->stream));   // the shared arrays are complete
+  bwgr_panel *P = new bwgr_panel(*root);
+  P->parent = root; P->nclones = 0; P->own_stream = nullptr; P->stream = nullptr;
+  P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->stamps = nullptr;
+  root->nclones++;
+  auto bail = [&](int code) { bwgr_panel_destroy(P); return code; };
+#define PCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return bail(fail(BWGR_EHIP, "%s failed: %s", #x, hipGetErrorString(e_))); } while (0)
+  const int K = P->K;
+  if (root->xspec2) PCHK(hipMalloc(&P->xspec2, sizeof(double) * (size_t)P->nblocks * SW_MAXM));
+  if (root->xspec3) PCHK(hipMalloc(&P->xspec3, sizeof(double) * (size_t)P->nblocks * SW_MAXM));
+  PCHK(hipMalloc(&P->ps.spec, sizeof(SpecBuf) * (size_t)P->nblocks));
+  PCHK(hipMalloc(&P->ps.blocks, sizeof(StageBuf) * (size_t)P->nblocks));
+  PCHK(hipMalloc(&P->xpart, sizeof(double) * 2 * (size_t)K * SW_MAXM));
+  PCHK(hipMalloc(&P->xflags, sizeof(uint32_t) * ((size_t)K + 1) * SW_FLAG_STRIDE));
+  PCHK(hipMalloc(&P->qpart, sizeof(double) * S2_NSLOT * ((size_t)K + 1) * SW_MAXM));
+  PCHK(hipMalloc(&P->dgran, sizeof(unsigned long long) * S2_NSLOT * SW_MAXM));
+#ifdef BWGR_STAMPS
+  PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 64));
+  PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 64));
+#endif
+  PCHK(hipStreamCreateWithFlags(&P->own_stream, hipStreamNonBlocking));
+#undef PCHK
+  P->stream = P->own_stream;
+  *out = P;
+  return BWGR_OK;
+}
+
+// chains (one per panel or clone) whose sweep kernels fit the chip side by side: each takes nwg + 1 (+ feeders) CUs
+extern "C" int bwgr_panel_max_concurrent(const bwgr_panel *P, int selection, int *count) {
+  if (!P || !count) return fail(BWGR_EINVAL, "null pointer");
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, P->device));
+  const int wgs = P->K + 1 + ((P->sweep_version == 2 && selection) ? P->nfeed : 0);
+  *count = std::max(1, prop.multiProcessorCount / wgs);
+  return BWGR_OK;
+}
 
 extern "C" int bwgr_panel_set_stream(bwgr_panel *P, void *hip_stream) {
   if (!P) return fail(BWGR_EINVAL, "null panel");
@@ -1176,8 +1240,8 @@ extern "C" int bwgr_panel_pipeline(const bwgr_panel *P, int selection, int info[
 extern "C" int bwgr_panel_stats(bwgr_panel *P, float *xx, float *vx, float *MSx) {
   if (!P) return fail(BWGR_EINVAL, "null panel");
   HIPCHK(hipSetDevice(P->device));
-  if (xx) HIPCHK(hipMemcpy(xx, P->xx, sizeof(float) * P->p, hipMemcpyDeviceToHost));
-  if (vx) HIPCHK(hipMemcpy(vx, P->vx, sizeof(float) * P->p, hipMemcpyDeviceToHost));
+  if (xx) HIPCHK(d2h(P->stream, xx, P->xx, sizeof(float) * P->p));
+  if (vx) HIPCHK(d2h(P->stream, vx, P->vx, sizeof(float) * P->p));
   if (MSx) *MSx = P->MSx;
   return BWGR_OK;
 }
@@ -1354,7 +1418,7 @@ extern "C" int bwgr_chain_sync(bwgr_chain *C) {
   HIPCHK(hipSetDevice(C->P->device));
   HIPCHK(hipStreamSynchronize(C->P->stream));
   ChainScalars h;
-  HIPCHK(hipMemcpy(&h, C->sc, sizeof(h), hipMemcpyDeviceToHost));
+  HIPCHK(d2h(C->P->stream, &h, C->sc, sizeof(h)));
   if (h.error) return fail(BWGR_ETIMEOUT, "a workgroup exchange timed out inside the sweep kernel (chain state is invalid)");
   return BWGR_OK;
 }
@@ -1392,9 +1456,9 @@ extern "C" int bwgr_chain_state(bwgr_chain *C, float *b, float *d, float *e, flo
   bwgr_panel *P = C->P;
   const size_t pb = sizeof(float) * P->p;
   ChainScalars h;
-  HIPCHK(hipMemcpy(&h, C->sc, sizeof(h), hipMemcpyDeviceToHost));
-  if (b) HIPCHK(hipMemcpy(b, C->b, pb, hipMemcpyDeviceToHost));
-  if (d) HIPCHK(hipMemcpy(d, C->d, pb, hipMemcpyDeviceToHost));
+  HIPCHK(d2h(P->stream, &h, C->sc, sizeof(h)));
+  if (b) HIPCHK(d2h(P->stream, b, C->b, pb));
+  if (d) HIPCHK(d2h(P->stream, d, C->d, pb));
   if (e) {
     float *ef = nullptr;
     HIPCHK(hipMalloc(&ef, sizeof(float) * P->n));
@@ -1404,7 +1468,7 @@ extern "C" int bwgr_chain_state(bwgr_chain *C, float *b, float *d, float *e, flo
     hipFree(ef);
   }
   if (vb) {
-    if (per_marker_vb(C->model)) HIPCHK(hipMemcpy(vb, C->vb, pb, hipMemcpyDeviceToHost));
+    if (per_marker_vb(C->model)) HIPCHK(d2h(P->stream, vb, C->vb, pb));
     else for (int64_t j = 0; j < P->p; ++j) vb[j] = h.vb;
   }
   if (scal) { scal[0] = h.mu; scal[1] = h.ve; scal[2] = h.vb; scal[3] = h.pi; }
@@ -1458,7 +1522,7 @@ extern "C" int bwgr_chain_result(bwgr_chain *C, float *mu, float *b, float *d, f
     HIPCHK(hipMalloc(&part, sizeof(double) * 256)); HIPCHK(hipMalloc(&sdev, sizeof(float)));
     hipLaunchKernelGGL(k_sum_stage1, dim3(256), dim3(256), 0, P->stream, C->VB, (int64_t)P->p, part);
     hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, P->stream, part, 256, sdev);
-    HIPCHK(hipMemcpy(&vg, sdev, sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(d2h(P->stream, &vg, sdev, sizeof(float)));
     hipFree(part); hipFree(sdev);
   } else {
     vg = VBs * C->MSx_eff;
@@ -1469,15 +1533,15 @@ extern "C" int bwgr_chain_result(bwgr_chain *C, float *mu, float *b, float *d, f
   if (h2) *h2 = vg / (vg + VE);
   if (MSx) *MSx = C->MSx_eff;
   if (pi) *pi = Pi;
-  if (b) HIPCHK(hipMemcpy(b, C->B, pb, hipMemcpyDeviceToHost));
-  if (d) HIPCHK(hipMemcpy(d, C->D, pb, hipMemcpyDeviceToHost));
-  if (vb) { if (per) HIPCHK(hipMemcpy(vb, C->VB, pb, hipMemcpyDeviceToHost)); else vb[0] = VBs; }
-  if (pval) { HIPCHK(hipMemcpy(pval, pval_dev, pb, hipMemcpyDeviceToHost)); hipFree(pval_dev); }
+  if (b) HIPCHK(d2h(P->stream, b, C->B, pb));
+  if (d) HIPCHK(d2h(P->stream, d, C->D, pb));
+  if (vb) { if (per) HIPCHK(d2h(P->stream, vb, C->VB, pb)); else vb[0] = VBs; }
+  if (pval) { HIPCHK(d2h(P->stream, pval, pval_dev, pb)); hipFree(pval_dev); }
   if (hat) {
     float *hat_dev = nullptr;
     HIPCHK(hipMalloc(&hat_dev, sizeof(float) * P->n));
     int rc = gemv_hat<float>(P, C->B, MU, hat_dev);
-    if (rc == BWGR_OK) HIPCHK(hipMemcpy(hat, hat_dev, sizeof(float) * P->n, hipMemcpyDeviceToHost));
+    if (rc == BWGR_OK) HIPCHK(d2h(P->stream, hat, hat_dev, sizeof(float) * P->n));
     hipFree(hat_dev);
     CHK(rc);
   }
@@ -1563,21 +1627,21 @@ extern "C" int bwgr_bayes2(bwgr_panel *P1, bwgr_panel *P2, int base_model, const
     BCHK(hipMalloc(&part, sizeof(double) * 256)); BCHK(hipMalloc(&sdev, sizeof(float)));
     hipLaunchKernelGGL(k_sum_stage1, dim3(256), dim3(256), 0, P1->stream, C1->VB, (int64_t)p1, part);
     hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, P1->stream, part, 256, sdev);
-    BCHK(hipMemcpy(&v1, sdev, sizeof(float), hipMemcpyDeviceToHost));
+    BCHK(d2h(P1->stream, &v1, sdev, sizeof(float)));
     hipLaunchKernelGGL(k_sum_stage1, dim3(256), dim3(256), 0, P1->stream, C2->VB, (int64_t)p2, part);
     hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, P1->stream, part, 256, sdev);
-    BCHK(hipMemcpy(&v2, sdev, sizeof(float), hipMemcpyDeviceToHost));
+    BCHK(d2h(P1->stream, &v2, sdev, sizeof(float)));
     vg = v1 + v2;
   } else vg = VB1s * P1->MSx + VB2s * P2->MSx;                                       // :1213
   if (mu) *mu = MU;
   if (ve) *ve = VE;
   if (h2) *h2 = vg / (vg + VE);
-  if (b1) BCHK(hipMemcpy(b1, C1->B, sizeof(float) * p1, hipMemcpyDeviceToHost));
-  if (b2) BCHK(hipMemcpy(b2, C2->B, sizeof(float) * p2, hipMemcpyDeviceToHost));
-  if (d1) BCHK(hipMemcpy(d1, C1->D, sizeof(float) * p1, hipMemcpyDeviceToHost));
-  if (d2) BCHK(hipMemcpy(d2, C2->D, sizeof(float) * p2, hipMemcpyDeviceToHost));
-  if (vb1) { if (per) BCHK(hipMemcpy(vb1, C1->VB, sizeof(float) * p1, hipMemcpyDeviceToHost)); else vb1[0] = VB1s; }
-  if (vb2) { if (per) BCHK(hipMemcpy(vb2, C2->VB, sizeof(float) * p2, hipMemcpyDeviceToHost)); else vb2[0] = VB2s; }
+  if (b1) BCHK(d2h(P1->stream, b1, C1->B, sizeof(float) * p1));
+  if (b2) BCHK(d2h(P1->stream, b2, C2->B, sizeof(float) * p2));
+  if (d1) BCHK(d2h(P1->stream, d1, C1->D, sizeof(float) * p1));
+  if (d2) BCHK(d2h(P1->stream, d2, C2->D, sizeof(float) * p2));
+  if (vb1) { if (per) BCHK(d2h(P1->stream, vb1, C1->VB, sizeof(float) * p1)); else vb1[0] = VB1s; }
+  if (vb2) { if (per) BCHK(d2h(P1->stream, vb2, C2->VB, sizeof(float) * p2)); else vb2[0] = VB2s; }
   if (hat) {                                                                         // fit = X1*B1 + X2*B2; fit += MU, :1052-1053
     BCHK(hipMalloc(&h1d, sizeof(float) * n)); BCHK(hipMalloc(&h2d, sizeof(float) * n)); BCHK(hipMalloc(&hatd, sizeof(float) * n));
     rc = gemv_hat<float>(P1, C1->B, 0.0f, h1d);
@@ -1585,7 +1649,7 @@ extern "C" int bwgr_bayes2(bwgr_panel *P1, bwgr_panel *P2, int base_model, const
     if (rc != BWGR_OK) return done(rc);
     hipLaunchKernelGGL(k_hat2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, P1->stream, h1d, h2d, MU, hatd, (int)n);
     BCHK(hipGetLastError());
-    BCHK(hipMemcpy(hat, hatd, sizeof(float) * n, hipMemcpyDeviceToHost));
+    BCHK(d2h(P1->stream, hat, hatd, sizeof(float) * n));
   }
 #undef BCHK
   return done(BWGR_OK);
@@ -1783,11 +1847,11 @@ extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int t
     if (mu) *mu = B0;
     if (Ve) *Ve = h.VE / mc;
     if (cxx) *cxx = h.cxx * bag;                                                   // mean(xx), xx = crossprod * bag
-    if (b) WCHK(hipMemcpy(b, B, pd, hipMemcpyDeviceToHost));
-    if (d) WCHK(hipMemcpy(d, D, pd, hipMemcpyDeviceToHost));
-    if (Vb) { if (iv) WCHK(hipMemcpy(Vb, VB, pd, hipMemcpyDeviceToHost)); else Vb[0] = h.VA / mc; }
-    if (hat) WCHK(hipMemcpy(hat, hatd, sizeof(double) * n, hipMemcpyDeviceToHost));
-    if (pk > 0 && u) WCHK(hipMemcpy(u, uhd, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (b) WCHK(d2h(P->stream, b, B, pd));
+    if (d) WCHK(d2h(P->stream, d, D, pd));
+    if (Vb) { if (iv) WCHK(d2h(P->stream, Vb, VB, pd)); else Vb[0] = h.VA / mc; }
+    if (hat) WCHK(d2h(P->stream, hat, hatd, sizeof(double) * n));
+    if (pk > 0 && u) WCHK(d2h(P->stream, u, uhd, sizeof(double) * n));
     if (pk > 0 && Vk) *Vk = h.VP / mc;
   }
 done:

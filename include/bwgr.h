@@ -66,6 +66,13 @@ int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int memloc, in
                       int device, int block, int nwg);
 int bwgr_panel_destroy(bwgr_panel *P);
 int bwgr_panel_set_stream(bwgr_panel *P, void *hip_stream); /* NULL = the default stream */
+/* A second handle on the same resident genotypes: shares X, the Gram arrays and xx/vx with `src` (read-only during
+ * sweeps) and owns its own sweep scratch and its own non-blocking stream, so chains on `src` and on its clones run
+ * side by side on disjoint compute units (a sweep occupies nwg + 1 + feeders of the 256).  This is how the callers
+ * that fit many models on one X -- mcmcCV's folds x models loop, R/cv.R:113-216 -- fill the chip.  Destroy the clones
+ * before `src`.  bwgr_panel_max_concurrent: how many sweeps of this geometry fit at once (more would time out). */
+int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src);
+int bwgr_panel_max_concurrent(const bwgr_panel *P, int selection, int *count);
 /* geometry actually chosen: info[0]=n, [1]=p, [2]=ld (padded rows), [3]=block, [4]=nwg, [5]=slab rows,
  * [6]=bytes of X resident, [7]=bytes of Gram resident */
 int bwgr_panel_info(const bwgr_panel *P, int64_t info[8]);

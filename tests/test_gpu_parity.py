@@ -427,3 +427,31 @@ def test_full_size_properties_c4(monkeypatch):
     assert np.array_equal(out["1"]["d"], out["2"]["d"])
     assert scaled_err(out["1"]["b"], out["2"]["b"]) < 1e-9
     assert 0.003 < st["d"].mean() < 0.05
+
+
+def test_fit_many_runs_the_same_chains_side_by_side():
+    """fit_many: seven samplers on one resident panel, side by side on clones (private scratch + stream).  Every fit must be
+    the chain the sampler runs alone -- bit for bit: a chain's arithmetic does not depend on what else is on the chip."""
+    import bwgr_amd
+    rng = np.random.default_rng(11)
+    n, p = 300, 700
+    X = rng.integers(0, 3, size=(n, p)).astype(np.int8)
+    y = (X[:, :10].astype(np.float64) @ rng.normal(size=10) + rng.normal(size=n)).astype(np.float32)
+    models = ["BayesA", "BayesB", "BayesC", "BayesL", "BayesRR", "BayesCpi", "BayesDpi"]
+    P = bwgr_amd.Panel(X)
+    try:
+        assert P.max_concurrent(True) >= 2
+        jobs = [dict(model=m, y=y, it=30, bi=10, seed=100 + i) for i, m in enumerate(models)]
+        many = bwgr_amd.fit_many(P, jobs)
+        few = bwgr_amd.fit_many(P, jobs, concurrent=3, chunk=7)
+        for i, m in enumerate(models):
+            alone = getattr(bwgr_amd, m)(y, P, it=30, bi=10, seed=100 + i)
+            for got in (many[i], few[i]):
+                assert list(got) == list(alone)
+                for k in alone:
+                    np.testing.assert_array_equal(np.asarray(got[k]), np.asarray(alone[k]), err_msg="%s %s" % (m, k))
+        # a clone cannot outlive its parent silently: the parent's close() closes it
+        q = P.clone()
+        assert q.n == P.n and q.p == P.p
+    finally:
+        P.close()
