@@ -1208,7 +1208,9 @@ extern "C" int bwgr_panel_max_concurrent(const bwgr_panel *P, int selection, int
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, P->device));
   const int wgs = P->K + 1 + ((P->sweep_version == 2 && selection) ? P->nfeed : 0);
+  // one sweep workgroup per CU even where the LDS would admit two (small blocks): measured, sharing a CU costs more than it adds
   *count = std::max(1, prop.multiProcessorCount / wgs);
+  if (const char *ov = getenv("BWGR_MAX_CONCURRENT")) { const int v = atoi(ov); if (v > 0) *count = v; }   // experiments
   return BWGR_OK;
 }
 
