@@ -31,6 +31,8 @@ def lib():
     L.bwgr_panel_destroy.argtypes = [vp]
     L.bwgr_panel_set_stream.argtypes = [vp, vp]
     L.bwgr_panel_info.argtypes = [vp, C.POINTER(i64)]
+    L.bwgr_em.argtypes = [vp, i32, c_f, f32, f32, c_f, i32, C.POINTER(f32), c_f, c_f, c_f, c_f, C.POINTER(i32)]
+    L.bwgr_em_order.argtypes = [i64, i32, C.POINTER(C.c_int32)]
     L.bwgr_panel_clone.argtypes = [C.POINTER(vp), vp]
     L.bwgr_panel_max_concurrent.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.bwgr_panel_pipeline.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
@@ -72,7 +74,7 @@ def device_count():
 
 
 EXPORTS = ["bwgr_abi_version", "bwgr_last_error", "bwgr_device_count", "bwgr_panel_create", "bwgr_panel_destroy",
-           "bwgr_panel_set_stream", "bwgr_panel_info", "bwgr_panel_pipeline", "bwgr_panel_clone", "bwgr_panel_max_concurrent", "bwgr_panel_stats", "bwgr_kmup", "bwgr_chain_create",
+           "bwgr_panel_set_stream", "bwgr_panel_info", "bwgr_panel_pipeline", "bwgr_panel_clone", "bwgr_em", "bwgr_em_order", "bwgr_panel_max_concurrent", "bwgr_panel_stats", "bwgr_kmup", "bwgr_chain_create",
            "bwgr_chain_create_sharded", "bwgr_chain_sweep_blocks", "bwgr_chain_get_sums", "bwgr_chain_end_iteration",
            "bwgr_chain_destroy", "bwgr_chain_run", "bwgr_chain_sync", "bwgr_chain_iterations", "bwgr_chain_result",
            "bwgr_chain_state", "bwgr_chain_sweep_ms", "bwgr_bayes", "bwgr_bayes2", "bwgr_wgr", "bwgr_wgr_ex", "bwgr_synth_genotypes",

@@ -328,6 +328,59 @@ def fit_many(X, jobs, concurrent=None, chunk=4, **panel_kw):
             P.close()
 
 
+_EM = {"emRR": 0, "emBA": 1, "emDE": 2, "emML": 3}
+
+
+def _em(model, y, gen, df, R2, D=None, maxit=0, **panel_kw):
+    """The EM / Gauss-Seidel family over bwgr_em (include/bwgr.h); returns (mu, b, hat, vbvec, scal, iters)."""
+    P, own = _as_panel(gen, **panel_kw)
+    try:
+        yv = np.ascontiguousarray(y, np.float32)
+        assert yv.size == P.n, "length(y) must equal nrow(gen)"
+        b = np.empty(P.p, np.float32); hat = np.empty(P.n, np.float32); vbv = np.empty(P.p, np.float32)
+        scal = np.zeros(4, np.float32); mu = C.c_float(); iters = C.c_int()
+        Dv = None if D is None else np.ascontiguousarray(D, np.float32)
+        if Dv is not None:
+            assert Dv.size == P.p, "length(D) must equal ncol(gen)"
+        check(_lib.lib().bwgr_em(P._h, _EM[model], _fp(yv), float(df), float(R2), None if Dv is None else _fp(Dv), int(maxit),
+                                 C.byref(mu), _fp(b), _fp(hat), _fp(vbv), _fp(scal), C.byref(iters)))
+        return float(mu.value), b, hat, vbv, scal, int(iters.value)
+    finally:
+        if own:
+            P.close()
+
+
+def emRR(y, gen, df=10, R2=0.5, **kw):
+    """emRR(y, gen, df = 10, R2 = 0.5), src/Rcpp20260726ai.cpp:308-354: list(mu, b, hat, Va, Ve, h2)."""
+    mu, b, hat, _, s, _ = _em("emRR", y, gen, df, R2, **kw)
+    return {"mu": mu, "b": b, "hat": hat, "Va": float(s[0]), "Ve": float(s[1]), "h2": float(s[2])}
+
+
+def emBA(y, gen, df=10, R2=0.5, **kw):
+    """emBA(y, gen, df = 10, R2 = 0.5), src/Rcpp20260726ai.cpp:80-128: list(mu, b, hat, Vb, Ve, h2)."""
+    mu, b, hat, vb, s, _ = _em("emBA", y, gen, df, R2, **kw)
+    return {"mu": mu, "b": b, "hat": hat, "Vb": vb, "Ve": float(s[1]), "h2": float(s[2])}
+
+
+def emDE(y, gen, R2=0.5, **kw):
+    """emDE(y, gen, R2 = 0.5), src/Rcpp20260726ai.cpp:250-305: list(mu, b, hat, Vb, Ve, h2)."""
+    mu, b, hat, vb, s, _ = _em("emDE", y, gen, 0.0, R2, **kw)
+    return {"mu": mu, "b": b, "hat": hat, "Vb": vb, "Ve": float(s[1]), "h2": float(s[2])}
+
+
+def emML(y, gen, D=None, **kw):
+    """emML(y, gen, D = NULL), src/Rcpp20260726ai.cpp:463-521: list(mu, b, hat, h2, Vb, Va, Ve)."""
+    mu, b, hat, _, s, _ = _em("emML", y, gen, 0.0, 0.5, D=D, **kw)
+    return {"mu": mu, "b": b, "hat": hat, "h2": float(s[2]), "Vb": float(s[0]), "Va": float(s[3]), "Ve": float(s[1])}
+
+
+def em_order(p, upto):
+    """Marker order of sweep `upto` (0-based) of the EM family: std::shuffle with std::mt19937(0..upto) (host only)."""
+    out = np.zeros(int(p), np.int32)
+    check(_lib.lib().bwgr_em_order(int(p), int(upto), out.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out
+
+
 def _fused2(base, y, X1, X2, it, bi, pi, df, R2, seed, rng_mode, **panel_kw):
     """BayesA2 / BayesB2 / BayesRR2(y, X1, X2, ...), src/Rcpp20260726ai.cpp:990-1218: two panels, one residual."""
     P1, own1 = _as_panel(X1, **panel_kw)

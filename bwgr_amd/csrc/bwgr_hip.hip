@@ -7,6 +7,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <random>
 #include <algorithm>
 #include "../../include/bwgr.h"
 #include "rng.hip.h"
@@ -756,6 +757,7 @@ struct bwgr_panel {
   int sweep_version = 2;   // 2: streamer/sequencer pipeline (k_sweep2); 1: replicated recurrence (k_sweep)
   unsigned long long *stamps = nullptr;   // diagnostic build only
   PreStage ps = {};
+  int gram_maxdist = 3;           // panel_build_gram stops at this block distance (the EM scratch panel needs 1)
   bwgr_panel *parent = nullptr;   // a clone shares the parent's read-only arrays (X, Gram, xx, vx) and owns only the scratch
   int nclones = 0;
   hipStream_t own_stream = nullptr;
@@ -995,7 +997,7 @@ static int panel_build_gram(bwgr_panel *P) {
   }
   HIPCHK(hipGetLastError());
   for (int dist = 1; dist <= 3; ++dist) {   // off-diagonal blocks (blk-dist, blk): the cross terms of the lag-2 / 3 / 4 pipelines
-    if (P->nblocks <= dist || (dist == 2 && !P->gramx2) || (dist == 3 && !P->gramx3)) continue;
+    if (P->nblocks <= dist || dist > P->gram_maxdist || (dist == 2 && !P->gramx2) || (dist == 3 && !P->gramx3)) continue;
     const unsigned nbx = (unsigned)(P->nblocks - dist);
     if (P->is_f32) {
       const size_t lds = (size_t)2 * m * 65 * sizeof(float);
@@ -1869,6 +1871,305 @@ done:
 
 // ------------------------------------------------------------------------------------------------
 // synthetic data and test hooks
+// ------------------------------------------------------------------------------------------------
+// f4: EM / Gauss-Seidel family (emRR, emBA, emDE, emML), src/Rcpp20260726ai.cpp:80-128, :250-305, :308-354, :463-521
+//
+// Deterministic coordinate updates b_j = (X_j.e + xx_j b_j)/(xx_j + lambda_j) -- the affine sweep with the variates
+// switched off -- in a marker order that the reference re-shuffles before every sweep (std::shuffle with
+// std::mt19937(i), :103 ...).  The exact blocked sweep needs the Gram blocks of consecutive markers, so every sweep
+//   (1) shuffles the order on the host with the very library call the reference makes,
+//   (2) gathers the columns of the resident panel into a scratch panel in that order (one pass over X),
+//   (3) rebuilds the scratch panel's diagonal and distance-1 Gram blocks,
+//   (4) runs the affine sweep kernel on it (b, xx, lambda gathered; b scattered back),
+//   (5) runs the model's tail (variance components, lambda, intercept) in one workgroup.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void k_permute_cols(const uint4 *__restrict__ X, uint4 *__restrict__ Xp, const int32_t *__restrict__ order,
+                               int64_t p, int K, int cps) {
+  // slab-major layout: (slab s, marker j) is one segment of R elements = cps 16-byte chunks
+  const int64_t total = (int64_t)K * p * cps;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t seg = c / cps;
+    const int off = (int)(c - seg * cps);
+    const int64_t sl = seg / p, jj = seg - sl * p;
+    Xp[c] = X[(sl * p + order[jj]) * cps + off];
+  }
+}
+
+struct EmState {
+  float mu, ve, vb, Lmb, cnv, Sb, Se, Rho, cxx, df, vy, MSx;
+};
+
+// per-marker inputs of one sweep, in sweep order: b, xx, lambda
+__global__ void k_em_stage(const int32_t *__restrict__ order, int64_t p, int model, int weighted, const float *__restrict__ b,
+                           const float *__restrict__ xx, const float *__restrict__ lam, const float *__restrict__ D,
+                           const EmState *__restrict__ st, float *__restrict__ bq, float *__restrict__ xxq, float *__restrict__ lamq) {
+  const float Lmb = st->Lmb;
+  for (int64_t jj = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; jj < p; jj += (int64_t)gridDim.x * blockDim.x) {
+    const int j = order[jj];
+    bq[jj] = b[j]; xxq[jj] = xx[j];
+    float l;
+    if (model == BWGR_EM_BA || model == BWGR_EM_DE) l = lam[j];
+    else if (weighted) l = Lmb / D[j];                                               // :496
+    else l = Lmb;
+    lamq[jj] = l;
+  }
+}
+__global__ void k_em_unstage(const int32_t *__restrict__ order, int64_t p, const float *__restrict__ bq, float *__restrict__ b) {
+  for (int64_t jj = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; jj < p; jj += (int64_t)gridDim.x * blockDim.x) b[order[jj]] = bq[jj];
+}
+__global__ void k_em_fix_xx(float *xx, int64_t p) {                                   // if(xx[k]==0) xx[k]=0.1f, :261
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < p; j += (int64_t)gridDim.x * blockDim.x) if (xx[j] == 0.0f) xx[j] = 0.1f;
+}
+__global__ void k_em_init(const float *__restrict__ y, double *__restrict__ e, int n, int64_t ld, EmState *st) {
+  // mu = y.mean(); e = y.array()-mu  (float), :98-99; padding rows of e stay 0
+  __shared__ double sh[1024];
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += (double)y[i];
+  sh[threadIdx.x] = s; __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  const float mu = (float)(sh[0] / (double)n);
+  for (int64_t i = threadIdx.x; i < ld; i += 1024) e[i] = i < n ? (double)(y[i] - mu) : 0.0;
+  if (threadIdx.x == 0) st->mu = mu;
+}
+
+struct EmTailArgs {
+  int model, n, conv; int64_t p;
+  double *e; const float *y; const float *b; const float *bc; float *lam; float *vbv; const float *xx; EmState *st;
+};
+
+__device__ double em_block_sum(double v, double *sh) {
+  __syncthreads();
+  sh[threadIdx.x] = v; __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  return sh[0];
+}
+
+// what follows a sweep, one workgroup: the model's variance components and lambda, then eM = e.mean(); mu += eM; e -= eM
+__global__ __launch_bounds__(1024) void k_em_tail(const EmTailArgs a) {
+  __shared__ double sh[1024];
+  EmState st = *a.st;
+  const int n = a.n; const int64_t p = a.p; const int tid = threadIdx.x;
+  const float df = st.df;
+  if (a.model == BWGR_EM_BA) {
+    double s = 0; for (int i = tid; i < n; i += 1024) s = fma(a.e[i], a.e[i], s);
+    const float e2 = (float)em_block_sum(s, sh);
+    st.ve = (e2 + st.Se) / ((float)n + df);                                          // :113
+    for (int64_t j = tid; j < p; j += 1024) {
+      const float bj = a.b[j];
+      const float vbj = (st.Sb + bj * bj) / (df + 1);                                // :110
+      a.vbv[j] = vbj;
+      a.lam[j] = st.ve * (1.0f / vbj);                                               // Lmb = ve * vb.cwiseInverse(), :114
+    }
+  } else if (a.model == BWGR_EM_RR) {
+    double s = 0; for (int64_t j = tid; j < p; j += 1024) s = fma((double)a.b[j], (double)a.b[j], s);
+    const float b2 = (float)em_block_sum(s, sh);
+    s = 0; for (int i = tid; i < n; i += 1024) s = fma(a.e[i], a.e[i], s);
+    const float e2 = (float)em_block_sum(s, sh);
+    st.vb = (b2 + st.Sb) / ((float)p + df);                                          // :338
+    st.ve = (e2 + st.Se) / ((float)n + df);                                          // :339
+    st.Lmb = sqrtf(st.Rho * st.ve / st.vb);                                          // :340
+  }
+  {
+    double s = 0; for (int i = tid; i < n; i += 1024) s += a.e[i];
+    const float eM = (float)(em_block_sum(s, sh) / (double)n);                       // :115-117
+    st.mu += eM;
+    for (int i = tid; i < n; i += 1024) a.e[i] = a.e[i] - (double)eM;
+    __syncthreads();
+  }
+  if (a.model == BWGR_EM_DE) {
+    double s = 0; for (int i = tid; i < n; i += 1024) s = fma(a.e[i], (double)a.y[i], s);
+    st.ve = (float)em_block_sum(s, sh) / (float)(n - 1);                             // Ve = e.dot(y)/(n-1), :289
+    for (int64_t j = tid; j < p; j += 1024) {
+      const float bj = a.b[j];
+      const float vbj = bj * bj + st.ve / (a.xx[j] + a.lam[j] + 0.0001f);            // :290
+      a.vbv[j] = vbj;
+      a.lam[j] = sqrtf(st.cxx * st.ve / vbj);                                        // :292
+    }
+  } else if (a.model == BWGR_EM_ML) {
+    double s1 = 0, s2 = 0;
+    for (int i = tid; i < n; i += 1024) {
+      const float ym = a.y[i] - st.mu;
+      s1 = fma((double)ym, a.e[i], s1);                                              // :505
+      s2 = fma((double)ym, (double)ym - a.e[i], s2);                                 // :506
+    }
+    const float d1 = (float)em_block_sum(s1, sh), d2 = (float)em_block_sum(s2, sh);
+    st.ve = d1 / (float)n;
+    st.vb = d2 / (float)((float)n * st.MSx);
+    st.Lmb = st.ve / st.vb;                                                          // :507
+  }
+  if (a.conv) {
+    double s = 0; for (int64_t j = tid; j < p; j += 1024) s += (double)fabsf(a.bc[j] - a.b[j]);
+    st.cnv = (float)em_block_sum(s, sh);                                             // :295, :509
+  }
+  if (tid == 0) *a.st = st;
+}
+
+__global__ void k_em_fit_ml(const float *__restrict__ y, const double *__restrict__ e, float *__restrict__ hat, int n) {   // fit = y - e, :512
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) hat[i] = (float)((double)y[i] - e[i]);
+}
+
+}  // namespace
+
+// the marker order of sweep `upto` (0-based): identity shuffled with std::mt19937(0), (1), ..., (upto) -- the library's own
+// std::shuffle, so that the oracle's restatement of it can be pinned (tests/test_em_order.py)
+extern "C" int bwgr_em_order(int64_t p, int upto, int32_t *order) {
+  if (!order || p < 1 || p > 0x7FFFFF00ll) return fail(BWGR_EINVAL, "em_order: bad arguments");
+  std::vector<int> ord((size_t)p);
+  for (int64_t j = 0; j < p; ++j) ord[(size_t)j] = (int)j;
+  for (int i = 0; i <= upto; ++i) std::shuffle(ord.begin(), ord.end(), std::mt19937(i));
+  for (int64_t j = 0; j < p; ++j) order[j] = ord[(size_t)j];
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float R2, const float *D, int maxit_in,
+                       float *mu, float *b, float *hat, float *vbvec, float *scal, int *iters) {
+  if (!P || !y || !b || !scal) return fail(BWGR_EINVAL, "em: null pointer");
+  if (model < BWGR_EM_RR || model > BWGR_EM_ML) return fail(BWGR_EINVAL, "em: bad model %d", model);
+  if (D && model != BWGR_EM_ML) return fail(BWGR_EINVAL, "em: marker weights D belong to emML only");
+  HIPCHK(hipSetDevice(P->device));
+  const int64_t p = P->p, n = P->n;
+  const bool conv = (model == BWGR_EM_DE || model == BWGR_EM_ML);
+  const int maxit = maxit_in > 0 ? maxit_in : (conv ? 300 : 200);                     // :81, :251, :309, :465
+  const float tol = (model == BWGR_EM_DE) ? 10e-6f : 10e-8f;                          // :252, :466
+  hipStream_t st = P->stream;
+  // scratch panel: same geometry, its own X and Gram; only the diagonal and distance-1 blocks are ever built (lag 2)
+  bwgr_panel *Q = nullptr;
+  CHK(panel_alloc(&Q, P->is_f32, n, p, P->device, P->m, P->K));
+  Q->stream = st; Q->gram_maxdist = 1;
+  hipFree(Q->gramx2); hipFree(Q->gramx3); hipFree(Q->xspec2); hipFree(Q->xspec3); hipFree(Q->gramp16); hipFree(Q->gramx16);
+  Q->gramx2 = Q->gramx3 = nullptr; Q->xspec2 = Q->xspec3 = nullptr; Q->gramp16 = Q->gramx16 = nullptr;
+  std::vector<void *> owned;
+  int rc = BWGR_OK;
+  auto done = [&](int code) { (void)hipStreamSynchronize(st); for (void *q : owned) hipFree(q); bwgr_panel_destroy(Q); return code; };
+#define ECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return done(fail(BWGR_EHIP, "%s failed: %s", #x, hipGetErrorString(e_))); } while (0)
+  if (Q->K != P->K || Q->R != P->R || Q->m != P->m) return done(fail(BWGR_EINVAL, "em: scratch panel geometry differs"));
+  const size_t pb = sizeof(float) * (size_t)p;
+  float *yd = nullptr, *bd = nullptr, *bcd = nullptr, *lamd = nullptr, *vbd = nullptr, *xxd = nullptr, *Dd = nullptr;
+  float *bq = nullptr, *lamq = nullptr, *dq = nullptr, *vq = nullptr, *hatd = nullptr;
+  double *ed = nullptr; int32_t *ordd = nullptr; EmState *std_ = nullptr; ChainScalars *sc = nullptr;
+  auto dmalloc = [&](void **q, size_t bytes) { hipError_t e_ = hipMalloc(q, bytes); if (e_ == hipSuccess) owned.push_back(*q); return e_; };
+  ECHK(dmalloc((void **)&yd, sizeof(float) * n)); ECHK(dmalloc((void **)&bd, pb)); ECHK(dmalloc((void **)&bcd, pb));
+  ECHK(dmalloc((void **)&lamd, pb)); ECHK(dmalloc((void **)&vbd, pb)); ECHK(dmalloc((void **)&xxd, pb));
+  ECHK(dmalloc((void **)&bq, pb)); ECHK(dmalloc((void **)&lamq, pb)); ECHK(dmalloc((void **)&dq, pb)); ECHK(dmalloc((void **)&vq, pb));
+  ECHK(dmalloc((void **)&ed, sizeof(double) * P->ld)); ECHK(dmalloc((void **)&ordd, sizeof(int32_t) * p));
+  ECHK(dmalloc((void **)&std_, sizeof(EmState))); ECHK(dmalloc((void **)&sc, sizeof(ChainScalars)));
+  ECHK(dmalloc((void **)&hatd, sizeof(float) * n));
+  if (D) { ECHK(dmalloc((void **)&Dd, pb)); ECHK(hipMemcpyAsync(Dd, D, pb, hipMemcpyHostToDevice, st)); }
+  ECHK(hipMemcpyAsync(yd, y, sizeof(float) * n, hipMemcpyHostToDevice, st));
+  ECHK(hipMemsetAsync(bd, 0, pb, st));
+  ECHK(hipMemcpyAsync(xxd, P->xx, pb, hipMemcpyDeviceToDevice, st));
+  // vy = fvar(y) with the library's reduction (float result of fp64 sums, like the fused samplers' setup)
+  float vy = 0;
+  {
+    InitArgs ia; memset(&ia, 0, sizeof(ia));
+    ChainScalars h0; memset(&h0, 0, sizeof(h0));
+    ECHK(hipMemcpyAsync(sc, &h0, sizeof(h0), hipMemcpyHostToDevice, st));
+    ia.y = yd; ia.e = ed; ia.n = (int)n; ia.p = (int)p; ia.ld = P->ld; ia.model = BWGR_BAYESRR; ia.pi = 0; ia.df = df; ia.R2 = R2; ia.MSx = P->MSx; ia.sc = sc;
+    hipLaunchKernelGGL(k_chain_init, dim3(1), dim3(1024), 0, st, ia);
+    ECHK(hipGetLastError());
+    ECHK(d2h(st, &h0, sc, sizeof(h0)));
+    vy = h0.vy;
+  }
+  const float MSx = P->MSx;
+  EmState h; memset(&h, 0, sizeof(h));
+  h.df = df; h.vy = vy; h.MSx = MSx;
+  if (model == BWGR_EM_BA) {
+    h.ve = 1;                                                                        // :84
+    h.Sb = R2 * (df + 2) * vy / MSx;                                                 // :96
+    h.Se = (1 - R2) * (df + 2) * vy;                                                 // :97
+    std::vector<float> ones((size_t)p, 1.0f);                                        // vb = 1, Lmb = ve * vb^-1 = 1, :87-88
+    ECHK(hipMemcpyAsync(lamd, ones.data(), pb, hipMemcpyHostToDevice, st));
+    ECHK(hipMemcpyAsync(vbd, ones.data(), pb, hipMemcpyHostToDevice, st));
+    ECHK(hipStreamSynchronize(st));
+  } else if (model == BWGR_EM_RR) {
+    h.Lmb = MSx;                                                                     // :319
+    h.Rho = MSx * (1 - R2) / R2;                                                     // :320
+    h.ve = 0.5f * vy;                                                                // :322
+    h.vb = h.ve / MSx;                                                               // :323
+    h.Se = (1 - R2) * (df + 2) * vy;                                                 // :324
+    h.Sb = R2 * (df + 2) * vy / MSx;                                                 // :325
+  } else if (model == BWGR_EM_DE) {
+    hipLaunchKernelGGL(k_em_fix_xx, dim3(1024), dim3(256), 0, st, xxd, p);           // :261
+    h.cxx = MSx * (1 - R2) / R2;                                                     // :265
+    std::vector<float> l0((size_t)p, (float)p + h.cxx);                              // :269
+    ECHK(hipMemcpyAsync(lamd, l0.data(), pb, hipMemcpyHostToDevice, st));
+    ECHK(hipStreamSynchronize(st));
+  } else {
+    h.Lmb = MSx;                                                                     // :486
+  }
+  ECHK(hipMemcpyAsync(std_, &h, sizeof(h), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_em_init, dim3(1), dim3(1024), 0, st, yd, ed, (int)n, P->ld, std_);   // mu, e (overwrites k_chain_init's e)
+  ECHK(hipGetLastError());
+  {
+    ChainScalars h0; memset(&h0, 0, sizeof(h0));
+    h0.ve = 1.0f; h0.pi = 0.0f; h0.C = -0.5f; h0.odds = 0.0f; h0.dfp1 = 1.0f;        // the sweep's variates are switched off
+    ECHK(hipMemcpyAsync(sc, &h0, sizeof(h0), hipMemcpyHostToDevice, st));
+  }
+  std::vector<int> order((size_t)p);
+  for (int64_t j = 0; j < p; ++j) order[(size_t)j] = (int)j;
+  const int cps = (int)((size_t)P->R * (P->is_f32 ? 4 : 1) / 16);
+  int numit = 0;
+  for (int i = 0; i < maxit; ++i) {
+    std::shuffle(order.begin(), order.end(), std::mt19937(i));                       // :103, :277, :331, :491 -- the reference's own call
+    ECHK(hipMemcpyAsync(ordd, order.data(), sizeof(int32_t) * p, hipMemcpyHostToDevice, st));
+    if (conv) ECHK(hipMemcpyAsync(bcd, bd, pb, hipMemcpyDeviceToDevice, st));        // bc = b
+    hipLaunchKernelGGL(k_permute_cols, dim3(8192), dim3(256), 0, st, (const uint4 *)P->X, (uint4 *)Q->X, ordd, p, P->K, cps);
+    hipLaunchKernelGGL(k_em_stage, dim3(1024), dim3(256), 0, st, ordd, p, model, D ? 1 : 0, bd, xxd, lamd, Dd, std_, bq, Q->xx, lamq);
+    ECHK(hipGetLastError());
+    rc = panel_build_gram(Q);
+    if (rc != BWGR_OK) return done(rc);
+    SweepArgs a; memset(&a, 0, sizeof(a));
+    fill_panel_args(Q, a);
+    a.flags = SWF_LAM_VEC | (model == BWGR_EM_BA ? SWF_DELTA2 : 0);
+    a.e = ed; a.b = bq; a.d = dq; a.vb = vq; a.xx = Q->xx; a.lam = lamq; a.sc = sc;
+    a.iter = (uint32_t)i; a.rng = make_rng(0, BWGR_RNG_DEGENERATE);
+    rc = launch_sweep(Q, a);
+    if (rc != BWGR_OK) return done(rc);
+    hipLaunchKernelGGL(k_em_unstage, dim3(1024), dim3(256), 0, st, ordd, p, bq, bd);
+    EmTailArgs t; t.model = model; t.n = (int)n; t.conv = conv ? 1 : 0; t.p = p; t.e = ed; t.y = yd; t.b = bd; t.bc = bcd;
+    t.lam = lamd; t.vbv = vbd; t.xx = xxd; t.st = std_;
+    hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(1024), 0, st, t);
+    ECHK(hipGetLastError());
+    ++numit;
+    // the order vector is reused by the next shuffle: the upload must have been consumed; the convergence test needs cnv
+    ChainScalars hc;
+    ECHK(hipMemcpyAsync(&h, std_, sizeof(h), hipMemcpyDeviceToHost, st));
+    ECHK(hipMemcpyAsync(&hc, sc, sizeof(hc), hipMemcpyDeviceToHost, st));
+    ECHK(hipStreamSynchronize(st));
+    if (hc.error) return done(fail(BWGR_ETIMEOUT, "em: a workgroup exchange timed out inside the sweep kernel"));
+    if (conv && h.cnv < tol) break;                                                  // :296, :510
+  }
+  float h2;
+  if (model == BWGR_EM_ML) {
+    hipLaunchKernelGGL(k_em_fit_ml, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, yd, ed, hatd, (int)n);
+    h2 = h.vb * MSx / (h.vb * MSx + h.ve);                                           // :513
+  } else {
+    rc = gemv_hat<float>(P, bd, h.mu, hatd);                                         // fit = gen*b + mu, :120-121
+    if (rc != BWGR_OK) return done(rc);
+    if (model == BWGR_EM_DE) {                                                       // h2 = Vb.sum()/(Vb.sum()+Ve), :304
+      double *part = nullptr; float *sdev = nullptr; float sv = 0;
+      ECHK(dmalloc((void **)&part, sizeof(double) * 256)); ECHK(dmalloc((void **)&sdev, sizeof(float)));
+      hipLaunchKernelGGL(k_sum_stage1, dim3(256), dim3(256), 0, st, vbd, p, part);
+      hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, st, part, 256, sdev);
+      ECHK(d2h(st, &sv, sdev, sizeof(float)));
+      h2 = sv / (sv + h.ve);
+    } else h2 = 1 - h.ve / vy;                                                       // :119, :344
+  }
+  ECHK(hipGetLastError());
+  if (mu) *mu = h.mu;
+  ECHK(d2h(st, b, bd, pb));
+  if (hat) ECHK(d2h(st, hat, hatd, sizeof(float) * n));
+  if (vbvec && (model == BWGR_EM_BA || model == BWGR_EM_DE)) ECHK(d2h(st, vbvec, vbd, pb));
+  scal[0] = (model == BWGR_EM_RR || model == BWGR_EM_ML) ? h.vb : 0.0f; scal[1] = h.ve; scal[2] = h2;
+  scal[3] = (model == BWGR_EM_ML) ? h.vb * MSx : 0.0f;                               // Va = vb*MSx, :519
+  if (iters) *iters = numit;
+#undef ECHK
+  return done(BWGR_OK);
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" int bwgr_synth_genotypes(void *Xdev, int64_t n, int64_t p, int64_t ldx, int64_t col0, uint64_t seed,
                                     float *freq_dev, int device, void *hip_stream) {

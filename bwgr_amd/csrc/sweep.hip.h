@@ -39,7 +39,8 @@ enum : int {
   SWF_MH = 4,         // BayesDpi acceptance  min(1,(1-pi) exp(C(|e1|^2-|e2|^2)))
   SWF_LAM_VEC = 8,    // per-marker lambda array (else the common scalar)
   SWF_VB_VEC = 16,    // per-marker variance draw vb_j = (Sb + b_j^2)/chisq(df+1)
-  SWF_KMUP2 = 32      // KMUP2's conditional mean: numerator + b0 (not xx*b0), denominator xx*bg + L (src/Rcpp20260726ai.cpp:59)
+  SWF_KMUP2 = 32,     // KMUP2's conditional mean: numerator + b0 (not xx*b0), denominator xx*bg + L (src/Rcpp20260726ai.cpp:59)
+  SWF_DELTA2 = 64     // emBA applies every marker's step to the residual twice (src/Rcpp20260726ai.cpp:108, :111): affine sweeps only
 };
 
 // scalars produced on the device by the per-iteration tail kernel (or filled by the host for KMUP)
@@ -345,6 +346,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
 
   // scalars of this iteration
   const float Cc = a.sc->C, odds = a.sc->odds;
+  const double dscale = (a.flags & SWF_DELTA2) ? 2.0 : 1.0;   // emBA's doubled residual update (affine path)
   const float one_minus_pi = 1.0f - a.sc->pi, Sb = a.sc->Sb;
 
   const int nb = a.blk_end - a.blk_begin;
@@ -555,8 +557,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
               const float b1 = lane_b1(r[q], lc[q]);
               const float dl = b1 - lc[q].b0;
               const double dd = (double)readlane_f32(dl, l);
-              r[q] = fma(-(double)g0, dd, r[q]);
-              if (q == 0 && ngrp > 1) r[1] = fma(-(double)g1, dd, r[1]);
+              r[q] = fma(-(double)g0 * dscale, dd, r[q]);   // (the scaled Gram entry is ready before dd: off the chain)
+              if (q == 0 && ngrp > 1) r[1] = fma(-(double)g1 * dscale, dd, r[1]);
             }
           } else {
             // speculative rounds: lanes >= front decide as if every earlier unfinalized marker is rejected
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
           const bool inc = SELECT ? (((accmask[q] >> lane) & 1ull) != 0ull) : true;
           const float bn = inc ? b1 : lc[q].b2;
           const float dn = inc ? 1.0f : 0.0f;
-          delta_s[t] = (double)(bn - lc[q].b0); bnew_s[t] = bn; dnew_s[t] = dn;
+          delta_s[t] = (double)((bn - lc[q].b0) * (float)dscale); bnew_s[t] = bn; dnew_s[t] = dn;
           sum_d += (double)dn;
           sum_b2 = fma((double)bn, (double)bn, sum_b2);
         }

@@ -636,6 +636,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
   const GT *gramp = reinterpret_cast<const GT *>(a.gramp);
   const GT *gramx = reinterpret_cast<const GT *>(a.gramx);
   const float Cc = a.sc->C, odds = a.sc->odds, one_minus_pi = 1.0f - a.sc->pi, Sb = a.sc->Sb;
+  const double dscale = (a.flags & SWF_DELTA2) ? 2.0 : 1.0;   // emBA's doubled residual update (affine path)
   const int pchunks = pstride / GPT, xchunks = m * m / GPT;
   auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
   auto prow = [&](int k) { return k * (m - 1) - k * (k - 1) / 2; };   // offset of packed row k
@@ -769,8 +770,8 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
                 gn0 = gp[oA + lane]; gn1 = gp[oB + lane];          /* next row (slack makes the last one harmless) */ \
                 const float dl = lane_b1(r[0], lc[0]) - lc[0].b0; \
                 const double dd = (double)readlane_f32(dl, (l_)); \
-                r[0] = fma(-(double)g0, dd, r[0]); \
-                r[1] = fma(-(double)g1, dd, r[1]); }
+                r[0] = fma(-(double)g0 * dscale, dd, r[0]); \
+                r[1] = fma(-(double)g1 * dscale, dd, r[1]); }
               int l = 0;
               for (; l + 8 <= cnt; l += 8) { S2_AFFINE_STEP2(l) S2_AFFINE_STEP2(l + 1) S2_AFFINE_STEP2(l + 2) S2_AFFINE_STEP2(l + 3) S2_AFFINE_STEP2(l + 4) S2_AFFINE_STEP2(l + 5) S2_AFFINE_STEP2(l + 6) S2_AFFINE_STEP2(l + 7) }
               for (; l < cnt; ++l) S2_AFFINE_STEP2(l)
@@ -783,7 +784,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
                 gn0 = gp[oA + lane]; \
                 const float dl = lane_b1(r[q], lc[q]) - lc[q].b0; \
                 const double dd = (double)readlane_f32(dl, (l_)); \
-                r[q] = fma(-(double)g0, dd, r[q]); }
+                r[q] = fma(-(double)g0 * dscale, dd, r[q]); }
               int l = 0;
               for (; l + 8 <= cnt; l += 8) { S2_AFFINE_STEP1(l) S2_AFFINE_STEP1(l + 1) S2_AFFINE_STEP1(l + 2) S2_AFFINE_STEP1(l + 3) S2_AFFINE_STEP1(l + 4) S2_AFFINE_STEP1(l + 5) S2_AFFINE_STEP1(l + 6) S2_AFFINE_STEP1(l + 7) }
               for (; l < cnt; ++l) S2_AFFINE_STEP1(l)
@@ -820,7 +821,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
           const bool inc = SELECT ? (((accmask[q] >> lane) & 1ull) != 0ull) : true;
           const float bn = inc ? b1 : lc[q].b2;
           const float dn = inc ? 1.0f : 0.0f;
-          const float dl = bn - lc[q].b0;
+          const float dl = (bn - lc[q].b0) * (float)dscale;
           dl_own[q] = dl;
           delta_s[t] = (double)dl; bnew_s[t] = bn; dnew_s[t] = dn;
           if (SELECT && inc) {   // what this marker changed relative to the speculated step

@@ -176,6 +176,21 @@ int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, 
                 uint64_t seed, int rng_mode, const double *U, const double *V, int64_t pk, double bag, int rp, double *mu,
                 double *b, double *Vb, double *d, double *Ve, double *hat, double *cxx, double *u, double *Vk);
 
+/* ---- EM / Gauss-Seidel family --------------------------------------------------------
+ * Replaces SEXP emRR(y,gen,df,R2) src/Rcpp20260726ai.cpp:308-354, emBA(y,gen,df,R2) :80-128, emDE(y,gen,R2) :250-305,
+ * emML(y,gen,D) :463-521 (_bWGR_emRR ... in src/RcppExports.cpp).  Deterministic coordinate updates in the marker order
+ * the reference re-shuffles before every sweep with std::shuffle(order, std::mt19937(i)): the library makes the same
+ * standard-library call, gathers the resident panel into that order on the device, rebuilds the Gram blocks and runs
+ * the affine sweep kernel with the variates switched off.  maxit = 0: the reference's count (200 sweeps; emDE / emML up
+ * to 300 with their convergence tests).  D: emML's optional marker weights (p floats) or NULL.  Outputs (host):
+ * mu, b[p], hat[n], vbvec[p] (emBA / emDE: Vb; ignored otherwise, may be NULL), scal[4] = emRR {Va, Ve, h2, 0},
+ * emBA / emDE {0, Ve, h2, 0}, emML {Vb, Ve, h2, Va}; iters = sweeps run. */
+enum { BWGR_EM_RR = 0, BWGR_EM_BA = 1, BWGR_EM_DE = 2, BWGR_EM_ML = 3 };
+int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float R2, const float *D, int maxit, float *mu, float *b,
+            float *hat, float *vbvec, float *scal, int *iters);
+/* the marker order of sweep `upto` (0-based): the identity shuffled with std::mt19937(0), (1), ... (upto) (host only) */
+int bwgr_em_order(int64_t p, int upto, int32_t *order);
+
 /* ---- synthetic panels ----------------------------------------------------------
  * X_ij ~ Binomial(2, f_j), f_j ~ U(0.05,0.5), int8 column-major written to device memory Xdev
  * (ldx >= n); freq (p floats, device, may be NULL) receives f_j.  The p columns written are columns

@@ -761,3 +761,209 @@ int FN(oracle_wgr)(const double *y, const double *X, int64_t n, int64_t p, int64
   free(Uf); free(hf); free(dhf); free(xxKf); free(Lkf); free(h); free(H); free(use); free(ebag);
   return 0;
 }
+
+/* ---- EM / Gauss-Seidel family, /root/reference/src/Rcpp20260726ai.cpp:80-128 (emBA), :250-305 (emDE), :308-354 (emRR),
+ * :463-521 (emML) -------------------------------------------------------------------------------------------------------
+ * Deterministic coordinate updates b_j = (X_j.e + xx_j b_j)/(xx_j + lambda_j) in a marker order that is re-shuffled in
+ * place before every sweep: std::shuffle(order.begin(), order.end(), std::mt19937(i)) (:103, :277, :331, :491).
+ *
+ * THIRD-PARTY ALGORITHM (not under /root/reference): the C++ standard library's std::mt19937, std::shuffle and
+ * std::uniform_int_distribution.  The reference pins no toolchain (DESCRIPTION:13-15), and std::shuffle's draw sequence is
+ * implementation-defined; restated here is GNU libstdc++ as of GCC 11 (bits/stl_algo.h shuffle + __gen_two_uniform_ints,
+ * bits/uniform_int_dist.h Lemire "nearly divisionless" downscaling for 32-bit generators), i.e. what an R package built
+ * with g++ >= 11 on Linux runs.  tests/test_em_order.py pins this restatement against the std::shuffle of the libstdc++
+ * installed in this image (through the product's bwgr_em_order, which calls the library itself). */
+#ifndef BWGR_ORACLE_MT_DEFINED
+#define BWGR_ORACLE_MT_DEFINED
+typedef struct { uint32_t s[624]; int idx; } omt_t;
+static void omt_seed(omt_t *g, uint32_t seed) {                       /* std::mt19937(seed) */
+  g->s[0] = seed;
+  for (int k = 1; k < 624; k++) g->s[k] = 1812433253u * (g->s[k - 1] ^ (g->s[k - 1] >> 30)) + (uint32_t)k;
+  g->idx = 624;
+}
+static uint32_t omt_next(omt_t *g) {
+  if (g->idx >= 624) {
+    for (int k = 0; k < 624; k++) {
+      uint32_t yv = (g->s[k] & 0x80000000u) | (g->s[(k + 1) % 624] & 0x7FFFFFFFu);
+      uint32_t v = g->s[(k + 397) % 624] ^ (yv >> 1);
+      if (yv & 1u) v ^= 0x9908B0DFu;
+      g->s[k] = v;
+    }
+    g->idx = 0;
+  }
+  uint32_t yv = g->s[g->idx++];
+  yv ^= yv >> 11; yv ^= (yv << 7) & 0x9D2C5680u; yv ^= (yv << 15) & 0xEFC60000u; yv ^= yv >> 18;
+  return yv;
+}
+/* uniform_int_distribution<unsigned long>{0, range-1}(g) for a 32-bit generator: _S_nd<uint64_t>(g, (uint32_t)range) */
+static uint32_t omt_below(omt_t *g, uint32_t range) {
+  uint64_t product = (uint64_t)omt_next(g) * (uint64_t)range;
+  uint32_t low = (uint32_t)product;
+  if (low < range) {
+    uint32_t threshold = (uint32_t)(0u - range) % range;
+    while (low < threshold) { product = (uint64_t)omt_next(g) * (uint64_t)range; low = (uint32_t)product; }
+  }
+  return (uint32_t)(product >> 32);
+}
+static void oem_shuffle(int *order, int64_t p, uint32_t seed) {        /* std::shuffle(first, last, std::mt19937(seed)) */
+  if (p <= 0) return;
+  omt_t g; omt_seed(&g, seed);
+  const uint64_t urngrange = 0xFFFFFFFFull, urange = (uint64_t)p;
+#define OEM_SWAP(a_, b_) do { int t_ = order[a_]; order[a_] = order[b_]; order[b_] = t_; } while (0)
+  if (urngrange / urange >= urange) {                                  /* two swap positions per draw */
+    int64_t i = 1;
+    if ((urange % 2) == 0) { uint32_t r = omt_below(&g, 2u); OEM_SWAP(i, (int64_t)r); i++; }
+    while (i != p) {
+      const uint64_t swap_range = (uint64_t)i + 1;
+      const uint64_t b1 = swap_range + 1;
+      const uint32_t x = omt_below(&g, (uint32_t)(swap_range * b1));   /* {0, b0*b1 - 1} */
+      const uint64_t pos0 = x / b1, pos1 = x % b1;
+      OEM_SWAP(i, (int64_t)pos0); i++;
+      OEM_SWAP(i, (int64_t)pos1); i++;
+    }
+    return;
+  }
+  for (int64_t i = 1; i != p; ++i) { uint32_t r = omt_below(&g, (uint32_t)(i + 1)); OEM_SWAP(i, (int64_t)r); }
+#undef OEM_SWAP
+}
+#endif
+
+/* the marker order of sweep `upto` (0-based): identity shuffled with seeds 0, 1, ..., upto */
+int FN(oracle_em_order)(int64_t p, int upto, int *order) {
+  for (int64_t j = 0; j < p; j++) order[j] = (int)j;
+  for (int i = 0; i <= upto; i++) oem_shuffle(order, p, (uint32_t)i);
+  return 0;
+}
+
+enum { EM_RR = 0, EM_BA = 1, EM_DE = 2, EM_ML = 3 };
+
+/* dot of two n-vectors, one of them the residual */
+static ACC_T oem_dot_ey(const E_T *e, const float *y, int64_t n) {
+  ACC_T s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t i = 0;
+  for (; i + 8 <= n; i += 8)
+    for (int l = 0; l < 8; l++) s[l] += (ACC_T)e[i + l] * (ACC_T)y[i + l];
+  for (int l = 0; i < n; i++, l++) s[l] += (ACC_T)e[i] * (ACC_T)y[i];
+  return red8(s);
+}
+
+/* o_vbvec: p entries (emBA Vb, emDE Vb), untouched otherwise.  o_scal: emRR {Va, Ve, h2, 0}; emBA {0, Ve, h2, 0};
+ * emDE {0, Ve, h2, 0}; emML {Vb, Ve, h2, Va}.  maxit = 0: the reference's count (200 sweeps; 300 with the convergence
+ * test for emDE / emML).  D: emML's optional per-marker weights (NULL = none). */
+int FN(oracle_em)(int model, const float *y, const float *X, int64_t n, int64_t p, int64_t ldx, float df, float R2,
+                  const float *D, int maxit_in, float *o_mu, float *o_b, float *o_hat, float *o_vbvec, float *o_scal,
+                  int *o_iters) {
+  float *xx = (float *)malloc(sizeof(float) * p), *vx = (float *)malloc(sizeof(float) * p);
+  float *b = (float *)calloc(p, sizeof(float)), *bc = (float *)calloc(p, sizeof(float));
+  float *vbv = (float *)malloc(sizeof(float) * p), *Lmbv = (float *)malloc(sizeof(float) * p);
+  int *order = (int *)malloc(sizeof(int) * p);
+  E_T *e = (E_T *)malloc(sizeof(E_T) * n);
+  if (!xx || !vx || !b || !bc || !vbv || !Lmbv || !order || !e) return 1;
+  float MSx;
+  FN(oracle_stats)(X, n, p, ldx, xx, vx, &MSx);                         /* :90-94, :258-264, :312-317, :481-485 */
+  const float vy = v_fvar(y, n);
+  float mu = v_mean(y, n);                                              /* :98, :256, :326, :478 */
+  for (int64_t k = 0; k < n; k++) e[k] = (E_T)(y[k] - mu);              /* e = y.array()-mu (float) */
+  for (int64_t j = 0; j < p; j++) order[j] = (int)j;
+  float ve = 0, vb = 0, Lmb = 0, Sb = 0, Se = 0, Rho = 0, cxx = 0, h2 = 0;
+  const int conv = (model == EM_DE || model == EM_ML);
+  const int maxit = maxit_in > 0 ? maxit_in : (conv ? 300 : 200);        /* :81, :251, :309, :465 */
+  const float tol = (model == EM_DE) ? 10e-6f : 10e-8f;                  /* :252, :466 */
+  if (model == EM_BA) {
+    ve = 1;                                                               /* :84 */
+    for (int64_t j = 0; j < p; j++) { vbv[j] = 1.0f; Lmbv[j] = ve * (1.0f / vbv[j]); }   /* :87-88 */
+    Sb = R2 * (df + 2) * vy / MSx;                                        /* :96 */
+    Se = (1 - R2) * (df + 2) * vy;                                        /* :97 */
+  } else if (model == EM_RR) {
+    Lmb = MSx;                                                            /* :319 */
+    Rho = MSx * (1 - R2) / R2;                                            /* :320 */
+    ve = 0.5f * vy;                                                       /* :322 */
+    vb = ve / MSx;                                                        /* :323 */
+    Se = (1 - R2) * (df + 2) * vy;                                        /* :324 */
+    Sb = R2 * (df + 2) * vy / MSx;                                        /* :325 */
+  } else if (model == EM_DE) {
+    for (int64_t j = 0; j < p; j++) if (xx[j] == 0) xx[j] = 0.1f;         /* :261 */
+    cxx = MSx * (1 - R2) / R2;                                            /* :265 */
+    for (int64_t j = 0; j < p; j++) Lmbv[j] = (float)p + cxx;             /* :269 */
+  } else {
+    Lmb = MSx;                                                            /* :486 */
+  }
+  int numit = 0;
+  for (int i = 0; i < maxit; i++) {
+    if (conv) memcpy(bc, b, sizeof(float) * p);                           /* bc = b, :276, :490 */
+    oem_shuffle(order, p, (uint32_t)i);                                   /* :103, :277, :331, :491 */
+    for (int64_t jj = 0; jj < p; jj++) {
+      const int64_t j = order[jj];
+      const float *xj = X + j * ldx;
+      const float b0 = b[j];
+      float den;
+      if (model == EM_BA || model == EM_DE) den = xx[j] + Lmbv[j];        /* :107, :282 */
+      else if (model == EM_ML && D) den = xx[j] + Lmb / D[j];             /* :496 */
+      else den = xx[j] + Lmb;                                             /* :335, :498 */
+      const float b1 = draw_b1(xj, e, n, xx[j], b0, den, 0.0f, 0.0);
+      const float db = b1 - b0;
+      v_axpy(e, xj, db, n);                                               /* :108, :284, :336, :500 */
+      b[j] = b1;
+      if (model == EM_BA) {
+        vbv[j] = (Sb + b[j] * b[j]) / (df + 1);                           /* :110 */
+        v_axpy(e, xj, db, n);                                             /* :111 -- the second, identical update is the reference's */
+      }
+    }
+    if (model == EM_BA) {
+      ve = (e_sqnorm(e, n) + Se) / ((float)n + df);                       /* :113 */
+      for (int64_t j = 0; j < p; j++) Lmbv[j] = ve * (1.0f / vbv[j]);     /* :114 */
+    } else if (model == EM_RR) {
+      ACC_T sb = 0; for (int64_t j = 0; j < p; j++) sb += (ACC_T)b[j] * (ACC_T)b[j];
+      vb = ((float)sb + Sb) / ((float)p + df);                            /* :338 */
+      ve = (e_sqnorm(e, n) + Se) / ((float)n + df);                       /* :339 */
+      Lmb = sqrtf(Rho * ve / vb);                                         /* :340 */
+    }
+    const float eM = e_mean(e, n);                                        /* :115-117, :286-288, :341-343, :502-504 */
+    mu += eM;
+    for (int64_t k = 0; k < n; k++) e[k] = e[k] - (E_T)eM;
+    if (model == EM_DE) {
+      ve = (float)oem_dot_ey(e, y, n) / (float)(n - 1);                   /* Ve = e.dot(y)/(n-1), :289 */
+      for (int64_t j = 0; j < p; j++) {
+        vbv[j] = b[j] * b[j] + ve / (xx[j] + Lmbv[j] + 0.0001f);          /* :290 */
+        Lmbv[j] = sqrtf(cxx * ve / vbv[j]);                               /* :292 */
+      }
+    } else if (model == EM_ML) {
+      ACC_T s1 = 0, s2 = 0;
+      for (int64_t k = 0; k < n; k++) {
+        const float ym = y[k] - mu;                                       /* (y.array()-mu) */
+        s1 += (ACC_T)ym * (ACC_T)e[k];                                    /* :505 */
+        const E_T dif = (E_T)ym - e[k];                                   /* (y-mu) - e */
+        s2 += (ACC_T)ym * (ACC_T)dif;                                     /* :506 */
+      }
+      ve = (float)s1 / (float)n;
+      vb = (float)s2 / (float)((float)n * MSx);
+      Lmb = ve / vb;                                                      /* :507 */
+    }
+    ++numit;
+    if (conv) {
+      ACC_T c = 0; for (int64_t j = 0; j < p; j++) c += (ACC_T)fabsf(bc[j] - b[j]);
+      if ((float)c < tol) break;                                          /* :295-296, :509-510 */
+    }
+  }
+  /* fit */
+  if (model == EM_ML) {
+    for (int64_t k = 0; k < n; k++) o_hat[k] = (float)((E_T)y[k] - e[k]); /* fit = y - e, :512 */
+    h2 = vb * MSx / (vb * MSx + ve);                                      /* :513 */
+  } else {
+    ACC_T *acc = (ACC_T *)calloc(n, sizeof(ACC_T));
+    for (int64_t j = 0; j < p; j++) { const float *xj = X + j * ldx; ACC_T Bj = (ACC_T)b[j]; for (int64_t k = 0; k < n; k++) acc[k] += (ACC_T)xj[k] * Bj; }
+    for (int64_t k = 0; k < n; k++) { float f = (float)acc[k]; o_hat[k] = f + mu; }   /* :120-121 */
+    free(acc);
+    if (model == EM_DE) {
+      ACC_T sv = 0; for (int64_t j = 0; j < p; j++) sv += (ACC_T)vbv[j];
+      h2 = (float)sv / ((float)sv + ve);                                  /* :304 */
+    } else h2 = 1 - ve / vy;                                              /* :119, :344 */
+  }
+  *o_mu = mu; memcpy(o_b, b, sizeof(float) * p);
+  if (o_vbvec && (model == EM_BA || model == EM_DE)) memcpy(o_vbvec, vbv, sizeof(float) * p);
+  o_scal[0] = (model == EM_RR || model == EM_ML) ? vb : 0.0f; o_scal[1] = ve; o_scal[2] = h2;
+  o_scal[3] = (model == EM_ML) ? vb * MSx : 0.0f;                         /* Va = vb*MSx, :519 */
+  *o_iters = numit;
+  free(xx); free(vx); free(b); free(bc); free(vbv); free(Lmbv); free(order); free(e);
+  return 0;
+}

@@ -199,3 +199,38 @@ def wgr(y, X, it=1500, bi=500, th=1, bag=1.0, rp=False, iv=False, de=False, pi=0
         return {"mu": mu.value, "b": b, "Vb": Vb if per else float(Vb[0]), "d": d, "Ve": Ve.value, "hat": hat, "u": u,
                 "Vk": Vk.value, "cxx": cxx.value}
     return {"mu": mu.value, "b": b, "Vb": Vb if per else float(Vb[0]), "d": d, "Ve": Ve.value, "hat": hat, "cxx": cxx.value}
+
+
+EM_MODELS = {"emRR": 0, "emBA": 1, "emDE": 2, "emML": 3}
+
+
+def em_order(p, upto):
+    """Marker order of sweep `upto` (0-based) of the EM family: the oracle's restatement of libstdc++'s
+    std::shuffle(order, std::mt19937(i)) applied for i = 0..upto (src/Rcpp20260726ai.cpp:103)."""
+    out = np.zeros(int(p), np.int32)
+    rc = lib().oracle_em_order_w(C.c_int64(p), C.c_int(upto), out.ctypes.data_as(C.POINTER(C.c_int)))
+    assert rc == 0
+    return out
+
+
+def em(model, y, X, df=10.0, R2=0.5, D=None, maxit=0, flavour="w", fast=False):
+    """Reference emRR / emBA / emDE / emML (src/Rcpp20260726ai.cpp:308-354, :80-128, :250-305, :463-521); returns the
+    reference's list as a dict plus 'iters' (sweeps run)."""
+    Xf = as_f32_colmajor(X)
+    n, p = Xf.shape
+    y = np.ascontiguousarray(y, np.float32)
+    b = np.zeros(p, np.float32); hat = np.zeros(n, np.float32); vbv = np.zeros(p, np.float32); scal = np.zeros(4, np.float32)
+    mu = C.c_float(); iters = C.c_int()
+    Dv = None if D is None else np.ascontiguousarray(D, np.float32)
+    rc = getattr(lib(fast), "oracle_em_" + flavour)(
+        C.c_int(EM_MODELS[model]), _fp(y), _fp(Xf), C.c_int64(n), C.c_int64(p), C.c_int64(n), C.c_float(df), C.c_float(R2),
+        None if Dv is None else _fp(Dv), C.c_int(maxit), C.byref(mu), _fp(b), _fp(hat), _fp(vbv), _fp(scal), C.byref(iters))
+    assert rc == 0
+    if model == "emRR":
+        out = {"mu": mu.value, "b": b, "hat": hat, "Va": float(scal[0]), "Ve": float(scal[1]), "h2": float(scal[2])}
+    elif model in ("emBA", "emDE"):
+        out = {"mu": mu.value, "b": b, "hat": hat, "Vb": vbv, "Ve": float(scal[1]), "h2": float(scal[2])}
+    else:
+        out = {"mu": mu.value, "b": b, "hat": hat, "h2": float(scal[2]), "Vb": float(scal[0]), "Va": float(scal[3]), "Ve": float(scal[1])}
+    out["iters"] = int(iters.value)
+    return out

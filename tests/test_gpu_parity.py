@@ -455,3 +455,60 @@ def test_fit_many_runs_the_same_chains_side_by_side():
         assert q.n == P.n and q.p == P.p
     finally:
         P.close()
+
+
+EM_MODELS = ["emRR", "emBA", "emDE", "emML"]
+
+
+def _em_check(model, got, ref, tol=TOL):
+    assert list(got) == [k for k in ref if k != "iters"], (model, list(got))
+    for k in got:
+        g, r = np.asarray(got[k], np.float64), np.asarray(ref[k], np.float64)
+        if g.ndim:
+            assert scaled_err(g, r) < tol, (model, k, scaled_err(g, r))
+        else:
+            assert _rel(g, r) < 10 * tol, (model, k, float(g), float(r))
+
+
+@pytest.mark.parametrize("model", EM_MODELS)
+def test_em_family_matches_oracle(model):
+    """f4: emRR / emBA / emDE / emML in the reference's shuffled marker order (src/Rcpp20260726ai.cpp:80-128, :250-354,
+    :463-521) against the oracle's wide flavour, 1e-6; the full default run (200 sweeps, or up to 300 with the
+    convergence test) and a short one."""
+    import bwgr_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    n, p = 260, 700
+    X = rng.integers(0, 3, size=(n, p)).astype(np.int8)
+    X[:, 17] = 0                                      # a monomorphic marker: xx = 0 (emDE replaces it by 0.1, :261)
+    y = (X[:, :12].astype(np.float64) @ rng.normal(size=12) + 2.0 * rng.normal(size=n)).astype(np.float32)
+    P = bwgr_amd.Panel(X)
+    try:
+        for maxit in (7, 0):
+            got = getattr(bwgr_amd, model)(y, P, maxit=maxit)
+            ref = O.em(model, y, X, df=10.0, R2=0.5, maxit=maxit)
+            _em_check(model, got, ref)
+    finally:
+        P.close()
+
+
+def test_em_family_other_shapes():
+    """Marker weights for emML, non-default df / R2, a float (centred) panel, a panel smaller than one block, and a
+    p above 65535 (libstdc++'s shuffle switches from two swap positions per draw to one)."""
+    import bwgr_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng(4)
+    n, p = 150, 400
+    X = rng.integers(0, 3, size=(n, p)).astype(np.int8)
+    y = (X[:, :6].astype(np.float64) @ rng.normal(size=6) + rng.normal(size=n)).astype(np.float32)
+    D = rng.uniform(0.5, 2.0, size=p).astype(np.float32)
+    _em_check("emML", bwgr_amd.emML(y, X, D=D, maxit=40), O.em("emML", y, X, D=D, maxit=40))
+    _em_check("emRR", bwgr_amd.emRR(y, X, df=4, R2=0.3, maxit=30), O.em("emRR", y, X, df=4, R2=0.3, maxit=30))
+    _em_check("emBA", bwgr_amd.emBA(y, X, df=6, R2=0.7, maxit=30), O.em("emBA", y, X, df=6, R2=0.7, maxit=30))
+    Xc = (X - X.mean(axis=0)).astype(np.float32)
+    _em_check("emDE", bwgr_amd.emDE(y, Xc, R2=0.4, maxit=30, as_int8=False), O.em("emDE", y, Xc, R2=0.4, maxit=30), tol=5e-6)
+    _em_check("emRR", bwgr_amd.emRR(y, X[:, :11], maxit=30), O.em("emRR", y, X[:, :11], maxit=30))
+    n2, p2 = 64, 66000
+    X2 = rng.integers(0, 3, size=(n2, p2)).astype(np.int8)
+    y2 = (X2[:, :5].astype(np.float64) @ rng.normal(size=5) + rng.normal(size=n2)).astype(np.float32)
+    _em_check("emML", bwgr_amd.emML(y2, X2, maxit=3), O.em("emML", y2, X2, maxit=3))
