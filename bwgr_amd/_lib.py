@@ -31,7 +31,7 @@ def lib():
     L.bwgr_panel_destroy.argtypes = [vp]
     L.bwgr_panel_set_stream.argtypes = [vp, vp]
     L.bwgr_panel_info.argtypes = [vp, C.POINTER(i64)]
-    L.bwgr_em.argtypes = [vp, i32, c_f, f32, f32, c_f, i32, C.POINTER(f32), c_f, c_f, c_f, c_f, C.POINTER(i32)]
+    L.bwgr_em.argtypes = [vp, i32, c_f, f32, f32, f32, c_f, i32, C.POINTER(f32), c_f, c_f, c_f, c_f, c_f, C.POINTER(i32)]
     L.bwgr_em_order.argtypes = [i64, i32, C.POINTER(C.c_int32)]
     L.bwgr_panel_clone.argtypes = [C.POINTER(vp), vp]
     L.bwgr_panel_max_concurrent.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]

@@ -328,23 +328,23 @@ def fit_many(X, jobs, concurrent=None, chunk=4, **panel_kw):
             P.close()
 
 
-_EM = {"emRR": 0, "emBA": 1, "emDE": 2, "emML": 3}
+_EM = {"emRR": 0, "emBA": 1, "emDE": 2, "emML": 3, "emBB": 4, "emBC": 5, "emBCpi": 6, "emBL": 7, "emEN": 8}
 
 
-def _em(model, y, gen, df, R2, D=None, maxit=0, **panel_kw):
-    """The EM / Gauss-Seidel family over bwgr_em (include/bwgr.h); returns (mu, b, hat, vbvec, scal, iters)."""
+def _em(model, y, gen, df=10.0, R2=0.5, par=0.0, D=None, maxit=0, **panel_kw):
+    """The EM / Gauss-Seidel family over bwgr_em (include/bwgr.h); returns dict(mu, b, d, hat, vbvec, scal, iters)."""
     P, own = _as_panel(gen, **panel_kw)
     try:
         yv = np.ascontiguousarray(y, np.float32)
         assert yv.size == P.n, "length(y) must equal nrow(gen)"
-        b = np.empty(P.p, np.float32); hat = np.empty(P.n, np.float32); vbv = np.empty(P.p, np.float32)
-        scal = np.zeros(4, np.float32); mu = C.c_float(); iters = C.c_int()
+        b = np.empty(P.p, np.float32); d = np.zeros(P.p, np.float32); hat = np.empty(P.n, np.float32); vbv = np.empty(P.p, np.float32)
+        scal = np.zeros(6, np.float32); mu = C.c_float(); iters = C.c_int()
         Dv = None if D is None else np.ascontiguousarray(D, np.float32)
         if Dv is not None:
             assert Dv.size == P.p, "length(D) must equal ncol(gen)"
-        check(_lib.lib().bwgr_em(P._h, _EM[model], _fp(yv), float(df), float(R2), None if Dv is None else _fp(Dv), int(maxit),
-                                 C.byref(mu), _fp(b), _fp(hat), _fp(vbv), _fp(scal), C.byref(iters)))
-        return float(mu.value), b, hat, vbv, scal, int(iters.value)
+        check(_lib.lib().bwgr_em(P._h, _EM[model], _fp(yv), float(df), float(R2), float(par), None if Dv is None else _fp(Dv),
+                                 int(maxit), C.byref(mu), _fp(b), _fp(d), _fp(hat), _fp(vbv), _fp(scal), C.byref(iters)))
+        return {"mu": float(mu.value), "b": b, "d": d, "hat": hat, "vbvec": vbv, "scal": [float(v) for v in scal], "iters": int(iters.value)}
     finally:
         if own:
             P.close()
@@ -352,26 +352,57 @@ def _em(model, y, gen, df, R2, D=None, maxit=0, **panel_kw):
 
 def emRR(y, gen, df=10, R2=0.5, **kw):
     """emRR(y, gen, df = 10, R2 = 0.5), src/Rcpp20260726ai.cpp:308-354: list(mu, b, hat, Va, Ve, h2)."""
-    mu, b, hat, _, s, _ = _em("emRR", y, gen, df, R2, **kw)
-    return {"mu": mu, "b": b, "hat": hat, "Va": float(s[0]), "Ve": float(s[1]), "h2": float(s[2])}
+    r = _em("emRR", y, gen, df, R2, **kw); s = r["scal"]
+    return {"mu": r["mu"], "b": r["b"], "hat": r["hat"], "Va": s[0], "Ve": s[1], "h2": s[2]}
 
 
 def emBA(y, gen, df=10, R2=0.5, **kw):
     """emBA(y, gen, df = 10, R2 = 0.5), src/Rcpp20260726ai.cpp:80-128: list(mu, b, hat, Vb, Ve, h2)."""
-    mu, b, hat, vb, s, _ = _em("emBA", y, gen, df, R2, **kw)
-    return {"mu": mu, "b": b, "hat": hat, "Vb": vb, "Ve": float(s[1]), "h2": float(s[2])}
+    r = _em("emBA", y, gen, df, R2, **kw); s = r["scal"]
+    return {"mu": r["mu"], "b": r["b"], "hat": r["hat"], "Vb": r["vbvec"], "Ve": s[1], "h2": s[2]}
+
+
+def emBB(y, gen, df=10, R2=0.5, Pi=0.75, **kw):
+    """emBB(y, gen, df = 10, R2 = 0.5, Pi = 0.75), src/Rcpp20260726ai.cpp:131-187: list(mu, b, d, hat, Vb, Ve, h2)."""
+    r = _em("emBB", y, gen, df, R2, Pi, **kw); s = r["scal"]
+    return {"mu": r["mu"], "b": r["b"], "d": r["d"], "hat": r["hat"], "Vb": r["vbvec"], "Ve": s[1], "h2": s[2]}
+
+
+def emBC(y, gen, df=10, R2=0.5, Pi=0.75, **kw):
+    """emBC(y, gen, df = 10, R2 = 0.5, Pi = 0.75), src/Rcpp20260726ai.cpp:190-247: list(mu, b, d, hat, Vg, Va, Ve, h2)."""
+    r = _em("emBC", y, gen, df, R2, Pi, **kw); s = r["scal"]
+    return {"mu": r["mu"], "b": r["b"], "d": r["d"], "hat": r["hat"], "Vg": s[3], "Va": s[0], "Ve": s[1], "h2": s[2]}
+
+
+def emBCpi(y, gen, df=10, R2=0.5, Pi=0.75, **kw):
+    """emBCpi(y, gen, df = 10, R2 = 0.5, Pi = 0.75), src/Rcpp20260726ai.cpp:1502-1550 (natural marker order):
+    list(mu, b, d, pi, hat, Vg, Va, Ve, h2)."""
+    r = _em("emBCpi", y, gen, df, R2, Pi, **kw); s = r["scal"]
+    return {"mu": r["mu"], "b": r["b"], "d": r["d"], "pi": s[4], "hat": r["hat"], "Vg": s[3], "Va": s[0], "Ve": s[1], "h2": s[2]}
 
 
 def emDE(y, gen, R2=0.5, **kw):
     """emDE(y, gen, R2 = 0.5), src/Rcpp20260726ai.cpp:250-305: list(mu, b, hat, Vb, Ve, h2)."""
-    mu, b, hat, vb, s, _ = _em("emDE", y, gen, 0.0, R2, **kw)
-    return {"mu": mu, "b": b, "hat": hat, "Vb": vb, "Ve": float(s[1]), "h2": float(s[2])}
+    r = _em("emDE", y, gen, 0.0, R2, **kw); s = r["scal"]
+    return {"mu": r["mu"], "b": r["b"], "hat": r["hat"], "Vb": r["vbvec"], "Ve": s[1], "h2": s[2]}
+
+
+def emBL(y, gen, R2=0.5, alpha=0.02, **kw):
+    """emBL(y, gen, R2 = 0.5, alpha = 0.02), src/Rcpp20260726ai.cpp:357-397: list(mu, b, hat, h2)."""
+    r = _em("emBL", y, gen, 0.0, R2, alpha, **kw)
+    return {"mu": r["mu"], "b": r["b"], "hat": r["hat"], "h2": r["scal"][2]}
+
+
+def emEN(y, gen, R2=0.5, alpha=0.02, **kw):
+    """emEN(y, gen, R2 = 0.5, alpha = 0.02), src/Rcpp20260726ai.cpp:400-460: list(mu, b, hat, Va, Ve, h2)."""
+    r = _em("emEN", y, gen, 0.0, R2, alpha, **kw); s = r["scal"]
+    return {"mu": r["mu"], "b": r["b"], "hat": r["hat"], "Va": s[0], "Ve": s[1], "h2": s[2]}
 
 
 def emML(y, gen, D=None, **kw):
     """emML(y, gen, D = NULL), src/Rcpp20260726ai.cpp:463-521: list(mu, b, hat, h2, Vb, Va, Ve)."""
-    mu, b, hat, _, s, _ = _em("emML", y, gen, 0.0, 0.5, D=D, **kw)
-    return {"mu": mu, "b": b, "hat": hat, "h2": float(s[2]), "Vb": float(s[0]), "Va": float(s[3]), "Ve": float(s[1])}
+    r = _em("emML", y, gen, 0.0, 0.5, 0.0, D=D, **kw); s = r["scal"]
+    return {"mu": r["mu"], "b": r["b"], "hat": r["hat"], "h2": s[2], "Vb": s[0], "Va": s[3], "Ve": s[1]}
 
 
 def em_order(p, upto):

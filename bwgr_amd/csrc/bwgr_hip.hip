@@ -1870,12 +1870,10 @@ done:
 }
 
 // ------------------------------------------------------------------------------------------------
-// synthetic data and test hooks
-// ------------------------------------------------------------------------------------------------
-// f4: EM / Gauss-Seidel family (emRR, emBA, emDE, emML), src/Rcpp20260726ai.cpp:80-128, :250-305, :308-354, :463-521
+// f4: EM / Gauss-Seidel family (emRR, emBA, emBB, emBC, emBCpi, emDE, emBL, emEN, emML), src/Rcpp20260726ai.cpp:80-521, :1502-1545
 //
-// Deterministic coordinate updates b_j = (X_j.e + xx_j b_j)/(xx_j + lambda_j) -- the affine sweep with the variates
-// switched off -- in a marker order that the reference re-shuffles before every sweep (std::shuffle with
+// Deterministic coordinate updates -- b_j = (X_j.e + xx_j b_j)/(xx_j + lambda_j), i.e. the affine sweep with the variates
+// switched off, or the member's soft-selection / soft-threshold update (lane_em) -- in a marker order that the reference re-shuffles before every sweep (std::shuffle with
 // std::mt19937(i), :103 ...).  The exact blocked sweep needs the Gram blocks of consecutive markers, so every sweep
 //   (1) shuffles the order on the host with the very library call the reference makes,
 //   (2) gathers the columns of the resident panel into a scratch panel in that order (one pass over X),
@@ -1899,25 +1897,32 @@ __global__ void k_permute_cols(const uint4 *__restrict__ X, uint4 *__restrict__ 
 
 struct EmState {
   float mu, ve, vb, Lmb, cnv, Sb, Se, Rho, cxx, df, vy, MSx;
+  float va, Sa, Pi, Pi0, PriorPi, sumvx, R2, alpha, Lmb1, Lmb2, Sy, trAC22;
 };
 
 // per-marker inputs of one sweep, in sweep order: b, xx, lambda
 __global__ void k_em_stage(const int32_t *__restrict__ order, int64_t p, int model, int weighted, const float *__restrict__ b,
                            const float *__restrict__ xx, const float *__restrict__ lam, const float *__restrict__ D,
                            const EmState *__restrict__ st, float *__restrict__ bq, float *__restrict__ xxq, float *__restrict__ lamq) {
-  const float Lmb = st->Lmb;
+  const float Lmb = st->Lmb, Lmb2 = st->Lmb2;
   for (int64_t jj = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; jj < p; jj += (int64_t)gridDim.x * blockDim.x) {
     const int j = order[jj];
     bq[jj] = b[j]; xxq[jj] = xx[j];
     float l;
-    if (model == BWGR_EM_BA || model == BWGR_EM_DE) l = lam[j];
+    if (model == BWGR_EM_BA || model == BWGR_EM_DE || model == BWGR_EM_BB) l = lam[j];
+    else if (model == BWGR_EM_BL || model == BWGR_EM_EN) l = Lmb2;                   // denominators Lmb2 + xx, :382, :434
     else if (weighted) l = Lmb / D[j];                                               // :496
     else l = Lmb;
     lamq[jj] = l;
   }
 }
-__global__ void k_em_unstage(const int32_t *__restrict__ order, int64_t p, const float *__restrict__ bq, float *__restrict__ b) {
-  for (int64_t jj = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; jj < p; jj += (int64_t)gridDim.x * blockDim.x) b[order[jj]] = bq[jj];
+__global__ void k_em_unstage(const int32_t *__restrict__ order, int64_t p, const float *__restrict__ bq, float *__restrict__ b,
+                             const float *__restrict__ dq, float *__restrict__ d) {
+  for (int64_t jj = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; jj < p; jj += (int64_t)gridDim.x * blockDim.x) {
+    const int j = order[jj];
+    b[j] = bq[jj];
+    if (d) d[j] = dq[jj];
+  }
 }
 __global__ void k_em_fix_xx(float *xx, int64_t p) {                                   // if(xx[k]==0) xx[k]=0.1f, :261
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < p; j += (int64_t)gridDim.x * blockDim.x) if (xx[j] == 0.0f) xx[j] = 0.1f;
@@ -1936,7 +1941,8 @@ __global__ void k_em_init(const float *__restrict__ y, double *__restrict__ e, i
 
 struct EmTailArgs {
   int model, n, conv; int64_t p;
-  double *e; const float *y; const float *b; const float *bc; float *lam; float *vbv; const float *xx; EmState *st;
+  double *e; const float *y; const float *b; const float *bc; const float *d; float *lam; float *vbv; const float *xx;
+  EmState *st; ChainScalars *sc;
 };
 
 __device__ double em_block_sum(double v, double *sh) {
@@ -1946,30 +1952,50 @@ __device__ double em_block_sum(double v, double *sh) {
   return sh[0];
 }
 
-// what follows a sweep, one workgroup: the model's variance components and lambda, then eM = e.mean(); mu += eM; e -= eM
+// what follows a sweep, one workgroup: the model's variance components and lambda, then eM = e.mean(); mu += eM; e -= eM;
+// last, the scalars the next sweep's kernels read (C, Pi0, Lmb1) are refreshed in the ChainScalars block
 __global__ __launch_bounds__(1024) void k_em_tail(const EmTailArgs a) {
   __shared__ double sh[1024];
   EmState st = *a.st;
-  const int n = a.n; const int64_t p = a.p; const int tid = threadIdx.x;
+  const int n = a.n; const int64_t p = a.p; const int tid = threadIdx.x; const int model = a.model;
   const float df = st.df;
-  if (a.model == BWGR_EM_BA) {
+  float b2n = 0, e2n = 0, dmean = 0;
+  if (model == BWGR_EM_RR || model == BWGR_EM_BC || model == BWGR_EM_BCPI || model == BWGR_EM_EN) {
+    double s = 0; for (int64_t j = tid; j < p; j += 1024) s = fma((double)a.b[j], (double)a.b[j], s);
+    b2n = (float)em_block_sum(s, sh);                                                // b.squaredNorm()
+  }
+  if (model == BWGR_EM_BC || model == BWGR_EM_BCPI) {
+    double s = 0; for (int64_t j = tid; j < p; j += 1024) s += (double)a.d[j];
+    dmean = (float)(em_block_sum(s, sh) / (double)p);                                // d.mean()
+  }
+  if (model == BWGR_EM_BA || model == BWGR_EM_BB || model == BWGR_EM_RR || model == BWGR_EM_BC || model == BWGR_EM_BCPI) {
     double s = 0; for (int i = tid; i < n; i += 1024) s = fma(a.e[i], a.e[i], s);
-    const float e2 = (float)em_block_sum(s, sh);
-    st.ve = (e2 + st.Se) / ((float)n + df);                                          // :113
+    e2n = (float)em_block_sum(s, sh);                                                // e.squaredNorm() (before centring)
+  }
+  if (model == BWGR_EM_BA || model == BWGR_EM_BB) {
+    st.ve = (e2n + st.Se) / ((float)n + df);                                         // :113, :170
     for (int64_t j = tid; j < p; j += 1024) {
       const float bj = a.b[j];
-      const float vbj = (st.Sb + bj * bj) / (df + 1);                                // :110
+      const float vbj = (st.Sb + bj * bj) / (df + 1);                                // :110, :167
       a.vbv[j] = vbj;
-      a.lam[j] = st.ve * (1.0f / vbj);                                               // Lmb = ve * vb.cwiseInverse(), :114
+      a.lam[j] = st.ve * (1.0f / vbj);                                               // Lmb = ve * vb.cwiseInverse(), :114, :171
     }
-  } else if (a.model == BWGR_EM_RR) {
-    double s = 0; for (int64_t j = tid; j < p; j += 1024) s = fma((double)a.b[j], (double)a.b[j], s);
-    const float b2 = (float)em_block_sum(s, sh);
-    s = 0; for (int i = tid; i < n; i += 1024) s = fma(a.e[i], a.e[i], s);
-    const float e2 = (float)em_block_sum(s, sh);
-    st.vb = (b2 + st.Sb) / ((float)p + df);                                          // :338
-    st.ve = (e2 + st.Se) / ((float)n + df);                                          // :339
+  } else if (model == BWGR_EM_RR) {
+    st.vb = (b2n + st.Sb) / ((float)p + df);                                         // :338
+    st.ve = (e2n + st.Se) / ((float)n + df);                                         // :339
     st.Lmb = sqrtf(st.Rho * st.ve / st.vb);                                          // :340
+  } else if (model == BWGR_EM_BC) {
+    st.ve = (e2n + st.Se) / ((float)n + df);                                         // :229
+    st.va = (b2n + st.Sa) / ((float)p + df) / (dmean - st.Pi);                       // :230
+    st.Lmb = st.ve / st.va;                                                          // :231
+  } else if (model == BWGR_EM_BCPI) {
+    st.Pi = ((1.0f - dmean) * (float)p + st.PriorPi * df) / ((float)p + df);         // :1533
+    st.Pi0 = (1.0f - st.Pi) / st.Pi;                                                 // :1534
+    st.MSx = st.sumvx * st.Pi * (1.0f - st.Pi);                                      // :1535
+    st.Sa = st.R2 * (df + 2) * st.vy / st.MSx;                                       // :1536
+    st.ve = (e2n + st.Se) / ((float)n + df);                                         // :1538
+    st.va = (b2n + st.Sa) / ((float)p + df) / (dmean - st.Pi);                       // :1539
+    st.Lmb = st.ve / st.va;                                                          // :1540
   }
   {
     double s = 0; for (int i = tid; i < n; i += 1024) s += a.e[i];
@@ -1978,16 +2004,23 @@ __global__ __launch_bounds__(1024) void k_em_tail(const EmTailArgs a) {
     for (int i = tid; i < n; i += 1024) a.e[i] = a.e[i] - (double)eM;
     __syncthreads();
   }
-  if (a.model == BWGR_EM_DE) {
+  if (model == BWGR_EM_DE || model == BWGR_EM_EN) {
     double s = 0; for (int i = tid; i < n; i += 1024) s = fma(a.e[i], (double)a.y[i], s);
-    st.ve = (float)em_block_sum(s, sh) / (float)(n - 1);                             // Ve = e.dot(y)/(n-1), :289
+    st.ve = (float)em_block_sum(s, sh) / (float)(n - 1);                             // Ve = e.dot(y)/(n-1), :289, :445
+  }
+  if (model == BWGR_EM_DE) {
     for (int64_t j = tid; j < p; j += 1024) {
       const float bj = a.b[j];
       const float vbj = bj * bj + st.ve / (a.xx[j] + a.lam[j] + 0.0001f);            // :290
       a.vbv[j] = vbj;
       a.lam[j] = sqrtf(st.cxx * st.ve / vbj);                                        // :292
     }
-  } else if (a.model == BWGR_EM_ML) {
+  } else if (model == BWGR_EM_EN) {
+    st.va = (b2n + st.trAC22 * st.ve) / (float)p;                                    // :446
+    st.Lmb = st.ve / st.va;                                                          // :447
+    st.Lmb1 = 0.5f * st.Lmb * st.alpha * st.Sy;                                      // :448
+    st.Lmb2 = st.Lmb * (1 - st.alpha);                                               // :449
+  } else if (model == BWGR_EM_ML) {
     double s1 = 0, s2 = 0;
     for (int i = tid; i < n; i += 1024) {
       const float ym = a.y[i] - st.mu;
@@ -2001,9 +2034,14 @@ __global__ __launch_bounds__(1024) void k_em_tail(const EmTailArgs a) {
   }
   if (a.conv) {
     double s = 0; for (int64_t j = tid; j < p; j += 1024) s += (double)fabsf(a.bc[j] - a.b[j]);
-    st.cnv = (float)em_block_sum(s, sh);                                             // :295, :509
+    st.cnv = (float)em_block_sum(s, sh);                                             // :295, :451, :509
   }
-  if (tid == 0) *a.st = st;
+  if (tid == 0) {
+    *a.st = st;
+    a.sc->C = -0.5f / sqrtf(st.ve);                                                  // C of the next sweep, :157, :216, :1522
+    a.sc->odds = st.Pi0;
+    a.sc->lam = st.Lmb1;
+  }
 }
 
 __global__ void k_em_fit_ml(const float *__restrict__ y, const double *__restrict__ e, float *__restrict__ hat, int n) {   // fit = y - e, :512
@@ -2024,42 +2062,49 @@ extern "C" int bwgr_em_order(int64_t p, int upto, int32_t *order) {
   return BWGR_OK;
 }
 
-extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float R2, const float *D, int maxit_in,
-                       float *mu, float *b, float *hat, float *vbvec, float *scal, int *iters) {
+extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float R2, float par, const float *D, int maxit_in,
+                       float *mu, float *b, float *d, float *hat, float *vbvec, float *scal, int *iters) {
   if (!P || !y || !b || !scal) return fail(BWGR_EINVAL, "em: null pointer");
-  if (model < BWGR_EM_RR || model > BWGR_EM_ML) return fail(BWGR_EINVAL, "em: bad model %d", model);
+  if (model < BWGR_EM_RR || model > BWGR_EM_EN) return fail(BWGR_EINVAL, "em: bad model %d", model);
   if (D && model != BWGR_EM_ML) return fail(BWGR_EINVAL, "em: marker weights D belong to emML only");
+  const bool soft = (model == BWGR_EM_BB || model == BWGR_EM_BC || model == BWGR_EM_BCPI);
+  const bool nonaffine = soft || model == BWGR_EM_BL || model == BWGR_EM_EN;
+  if (nonaffine && P->sweep_version != 2) return fail(BWGR_EINVAL, "em: this member needs the pipelined sweep engine (k_sweep2), which this panel's geometry does not fit");
   HIPCHK(hipSetDevice(P->device));
   const int64_t p = P->p, n = P->n;
-  const bool conv = (model == BWGR_EM_DE || model == BWGR_EM_ML);
-  const int maxit = maxit_in > 0 ? maxit_in : (conv ? 300 : 200);                     // :81, :251, :309, :465
-  const float tol = (model == BWGR_EM_DE) ? 10e-6f : 10e-8f;                          // :252, :466
+  const bool conv = (model == BWGR_EM_DE || model == BWGR_EM_ML || model == BWGR_EM_EN);
+  const bool shuffled = (model != BWGR_EM_BCPI);                                      // emBCpi sweeps in natural order, :1523
+  const int maxit = maxit_in > 0 ? maxit_in : (conv ? 300 : 200);                     // :81, :251, :309, :401, :465
+  const float tol = (model == BWGR_EM_DE) ? 10e-6f : (model == BWGR_EM_EN) ? 10e-11f : 10e-8f;   // :252, :402, :466
   hipStream_t st = P->stream;
   // scratch panel: same geometry, its own X and Gram; only the diagonal and distance-1 blocks are ever built (lag 2)
   bwgr_panel *Q = nullptr;
-  CHK(panel_alloc(&Q, P->is_f32, n, p, P->device, P->m, P->K));
-  Q->stream = st; Q->gram_maxdist = 1;
-  hipFree(Q->gramx2); hipFree(Q->gramx3); hipFree(Q->xspec2); hipFree(Q->xspec3); hipFree(Q->gramp16); hipFree(Q->gramx16);
-  Q->gramx2 = Q->gramx3 = nullptr; Q->xspec2 = Q->xspec3 = nullptr; Q->gramp16 = Q->gramx16 = nullptr;
+  if (shuffled) {
+    CHK(panel_alloc(&Q, P->is_f32, n, p, P->device, P->m, P->K));
+    Q->stream = st; Q->gram_maxdist = 1;
+    hipFree(Q->gramx2); hipFree(Q->gramx3); hipFree(Q->xspec2); hipFree(Q->xspec3); hipFree(Q->gramp16); hipFree(Q->gramx16);
+    Q->gramx2 = Q->gramx3 = nullptr; Q->xspec2 = Q->xspec3 = nullptr; Q->gramp16 = Q->gramx16 = nullptr;
+  }
   std::vector<void *> owned;
   int rc = BWGR_OK;
-  auto done = [&](int code) { (void)hipStreamSynchronize(st); for (void *q : owned) hipFree(q); bwgr_panel_destroy(Q); return code; };
+  auto done = [&](int code) { (void)hipStreamSynchronize(st); for (void *q : owned) hipFree(q); if (Q) bwgr_panel_destroy(Q); return code; };
 #define ECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return done(fail(BWGR_EHIP, "%s failed: %s", #x, hipGetErrorString(e_))); } while (0)
-  if (Q->K != P->K || Q->R != P->R || Q->m != P->m) return done(fail(BWGR_EINVAL, "em: scratch panel geometry differs"));
+  if (Q && (Q->K != P->K || Q->R != P->R || Q->m != P->m || Q->sweep_version != P->sweep_version)) return done(fail(BWGR_EINVAL, "em: scratch panel geometry differs"));
+  bwgr_panel *S = Q ? Q : P;                                                          // the panel the sweeps run on
   const size_t pb = sizeof(float) * (size_t)p;
-  float *yd = nullptr, *bd = nullptr, *bcd = nullptr, *lamd = nullptr, *vbd = nullptr, *xxd = nullptr, *Dd = nullptr;
-  float *bq = nullptr, *lamq = nullptr, *dq = nullptr, *vq = nullptr, *hatd = nullptr;
+  float *yd = nullptr, *bd = nullptr, *bcd = nullptr, *dd = nullptr, *lamd = nullptr, *vbd = nullptr, *xxd = nullptr, *Dd = nullptr;
+  float *bq = nullptr, *xxq = nullptr, *lamq = nullptr, *dq = nullptr, *vq = nullptr, *hatd = nullptr;
   double *ed = nullptr; int32_t *ordd = nullptr; EmState *std_ = nullptr; ChainScalars *sc = nullptr;
   auto dmalloc = [&](void **q, size_t bytes) { hipError_t e_ = hipMalloc(q, bytes); if (e_ == hipSuccess) owned.push_back(*q); return e_; };
-  ECHK(dmalloc((void **)&yd, sizeof(float) * n)); ECHK(dmalloc((void **)&bd, pb)); ECHK(dmalloc((void **)&bcd, pb));
+  ECHK(dmalloc((void **)&yd, sizeof(float) * n)); ECHK(dmalloc((void **)&bd, pb)); ECHK(dmalloc((void **)&bcd, pb)); ECHK(dmalloc((void **)&dd, pb));
   ECHK(dmalloc((void **)&lamd, pb)); ECHK(dmalloc((void **)&vbd, pb)); ECHK(dmalloc((void **)&xxd, pb));
-  ECHK(dmalloc((void **)&bq, pb)); ECHK(dmalloc((void **)&lamq, pb)); ECHK(dmalloc((void **)&dq, pb)); ECHK(dmalloc((void **)&vq, pb));
+  ECHK(dmalloc((void **)&bq, pb)); ECHK(dmalloc((void **)&xxq, pb)); ECHK(dmalloc((void **)&lamq, pb)); ECHK(dmalloc((void **)&dq, pb)); ECHK(dmalloc((void **)&vq, pb));
   ECHK(dmalloc((void **)&ed, sizeof(double) * P->ld)); ECHK(dmalloc((void **)&ordd, sizeof(int32_t) * p));
   ECHK(dmalloc((void **)&std_, sizeof(EmState))); ECHK(dmalloc((void **)&sc, sizeof(ChainScalars)));
   ECHK(dmalloc((void **)&hatd, sizeof(float) * n));
   if (D) { ECHK(dmalloc((void **)&Dd, pb)); ECHK(hipMemcpyAsync(Dd, D, pb, hipMemcpyHostToDevice, st)); }
   ECHK(hipMemcpyAsync(yd, y, sizeof(float) * n, hipMemcpyHostToDevice, st));
-  ECHK(hipMemsetAsync(bd, 0, pb, st));
+  ECHK(hipMemsetAsync(bd, 0, pb, st)); ECHK(hipMemsetAsync(dd, 0, pb, st));
   ECHK(hipMemcpyAsync(xxd, P->xx, pb, hipMemcpyDeviceToDevice, st));
   // vy = fvar(y) with the library's reduction (float result of fp64 sums, like the fused samplers' setup)
   float vy = 0;
@@ -2073,64 +2118,105 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
     ECHK(d2h(st, &h0, sc, sizeof(h0)));
     vy = h0.vy;
   }
-  const float MSx = P->MSx;
+  const float sumvx = P->MSx;                                                        // vx.sum()
   EmState h; memset(&h, 0, sizeof(h));
-  h.df = df; h.vy = vy; h.MSx = MSx;
-  if (model == BWGR_EM_BA) {
-    h.ve = 1;                                                                        // :84
-    h.Sb = R2 * (df + 2) * vy / MSx;                                                 // :96
-    h.Se = (1 - R2) * (df + 2) * vy;                                                 // :97
-    std::vector<float> ones((size_t)p, 1.0f);                                        // vb = 1, Lmb = ve * vb^-1 = 1, :87-88
-    ECHK(hipMemcpyAsync(lamd, ones.data(), pb, hipMemcpyHostToDevice, st));
-    ECHK(hipMemcpyAsync(vbd, ones.data(), pb, hipMemcpyHostToDevice, st));
-    ECHK(hipStreamSynchronize(st));
+  h.df = df; h.vy = vy; h.MSx = sumvx; h.sumvx = sumvx; h.R2 = R2; h.ve = 1.0f;
+  std::vector<float> hostv;
+  auto fill = [&](float *dst, float v) { hostv.assign((size_t)p, v); hipError_t e_ = hipMemcpyAsync(dst, hostv.data(), pb, hipMemcpyHostToDevice, st); return e_ != hipSuccess ? e_ : hipStreamSynchronize(st); };
+  if (model == BWGR_EM_BA || model == BWGR_EM_BB) {
+    h.ve = 1;                                                                        // :84, :135
+    if (model == BWGR_EM_BB) {
+      float Pi = par; if (Pi > 0.5f) Pi = 1 - Pi;                                    // :141
+      h.Pi = Pi; h.MSx = sumvx * Pi;                                                 // :147
+      h.Pi0 = (1 - Pi) / Pi;                                                         // :154
+    }
+    h.Sb = R2 * (df + 2) * vy / h.MSx;                                               // :96, :148
+    h.Se = (1 - R2) * (df + 2) * vy;                                                 // :97, :149
+    ECHK(fill(lamd, 1.0f)); ECHK(fill(vbd, 1.0f));                                   // vb = 1, Lmb = ve * vb^-1 = 1, :87-88
   } else if (model == BWGR_EM_RR) {
-    h.Lmb = MSx;                                                                     // :319
-    h.Rho = MSx * (1 - R2) / R2;                                                     // :320
+    h.Lmb = sumvx;                                                                   // :319
+    h.Rho = sumvx * (1 - R2) / R2;                                                   // :320
     h.ve = 0.5f * vy;                                                                // :322
-    h.vb = h.ve / MSx;                                                               // :323
+    h.vb = h.ve / sumvx;                                                             // :323
     h.Se = (1 - R2) * (df + 2) * vy;                                                 // :324
-    h.Sb = R2 * (df + 2) * vy / MSx;                                                 // :325
+    h.Sb = R2 * (df + 2) * vy / sumvx;                                               // :325
   } else if (model == BWGR_EM_DE) {
     hipLaunchKernelGGL(k_em_fix_xx, dim3(1024), dim3(256), 0, st, xxd, p);           // :261
-    h.cxx = MSx * (1 - R2) / R2;                                                     // :265
-    std::vector<float> l0((size_t)p, (float)p + h.cxx);                              // :269
-    ECHK(hipMemcpyAsync(lamd, l0.data(), pb, hipMemcpyHostToDevice, st));
-    ECHK(hipStreamSynchronize(st));
-  } else {
-    h.Lmb = MSx;                                                                     // :486
+    h.cxx = sumvx * (1 - R2) / R2;                                                   // :265
+    ECHK(fill(lamd, (float)p + h.cxx));                                              // :269
+  } else if (model == BWGR_EM_ML) {
+    h.Lmb = sumvx;                                                                   // :486
+  } else if (model == BWGR_EM_BC || model == BWGR_EM_BCPI) {
+    float Pi = par; if (Pi > 0.5f) Pi = 1 - Pi;                                      // :197, :1508
+    h.Pi = Pi; h.PriorPi = Pi;                                                       // :1511
+    h.MSx = sumvx * Pi * (1 - Pi);                                                   // :203, :1512
+    h.Sa = R2 * (df + 2) * vy / h.MSx;                                               // :204
+    h.Se = (1 - R2) * (df + 2) * vy;                                                 // :205
+    h.ve = h.Sa; h.va = h.Se; h.Lmb = h.ve / h.va;                                   // :209-211 (sic)
+    h.Pi0 = (1 - Pi) / Pi;                                                           // :213
+  } else if (model == BWGR_EM_BL || model == BWGR_EM_EN) {
+    std::vector<float> xxh((size_t)p);
+    ECHK(d2h(st, xxh.data(), xxd, pb));
+    h.alpha = par;
+    if (model == BWGR_EM_BL) {
+      double sx = 0; for (int64_t j = 0; j < p; ++j) sx += (double)xxh[(size_t)j];
+      h.cxx = (float)(sx / (double)p);                                               // xx.mean(), :368
+      const float hh = R2;                                                           // h2 = R2, :359
+      h.Lmb1 = h.cxx * ((1 - hh) / hh) * h.alpha * 0.5f;                             // :369
+      h.Lmb2 = h.cxx * ((1 - hh) / hh) * (1 - h.alpha);                              // :370
+    } else {
+      h.cxx = sumvx * (1 - R2) / R2;                                                 // :412
+      h.Sy = sqrtf(vy);                                                              // :414
+      h.Lmb = h.cxx;                                                                 // :415
+      h.Lmb1 = 0.5f * h.Lmb * h.alpha * h.Sy;                                        // :416
+      h.Lmb2 = h.Lmb * (1 - h.alpha);                                                // :417
+      float tr = 0; for (int64_t k = 0; k < p; ++k) tr += 1.0f / (xxh[(size_t)k] + h.Lmb);   // the reference's own float loop, :418-419
+      h.trAC22 = tr;
+    }
   }
   ECHK(hipMemcpyAsync(std_, &h, sizeof(h), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_em_init, dim3(1), dim3(1024), 0, st, yd, ed, (int)n, P->ld, std_);   // mu, e (overwrites k_chain_init's e)
   ECHK(hipGetLastError());
   {
     ChainScalars h0; memset(&h0, 0, sizeof(h0));
-    h0.ve = 1.0f; h0.pi = 0.0f; h0.C = -0.5f; h0.odds = 0.0f; h0.dfp1 = 1.0f;        // the sweep's variates are switched off
+    h0.ve = 1.0f; h0.pi = 0.0f; h0.dfp1 = 1.0f;                                      // the sweep's variates are switched off
+    h0.C = -0.5f / sqrtf(h.ve);                                                      // :157, :216, :1522
+    h0.odds = h.Pi0; h0.lam = h.Lmb1; h0.Sb = h.cxx;                                 // Pi0; Lmb1; emBL's cxx (k_prestage)
     ECHK(hipMemcpyAsync(sc, &h0, sizeof(h0), hipMemcpyHostToDevice, st));
   }
   std::vector<int> order((size_t)p);
   for (int64_t j = 0; j < p; ++j) order[(size_t)j] = (int)j;
+  if (!shuffled) ECHK(hipMemcpyAsync(ordd, order.data(), sizeof(int32_t) * p, hipMemcpyHostToDevice, st));
   const int cps = (int)((size_t)P->R * (P->is_f32 ? 4 : 1) / 16);
+  uint32_t flags = SWF_LAM_VEC;
+  if (model == BWGR_EM_BA) flags |= SWF_DELTA2;
+  if (soft) flags |= SWF_EM_SEL;
+  if (model == BWGR_EM_EN) flags |= SWF_EM_EN;
+  if (model == BWGR_EM_BL) flags |= SWF_EM_BL;
   int numit = 0;
   for (int i = 0; i < maxit; ++i) {
-    std::shuffle(order.begin(), order.end(), std::mt19937(i));                       // :103, :277, :331, :491 -- the reference's own call
-    ECHK(hipMemcpyAsync(ordd, order.data(), sizeof(int32_t) * p, hipMemcpyHostToDevice, st));
+    if (shuffled) {
+      std::shuffle(order.begin(), order.end(), std::mt19937(i));                     // :103, :277, :331, :491 ... -- the reference's own call
+      ECHK(hipMemcpyAsync(ordd, order.data(), sizeof(int32_t) * p, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_permute_cols, dim3(8192), dim3(256), 0, st, (const uint4 *)P->X, (uint4 *)Q->X, ordd, p, P->K, cps);
+    }
     if (conv) ECHK(hipMemcpyAsync(bcd, bd, pb, hipMemcpyDeviceToDevice, st));        // bc = b
-    hipLaunchKernelGGL(k_permute_cols, dim3(8192), dim3(256), 0, st, (const uint4 *)P->X, (uint4 *)Q->X, ordd, p, P->K, cps);
-    hipLaunchKernelGGL(k_em_stage, dim3(1024), dim3(256), 0, st, ordd, p, model, D ? 1 : 0, bd, xxd, lamd, Dd, std_, bq, Q->xx, lamq);
+    hipLaunchKernelGGL(k_em_stage, dim3(1024), dim3(256), 0, st, ordd, p, model, D ? 1 : 0, bd, xxd, lamd, Dd, std_, bq, xxq, lamq);
     ECHK(hipGetLastError());
-    rc = panel_build_gram(Q);
-    if (rc != BWGR_OK) return done(rc);
+    if (shuffled) {
+      rc = panel_build_gram(Q);
+      if (rc != BWGR_OK) return done(rc);
+    }
     SweepArgs a; memset(&a, 0, sizeof(a));
-    fill_panel_args(Q, a);
-    a.flags = SWF_LAM_VEC | (model == BWGR_EM_BA ? SWF_DELTA2 : 0);
-    a.e = ed; a.b = bq; a.d = dq; a.vb = vq; a.xx = Q->xx; a.lam = lamq; a.sc = sc;
+    fill_panel_args(S, a);
+    a.flags = flags;
+    a.e = ed; a.b = bq; a.d = dq; a.vb = vq; a.xx = xxq; a.lam = lamq; a.sc = sc;
     a.iter = (uint32_t)i; a.rng = make_rng(0, BWGR_RNG_DEGENERATE);
-    rc = launch_sweep(Q, a);
+    rc = launch_sweep(S, a);
     if (rc != BWGR_OK) return done(rc);
-    hipLaunchKernelGGL(k_em_unstage, dim3(1024), dim3(256), 0, st, ordd, p, bq, bd);
-    EmTailArgs t; t.model = model; t.n = (int)n; t.conv = conv ? 1 : 0; t.p = p; t.e = ed; t.y = yd; t.b = bd; t.bc = bcd;
-    t.lam = lamd; t.vbv = vbd; t.xx = xxd; t.st = std_;
+    hipLaunchKernelGGL(k_em_unstage, dim3(1024), dim3(256), 0, st, ordd, p, bq, bd, soft ? dq : nullptr, soft ? dd : nullptr);
+    EmTailArgs t; t.model = model; t.n = (int)n; t.conv = conv ? 1 : 0; t.p = p; t.e = ed; t.y = yd; t.b = bd; t.bc = bcd; t.d = dd;
+    t.lam = lamd; t.vbv = vbd; t.xx = xxd; t.st = std_; t.sc = sc;
     hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(1024), 0, st, t);
     ECHK(hipGetLastError());
     ++numit;
@@ -2140,12 +2226,12 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
     ECHK(hipMemcpyAsync(&hc, sc, sizeof(hc), hipMemcpyDeviceToHost, st));
     ECHK(hipStreamSynchronize(st));
     if (hc.error) return done(fail(BWGR_ETIMEOUT, "em: a workgroup exchange timed out inside the sweep kernel"));
-    if (conv && h.cnv < tol) break;                                                  // :296, :510
+    if (conv && h.cnv < tol) break;                                                  // :296, :452, :510
   }
   float h2;
   if (model == BWGR_EM_ML) {
     hipLaunchKernelGGL(k_em_fit_ml, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, yd, ed, hatd, (int)n);
-    h2 = h.vb * MSx / (h.vb * MSx + h.ve);                                           // :513
+    h2 = h.vb * h.MSx / (h.vb * h.MSx + h.ve);                                       // :513
   } else {
     rc = gemv_hat<float>(P, bd, h.mu, hatd);                                         // fit = gen*b + mu, :120-121
     if (rc != BWGR_OK) return done(rc);
@@ -2156,20 +2242,37 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
       hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, st, part, 256, sdev);
       ECHK(d2h(st, &sv, sdev, sizeof(float)));
       h2 = sv / (sv + h.ve);
-    } else h2 = 1 - h.ve / vy;                                                       // :119, :344
+    } else if (model == BWGR_EM_BL) {                                                // h2 = 1 - fvar(e)/fvar(y), :396
+      std::vector<double> eh((size_t)n);
+      ECHK(d2h(st, eh.data(), ed, sizeof(double) * n));
+      double s = 0; for (int64_t k = 0; k < n; ++k) s += (double)(float)eh[(size_t)k];
+      const float m = (float)(s / (double)n);
+      double sv = 0; for (int64_t k = 0; k < n; ++k) { const float dev = (float)eh[(size_t)k] - m; const float sq = dev * dev; sv += (double)sq; }
+      h2 = 1 - (float)(sv / (double)(float)(n - 1)) / vy;
+    } else if (model == BWGR_EM_EN) h2 = h.va * h.cxx / (h.va * h.cxx + h.ve);       // :459
+    else h2 = 1 - h.ve / vy;                                                         // :119, :178, :237, :344, :1542
   }
   ECHK(hipGetLastError());
   if (mu) *mu = h.mu;
   ECHK(d2h(st, b, bd, pb));
+  if (d && soft) ECHK(d2h(st, d, dd, pb));
   if (hat) ECHK(d2h(st, hat, hatd, sizeof(float) * n));
-  if (vbvec && (model == BWGR_EM_BA || model == BWGR_EM_DE)) ECHK(d2h(st, vbvec, vbd, pb));
-  scal[0] = (model == BWGR_EM_RR || model == BWGR_EM_ML) ? h.vb : 0.0f; scal[1] = h.ve; scal[2] = h2;
-  scal[3] = (model == BWGR_EM_ML) ? h.vb * MSx : 0.0f;                               // Va = vb*MSx, :519
+  if (vbvec && (model == BWGR_EM_BA || model == BWGR_EM_DE || model == BWGR_EM_BB)) ECHK(d2h(st, vbvec, vbd, pb));
+  for (int k = 0; k < 6; ++k) scal[k] = 0.0f;
+  scal[1] = h.ve; scal[2] = h2;
+  if (model == BWGR_EM_RR || model == BWGR_EM_ML) scal[0] = h.vb;
+  if (model == BWGR_EM_ML) scal[3] = h.vb * h.MSx;                                   // Va = vb*MSx, :519
+  if (model == BWGR_EM_BC || model == BWGR_EM_BCPI) { scal[0] = h.va; scal[3] = h.va * h.MSx; }   // Va, Vg = va*MSx, :243, :1547
+  if (model == BWGR_EM_BCPI) scal[4] = h.Pi;
+  if (model == BWGR_EM_EN) scal[0] = h.va * h.cxx;                                   // :457
+  if (model == BWGR_EM_BL) scal[1] = 0.0f;
   if (iters) *iters = numit;
 #undef ECHK
   return done(BWGR_OK);
 }
 
+// ------------------------------------------------------------------------------------------------
+// synthetic data and test hooks
 // ------------------------------------------------------------------------------------------------
 extern "C" int bwgr_synth_genotypes(void *Xdev, int64_t n, int64_t p, int64_t ldx, int64_t col0, uint64_t seed,
                                     float *freq_dev, int device, void *hip_stream) {

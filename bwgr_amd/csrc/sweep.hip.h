@@ -40,7 +40,12 @@ enum : int {
   SWF_LAM_VEC = 8,    // per-marker lambda array (else the common scalar)
   SWF_VB_VEC = 16,    // per-marker variance draw vb_j = (Sb + b_j^2)/chisq(df+1)
   SWF_KMUP2 = 32,     // KMUP2's conditional mean: numerator + b0 (not xx*b0), denominator xx*bg + L (src/Rcpp20260726ai.cpp:59)
-  SWF_DELTA2 = 64     // emBA applies every marker's step to the residual twice (src/Rcpp20260726ai.cpp:108, :111): affine sweeps only
+  SWF_DELTA2 = 64,    // emBA applies every marker's step to the residual twice (src/Rcpp20260726ai.cpp:108, :111): affine sweeps only
+  // deterministic EM coordinate updates that are not affine in the marker's dot product (k_sweep2's generic sequencer only):
+  SWF_EM_SEL = 128,   // emBB / emBC / emBCpi: b = b1 * d, d = 1/(1 + Pi0 exp(C(|e2|^2-|e1|^2)))  (:165-170, :224-229, :1526-1532)
+  SWF_EM_EN = 256,    // emEN: soft threshold (OLS -/+ Lmb1)/(Lmb2 + xx), clamped at 0 (:433-438); Lmb1 rides in sc->lam
+  SWF_EM_BL = 512,    // emBL: G + Half_L2 (:379-387); Lmb1 in sc->lam, 1/(xx + cxx) in the sdz1 slot (cxx in sc->Sb)
+  SWF_EM_ANY = SWF_EM_SEL | SWF_EM_EN | SWF_EM_BL
 };
 
 // scalars produced on the device by the per-iteration tail kernel (or filled by the host for KMUP)
@@ -202,7 +207,8 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
       st.b0[t] = b0;
       st.xxb0[t] = k2 ? b0 : xxj * b0;
       st.rden[t] = 1.0 / (double)den;
-      st.sdz1[t] = (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z1, 0);
+      st.sdz1[t] = (a.flags & SWF_EM_BL) ? 1.0 / (double)(xxj + sc.Sb)             // emBL's second denominator xx + cxx, :380
+                                          : (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z1, 0);
     } else if (piece == 1) {
       const float b2 = sel ? (float)((double)0.0f + (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z2, 0)) : 0.0f;
       st.b2[t] = b2;
@@ -289,6 +295,33 @@ struct LaneConst {
 // cvt/add/cvt/mul/cvt/cvt/add chain that the reference's float rounding points would force on the serial path.
 __device__ __forceinline__ float lane_b1(double r, const LaneConst &c) {
   return (float)fma(r + (double)c.xxb0, c.rden, c.sdz1);
+}
+// The EM family's non-affine coordinate updates (deterministic): the new effect given the marker's current dot product r;
+// *dout = the inclusion weight d_j of the soft-selection members (1 otherwise).  Like lane_b1, the dot product and what is
+// formed from it stay in fp64 and only the stored effect is rounded to float.
+__device__ __forceinline__ float lane_em(double r, const LaneConst &c, int flags, float Cc, float Pi0, float L1, float *dout) {
+  const double ols = r + (double)c.xxb0;                    // gen.col(j).dot(e) + xx[j]*b0
+  if (flags & SWF_EM_SEL) {
+    const float b1 = (float)(ols * c.rden);
+    const double D1 = (double)(b1 - c.b0), D2 = (double)(0.0f - c.b0);
+    const double diffd = 2.0 * r * (D1 - D2) + c.gjj * (D2 * D2 - D1 * D1);   // |e2|^2 - |e1|^2, e_k = e - x d_k
+    // std::exp(float) rounded from the fp64 exponential: emBC / emBCpi divide by (mean(d) - Pi), which amplifies an ulp of d
+    const float LR = Pi0 * (float)exp((double)(Cc * (float)diffd));
+    const float d = 1.0f / (1.0f + LR);
+    *dout = d;
+    return b1 * d;
+  }
+  *dout = 1.0f;
+  if (flags & SWF_EM_EN) {
+    if (ols > 0.0) { const float b1 = (float)((ols - (double)L1) * c.rden); return b1 < 0.0f ? 0.0f : b1; }
+    const float b1 = (float)((ols + (double)L1) * c.rden);
+    return b1 > 0.0f ? 0.0f : b1;
+  }
+  // SWF_EM_BL
+  const double half = 0.5 * ols * c.sdz1;                   // Half_L2 = 0.5*OLS/(xx+cxx)
+  if (ols > 0.0) { const double G = 0.5 * (ols - (double)L1) * c.rden; return (float)(G > 0.0 ? G + half : half); }
+  const double G = 0.5 * (ols + (double)L1) * c.rden;
+  return (float)(G < 0.0 ? G + half : half);
 }
 __device__ __forceinline__ bool lane_accept(double r, float b1, const LaneConst &c, int flags, float Cc, float odds,
                                             float one_minus_pi) {

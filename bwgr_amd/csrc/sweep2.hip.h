@@ -637,6 +637,8 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
   const GT *gramx = reinterpret_cast<const GT *>(a.gramx);
   const float Cc = a.sc->C, odds = a.sc->odds, one_minus_pi = 1.0f - a.sc->pi, Sb = a.sc->Sb;
   const double dscale = (a.flags & SWF_DELTA2) ? 2.0 : 1.0;   // emBA's doubled residual update (affine path)
+  const int emflags = SELECT ? 0 : (a.flags & SWF_EM_ANY);     // the EM family's non-affine updates (lane_em)
+  const float L1 = a.sc->lam;
   const int pchunks = pstride / GPT, xchunks = m * m / GPT;
   auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
   auto prow = [&](int k) { return k * (m - 1) - k * (k - 1) / 2; };   // offset of packed row k
@@ -760,7 +762,22 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
             // (q == 0: marker 64+lane) at oB + lane.  The buffers carry slack, so loads are unconditional; the own-group
             // value is masked, the other-group value of dead lanes (marker >= m) only feeds registers nobody reads.
             int oA = prow(base) - 1, oB = prow(base) + 63;   // + lane, at l = 0
-            if (q == 0 && ngrp > 1) {
+            if (emflags) {
+              // the EM family's non-affine updates: the same lane-ordered recurrence, one marker per trip (the update has an
+              // exponential or a threshold on its dependent chain, so the trip is not fetch-bound like the affine one)
+              const bool two = (q == 0 && ngrp > 1);
+              GT gn0 = gp[oA + lane], gn1 = gp[oB + lane];
+              for (int l = 0; l < cnt; ++l) {
+                const GT g0 = (lane > l) ? gn0 : (GT)0, g1 = gn1;
+                oA += m - 2 - (base + l); oB += m - 2 - (base + l);
+                gn0 = gp[oA + lane]; gn1 = gp[oB + lane];
+                float dtmp;
+                const float dl = lane_em(r[q], lc[q], emflags, Cc, odds, L1, &dtmp) - lc[q].b0;
+                const double dd = (double)readlane_f32(dl, l);
+                r[q] = fma(-(double)g0, dd, r[q]);
+                if (two) r[1] = fma(-(double)g1, dd, r[1]);
+              }
+            } else if (q == 0 && ngrp > 1) {
               GT gn0 = gp[oA + lane], gn1 = gp[oB + lane];
               // eight markers per trip (cnt = 64 except in the last block): the serial chain is ~24 instructions per marker on
               // one wave, and with one marker per trip its speed followed the loop's placement in the instruction-fetch lines
@@ -817,10 +834,11 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
       for (int q = 0; q < 2; ++q) {
         const int t = 64 * q + lane;
         if (t < mB) {
-          const float b1 = lane_b1(r[q], lc[q]);
+          float dem = 1.0f;
+          const float b1 = (!SELECT && emflags) ? lane_em(r[q], lc[q], emflags, Cc, odds, L1, &dem) : lane_b1(r[q], lc[q]);
           const bool inc = SELECT ? (((accmask[q] >> lane) & 1ull) != 0ull) : true;
           const float bn = inc ? b1 : lc[q].b2;
-          const float dn = inc ? 1.0f : 0.0f;
+          const float dn = inc ? dem : 0.0f;
           const float dl = (bn - lc[q].b0) * (float)dscale;
           dl_own[q] = dl;
           delta_s[t] = (double)dl; bnew_s[t] = bn; dnew_s[t] = dn;

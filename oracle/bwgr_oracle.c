@@ -835,7 +835,7 @@ int FN(oracle_em_order)(int64_t p, int upto, int *order) {
   return 0;
 }
 
-enum { EM_RR = 0, EM_BA = 1, EM_DE = 2, EM_ML = 3 };
+enum { EM_RR = 0, EM_BA = 1, EM_DE = 2, EM_ML = 3, EM_BB = 4, EM_BC = 5, EM_BCPI = 6, EM_BL = 7, EM_EN = 8 };
 
 /* dot of two n-vectors, one of them the residual */
 static ACC_T oem_dot_ey(const E_T *e, const float *y, int64_t n) {
@@ -847,33 +847,46 @@ static ACC_T oem_dot_ey(const E_T *e, const float *y, int64_t n) {
   return red8(s);
 }
 
-/* o_vbvec: p entries (emBA Vb, emDE Vb), untouched otherwise.  o_scal: emRR {Va, Ve, h2, 0}; emBA {0, Ve, h2, 0};
- * emDE {0, Ve, h2, 0}; emML {Vb, Ve, h2, Va}.  maxit = 0: the reference's count (200 sweeps; 300 with the convergence
- * test for emDE / emML).  D: emML's optional per-marker weights (NULL = none). */
-int FN(oracle_em)(int model, const float *y, const float *X, int64_t n, int64_t p, int64_t ldx, float df, float R2,
-                  const float *D, int maxit_in, float *o_mu, float *o_b, float *o_hat, float *o_vbvec, float *o_scal,
-                  int *o_iters) {
+/* Members and reference lines: emRR :308-354, emBA :80-128, emDE :250-305, emML :463-521, emBB :131-187, emBC :190-247,
+ * emBCpi :1502-1545 (natural marker order: no shuffle), emBL :357-397, emEN :400-460.
+ * par: Pi for emBB / emBC / emBCpi (reference default 0.75), alpha for emBL / emEN (0.02); ignored otherwise.
+ * o_d: p entries (emBB / emBC / emBCpi), o_vbvec: p entries (emBA / emBB / emDE Vb); untouched otherwise.
+ * o_scal[6]: emRR {Va, Ve, h2}; emBA / emBB / emDE {0, Ve, h2}; emML {Vb, Ve, h2, Va}; emBC {Va, Ve, h2, Vg};
+ * emBCpi {Va, Ve, h2, Vg, pi}; emBL {0, 0, h2}; emEN {Va*cxx, Ve, h2}.
+ * maxit = 0: the reference's count (200 sweeps; 300 with the convergence test for emDE / emML / emEN).
+ * D: emML's optional per-marker weights (NULL = none). */
+int FN(oracle_em)(int model, const float *y, const float *X, int64_t n, int64_t p, int64_t ldx, float df, float R2, float par,
+                  const float *D, int maxit_in, float *o_mu, float *o_b, float *o_d, float *o_hat, float *o_vbvec,
+                  float *o_scal, int *o_iters) {
   float *xx = (float *)malloc(sizeof(float) * p), *vx = (float *)malloc(sizeof(float) * p);
-  float *b = (float *)calloc(p, sizeof(float)), *bc = (float *)calloc(p, sizeof(float));
+  float *b = (float *)calloc(p, sizeof(float)), *bc = (float *)calloc(p, sizeof(float)), *d = (float *)calloc(p, sizeof(float));
   float *vbv = (float *)malloc(sizeof(float) * p), *Lmbv = (float *)malloc(sizeof(float) * p);
   int *order = (int *)malloc(sizeof(int) * p);
-  E_T *e = (E_T *)malloc(sizeof(E_T) * n);
-  if (!xx || !vx || !b || !bc || !vbv || !Lmbv || !order || !e) return 1;
-  float MSx;
-  FN(oracle_stats)(X, n, p, ldx, xx, vx, &MSx);                         /* :90-94, :258-264, :312-317, :481-485 */
+  E_T *e = (E_T *)malloc(sizeof(E_T) * n), *e1 = (E_T *)malloc(sizeof(E_T) * n), *e2 = (E_T *)malloc(sizeof(E_T) * n);
+  if (!xx || !vx || !b || !bc || !d || !vbv || !Lmbv || !order || !e || !e1 || !e2) return 1;
+  float sumvx;
+  FN(oracle_stats)(X, n, p, ldx, xx, vx, &sumvx);                       /* xx, vx, vx.sum() */
+  float MSx = sumvx;
   const float vy = v_fvar(y, n);
   float mu = v_mean(y, n);                                              /* :98, :256, :326, :478 */
   for (int64_t k = 0; k < n; k++) e[k] = (E_T)(y[k] - mu);              /* e = y.array()-mu (float) */
   for (int64_t j = 0; j < p; j++) order[j] = (int)j;
-  float ve = 0, vb = 0, Lmb = 0, Sb = 0, Se = 0, Rho = 0, cxx = 0, h2 = 0;
-  const int conv = (model == EM_DE || model == EM_ML);
-  const int maxit = maxit_in > 0 ? maxit_in : (conv ? 300 : 200);        /* :81, :251, :309, :465 */
-  const float tol = (model == EM_DE) ? 10e-6f : 10e-8f;                  /* :252, :466 */
-  if (model == EM_BA) {
-    ve = 1;                                                               /* :84 */
+  float ve = 0, vb = 0, va = 0, Lmb = 0, Sb = 0, Se = 0, Sa = 0, Rho = 0, cxx = 0, h2 = 0;
+  float Pi = par, Pi0 = 0, PriorPi = 0, alpha = par, Lmb1 = 0, Lmb2 = 0, Sy = 0, trAC22 = 0;
+  const int conv = (model == EM_DE || model == EM_ML || model == EM_EN);
+  const int shuffled = (model != EM_BCPI);
+  const int maxit = maxit_in > 0 ? maxit_in : (conv ? 300 : 200);        /* :81, :251, :309, :465, :401 */
+  const float tol = (model == EM_DE) ? 10e-6f : (model == EM_EN) ? 10e-11f : 10e-8f;   /* :252, :402, :466 */
+  if (model == EM_BA || model == EM_BB) {
+    ve = 1;                                                               /* :84, :135 */
     for (int64_t j = 0; j < p; j++) { vbv[j] = 1.0f; Lmbv[j] = ve * (1.0f / vbv[j]); }   /* :87-88 */
-    Sb = R2 * (df + 2) * vy / MSx;                                        /* :96 */
-    Se = (1 - R2) * (df + 2) * vy;                                        /* :97 */
+    if (model == EM_BB) {
+      if (Pi > 0.5f) Pi = 1 - Pi;                                         /* :141 */
+      MSx = sumvx * Pi;                                                   /* :147 */
+      Pi0 = (1 - Pi) / Pi;                                                /* :154 */
+    }
+    Sb = R2 * (df + 2) * vy / MSx;                                        /* :96, :148 */
+    Se = (1 - R2) * (df + 2) * vy;                                        /* :97, :149 */
   } else if (model == EM_RR) {
     Lmb = MSx;                                                            /* :319 */
     Rho = MSx * (1 - R2) / R2;                                            /* :320 */
@@ -885,40 +898,105 @@ int FN(oracle_em)(int model, const float *y, const float *X, int64_t n, int64_t 
     for (int64_t j = 0; j < p; j++) if (xx[j] == 0) xx[j] = 0.1f;         /* :261 */
     cxx = MSx * (1 - R2) / R2;                                            /* :265 */
     for (int64_t j = 0; j < p; j++) Lmbv[j] = (float)p + cxx;             /* :269 */
-  } else {
+  } else if (model == EM_ML) {
     Lmb = MSx;                                                            /* :486 */
+  } else if (model == EM_BC || model == EM_BCPI) {
+    if (Pi > 0.5f) Pi = 1 - Pi;                                           /* :197, :1508 */
+    PriorPi = Pi;                                                         /* :1511 */
+    MSx = sumvx * Pi * (1 - Pi);                                          /* :203, :1512 */
+    Sa = R2 * (df + 2) * vy / MSx;                                        /* :204 */
+    Se = (1 - R2) * (df + 2) * vy;                                        /* :205 */
+    ve = Sa; va = Se; Lmb = ve / va;                                      /* :209-211 (sic) */
+    Pi0 = (1 - Pi) / Pi;                                                  /* :213 */
+  } else if (model == EM_BL) {
+    { ACC_T sx = 0; for (int64_t j = 0; j < p; j++) sx += (ACC_T)xx[j]; cxx = (float)(sx / (ACC_T)p); }   /* xx.mean(), :368 */
+    const float hh = R2;                                                  /* h2 = R2, :359 */
+    Lmb1 = cxx * ((1 - hh) / hh) * alpha * 0.5f;                          /* :369 */
+    Lmb2 = cxx * ((1 - hh) / hh) * (1 - alpha);                           /* :370 */
+  } else if (model == EM_EN) {
+    cxx = sumvx * (1 - R2) / R2;                                          /* :412 */
+    Sy = sqrtf(vy);                                                       /* :414 */
+    Lmb = cxx;                                                            /* :415 */
+    Lmb1 = 0.5f * Lmb * alpha * Sy;                                       /* :416 */
+    Lmb2 = Lmb * (1 - alpha);                                             /* :417 */
+    for (int64_t k = 0; k < p; k++) trAC22 += 1.0f / (xx[k] + Lmb);       /* a plain float loop in the reference, :418-419 */
   }
   int numit = 0;
   for (int i = 0; i < maxit; i++) {
-    if (conv) memcpy(bc, b, sizeof(float) * p);                           /* bc = b, :276, :490 */
-    oem_shuffle(order, p, (uint32_t)i);                                   /* :103, :277, :331, :491 */
+    if (conv) memcpy(bc, b, sizeof(float) * p);                           /* bc = b, :276, :490, :424 */
+    if (shuffled) oem_shuffle(order, p, (uint32_t)i);                     /* :103, :158, :217, :277, :331, :374, :427, :491 */
+    const float Cc = -0.5f / sqrtf(ve);                                   /* :157, :216, :1522 (used by the soft-selection members) */
     for (int64_t jj = 0; jj < p; jj++) {
       const int64_t j = order[jj];
       const float *xj = X + j * ldx;
       const float b0 = b[j];
-      float den;
-      if (model == EM_BA || model == EM_DE) den = xx[j] + Lmbv[j];        /* :107, :282 */
-      else if (model == EM_ML && D) den = xx[j] + Lmb / D[j];             /* :496 */
-      else den = xx[j] + Lmb;                                             /* :335, :498 */
-      const float b1 = draw_b1(xj, e, n, xx[j], b0, den, 0.0f, 0.0);
-      const float db = b1 - b0;
-      v_axpy(e, xj, db, n);                                               /* :108, :284, :336, :500 */
-      b[j] = b1;
+      float bnew;
+      if (model == EM_BB || model == EM_BC || model == EM_BCPI) {
+        const float den = xx[j] + ((model == EM_BB) ? Lmbv[j] : Lmb);
+        const float b1 = draw_b1(xj, e, n, xx[j], b0, den, 0.0f, 0.0);    /* :161, :220, :1525 */
+        v_axpy_to(e1, e, xj, b1 - b0, n);                                 /* e1 = e - gen.col(j)*(b1-b0) */
+        v_axpy_to(e2, e, xj, 0.0f - b0, n);                               /* e2 = e - gen.col(j)*(0-b0) */
+#ifdef ACC_WIDE
+        const float dif = (float)(e_sqnorm_acc(e2, n) - e_sqnorm_acc(e1, n));
+#else
+        const float dif = e_sqnorm(e2, n) - e_sqnorm(e1, n);
+#endif
+        const float LR = Pi0 * f_exp(Cc * dif);                           /* :164, :223, :1528 */
+        d[j] = 1.0f / (1.0f + LR);
+        bnew = b1 * d[j];
+        if (model == EM_BB) vbv[j] = (Sb + bnew * bnew) / (df + 1);       /* :167 */
+      } else if (model == EM_EN || model == EM_BL) {
+        /* OLS = gen.col(j).dot(e) + xx[j]*b0: kept in the accumulator type, like the conditional mean of draw_b1 */
+        const ACC_T ols = v_dot_acc(xj, e, n) + (ACC_T)(xx[j] * b0);
+        if (model == EM_EN) {
+          const float den = Lmb2 + xx[j];
+          if (ols > 0) { bnew = (float)((ols - (ACC_T)Lmb1) / (ACC_T)den); if (bnew < 0) bnew = 0; }    /* :434 */
+          else { bnew = (float)((ols + (ACC_T)Lmb1) / (ACC_T)den); if (bnew > 0) bnew = 0; }            /* :436 */
+        } else {
+          const ACC_T half = (ACC_T)0.5f * ols / (ACC_T)(xx[j] + cxx);    /* Half_L2, :380 */
+          const float den = Lmb2 + xx[j];
+          if (ols > 0) { const ACC_T G = (ACC_T)0.5f * (ols - (ACC_T)Lmb1) / (ACC_T)den; bnew = (float)(G > 0 ? G + half : half); }   /* :382-383 */
+          else { const ACC_T G = (ACC_T)0.5f * (ols + (ACC_T)Lmb1) / (ACC_T)den; bnew = (float)(G < 0 ? G + half : half); }           /* :385-386 */
+        }
+      } else {
+        float den;
+        if (model == EM_BA || model == EM_DE) den = xx[j] + Lmbv[j];      /* :107, :282 */
+        else if (model == EM_ML && D) den = xx[j] + Lmb / D[j];           /* :496 */
+        else den = xx[j] + Lmb;                                           /* :335, :498 */
+        bnew = draw_b1(xj, e, n, xx[j], b0, den, 0.0f, 0.0);
+      }
+      const float db = bnew - b0;
+      v_axpy(e, xj, db, n);                                               /* :108, :168, :227, :284, :336, :388, :440, :500 */
+      b[j] = bnew;
       if (model == EM_BA) {
         vbv[j] = (Sb + b[j] * b[j]) / (df + 1);                           /* :110 */
         v_axpy(e, xj, db, n);                                             /* :111 -- the second, identical update is the reference's */
       }
     }
-    if (model == EM_BA) {
-      ve = (e_sqnorm(e, n) + Se) / ((float)n + df);                       /* :113 */
-      for (int64_t j = 0; j < p; j++) Lmbv[j] = ve * (1.0f / vbv[j]);     /* :114 */
+    ACC_T sb2 = 0, sd = 0;
+    for (int64_t j = 0; j < p; j++) { sb2 += (ACC_T)b[j] * (ACC_T)b[j]; sd += (ACC_T)d[j]; }
+    const float b2n = (float)sb2, dmean = (float)(sd / (ACC_T)p);         /* b.squaredNorm(), d.mean() */
+    if (model == EM_BA || model == EM_BB) {
+      ve = (e_sqnorm(e, n) + Se) / ((float)n + df);                       /* :113, :170 */
+      for (int64_t j = 0; j < p; j++) Lmbv[j] = ve * (1.0f / vbv[j]);     /* :114, :171 */
     } else if (model == EM_RR) {
-      ACC_T sb = 0; for (int64_t j = 0; j < p; j++) sb += (ACC_T)b[j] * (ACC_T)b[j];
-      vb = ((float)sb + Sb) / ((float)p + df);                            /* :338 */
+      vb = (b2n + Sb) / ((float)p + df);                                  /* :338 */
       ve = (e_sqnorm(e, n) + Se) / ((float)n + df);                       /* :339 */
       Lmb = sqrtf(Rho * ve / vb);                                         /* :340 */
+    } else if (model == EM_BC) {
+      ve = (e_sqnorm(e, n) + Se) / ((float)n + df);                       /* :229 */
+      va = (b2n + Sa) / ((float)p + df) / (dmean - Pi);                   /* :230 */
+      Lmb = ve / va;                                                      /* :231 */
+    } else if (model == EM_BCPI) {
+      Pi = ((1.0f - dmean) * (float)p + PriorPi * df) / ((float)p + df);  /* :1533 */
+      Pi0 = (1.0f - Pi) / Pi;                                             /* :1534 */
+      MSx = sumvx * Pi * (1.0f - Pi);                                     /* :1535 */
+      Sa = R2 * (df + 2) * vy / MSx;                                      /* :1536 */
+      ve = (e_sqnorm(e, n) + Se) / ((float)n + df);                       /* :1538 */
+      va = (b2n + Sa) / ((float)p + df) / (dmean - Pi);                   /* :1539 */
+      Lmb = ve / va;                                                      /* :1540 */
     }
-    const float eM = e_mean(e, n);                                        /* :115-117, :286-288, :341-343, :502-504 */
+    const float eM = e_mean(e, n);                                        /* :115-117, :286-288, :341-343, :502-504 ... */
     mu += eM;
     for (int64_t k = 0; k < n; k++) e[k] = e[k] - (E_T)eM;
     if (model == EM_DE) {
@@ -938,11 +1016,17 @@ int FN(oracle_em)(int model, const float *y, const float *X, int64_t n, int64_t 
       ve = (float)s1 / (float)n;
       vb = (float)s2 / (float)((float)n * MSx);
       Lmb = ve / vb;                                                      /* :507 */
+    } else if (model == EM_EN) {
+      ve = (float)oem_dot_ey(e, y, n) / (float)(n - 1);                   /* :445 */
+      va = (b2n + trAC22 * ve) / (float)p;                                /* :446 */
+      Lmb = ve / va;                                                      /* :447 */
+      Lmb1 = 0.5f * Lmb * alpha * Sy;                                     /* :448 */
+      Lmb2 = Lmb * (1 - alpha);                                           /* :449 */
     }
     ++numit;
     if (conv) {
       ACC_T c = 0; for (int64_t j = 0; j < p; j++) c += (ACC_T)fabsf(bc[j] - b[j]);
-      if ((float)c < tol) break;                                          /* :295-296, :509-510 */
+      if ((float)c < tol) break;                                          /* :295-296, :451-452, :509-510 */
     }
   }
   /* fit */
@@ -957,13 +1041,26 @@ int FN(oracle_em)(int model, const float *y, const float *X, int64_t n, int64_t 
     if (model == EM_DE) {
       ACC_T sv = 0; for (int64_t j = 0; j < p; j++) sv += (ACC_T)vbv[j];
       h2 = (float)sv / ((float)sv + ve);                                  /* :304 */
-    } else h2 = 1 - ve / vy;                                              /* :119, :344 */
+    } else if (model == EM_BL) {
+      float *ef = (float *)malloc(sizeof(float) * n);
+      for (int64_t k = 0; k < n; k++) ef[k] = (float)e[k];
+      h2 = 1 - v_fvar(ef, n) / vy;                                        /* :396 */
+      free(ef);
+    } else if (model == EM_EN) h2 = va * cxx / (va * cxx + ve);           /* :459 */
+    else h2 = 1 - ve / vy;                                                /* :119, :178, :237, :344, :1542 */
   }
   *o_mu = mu; memcpy(o_b, b, sizeof(float) * p);
-  if (o_vbvec && (model == EM_BA || model == EM_DE)) memcpy(o_vbvec, vbv, sizeof(float) * p);
-  o_scal[0] = (model == EM_RR || model == EM_ML) ? vb : 0.0f; o_scal[1] = ve; o_scal[2] = h2;
-  o_scal[3] = (model == EM_ML) ? vb * MSx : 0.0f;                         /* Va = vb*MSx, :519 */
+  if (o_d && (model == EM_BB || model == EM_BC || model == EM_BCPI)) memcpy(o_d, d, sizeof(float) * p);
+  if (o_vbvec && (model == EM_BA || model == EM_DE || model == EM_BB)) memcpy(o_vbvec, vbv, sizeof(float) * p);
+  for (int k = 0; k < 6; k++) o_scal[k] = 0;
+  o_scal[1] = ve; o_scal[2] = h2;
+  if (model == EM_RR || model == EM_ML) o_scal[0] = vb;
+  if (model == EM_ML) o_scal[3] = vb * MSx;                               /* Va = vb*MSx, :519 */
+  if (model == EM_BC || model == EM_BCPI) { o_scal[0] = va; o_scal[3] = va * MSx; }   /* Va, Vg = va*MSx, :243, :1547 */
+  if (model == EM_BCPI) o_scal[4] = Pi;
+  if (model == EM_EN) o_scal[0] = va * cxx;                               /* :457 */
+  if (model == EM_BL) o_scal[1] = 0;
   *o_iters = numit;
-  free(xx); free(vx); free(b); free(bc); free(vbv); free(Lmbv); free(order); free(e);
+  free(xx); free(vx); free(b); free(bc); free(d); free(vbv); free(Lmbv); free(order); free(e); free(e1); free(e2);
   return 0;
 }

@@ -201,7 +201,7 @@ def wgr(y, X, it=1500, bi=500, th=1, bag=1.0, rp=False, iv=False, de=False, pi=0
     return {"mu": mu.value, "b": b, "Vb": Vb if per else float(Vb[0]), "d": d, "Ve": Ve.value, "hat": hat, "cxx": cxx.value}
 
 
-EM_MODELS = {"emRR": 0, "emBA": 1, "emDE": 2, "emML": 3}
+EM_MODELS = {"emRR": 0, "emBA": 1, "emDE": 2, "emML": 3, "emBB": 4, "emBC": 5, "emBCpi": 6, "emBL": 7, "emEN": 8}
 
 
 def em_order(p, upto):
@@ -213,24 +213,37 @@ def em_order(p, upto):
     return out
 
 
-def em(model, y, X, df=10.0, R2=0.5, D=None, maxit=0, flavour="w", fast=False):
-    """Reference emRR / emBA / emDE / emML (src/Rcpp20260726ai.cpp:308-354, :80-128, :250-305, :463-521); returns the
-    reference's list as a dict plus 'iters' (sweeps run)."""
+def em(model, y, X, df=10.0, R2=0.5, Pi=0.75, alpha=0.02, D=None, maxit=0, flavour="w", fast=False):
+    """Reference emRR / emBA / emBB / emBC / emBCpi / emDE / emBL / emEN / emML (src/Rcpp20260726ai.cpp:80-521, :1502-1550);
+    returns the reference's list as a dict plus 'iters' (sweeps run)."""
     Xf = as_f32_colmajor(X)
     n, p = Xf.shape
     y = np.ascontiguousarray(y, np.float32)
-    b = np.zeros(p, np.float32); hat = np.zeros(n, np.float32); vbv = np.zeros(p, np.float32); scal = np.zeros(4, np.float32)
-    mu = C.c_float(); iters = C.c_int()
+    b = np.zeros(p, np.float32); d = np.zeros(p, np.float32); hat = np.zeros(n, np.float32); vbv = np.zeros(p, np.float32)
+    s = np.zeros(6, np.float32); mu = C.c_float(); iters = C.c_int()
     Dv = None if D is None else np.ascontiguousarray(D, np.float32)
+    par = Pi if model in ("emBB", "emBC", "emBCpi") else alpha
     rc = getattr(lib(fast), "oracle_em_" + flavour)(
         C.c_int(EM_MODELS[model]), _fp(y), _fp(Xf), C.c_int64(n), C.c_int64(p), C.c_int64(n), C.c_float(df), C.c_float(R2),
-        None if Dv is None else _fp(Dv), C.c_int(maxit), C.byref(mu), _fp(b), _fp(hat), _fp(vbv), _fp(scal), C.byref(iters))
+        C.c_float(par), None if Dv is None else _fp(Dv), C.c_int(maxit), C.byref(mu), _fp(b), _fp(d), _fp(hat), _fp(vbv), _fp(s),
+        C.byref(iters))
     assert rc == 0
+    s = [float(v) for v in s]
     if model == "emRR":
-        out = {"mu": mu.value, "b": b, "hat": hat, "Va": float(scal[0]), "Ve": float(scal[1]), "h2": float(scal[2])}
+        out = {"mu": mu.value, "b": b, "hat": hat, "Va": s[0], "Ve": s[1], "h2": s[2]}
     elif model in ("emBA", "emDE"):
-        out = {"mu": mu.value, "b": b, "hat": hat, "Vb": vbv, "Ve": float(scal[1]), "h2": float(scal[2])}
+        out = {"mu": mu.value, "b": b, "hat": hat, "Vb": vbv, "Ve": s[1], "h2": s[2]}
+    elif model == "emBB":
+        out = {"mu": mu.value, "b": b, "d": d, "hat": hat, "Vb": vbv, "Ve": s[1], "h2": s[2]}
+    elif model == "emBC":
+        out = {"mu": mu.value, "b": b, "d": d, "hat": hat, "Vg": s[3], "Va": s[0], "Ve": s[1], "h2": s[2]}
+    elif model == "emBCpi":
+        out = {"mu": mu.value, "b": b, "d": d, "pi": s[4], "hat": hat, "Vg": s[3], "Va": s[0], "Ve": s[1], "h2": s[2]}
+    elif model == "emBL":
+        out = {"mu": mu.value, "b": b, "hat": hat, "h2": s[2]}
+    elif model == "emEN":
+        out = {"mu": mu.value, "b": b, "hat": hat, "Va": s[0], "Ve": s[1], "h2": s[2]}
     else:
-        out = {"mu": mu.value, "b": b, "hat": hat, "h2": float(scal[2]), "Vb": float(scal[0]), "Va": float(scal[3]), "Ve": float(scal[1])}
+        out = {"mu": mu.value, "b": b, "hat": hat, "h2": s[2], "Vb": s[0], "Va": s[3], "Ve": s[1]}
     out["iters"] = int(iters.value)
     return out

@@ -457,7 +457,7 @@ def test_fit_many_runs_the_same_chains_side_by_side():
         P.close()
 
 
-EM_MODELS = ["emRR", "emBA", "emDE", "emML"]
+EM_MODELS = ["emRR", "emBA", "emBB", "emBC", "emBCpi", "emDE", "emBL", "emEN", "emML"]
 
 
 def _em_check(model, got, ref, tol=TOL):
@@ -486,14 +486,14 @@ def test_em_family_matches_oracle(model):
     try:
         for maxit in (7, 0):
             got = getattr(bwgr_amd, model)(y, P, maxit=maxit)
-            ref = O.em(model, y, X, df=10.0, R2=0.5, maxit=maxit)
+            ref = O.em(model, y, X, maxit=maxit)
             _em_check(model, got, ref)
     finally:
         P.close()
 
 
 def test_em_family_other_shapes():
-    """Marker weights for emML, non-default df / R2, a float (centred) panel, a panel smaller than one block, and a
+    """Marker weights for emML, non-default df / R2 / Pi / alpha, a float (centred) panel, a panel smaller than one block, and a
     p above 65535 (libstdc++'s shuffle switches from two swap positions per draw to one)."""
     import bwgr_amd
     from oracle import oracle as O
@@ -508,6 +508,11 @@ def test_em_family_other_shapes():
     Xc = (X - X.mean(axis=0)).astype(np.float32)
     _em_check("emDE", bwgr_amd.emDE(y, Xc, R2=0.4, maxit=30, as_int8=False), O.em("emDE", y, Xc, R2=0.4, maxit=30), tol=5e-6)
     _em_check("emRR", bwgr_amd.emRR(y, X[:, :11], maxit=30), O.em("emRR", y, X[:, :11], maxit=30))
+    _em_check("emBB", bwgr_amd.emBB(y, X, df=5, R2=0.4, Pi=0.9, maxit=30), O.em("emBB", y, X, df=5, R2=0.4, Pi=0.9, maxit=30))
+    _em_check("emBC", bwgr_amd.emBC(y, X, Pi=0.3, maxit=30), O.em("emBC", y, X, Pi=0.3, maxit=30))
+    _em_check("emBCpi", bwgr_amd.emBCpi(y, Xc, Pi=0.6, maxit=30, as_int8=False), O.em("emBCpi", y, Xc, Pi=0.6, maxit=30), tol=5e-6)
+    _em_check("emBL", bwgr_amd.emBL(y, X, R2=0.3, alpha=0.2, maxit=30), O.em("emBL", y, X, R2=0.3, alpha=0.2, maxit=30))
+    _em_check("emEN", bwgr_amd.emEN(y, X, R2=0.6, alpha=0.5, maxit=30), O.em("emEN", y, X, R2=0.6, alpha=0.5, maxit=30))
     n2, p2 = 64, 66000
     X2 = rng.integers(0, 3, size=(n2, p2)).astype(np.int8)
     y2 = (X2[:, :5].astype(np.float64) @ rng.normal(size=5) + rng.normal(size=n2)).astype(np.float32)

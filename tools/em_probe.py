@@ -1,4 +1,4 @@
-"""EM family timing probe (GPU box): emRR / emBA / emDE / emML sweeps per second on a synthetic int8 panel next to the
+"""EM family timing probe (GPU box): sweeps per second of every built member on a synthetic int8 panel next to the
 oracle's float-faithful restatement on one host core.  python tools/em_probe.py [n p gpu_sweeps cpu_sweeps]"""
 import json
 import sys
@@ -17,7 +17,7 @@ y = synth.scale_phenotype(synth.phenotype(X, n)).cpu().numpy()
 Xh = X[:, :n].cpu().numpy().T
 P = bwgr_amd.Panel(X, n=n, device=0)
 out = {"n": n, "p": p}
-for model in ("emRR", "emBA", "emDE", "emML"):
+for model in ("emRR", "emBA", "emBB", "emBC", "emBCpi", "emDE", "emBL", "emEN", "emML"):
     f = getattr(bwgr_amd, model)
     f(y, P, maxit=2)
     torch.cuda.synchronize()
