@@ -41,3 +41,16 @@ wgr <- function(y, X, it = 1500, bi = 500, th = 1, bag = 1, rp = FALSE, iv = FAL
   .Call("bwgrhip_wgr", as.double(y), .bwgr_panel(X), as.integer(it), as.integer(bi), as.integer(th), as.logical(iv), as.logical(de),
         as.double(pi), as.double(df), as.double(R2), U, V, as.double(bag), as.logical(rp))
 }
+
+# EM / Gauss-Seidel family, R/RcppExports.R (emRR, emBA, emBB, emBC, emBCpi, emDE, emBL, emEN, emML): same names, argument
+# order and defaults; the marker order of every sweep is the reference's std::shuffle(order, std::mt19937(i))
+.bwgr_em <- function(model, y, gen, df, R2, par, D = NULL) .Call("bwgrhip_em", as.integer(model), as.double(y), .bwgr_panel(gen), as.double(df), as.double(R2), as.double(par), D)
+emRR   <- function(y, gen, df = 10, R2 = 0.5) .bwgr_em(0L, y, gen, df, R2, 0)
+emBA   <- function(y, gen, df = 10, R2 = 0.5) .bwgr_em(1L, y, gen, df, R2, 0)
+emDE   <- function(y, gen, R2 = 0.5) .bwgr_em(2L, y, gen, 0, R2, 0)
+emML   <- function(y, gen, D = NULL) .bwgr_em(3L, y, gen, 0, 0.5, 0, D)
+emBB   <- function(y, gen, df = 10, R2 = 0.5, Pi = 0.75) .bwgr_em(4L, y, gen, df, R2, Pi)
+emBC   <- function(y, gen, df = 10, R2 = 0.5, Pi = 0.75) .bwgr_em(5L, y, gen, df, R2, Pi)
+emBCpi <- function(y, gen, df = 10, R2 = 0.5, Pi = 0.75) .bwgr_em(6L, y, gen, df, R2, Pi)
+emBL   <- function(y, gen, R2 = 0.5, alpha = 0.02) .bwgr_em(7L, y, gen, 0, R2, alpha)
+emEN   <- function(y, gen, R2 = 0.5, alpha = 0.02) .bwgr_em(8L, y, gen, 0, R2, alpha)

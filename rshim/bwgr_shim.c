@@ -171,6 +171,51 @@ SEXP bwgrhip_Bayes2(SEXP model, SEXP y, SEXP panel1, SEXP panel2, SEXP it, SEXP 
   return out;
 }
 
+/* EM / Gauss-Seidel family: emRR, emBA, emBB, emBC, emBCpi, emDE, emBL, emEN, emML  src/Rcpp20260726ai.cpp:80-521, :1502-1550;
+ * return lists :122-127, :181-187, :240-247, :298-304, :347-353, :394, :453-459, :514-520, :1545-1549 (names and order kept).
+ * model = BWGR_EM_*; par = Pi or alpha; D = emML's weights or NULL */
+SEXP bwgrhip_em(SEXP model, SEXP y, SEXP panel, SEXP df, SEXP R2, SEXP par, SEXP D) {
+  bwgr_panel *P = panel_of(panel);
+  int64_t info[8]; chk(bwgr_panel_info(P, info));
+  const R_xlen_t n = info[0], p = info[1];
+  const int m = Rf_asInteger(model);
+  if (XLENGTH(y) != n) Rf_error("length(y) must equal nrow(gen)");
+  float *fy = to_float(y, n), *fD = Rf_isNull(D) ? NULL : to_float(D, p);
+  float *B = (float *)R_alloc(p, 4), *Dv = (float *)R_alloc(p, 4), *V = (float *)R_alloc(p, 4), *hat = (float *)R_alloc(n, 4);
+  float mu, s[6]; int iters;
+  chk(bwgr_em(P, m, fy, (float)Rf_asReal(df), (float)Rf_asReal(R2), (float)Rf_asReal(par), fD, 0, &mu, B, Dv, hat, V, s, &iters));
+  SEXP out;
+#define EM_SET(k_, v_) SET_VECTOR_ELT(out, k_, v_)
+  if (m == BWGR_EM_RR) {
+    const char *nm[] = {"mu", "b", "hat", "Va", "Ve", "h2"}; out = PROTECT(named_list(6, nm));
+    EM_SET(0, Rf_ScalarReal(mu)); EM_SET(1, from_float(B, p)); EM_SET(2, from_float(hat, n)); EM_SET(3, Rf_ScalarReal(s[0])); EM_SET(4, Rf_ScalarReal(s[1])); EM_SET(5, Rf_ScalarReal(s[2]));
+  } else if (m == BWGR_EM_BA || m == BWGR_EM_DE) {
+    const char *nm[] = {"mu", "b", "hat", "Vb", "Ve", "h2"}; out = PROTECT(named_list(6, nm));
+    EM_SET(0, Rf_ScalarReal(mu)); EM_SET(1, from_float(B, p)); EM_SET(2, from_float(hat, n)); EM_SET(3, from_float(V, p)); EM_SET(4, Rf_ScalarReal(s[1])); EM_SET(5, Rf_ScalarReal(s[2]));
+  } else if (m == BWGR_EM_BB) {
+    const char *nm[] = {"mu", "b", "d", "hat", "Vb", "Ve", "h2"}; out = PROTECT(named_list(7, nm));
+    EM_SET(0, Rf_ScalarReal(mu)); EM_SET(1, from_float(B, p)); EM_SET(2, from_float(Dv, p)); EM_SET(3, from_float(hat, n)); EM_SET(4, from_float(V, p)); EM_SET(5, Rf_ScalarReal(s[1])); EM_SET(6, Rf_ScalarReal(s[2]));
+  } else if (m == BWGR_EM_BC) {
+    const char *nm[] = {"mu", "b", "d", "hat", "Vg", "Va", "Ve", "h2"}; out = PROTECT(named_list(8, nm));
+    EM_SET(0, Rf_ScalarReal(mu)); EM_SET(1, from_float(B, p)); EM_SET(2, from_float(Dv, p)); EM_SET(3, from_float(hat, n)); EM_SET(4, Rf_ScalarReal(s[3])); EM_SET(5, Rf_ScalarReal(s[0])); EM_SET(6, Rf_ScalarReal(s[1])); EM_SET(7, Rf_ScalarReal(s[2]));
+  } else if (m == BWGR_EM_BCPI) {
+    const char *nm[] = {"mu", "b", "d", "pi", "hat", "Vg", "Va", "Ve", "h2"}; out = PROTECT(named_list(9, nm));
+    EM_SET(0, Rf_ScalarReal(mu)); EM_SET(1, from_float(B, p)); EM_SET(2, from_float(Dv, p)); EM_SET(3, Rf_ScalarReal(s[4])); EM_SET(4, from_float(hat, n)); EM_SET(5, Rf_ScalarReal(s[3])); EM_SET(6, Rf_ScalarReal(s[0])); EM_SET(7, Rf_ScalarReal(s[1])); EM_SET(8, Rf_ScalarReal(s[2]));
+  } else if (m == BWGR_EM_BL) {
+    const char *nm[] = {"mu", "b", "hat", "h2"}; out = PROTECT(named_list(4, nm));
+    EM_SET(0, Rf_ScalarReal(mu)); EM_SET(1, from_float(B, p)); EM_SET(2, from_float(hat, n)); EM_SET(3, Rf_ScalarReal(s[2]));
+  } else if (m == BWGR_EM_EN) {
+    const char *nm[] = {"mu", "b", "hat", "Va", "Ve", "h2"}; out = PROTECT(named_list(6, nm));
+    EM_SET(0, Rf_ScalarReal(mu)); EM_SET(1, from_float(B, p)); EM_SET(2, from_float(hat, n)); EM_SET(3, Rf_ScalarReal(s[0])); EM_SET(4, Rf_ScalarReal(s[1])); EM_SET(5, Rf_ScalarReal(s[2]));
+  } else {
+    const char *nm[] = {"mu", "b", "hat", "h2", "Vb", "Va", "Ve"}; out = PROTECT(named_list(7, nm));
+    EM_SET(0, Rf_ScalarReal(mu)); EM_SET(1, from_float(B, p)); EM_SET(2, from_float(hat, n)); EM_SET(3, Rf_ScalarReal(s[2])); EM_SET(4, Rf_ScalarReal(s[0])); EM_SET(5, Rf_ScalarReal(s[3])); EM_SET(6, Rf_ScalarReal(s[1]));
+  }
+#undef EM_SET
+  UNPROTECT(1);
+  return out;
+}
+
 /* wgr(y,X,it,bi,th,bag=1,rp=FALSE,iv,de,pi,df,R2,eigK=NULL)    R/wgr.R:2-169 -> list(mu,b,Vb,d,Ve,hat,cxx), :155-168 */
 SEXP bwgrhip_wgr(SEXP y, SEXP panel, SEXP it, SEXP bi, SEXP th, SEXP iv, SEXP de, SEXP pi, SEXP df, SEXP R2, SEXP U, SEXP V, SEXP bag, SEXP rp) {
   bwgr_panel *P = panel_of(panel);
@@ -206,7 +251,7 @@ SEXP bwgrhip_wgr(SEXP y, SEXP panel, SEXP it, SEXP bi, SEXP th, SEXP iv, SEXP de
 static const R_CallMethodDef CallEntries[] = {   /* as src/RcppExports.cpp:1152-1228 registers _bWGR_* */
   {"bwgrhip_panel", (DL_FUNC)&bwgrhip_panel, 2}, {"bwgrhip_KMUP", (DL_FUNC)&bwgrhip_KMUP, 9},
   {"bwgrhip_Bayes", (DL_FUNC)&bwgrhip_Bayes, 8}, {"bwgrhip_Bayes2", (DL_FUNC)&bwgrhip_Bayes2, 9},
-  {"bwgrhip_wgr", (DL_FUNC)&bwgrhip_wgr, 14}, {NULL, NULL, 0}};
+  {"bwgrhip_wgr", (DL_FUNC)&bwgrhip_wgr, 14}, {"bwgrhip_em", (DL_FUNC)&bwgrhip_em, 7}, {NULL, NULL, 0}};
 
 void R_init_bwgrhip(DllInfo *dll) {              /* as R_init_bWGR, src/RcppExports.cpp:1230-1233 */
   R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
