@@ -328,7 +328,7 @@ def fit_many(X, jobs, concurrent=None, chunk=4, **panel_kw):
             P.close()
 
 
-_EM = {"emRR": 0, "emBA": 1, "emDE": 2, "emML": 3, "emBB": 4, "emBC": 5, "emBCpi": 6, "emBL": 7, "emEN": 8}
+_EM = {"emRR": 0, "emBA": 1, "emDE": 2, "emML": 3, "emBB": 4, "emBC": 5, "emBCpi": 6, "emBL": 7, "emEN": 8, "lasso": 9}
 
 
 def _em(model, y, gen, df=10.0, R2=0.5, par=0.0, D=None, maxit=0, **panel_kw):
@@ -397,6 +397,12 @@ def emEN(y, gen, R2=0.5, alpha=0.02, **kw):
     """emEN(y, gen, R2 = 0.5, alpha = 0.02), src/Rcpp20260726ai.cpp:400-460: list(mu, b, hat, Va, Ve, h2)."""
     r = _em("emEN", y, gen, 0.0, R2, alpha, **kw); s = r["scal"]
     return {"mu": r["mu"], "b": r["b"], "hat": r["hat"], "Va": s[0], "Ve": s[1], "h2": s[2]}
+
+
+def lasso(y, gen, **kw):
+    """lasso(y, gen), src/Rcpp20260726ai.cpp:1463-1500 (natural marker order): list(mu, b, h2, hat, Lmb)."""
+    r = _em("lasso", y, gen, 0.0, 0.5, 0.0, **kw); s = r["scal"]
+    return {"mu": r["mu"], "b": r["b"], "h2": s[2], "hat": r["hat"], "Lmb": s[0]}
 
 
 def emML(y, gen, D=None, **kw):

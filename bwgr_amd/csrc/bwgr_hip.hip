@@ -1911,6 +1911,7 @@ __global__ void k_em_stage(const int32_t *__restrict__ order, int64_t p, int mod
     float l;
     if (model == BWGR_EM_BA || model == BWGR_EM_DE || model == BWGR_EM_BB) l = lam[j];
     else if (model == BWGR_EM_BL || model == BWGR_EM_EN) l = Lmb2;                   // denominators Lmb2 + xx, :382, :434
+    else if (model == BWGR_EM_LASSO) l = 0.0f;                                       // denominator xx, :1480
     else if (weighted) l = Lmb / D[j];                                               // :496
     else l = Lmb;
     lamq[jj] = l;
@@ -2065,15 +2066,16 @@ extern "C" int bwgr_em_order(int64_t p, int upto, int32_t *order) {
 extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float R2, float par, const float *D, int maxit_in,
                        float *mu, float *b, float *d, float *hat, float *vbvec, float *scal, int *iters) {
   if (!P || !y || !b || !scal) return fail(BWGR_EINVAL, "em: null pointer");
-  if (model < BWGR_EM_RR || model > BWGR_EM_EN) return fail(BWGR_EINVAL, "em: bad model %d", model);
+  if (model < BWGR_EM_RR || model > BWGR_EM_LASSO) return fail(BWGR_EINVAL, "em: bad model %d", model);
   if (D && model != BWGR_EM_ML) return fail(BWGR_EINVAL, "em: marker weights D belong to emML only");
   const bool soft = (model == BWGR_EM_BB || model == BWGR_EM_BC || model == BWGR_EM_BCPI);
-  const bool nonaffine = soft || model == BWGR_EM_BL || model == BWGR_EM_EN;
+  const bool lasso = (model == BWGR_EM_LASSO);
+  const bool nonaffine = soft || lasso || model == BWGR_EM_BL || model == BWGR_EM_EN;
   if (nonaffine && P->sweep_version != 2) return fail(BWGR_EINVAL, "em: this member needs the pipelined sweep engine (k_sweep2), which this panel's geometry does not fit");
   HIPCHK(hipSetDevice(P->device));
   const int64_t p = P->p, n = P->n;
-  const bool conv = (model == BWGR_EM_DE || model == BWGR_EM_ML || model == BWGR_EM_EN);
-  const bool shuffled = (model != BWGR_EM_BCPI);                                      // emBCpi sweeps in natural order, :1523
+  const bool conv = (model == BWGR_EM_DE || model == BWGR_EM_ML || model == BWGR_EM_EN || lasso);
+  const bool shuffled = (model != BWGR_EM_BCPI && !lasso);                            // emBCpi and lasso sweep in natural order, :1523, :1476
   const int maxit = maxit_in > 0 ? maxit_in : (conv ? 300 : 200);                     // :81, :251, :309, :401, :465
   const float tol = (model == BWGR_EM_DE) ? 10e-6f : (model == BWGR_EM_EN) ? 10e-11f : 10e-8f;   // :252, :402, :466
   hipStream_t st = P->stream;
@@ -2121,7 +2123,7 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
   const float sumvx = P->MSx;                                                        // vx.sum()
   EmState h; memset(&h, 0, sizeof(h));
   h.df = df; h.vy = vy; h.MSx = sumvx; h.sumvx = sumvx; h.R2 = R2; h.ve = 1.0f;
-  std::vector<float> hostv;
+  std::vector<float> hostv, xxh, yxh, bh;
   auto fill = [&](float *dst, float v) { hostv.assign((size_t)p, v); hipError_t e_ = hipMemcpyAsync(dst, hostv.data(), pb, hipMemcpyHostToDevice, st); return e_ != hipSuccess ? e_ : hipStreamSynchronize(st); };
   if (model == BWGR_EM_BA || model == BWGR_EM_BB) {
     h.ve = 1;                                                                        // :84, :135
@@ -2154,11 +2156,14 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
     h.Se = (1 - R2) * (df + 2) * vy;                                                 // :205
     h.ve = h.Sa; h.va = h.Se; h.Lmb = h.ve / h.va;                                   // :209-211 (sic)
     h.Pi0 = (1 - Pi) / Pi;                                                           // :213
-  } else if (model == BWGR_EM_BL || model == BWGR_EM_EN) {
-    std::vector<float> xxh((size_t)p);
+  } else if (model == BWGR_EM_BL || model == BWGR_EM_EN || lasso) {
+    xxh.resize((size_t)p);
     ECHK(d2h(st, xxh.data(), xxd, pb));
     h.alpha = par;
-    if (model == BWGR_EM_BL) {
+    if (lasso) {
+      double sx = 0; for (int64_t j = 0; j < p; ++j) sx += (double)xxh[(size_t)j];
+      h.Lmb1 = (float)(sx / (double)p) / (float)p;                                   // Lmb = xx.mean()/p, :1472
+    } else if (model == BWGR_EM_BL) {
       double sx = 0; for (int64_t j = 0; j < p; ++j) sx += (double)xxh[(size_t)j];
       h.cxx = (float)(sx / (double)p);                                               // xx.mean(), :368
       const float hh = R2;                                                           // h2 = R2, :359
@@ -2193,6 +2198,7 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
   if (soft) flags |= SWF_EM_SEL;
   if (model == BWGR_EM_EN) flags |= SWF_EM_EN;
   if (model == BWGR_EM_BL) flags |= SWF_EM_BL;
+  if (lasso) flags |= SWF_EM_LASSO;
   int numit = 0;
   for (int i = 0; i < maxit; ++i) {
     if (shuffled) {
@@ -2214,7 +2220,7 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
     a.iter = (uint32_t)i; a.rng = make_rng(0, BWGR_RNG_DEGENERATE);
     rc = launch_sweep(S, a);
     if (rc != BWGR_OK) return done(rc);
-    hipLaunchKernelGGL(k_em_unstage, dim3(1024), dim3(256), 0, st, ordd, p, bq, bd, soft ? dq : nullptr, soft ? dd : nullptr);
+    hipLaunchKernelGGL(k_em_unstage, dim3(1024), dim3(256), 0, st, ordd, p, bq, bd, (soft || lasso) ? dq : nullptr, (soft || lasso) ? dd : nullptr);
     EmTailArgs t; t.model = model; t.n = (int)n; t.conv = conv ? 1 : 0; t.p = p; t.e = ed; t.y = yd; t.b = bd; t.bc = bcd; t.d = dd;
     t.lam = lamd; t.vbv = vbd; t.xx = xxd; t.st = std_; t.sc = sc;
     hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(1024), 0, st, t);
@@ -2226,12 +2232,30 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
     ECHK(hipMemcpyAsync(&hc, sc, sizeof(hc), hipMemcpyDeviceToHost, st));
     ECHK(hipStreamSynchronize(st));
     if (hc.error) return done(fail(BWGR_ETIMEOUT, "em: a workgroup exchange timed out inside the sweep kernel"));
-    if (conv && h.cnv < tol) break;                                                  // :296, :452, :510
+    if (lasso) {   // Lmb from the sweep's yx and b: the reference's own sequential float loop, :1487-1490
+      yxh.resize((size_t)p); bh.resize((size_t)p);
+      ECHK(d2h(st, yxh.data(), dd, pb)); ECHK(d2h(st, bh.data(), bd, pb));
+      float tmp = 0.0f;
+      for (int64_t j = 0; j < p; ++j) tmp += fabsf(yxh[(size_t)j]) - fabsf(bh[(size_t)j] * xxh[(size_t)j]);
+      float L = 2.0f * tmp / (float)p;
+      L = 2.0f * sqrtf(fabsf(L));
+      h.Lmb1 = L;
+      ECHK(hipMemcpyAsync(std_, &h, sizeof(h), hipMemcpyHostToDevice, st));
+      ECHK(hipMemcpyAsync(&sc->lam, &h.Lmb1, sizeof(float), hipMemcpyHostToDevice, st));
+      ECHK(hipStreamSynchronize(st));
+    }
+    if (conv && h.cnv < tol) break;                                                  // :296, :452, :510, :1492
   }
   float h2;
   if (model == BWGR_EM_ML) {
     hipLaunchKernelGGL(k_em_fit_ml, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, yd, ed, hatd, (int)n);
     h2 = h.vb * h.MSx / (h.vb * h.MSx + h.ve);                                       // :513
+  } else if (lasso) {
+    hipLaunchKernelGGL(k_em_fit_ml, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, yd, ed, hatd, (int)n);   // fit = y - e, :1493
+    std::vector<double> eh((size_t)n);
+    ECHK(d2h(st, eh.data(), ed, sizeof(double) * n));
+    double s = 0; for (int64_t k = 0; k < n; ++k) s = fma(eh[(size_t)k], (double)y[k], s);
+    h2 = 1.0f - ((float)s / (float)(n - 1)) / vy;                                    // :1494
   } else {
     rc = gemv_hat<float>(P, bd, h.mu, hatd);                                         // fit = gen*b + mu, :120-121
     if (rc != BWGR_OK) return done(rc);
@@ -2266,6 +2290,7 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
   if (model == BWGR_EM_BCPI) scal[4] = h.Pi;
   if (model == BWGR_EM_EN) scal[0] = h.va * h.cxx;                                   // :457
   if (model == BWGR_EM_BL) scal[1] = 0.0f;
+  if (lasso) { scal[0] = h.Lmb1; scal[1] = 0.0f; }                                   // Lmb, :1497
   if (iters) *iters = numit;
 #undef ECHK
   return done(BWGR_OK);

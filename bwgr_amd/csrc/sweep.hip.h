@@ -45,7 +45,8 @@ enum : int {
   SWF_EM_SEL = 128,   // emBB / emBC / emBCpi: b = b1 * d, d = 1/(1 + Pi0 exp(C(|e2|^2-|e1|^2)))  (:165-170, :224-229, :1526-1532)
   SWF_EM_EN = 256,    // emEN: soft threshold (OLS -/+ Lmb1)/(Lmb2 + xx), clamped at 0 (:433-438); Lmb1 rides in sc->lam
   SWF_EM_BL = 512,    // emBL: G + Half_L2 (:379-387); Lmb1 in sc->lam, 1/(xx + cxx) in the sdz1 slot (cxx in sc->Sb)
-  SWF_EM_ANY = SWF_EM_SEL | SWF_EM_EN | SWF_EM_BL
+  SWF_EM_LASSO = 1024, // lasso: yx = (e + x b0).x, soft threshold (yx -/+ Lmb)/xx clamped at 0 (:1477-1485); Lmb in sc->lam; yx_j leaves in d[j]
+  SWF_EM_ANY = SWF_EM_SEL | SWF_EM_EN | SWF_EM_BL | SWF_EM_LASSO
 };
 
 // scalars produced on the device by the per-iteration tail kernel (or filled by the host for KMUP)
@@ -312,6 +313,13 @@ __device__ __forceinline__ float lane_em(double r, const LaneConst &c, int flags
     return b1 * d;
   }
   *dout = 1.0f;
+  if (flags & SWF_EM_LASSO) {
+    const double yx = fma(c.gjj, (double)c.b0, r);          // e += gen.col(j)*b[j]; yx[j] = e.dot(gen.col(j))  (x.x = G_jj)
+    *dout = (float)yx;
+    if (yx > 0.0) { const float b1 = (float)((yx - (double)L1) * c.rden); return b1 < 0.0f ? 0.0f : b1; }
+    const float b1 = (float)((yx + (double)L1) * c.rden);
+    return b1 > 0.0f ? 0.0f : b1;
+  }
   if (flags & SWF_EM_EN) {
     if (ols > 0.0) { const float b1 = (float)((ols - (double)L1) * c.rden); return b1 < 0.0f ? 0.0f : b1; }
     const float b1 = (float)((ols + (double)L1) * c.rden);

@@ -179,7 +179,7 @@ int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, 
 /* ---- EM / Gauss-Seidel family --------------------------------------------------------
  * Replaces SEXP emRR(y,gen,df,R2) src/Rcpp20260726ai.cpp:308-354, emBA(y,gen,df,R2) :80-128, emBB(y,gen,df,R2,Pi) :131-187,
  * emBC(y,gen,df,R2,Pi) :190-247, emBCpi(y,gen,df,R2,Pi) :1502-1545, emDE(y,gen,R2) :250-305, emBL(y,gen,R2,alpha) :357-397,
- * emEN(y,gen,R2,alpha) :400-460, emML(y,gen,D) :463-521 (_bWGR_emRR ... in src/RcppExports.cpp).  Deterministic
+ * emEN(y,gen,R2,alpha) :400-460, emML(y,gen,D) :463-521, lasso(y,gen) :1463-1500 (_bWGR_emRR ... in src/RcppExports.cpp).  Deterministic
  * coordinate updates in the marker order the reference re-shuffles before every sweep with std::shuffle(order,
  * std::mt19937(i)) (emBCpi sweeps in natural order): the library makes the same standard-library call, gathers the
  * resident panel into that order on the device, rebuilds the Gram blocks and runs the sweep kernel with the variates
@@ -189,9 +189,10 @@ int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, 
  * tests).  D: emML's optional marker weights (p floats) or NULL.  Outputs (host): mu, b[p], d[p] (soft-selection
  * members; may be NULL), hat[n], vbvec[p] (emBA / emBB / emDE: Vb; may be NULL), scal[6] = emRR {Va, Ve, h2}, emBA / emBB /
  * emDE {0, Ve, h2}, emML {Vb, Ve, h2, Va}, emBC {Va, Ve, h2, Vg}, emBCpi {Va, Ve, h2, Vg, pi}, emBL {0, 0, h2},
- * emEN {Va, Ve, h2}; iters = sweeps run.  Not built: lasso (:1463-1500). */
+ * emEN {Va, Ve, h2}, lasso {Lmb, 0, h2}; iters = sweeps run.  lasso(y,gen) :1463-1500 sweeps in natural order; its
+ * penalty is re-estimated after every sweep from the per-marker yx the sweep hands back (host loop, as the reference). */
 enum { BWGR_EM_RR = 0, BWGR_EM_BA = 1, BWGR_EM_DE = 2, BWGR_EM_ML = 3, BWGR_EM_BB = 4, BWGR_EM_BC = 5, BWGR_EM_BCPI = 6,
-       BWGR_EM_BL = 7, BWGR_EM_EN = 8 };
+       BWGR_EM_BL = 7, BWGR_EM_EN = 8, BWGR_EM_LASSO = 9 };
 int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float R2, float par, const float *D, int maxit, float *mu,
             float *b, float *d, float *hat, float *vbvec, float *scal, int *iters);
 /* the marker order of sweep `upto` (0-based): the identity shuffled with std::mt19937(0), (1), ... (upto) (host only) */

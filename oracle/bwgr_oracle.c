@@ -835,7 +835,7 @@ int FN(oracle_em_order)(int64_t p, int upto, int *order) {
   return 0;
 }
 
-enum { EM_RR = 0, EM_BA = 1, EM_DE = 2, EM_ML = 3, EM_BB = 4, EM_BC = 5, EM_BCPI = 6, EM_BL = 7, EM_EN = 8 };
+enum { EM_RR = 0, EM_BA = 1, EM_DE = 2, EM_ML = 3, EM_BB = 4, EM_BC = 5, EM_BCPI = 6, EM_BL = 7, EM_EN = 8, EM_LASSO = 9 };
 
 /* dot of two n-vectors, one of them the residual */
 static ACC_T oem_dot_ey(const E_T *e, const float *y, int64_t n) {
@@ -848,11 +848,11 @@ static ACC_T oem_dot_ey(const E_T *e, const float *y, int64_t n) {
 }
 
 /* Members and reference lines: emRR :308-354, emBA :80-128, emDE :250-305, emML :463-521, emBB :131-187, emBC :190-247,
- * emBCpi :1502-1545 (natural marker order: no shuffle), emBL :357-397, emEN :400-460.
+ * emBCpi :1502-1545 (natural marker order: no shuffle), emBL :357-397, emEN :400-460, lasso :1463-1500 (natural order).
  * par: Pi for emBB / emBC / emBCpi (reference default 0.75), alpha for emBL / emEN (0.02); ignored otherwise.
  * o_d: p entries (emBB / emBC / emBCpi), o_vbvec: p entries (emBA / emBB / emDE Vb); untouched otherwise.
  * o_scal[6]: emRR {Va, Ve, h2}; emBA / emBB / emDE {0, Ve, h2}; emML {Vb, Ve, h2, Va}; emBC {Va, Ve, h2, Vg};
- * emBCpi {Va, Ve, h2, Vg, pi}; emBL {0, 0, h2}; emEN {Va*cxx, Ve, h2}.
+ * emBCpi {Va, Ve, h2, Vg, pi}; emBL {0, 0, h2}; emEN {Va*cxx, Ve, h2}; lasso {Lmb, 0, h2}.
  * maxit = 0: the reference's count (200 sweeps; 300 with the convergence test for emDE / emML / emEN).
  * D: emML's optional per-marker weights (NULL = none). */
 int FN(oracle_em)(int model, const float *y, const float *X, int64_t n, int64_t p, int64_t ldx, float df, float R2, float par,
@@ -873,8 +873,9 @@ int FN(oracle_em)(int model, const float *y, const float *X, int64_t n, int64_t 
   for (int64_t j = 0; j < p; j++) order[j] = (int)j;
   float ve = 0, vb = 0, va = 0, Lmb = 0, Sb = 0, Se = 0, Sa = 0, Rho = 0, cxx = 0, h2 = 0;
   float Pi = par, Pi0 = 0, PriorPi = 0, alpha = par, Lmb1 = 0, Lmb2 = 0, Sy = 0, trAC22 = 0;
-  const int conv = (model == EM_DE || model == EM_ML || model == EM_EN);
-  const int shuffled = (model != EM_BCPI);
+  const int conv = (model == EM_DE || model == EM_ML || model == EM_EN || model == EM_LASSO);
+  const int shuffled = (model != EM_BCPI && model != EM_LASSO);
+  float *yx = (model == EM_LASSO) ? (float *)calloc(p, sizeof(float)) : NULL;
   const int maxit = maxit_in > 0 ? maxit_in : (conv ? 300 : 200);        /* :81, :251, :309, :465, :401 */
   const float tol = (model == EM_DE) ? 10e-6f : (model == EM_EN) ? 10e-11f : 10e-8f;   /* :252, :402, :466 */
   if (model == EM_BA || model == EM_BB) {
@@ -920,6 +921,9 @@ int FN(oracle_em)(int model, const float *y, const float *X, int64_t n, int64_t 
     Lmb1 = 0.5f * Lmb * alpha * Sy;                                       /* :416 */
     Lmb2 = Lmb * (1 - alpha);                                             /* :417 */
     for (int64_t k = 0; k < p; k++) trAC22 += 1.0f / (xx[k] + Lmb);       /* a plain float loop in the reference, :418-419 */
+  } else if (model == EM_LASSO) {
+    ACC_T sx = 0; for (int64_t j = 0; j < p; j++) sx += (ACC_T)xx[j];
+    Lmb = (float)(sx / (ACC_T)p) / (float)p;                              /* Lmb = xx.mean()/p, :1472 */
   }
   int numit = 0;
   for (int i = 0; i < maxit; i++) {
@@ -931,6 +935,16 @@ int FN(oracle_em)(int model, const float *y, const float *X, int64_t n, int64_t 
       const float *xj = X + j * ldx;
       const float b0 = b[j];
       float bnew;
+      if (model == EM_LASSO) {
+        v_axpy(e, xj, 0.0f - b0, n);                                      /* e += gen.col(j)*b[j], :1477 */
+        const ACC_T yxa = v_dot_acc(xj, e, n);                            /* yx[j] = e.dot(gen.col(j)), :1478 */
+        yx[j] = (float)yxa;
+        if (yxa > 0) { bnew = (float)((yxa - (ACC_T)Lmb) / (ACC_T)xx[j]); if (bnew < 0) bnew = 0; }   /* :1480-1481 */
+        else { bnew = (float)((yxa + (ACC_T)Lmb) / (ACC_T)xx[j]); if (bnew > 0) bnew = 0; }           /* :1483-1484 */
+        v_axpy(e, xj, bnew, n);                                           /* e -= gen.col(j)*b[j], :1485 */
+        b[j] = bnew;
+        continue;
+      }
       if (model == EM_BB || model == EM_BC || model == EM_BCPI) {
         const float den = xx[j] + ((model == EM_BB) ? Lmbv[j] : Lmb);
         const float b1 = draw_b1(xj, e, n, xx[j], b0, den, 0.0f, 0.0);    /* :161, :220, :1525 */
@@ -996,6 +1010,12 @@ int FN(oracle_em)(int model, const float *y, const float *X, int64_t n, int64_t 
       va = (b2n + Sa) / ((float)p + df) / (dmean - Pi);                   /* :1539 */
       Lmb = ve / va;                                                      /* :1540 */
     }
+    if (model == EM_LASSO) {
+      float tmp = 0.0f;
+      for (int64_t j = 0; j < p; j++) tmp += fabsf(yx[j]) - fabsf(b[j] * xx[j]);   /* a plain float loop, :1487-1488 */
+      Lmb = 2.0f * tmp / (float)p;                                        /* :1489 */
+      Lmb = 2.0f * sqrtf(fabsf(Lmb));                                     /* :1490 */
+    }
     const float eM = e_mean(e, n);                                        /* :115-117, :286-288, :341-343, :502-504 ... */
     mu += eM;
     for (int64_t k = 0; k < n; k++) e[k] = e[k] - (E_T)eM;
@@ -1033,6 +1053,9 @@ int FN(oracle_em)(int model, const float *y, const float *X, int64_t n, int64_t 
   if (model == EM_ML) {
     for (int64_t k = 0; k < n; k++) o_hat[k] = (float)((E_T)y[k] - e[k]); /* fit = y - e, :512 */
     h2 = vb * MSx / (vb * MSx + ve);                                      /* :513 */
+  } else if (model == EM_LASSO) {
+    for (int64_t k = 0; k < n; k++) o_hat[k] = (float)((E_T)y[k] - e[k]); /* fit = y - e, :1493 */
+    h2 = 1.0f - ((float)oem_dot_ey(e, y, n) / (float)(n - 1)) / vy;       /* :1494 */
   } else {
     ACC_T *acc = (ACC_T *)calloc(n, sizeof(ACC_T));
     for (int64_t j = 0; j < p; j++) { const float *xj = X + j * ldx; ACC_T Bj = (ACC_T)b[j]; for (int64_t k = 0; k < n; k++) acc[k] += (ACC_T)xj[k] * Bj; }
@@ -1060,6 +1083,8 @@ int FN(oracle_em)(int model, const float *y, const float *X, int64_t n, int64_t 
   if (model == EM_BCPI) o_scal[4] = Pi;
   if (model == EM_EN) o_scal[0] = va * cxx;                               /* :457 */
   if (model == EM_BL) o_scal[1] = 0;
+  if (model == EM_LASSO) { o_scal[0] = Lmb; o_scal[1] = 0; }
+  free(yx);
   *o_iters = numit;
   free(xx); free(vx); free(b); free(bc); free(d); free(vbv); free(Lmbv); free(order); free(e); free(e1); free(e2);
   return 0;

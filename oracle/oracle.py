@@ -201,7 +201,7 @@ def wgr(y, X, it=1500, bi=500, th=1, bag=1.0, rp=False, iv=False, de=False, pi=0
     return {"mu": mu.value, "b": b, "Vb": Vb if per else float(Vb[0]), "d": d, "Ve": Ve.value, "hat": hat, "cxx": cxx.value}
 
 
-EM_MODELS = {"emRR": 0, "emBA": 1, "emDE": 2, "emML": 3, "emBB": 4, "emBC": 5, "emBCpi": 6, "emBL": 7, "emEN": 8}
+EM_MODELS = {"emRR": 0, "emBA": 1, "emDE": 2, "emML": 3, "emBB": 4, "emBC": 5, "emBCpi": 6, "emBL": 7, "emEN": 8, "lasso": 9}
 
 
 def em_order(p, upto):
@@ -243,6 +243,8 @@ def em(model, y, X, df=10.0, R2=0.5, Pi=0.75, alpha=0.02, D=None, maxit=0, flavo
         out = {"mu": mu.value, "b": b, "hat": hat, "h2": s[2]}
     elif model == "emEN":
         out = {"mu": mu.value, "b": b, "hat": hat, "Va": s[0], "Ve": s[1], "h2": s[2]}
+    elif model == "lasso":
+        out = {"mu": mu.value, "b": b, "h2": s[2], "hat": hat, "Lmb": s[0]}
     else:
         out = {"mu": mu.value, "b": b, "hat": hat, "h2": s[2], "Vb": s[0], "Va": s[3], "Ve": s[1]}
     out["iters"] = int(iters.value)

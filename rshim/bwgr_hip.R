@@ -54,3 +54,4 @@ emBC   <- function(y, gen, df = 10, R2 = 0.5, Pi = 0.75) .bwgr_em(5L, y, gen, df
 emBCpi <- function(y, gen, df = 10, R2 = 0.5, Pi = 0.75) .bwgr_em(6L, y, gen, df, R2, Pi)
 emBL   <- function(y, gen, R2 = 0.5, alpha = 0.02) .bwgr_em(7L, y, gen, 0, R2, alpha)
 emEN   <- function(y, gen, R2 = 0.5, alpha = 0.02) .bwgr_em(8L, y, gen, 0, R2, alpha)
+lasso  <- function(y, gen) .bwgr_em(9L, y, gen, 0, 0.5, 0)

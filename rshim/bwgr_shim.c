@@ -204,6 +204,9 @@ SEXP bwgrhip_em(SEXP model, SEXP y, SEXP panel, SEXP df, SEXP R2, SEXP par, SEXP
   } else if (m == BWGR_EM_BL) {
     const char *nm[] = {"mu", "b", "hat", "h2"}; out = PROTECT(named_list(4, nm));
     EM_SET(0, Rf_ScalarReal(mu)); EM_SET(1, from_float(B, p)); EM_SET(2, from_float(hat, n)); EM_SET(3, Rf_ScalarReal(s[2]));
+  } else if (m == BWGR_EM_LASSO) {
+    const char *nm[] = {"mu", "b", "h2", "hat", "Lmb"}; out = PROTECT(named_list(5, nm));
+    EM_SET(0, Rf_ScalarReal(mu)); EM_SET(1, from_float(B, p)); EM_SET(2, Rf_ScalarReal(s[2])); EM_SET(3, from_float(hat, n)); EM_SET(4, Rf_ScalarReal(s[0]));
   } else if (m == BWGR_EM_EN) {
     const char *nm[] = {"mu", "b", "hat", "Va", "Ve", "h2"}; out = PROTECT(named_list(6, nm));
     EM_SET(0, Rf_ScalarReal(mu)); EM_SET(1, from_float(B, p)); EM_SET(2, from_float(hat, n)); EM_SET(3, Rf_ScalarReal(s[0])); EM_SET(4, Rf_ScalarReal(s[1])); EM_SET(5, Rf_ScalarReal(s[2]));
