@@ -1088,6 +1088,7 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
     const char *sv = getenv("BWGR_SWEEP");   // A/B switch for tests and profiling
     P->sweep_version = (sv && sv[0] == '1') ? 1 : 2;
     P->nfeed = std::min(6, std::max(2, (K + 39) / 40 + 1));   // K = 40: 2, K = 79: 3, K >= 161: 6
+    if (const char *nf = getenv("BWGR_NFEED")) { const int v = atoi(nf); if (v >= 1 && v <= 6) P->nfeed = v; }   // experiments
     if (P->lds2_bytes > (size_t)160 * 1024 || K + 1 + P->nfeed > 256) P->sweep_version = 1;
   }
   P->x_bytes = (size_t)P->ld * (size_t)p * (P->is_f32 ? 4 : 1);

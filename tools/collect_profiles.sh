@@ -17,6 +17,11 @@ rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_cc -o ${TAG}cc --output-form
 find $OUT/prof_stats_cc -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_bench_c4_concurrent_kernel_stats.csv \;
 find $OUT/prof_stats_cc -name "*kernel_trace.csv" -delete
 echo "concurrent stats done"
+# the EM family at C2 size: kernel time split between the column gather, the Gram rebuild and the sweep
+PYTHONPATH=$OLDPWD rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_em -o ${TAG}em --output-format csv -- python3 $OLDPWD/tools/em_probe.py 5000 50000 5 1 > $OUT/${TAG}_em_c2_under_rocprof.json 2>> $OUT/${TAG}_rocprof.err
+find $OUT/prof_stats_em -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_em_c2_kernel_stats.csv \;
+find $OUT/prof_stats_em -name "*kernel_trace.csv" -delete
+echo "em stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_fetch -o ${TAG} --output-format csv -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu --chains 1 > $OUT/${TAG}_pmc_fetch.log 2>&1
 echo "fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write -o ${TAG} --output-format csv -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu --chains 1 > $OUT/${TAG}_pmc_write.log 2>&1
