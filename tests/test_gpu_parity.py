@@ -518,3 +518,12 @@ def test_em_family_other_shapes():
     X2 = rng.integers(0, 3, size=(n2, p2)).astype(np.int8)
     y2 = (X2[:, :5].astype(np.float64) @ rng.normal(size=5) + rng.normal(size=n2)).astype(np.float32)
     _em_check("emML", bwgr_amd.emML(y2, X2, maxit=3), O.em("emML", y2, X2, maxit=3))
+
+
+@pytest.mark.parametrize("model", EM_MODELS)
+def test_em_family_tpod_defaults(tpod, model):
+    """emXX(y, gen) with the reference's defaults on its own example data (data/tpod.RData)."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = tpod["gen"], tpod["y"]
+    _em_check(model, getattr(bwgr_amd, model)(y, X), O.em(model, y, X), tol=2e-6 if model in ("emBC", "emBCpi") else TOL)

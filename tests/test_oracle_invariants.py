@@ -146,3 +146,23 @@ def test_two_effect_residual_identity_and_flavours(tpod, model):
     assert np.abs(e - L["e"]).max() < 2e-4 * np.abs(y).max()
     assert np.abs(w["b1"] - f["b1"]).max() < 1e-3 * np.abs(w["b1"]).max() + 1e-6
     assert 0.0 < w["h2"] < 1.0 and w["ve"] > 0
+
+
+@pytest.mark.parametrize("model", ["emRR", "emBA", "emBB", "emBC", "emBCpi", "emDE", "emBL", "emEN", "emML", "lasso"])
+def test_em_members_on_tpod_two_flavours(tpod, model):
+    """The EM family on the reference's own example data (man/emRR.Rd style calls: emXX(y, gen) with defaults): the wide
+    and the float-faithful restatement describe the same fit (they differ only in where float rounding happens), the fit
+    explains the phenotype, and the residual identity e = y - hat holds for the members that return y - e."""
+    from oracle import oracle as O
+    X, y = tpod["gen"], tpod["y"]
+    w = O.em(model, y, X, flavour="w")
+    f = O.em(model, y, X, flavour="f")
+    assert w["iters"] == f["iters"] or model in ("emDE", "emML", "emEN", "lasso")
+    assert np.all(np.isfinite(w["b"])) and np.all(np.isfinite(f["b"]))
+    if np.std(w["b"]) > 0:
+        assert np.corrcoef(w["b"], f["b"])[0, 1] > 0.999
+    assert np.corrcoef(w["hat"], f["hat"])[0, 1] > 0.9999
+    assert np.corrcoef(w["hat"], y)[0, 1] > 0.5
+    assert 0.0 < w["h2"] < 1.0
+    if "d" in w:
+        assert np.all(w["d"] >= 0) and np.all(w["d"] <= 1)
