@@ -63,3 +63,16 @@ def test_host_mirror_signatures_match_reference():
         assert pos(f) == [("y", E), ("X", E), ("it", 1500), ("bi", 500), ("pi", 0.95), ("df", 5), ("R2", 0.5)]
     assert pos(B.wgr) == [("y", E), ("X", E), ("it", 1500), ("bi", 500), ("th", 1), ("bag", 1), ("rp", False), ("iv", False),
                           ("de", False), ("pi", 0), ("df", 5), ("R2", 0.5), ("eigK", None), ("VarK", 0.95), ("verb", False)]
+    # two-effect samplers and the EM / Gauss-Seidel family, R/RcppExports.R:12-46, 76-86 (names, order, defaults)
+    for f in (B.BayesA2, B.BayesRR2):
+        assert pos(f) == [("y", E), ("X1", E), ("X2", E), ("it", 1500), ("bi", 500), ("df", 5), ("R2", 0.5)]
+    assert pos(B.BayesB2) == [("y", E), ("X1", E), ("X2", E), ("it", 1500), ("bi", 500), ("pi", 0.95), ("df", 5), ("R2", 0.5)]
+    for f in (B.emRR, B.emBA):
+        assert pos(f) == [("y", E), ("gen", E), ("df", 10), ("R2", 0.5)]
+    for f in (B.emBB, B.emBC, B.emBCpi):
+        assert pos(f) == [("y", E), ("gen", E), ("df", 10), ("R2", 0.5), ("Pi", 0.75)]
+    assert pos(B.emDE) == [("y", E), ("gen", E), ("R2", 0.5)]
+    for f in (B.emBL, B.emEN):
+        assert pos(f) == [("y", E), ("gen", E), ("R2", 0.5), ("alpha", 0.02)]
+    assert pos(B.emML) == [("y", E), ("gen", E), ("D", None)]
+    assert pos(B.lasso) == [("y", E), ("gen", E)]
