@@ -1083,7 +1083,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
   auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
   auto prow = [&](int k) { return k * (m - 1) - k * (k - 1) / 2; };   // offset of packed row k
   constexpr int NCH = (int)(sizeof(StageBuf) / 16), NSP = (int)(sizeof(SpecBuf) / 16);
-  static_assert(NCH <= 384 && NSP <= 384, "one chunk per thread of waves 1-6");
+  static_assert(NCH <= 2 * 320 && NSP <= 320, "at most two StageBuf chunks and one SpecBuf chunk per thread of waves 1-5");
 
   double *qsum = a.qpart + (size_t)S2_NSLOT * a.K * SW_MAXM;   // the feeder's sums, [S2_NSLOT][SW_MAXM] tagged words
   uint32_t *abortw = a.xflags + (size_t)a.K * SW_FLAG_STRIDE;
@@ -1122,17 +1122,20 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
     }
   };
   // the helpers' work for block c (c >= 1): everything block c needs that does not depend on block c-1's recurrence
-  uint4 spre = make_uint4(0, 0, 0, 0), cpre = spre;   // block c's constants, requested one phase earlier
+  uint4 spre = make_uint4(0, 0, 0, 0), spre2 = spre, cpre = spre;   // block c's constants, requested one phase earlier
   // block c's Gram chunks, requested one phase earlier (plain named locals: an aggregate would end up in scratch memory)
-  constexpr int NHELP = SW_THREADS - 128;   // waves 1-6 stage Gram blocks and constants; wave 7 polls (in-order vmcnt: a
-                                            // poll behind a wave's own prefetch loads would wait for them)
+  // one kind of memory traffic per helper wave (the memory counter returns in order, so whatever a wave has in flight is in
+  // front of its next result): waves 1-5 stage Gram blocks and constants (prefetch, a whole period to land), wave 6 reads
+  // the sparse cross-term rows, wave 7 polls the feeders' sums
+  constexpr int NHELP = SW_THREADS - 192;
   constexpr int PFULLCH = ((SW_MAXM * (SW_MAXM - 1) / 2 + 7) / 8 * 8) / GPT, XFULLCH = SW_MAXM * SW_MAXM / GPT;
   constexpr int PSURE = PFULLCH / NHELP, XSURE = XFULLCH / NHELP;   // at m = 128 every helper thread's first PSURE / XSURE chunks exist
-  static_assert((PFULLCH + NHELP - 1) / NHELP <= 3 && (XFULLCH + NHELP - 1) / NHELP <= 6, "named prefetch registers cover 3 + 6 chunks per helper thread");
-  uint4 gq0 = spre, gq1 = spre, gq2 = spre, xq0 = spre, xq1 = spre, xq2 = spre, xq3 = spre, xq4 = spre, xq5 = spre;
+  static_assert((PFULLCH + NHELP - 1) / NHELP <= 4 && (XFULLCH + NHELP - 1) / NHELP <= 7, "named prefetch registers cover 4 + 7 chunks per helper thread");
+  static_assert(NCH >= NHELP, "every staging thread owns one StageBuf chunk unconditionally");
+  uint4 gq0 = spre, gq1 = spre, gq2 = spre, gq3 = spre, xq0 = spre, xq1 = spre, xq2 = spre, xq3 = spre, xq4 = spre, xq5 = spre, xq6 = spre;
   const bool fullm = (m == SW_MAXM);
-#define S16_G_EACH(X) X(0, gq0) X(1, gq1) X(2, gq2)
-#define S16_X_EACH(X) X(0, xq0) X(1, xq1) X(2, xq2) X(3, xq3) X(4, xq4) X(5, xq5)
+#define S16_G_EACH(X) X(0, gq0) X(1, gq1) X(2, gq2) X(3, gq3)
+#define S16_X_EACH(X) X(0, xq0) X(1, xq1) X(2, xq2) X(3, xq3) X(4, xq4) X(5, xq5) X(6, xq6)
 #define S16_GLD(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < pchunks) name = gsrc[c_]; }
 #define S16_XLD(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < xchunks) name = xsrc[c_]; }
 #define S16_GST(u, name) { const int c_ = (tid - 64) + (u) * NHELP; if (c_ < pchunks) gdst[c_] = name; }
@@ -1144,31 +1147,31 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
   auto helper_phase = [&](int c) {
     const int blk = a.blk_begin + c, mBc = blk_m(c);
     S2ONE(48, tid == 64 && c == 100 + L); S2ONE(51, tid == 448 && c == 100 + L);
-    if (wave <= 6) {
-      // waves 1-6: block c's packed G, Gx and constants, in registers since the previous phase, go to LDS; block c+1's are
+    if (wave <= 5) {
+      // waves 1-5: block c's packed G, Gx and constants, in registers since the previous phase, go to LDS; block c+1's are
       // requested and have a whole period to land.  (Register staging moves ~60 GB/s through this CU, LDS-DMA only ~25.)
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): tells the compiler that no prefetch load is in flight
       uint4 *gdst = reinterpret_cast<uint4 *>(Q16_GP(c));
       uint4 *xdst = reinterpret_cast<uint4 *>(Q16_GX(c));
       if (fullm) { S16_G_EACH(S16_GST_F) S16_X_EACH(S16_XST_F) } else { S16_G_EACH(S16_GST) S16_X_EACH(S16_XST) }
-      if (tid - 64 < NCH) reinterpret_cast<uint4 *>(&stage[c & 1])[tid - 64] = spre;
+      reinterpret_cast<uint4 *>(&stage[c & 1])[tid - 64] = spre;                                   // NCH >= NHELP: every thread has one
+      if (tid - 64 < NCH - NHELP) reinterpret_cast<uint4 *>(&stage[c & 1])[NHELP + tid - 64] = spre2;
       if (tid - 64 < NSP) reinterpret_cast<uint4 *>(&specb[c & 1])[tid - 64] = cpre;
       S2ONE(49, tid == 64 && c == 100 + L);
       if (c + 1 < nb) {
         const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(blk + 1) * pstride);
         const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(blk + 1) * m * m);
         if (fullm) { S16_G_EACH(S16_GLD_F) S16_X_EACH(S16_XLD_F) } else { S16_G_EACH(S16_GLD) S16_X_EACH(S16_XLD) }
-        if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 1)[tid - 64];
+        spre = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 1)[tid - 64];
+        if (tid - 64 < NCH - NHELP) spre2 = reinterpret_cast<const uint4 *>(a.ps.blocks + blk + 1)[NHELP + tid - 64];
         if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + blk + 1)[tid - 64];
       }
       S2ONE(50, tid == 64 && c == 100 + L);
-    } else {
-      // wave 7 holds no prefetch.  Its cross-term loads go out first (they depend on nothing of this phase and are ahead of
-      // waves 1-6's prefetch in this CU's queue), then the feeder's sums are polled, then the cross term is finished.
-      // wave 7: block c-2's state (left in LDS by wave 0, which issues no global memory operation but the delta granules)
-      // block c's cross terms with blocks c-2 .. c-L+1 = speculated parts (k_spec) + the rows of Gx2_c / Gx3_c that those
-      // blocks' accepted markers touch, straight from global memory (the lists have been final since their barriers).
-      // Every load unconditional (clamped indices) and issued before the first use: one round trip per 8 accepted markers.
+    } else if (wave == 6) {
+      // wave 6: block c's cross terms with blocks c-2 .. c-L+1 = speculated parts (k_spec) + the rows of Gx2_c / Gx3_c that
+      // those blocks' accepted markers touch, straight from global memory (the lists have been final since their barriers,
+      // the last one since this phase began).  Every load unconditional (clamped indices) and issued before the first use:
+      // one round trip per 8 accepted markers; nothing else is on this wave's memory counter.
       double *dst = carry2 + (size_t)(c & 1) * SW_MAXM;
       const int ja = min(lane, m - 1), jb = min(64 + lane, m - 1);
       const bool on2 = (L > 2 && c >= 2), on3 = (L > 3 && c >= 3);
@@ -1200,16 +1203,19 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       };
       if (on2) batch_load(0);   // (gx3 is only dereferenced for list entries of block c-3, i.e. when on3)
       else { for (int u = 0; u < 8; ++u) { ga[u] = 0; gb[u] = 0; cf[u] = 0.0; } }
-      if (!poll_qsum(c, mBc)) ctrl_s[0] = 0;   // (the first batch of rows and the speculated parts are in flight)
-      S2WALL(10, tid == 448 && c >= L);
-      S2WALL(14, tid == 448 && c == 100 + L);
-      S2ONE(52, tid == 448 && c == 100 + L);
       batch_use();
       for (int i0 = 8; i0 < ntot; i0 += 8) { batch_load(i0); batch_use(); }
       cva += x2a; cvb += x2b; cva += x3a; cvb += x3b;
       dst[lane] = (lane < mBc) ? cva : 0.0;
       dst[64 + lane] = (64 + lane < mBc) ? cvb : 0.0;
-      S2ONE(53, tid == 448 && c == 100 + L);
+      S2ONE(53, tid == 384 && c == 100 + L);
+    } else {
+      // wave 7: the feeders' sums (nothing else is on its memory counter but the state stores of the previous phase), then
+      // block c-2's state (left in LDS by wave 0, which issues no global memory operation but the delta granules)
+      if (!poll_qsum(c, mBc)) ctrl_s[0] = 0;
+      S2WALL(10, tid == 448 && c >= L);
+      S2WALL(14, tid == 448 && c == 100 + L);
+      S2ONE(52, tid == 448 && c == 100 + L);
       if (c >= 2) store_state(c - 2);   // last: the next phase's poll is behind these stores only
       S2ONE(54, tid == 448 && c == 100 + L);
     }
@@ -1223,14 +1229,15 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
     for (int c = tid; c < NSP; c += SW_THREADS) reinterpret_cast<uint4 *>(&specb[0])[c] = reinterpret_cast<const uint4 *>(a.ps.spec + a.blk_begin)[c];
     if (tid < 16) ctrl_s[tid] = (tid == 0) ? 1 : 0;
     __syncthreads();
-    if (wave >= 1 && wave <= 6) {
+    if (wave >= 1 && wave <= 5) {
       if (nb > 1) {
-        if (tid - 64 < NCH) spre = reinterpret_cast<const uint4 *>(a.ps.blocks + a.blk_begin + 1)[tid - 64];
+        spre = reinterpret_cast<const uint4 *>(a.ps.blocks + a.blk_begin + 1)[tid - 64];
+        if (tid - 64 < NCH - NHELP) spre2 = reinterpret_cast<const uint4 *>(a.ps.blocks + a.blk_begin + 1)[NHELP + tid - 64];
         if (tid - 64 < NSP) cpre = reinterpret_cast<const uint4 *>(a.ps.spec + a.blk_begin + 1)[tid - 64];
       }
     }
     if (wave == 7) { if (!poll_qsum(0, mB0)) ctrl_s[0] = 0; }
-    if (wave >= 1 && wave <= 6 && nb > 1) {
+    if (wave >= 1 && wave <= 5 && nb > 1) {
       const uint4 *gsrc = reinterpret_cast<const uint4 *>(gramp + (size_t)(a.blk_begin + 1) * pstride);
       const uint4 *xsrc = reinterpret_cast<const uint4 *>(gramx + (size_t)(a.blk_begin + 1) * m * m);
       if (fullm) { S16_G_EACH(S16_GLD_F) S16_X_EACH(S16_XLD_F) } else { S16_G_EACH(S16_GLD) S16_X_EACH(S16_XLD) }

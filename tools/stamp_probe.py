@@ -43,8 +43,8 @@ for key in sys.argv[1:] or ["c2", "c4s"]:
             mm = lambda k: ((~oo[k]) & 0xFFFFFFFFFFFFFFFF)
             print("   over all streamers (us after delta_100 stored): delta_100 seen first %.2f / last %.2f;  q_{100+lag} stored first %.2f / last %.2f"
                   % ((mm(58) - t0) / 100.0, (oo[59] - t0) / 100.0, (mm(56) - t0) / 100.0, (oo[57] - t0) / 100.0))
-            print("   sequencer helper phase for block 100+lag (us after it starts, i.e. after the barrier of block 98+lag): waves 1-6: Gram/constant stores done %.2f, next "
-                  "loads issued %.2f;  wave 7: sum of q polled %.2f, lag-3 cross term %.2f, state of block 98+lag stored %.2f;  barrier of block 99+lag at %.2f)" % tuple((x - oo[48]) / 100.0 for x in (oo[49], oo[50], oo[52], oo[53], oo[54], oo[55])))
+            print("   sequencer helper phase for block 100+lag (us after it starts, i.e. after the barrier of block 98+lag): waves 1-5: Gram/constant stores done %.2f, next "
+                  "loads issued %.2f;  wave 7: sum of q polled %.2f; wave 6: cross terms done %.2f; wave 7: state of block 98+lag stored %.2f;  barrier of block 99+lag at %.2f)" % tuple((x - oo[48]) / 100.0 for x in (oo[49], oo[50], oo[52], oo[53], oo[54], oo[55])))
     else:
         for nm, x in zip(names, v): print("   %-50s %9.0f ticks/block" % (nm, x / nblk))
     ms, nl = ch.sweep_ms(); print("   sweep ms", ms)
