@@ -749,6 +749,8 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
         lc[q].u = live ? st.u[t] : 2.0; lc[q].gjj = live ? sb.gjj[t] : 0.0;
       }
       S2STAMP(5);
+      // affine models: the recurrence's variable, the un-rounded draw t = (r + xx*b0)*rden + sd*z
+      double u[2] = {fma(r[0] + (double)lc[0].xxb0, lc[0].rden, lc[0].sdz1), fma(r[1] + (double)lc[1].xxb0, lc[1].rden, lc[1].sdz1)};
       // packed row k: entry for marker j (> k) sits at prow(k) + j - k - 1
       auto gat = [&](int k, int j) -> GT { return (j > k && j < m) ? gp[prow(k) + j - k - 1] : (GT)0; };
       unsigned long long accmask[2] = {0ull, 0ull};
@@ -777,35 +779,44 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
                 r[q] = fma(-(double)g0, dd, r[q]);
                 if (two) r[1] = fma(-(double)g1, dd, r[1]);
               }
-            } else if (q == 0 && ngrp > 1) {
-              GT gn0 = gp[oA + lane], gn1 = gp[oB + lane];
-              // eight markers per trip (cnt = 64 except in the last block): the serial chain is ~24 instructions per marker on
-              // one wave, and with one marker per trip its speed followed the loop's placement in the instruction-fetch lines
-#define S2_AFFINE_STEP2(l_) { \
-                const GT g0 = (lane > (l_)) ? gn0 : (GT)0, g1 = gn1; \
-                oA += m - 2 - (base + (l_)); oB += m - 2 - (base + (l_)); \
-                gn0 = gp[oA + lane]; gn1 = gp[oB + lane];          /* next row (slack makes the last one harmless) */ \
-                const float dl = lane_b1(r[0], lc[0]) - lc[0].b0; \
-                const double dd = (double)readlane_f32(dl, (l_)); \
-                r[0] = fma(-(double)g0 * dscale, dd, r[0]); \
-                r[1] = fma(-(double)g1 * dscale, dd, r[1]); }
-              int l = 0;
-              for (; l + 8 <= cnt; l += 8) { S2_AFFINE_STEP2(l) S2_AFFINE_STEP2(l + 1) S2_AFFINE_STEP2(l + 2) S2_AFFINE_STEP2(l + 3) S2_AFFINE_STEP2(l + 4) S2_AFFINE_STEP2(l + 5) S2_AFFINE_STEP2(l + 6) S2_AFFINE_STEP2(l + 7) }
-              for (; l < cnt; ++l) S2_AFFINE_STEP2(l)
-#undef S2_AFFINE_STEP2
             } else {
-              GT gn0 = gp[oA + lane];
-#define S2_AFFINE_STEP1(l_) { \
-                const GT g0 = (lane > (l_)) ? gn0 : (GT)0; \
-                oA += m - 2 - (base + (l_)); \
-                gn0 = gp[oA + lane]; \
-                const float dl = lane_b1(r[q], lc[q]) - lc[q].b0; \
+              // Affine models.  The recurrence runs on t = (r + xx*b0)*rden + sd*z, the un-rounded draw itself: a step's update
+              // r -= g*delta becomes t -= (g*rden)*delta with g*rden formed off the chain, which leaves five dependent
+              // operations per marker (fma, cvt, sub, readlane, cvt) instead of seven; eight markers per trip (with one per trip its speed followed the loop's placement in the
+              // instruction-fetch lines), and the packed Gram rows are read FOUR markers ahead: with the next row requested only
+              // one step ahead, every step waited out the LDS latency (~100 cycles) instead of its own ~50-cycle chain.
+              // Row k's offsets advance by m - 2 - k; the buffers' slack makes the reads past the last row harmless.
+              const bool two = (q == 0 && ngrp > 1);
+              double ua = u[q], ub = two ? u[1] : 0.0;
+              const double sclA = dscale * lc[q].rden, sclB = two ? dscale * lc[1].rden : 0.0; const float b0q = lc[q].b0;
+              int oL = oA;   // offset (+ lane) of the next row to request
+              GT ga0, ga1, ga2, ga3, gb0 = (GT)0, gb1 = (GT)0, gb2 = (GT)0, gb3 = (GT)0;
+#define S2_AFFINE_STEP(TWO_, l_, GA, GB) { \
+                const GT g0 = (lane > (l_)) ? GA : (GT)0, g1 = GB; \
+                GA = gp[oL + lane]; if (TWO_) GB = gp[oL + 64 + lane]; oL += m - 2 - (base + (l_) + 4);   /* row l + 4 */ \
+                const float dl = (float)ua - b0q; \
                 const double dd = (double)readlane_f32(dl, (l_)); \
-                r[q] = fma(-(double)g0 * dscale, dd, r[q]); }
-              int l = 0;
-              for (; l + 8 <= cnt; l += 8) { S2_AFFINE_STEP1(l) S2_AFFINE_STEP1(l + 1) S2_AFFINE_STEP1(l + 2) S2_AFFINE_STEP1(l + 3) S2_AFFINE_STEP1(l + 4) S2_AFFINE_STEP1(l + 5) S2_AFFINE_STEP1(l + 6) S2_AFFINE_STEP1(l + 7) }
-              for (; l < cnt; ++l) S2_AFFINE_STEP1(l)
-#undef S2_AFFINE_STEP1
+                ua = fma(-(double)g0 * sclA, dd, ua); \
+                if (TWO_) ub = fma(-(double)g1 * sclB, dd, ub); }
+#define S2_AFFINE_LOOP(TWO_) { \
+                ga0 = gp[oL + lane]; if (TWO_) gb0 = gp[oL + 64 + lane]; oL += m - 2 - (base + 0); \
+                ga1 = gp[oL + lane]; if (TWO_) gb1 = gp[oL + 64 + lane]; oL += m - 2 - (base + 1); \
+                ga2 = gp[oL + lane]; if (TWO_) gb2 = gp[oL + 64 + lane]; oL += m - 2 - (base + 2); \
+                ga3 = gp[oL + lane]; if (TWO_) gb3 = gp[oL + 64 + lane]; oL += m - 2 - (base + 3); \
+                int l = 0; \
+                for (; l + 8 <= cnt; l += 8) { \
+                  S2_AFFINE_STEP(TWO_, l, ga0, gb0) S2_AFFINE_STEP(TWO_, l + 1, ga1, gb1) S2_AFFINE_STEP(TWO_, l + 2, ga2, gb2) S2_AFFINE_STEP(TWO_, l + 3, ga3, gb3) \
+                  S2_AFFINE_STEP(TWO_, l + 4, ga0, gb0) S2_AFFINE_STEP(TWO_, l + 5, ga1, gb1) S2_AFFINE_STEP(TWO_, l + 6, ga2, gb2) S2_AFFINE_STEP(TWO_, l + 7, ga3, gb3) \
+                } \
+                for (; l < cnt; ++l) {   /* the last, partial block: rotate the four rows through ga0 / gb0 */ \
+                  S2_AFFINE_STEP(TWO_, l, ga0, gb0) \
+                  const GT ta = ga0, tb = gb0; \
+                  ga0 = ga1; ga1 = ga2; ga2 = ga3; ga3 = ta; gb0 = gb1; gb1 = gb2; gb2 = gb3; gb3 = tb; \
+                } }
+              if (two) S2_AFFINE_LOOP(1) else S2_AFFINE_LOOP(0)
+#undef S2_AFFINE_LOOP
+#undef S2_AFFINE_STEP
+              u[q] = ua; if (two) u[1] = ub;   // (group 1 continues from here)
             }
           } else {
             int front = 0;
@@ -835,7 +846,9 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
         const int t = 64 * q + lane;
         if (t < mB) {
           float dem = 1.0f;
-          const float b1 = (!SELECT && emflags) ? lane_em(r[q], lc[q], emflags, Cc, odds, L1, &dem) : lane_b1(r[q], lc[q]);
+          const float b1 = SELECT ? lane_b1(r[q], lc[q])
+                         : emflags ? lane_em(r[q], lc[q], emflags, Cc, odds, L1, &dem)
+                                   : (float)u[q];   // exactly the value the recurrence used
           const bool inc = SELECT ? (((accmask[q] >> lane) & 1ull) != 0ull) : true;
           const float bn = inc ? b1 : lc[q].b2;
           const float dn = inc ? dem : 0.0f;
