@@ -313,23 +313,25 @@ __device__ __forceinline__ float lane_em(double r, const LaneConst &c, int flags
     return b1 * d;
   }
   *dout = 1.0f;
+  // the soft thresholds, branch-free (the sign of the OLS term picks the side of the threshold and of the clamp)
   if (flags & SWF_EM_LASSO) {
     const double yx = fma(c.gjj, (double)c.b0, r);          // e += gen.col(j)*b[j]; yx[j] = e.dot(gen.col(j))  (x.x = G_jj)
     *dout = (float)yx;
-    if (yx > 0.0) { const float b1 = (float)((yx - (double)L1) * c.rden); return b1 < 0.0f ? 0.0f : b1; }
-    const float b1 = (float)((yx + (double)L1) * c.rden);
-    return b1 > 0.0f ? 0.0f : b1;
+    const bool pos = yx > 0.0;
+    const float b1 = (float)((yx - (pos ? (double)L1 : -(double)L1)) * c.rden);
+    return pos ? fmaxf(b1, 0.0f) : fminf(b1, 0.0f);
   }
+  const bool pos = ols > 0.0;
+  const double sl = pos ? (double)L1 : -(double)L1;
   if (flags & SWF_EM_EN) {
-    if (ols > 0.0) { const float b1 = (float)((ols - (double)L1) * c.rden); return b1 < 0.0f ? 0.0f : b1; }
-    const float b1 = (float)((ols + (double)L1) * c.rden);
-    return b1 > 0.0f ? 0.0f : b1;
+    const float b1 = (float)((ols - sl) * c.rden);
+    return pos ? fmaxf(b1, 0.0f) : fminf(b1, 0.0f);
   }
   // SWF_EM_BL
   const double half = 0.5 * ols * c.sdz1;                   // Half_L2 = 0.5*OLS/(xx+cxx)
-  if (ols > 0.0) { const double G = 0.5 * (ols - (double)L1) * c.rden; return (float)(G > 0.0 ? G + half : half); }
-  const double G = 0.5 * (ols + (double)L1) * c.rden;
-  return (float)(G < 0.0 ? G + half : half);
+  const double G = 0.5 * (ols - sl) * c.rden;
+  const bool keep = pos ? (G > 0.0) : (G < 0.0);
+  return (float)(keep ? G + half : half);
 }
 __device__ __forceinline__ bool lane_accept(double r, float b1, const LaneConst &c, int flags, float Cc, float odds,
                                             float one_minus_pi) {

@@ -763,22 +763,44 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
             // packed row k = base+l: own-group entry of lane at oA + lane (needed only for lane > l), other-group entry
             // (q == 0: marker 64+lane) at oB + lane.  The buffers carry slack, so loads are unconditional; the own-group
             // value is masked, the other-group value of dead lanes (marker >= m) only feeds registers nobody reads.
-            int oA = prow(base) - 1, oB = prow(base) + 63;   // + lane, at l = 0
+            const int oA = prow(base) - 1;   // + lane: own-group entry of packed row `base`; the other group's is 64 further
             if (emflags) {
-              // the EM family's non-affine updates: the same lane-ordered recurrence, one marker per trip (the update has an
-              // exponential or a threshold on its dependent chain, so the trip is not fetch-bound like the affine one)
+              // the EM family's non-affine updates (lane_em): the same lane-ordered recurrence on r, four markers per trip, Gram rows
+              // read four markers ahead, loops specialised for one / two lane groups (as the affine loop below)
               const bool two = (q == 0 && ngrp > 1);
-              GT gn0 = gp[oA + lane], gn1 = gp[oB + lane];
-              for (int l = 0; l < cnt; ++l) {
-                const GT g0 = (lane > l) ? gn0 : (GT)0, g1 = gn1;
-                oA += m - 2 - (base + l); oB += m - 2 - (base + l);
-                gn0 = gp[oA + lane]; gn1 = gp[oB + lane];
-                float dtmp;
-                const float dl = lane_em(r[q], lc[q], emflags, Cc, odds, L1, &dtmp) - lc[q].b0;
-                const double dd = (double)readlane_f32(dl, l);
-                r[q] = fma(-(double)g0, dd, r[q]);
-                if (two) r[1] = fma(-(double)g1, dd, r[1]);
-              }
+              double ra = r[q], rb = two ? r[1] : 0.0;
+              int oL = oA;
+              GT ga0, ga1, ga2, ga3, gb0 = (GT)0, gb1 = (GT)0, gb2 = (GT)0, gb3 = (GT)0;
+#define S2_EM_STEP(TWO_, MODE_, l_, GA, GB) { \
+                const GT g0 = (lane > (l_)) ? GA : (GT)0, g1 = GB; \
+                GA = gp[oL + lane]; if (TWO_) GB = gp[oL + 64 + lane]; oL += m - 2 - (base + (l_) + 4); \
+                float dtmp; \
+                const float dl = lane_em(ra, lc[q], (MODE_), Cc, odds, L1, &dtmp) - lc[q].b0; \
+                const double dd = (double)readlane_f32(dl, (l_)); \
+                ra = fma(-(double)g0, dd, ra); \
+                if (TWO_) rb = fma(-(double)g1, dd, rb); }
+#define S2_EM_LOOP(TWO_, MODE_) { \
+                ga0 = gp[oL + lane]; if (TWO_) gb0 = gp[oL + 64 + lane]; oL += m - 2 - (base + 0); \
+                ga1 = gp[oL + lane]; if (TWO_) gb1 = gp[oL + 64 + lane]; oL += m - 2 - (base + 1); \
+                ga2 = gp[oL + lane]; if (TWO_) gb2 = gp[oL + 64 + lane]; oL += m - 2 - (base + 2); \
+                ga3 = gp[oL + lane]; if (TWO_) gb3 = gp[oL + 64 + lane]; oL += m - 2 - (base + 3); \
+                int l = 0; \
+                for (; l + 4 <= cnt; l += 4) { S2_EM_STEP(TWO_, MODE_, l, ga0, gb0) S2_EM_STEP(TWO_, MODE_, l + 1, ga1, gb1) S2_EM_STEP(TWO_, MODE_, l + 2, ga2, gb2) S2_EM_STEP(TWO_, MODE_, l + 3, ga3, gb3) } \
+                for (; l < cnt; ++l) { \
+                  S2_EM_STEP(TWO_, MODE_, l, ga0, gb0) \
+                  const GT ta = ga0, tb = gb0; \
+                  ga0 = ga1; ga1 = ga2; ga2 = ga3; ga3 = ta; gb0 = gb1; gb1 = gb2; gb2 = gb3; gb3 = tb; \
+                } }
+              // one copy of the loop per member class, so that lane_em's mode tests fold away
+#define S2_EM_BOTH(MODE_) { if (two) S2_EM_LOOP(1, MODE_) else S2_EM_LOOP(0, MODE_) }
+              if (emflags & SWF_EM_SEL) S2_EM_BOTH(SWF_EM_SEL)
+              else if (emflags & SWF_EM_EN) S2_EM_BOTH(SWF_EM_EN)
+              else if (emflags & SWF_EM_BL) S2_EM_BOTH(SWF_EM_BL)
+              else S2_EM_BOTH(SWF_EM_LASSO)
+#undef S2_EM_BOTH
+#undef S2_EM_LOOP
+#undef S2_EM_STEP
+              r[q] = ra; if (two) r[1] = rb;
             } else {
               // Affine models.  The recurrence runs on t = (r + xx*b0)*rden + sd*z, the un-rounded draw itself: a step's update
               // r -= g*delta becomes t -= (g*rden)*delta with g*rden formed off the chain, which leaves five dependent
