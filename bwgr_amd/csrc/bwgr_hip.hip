@@ -1066,7 +1066,8 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
     const char *sv = getenv("BWGR_SWEEP");
     int R2 = 0;
     for (int Rt = 128; Rt <= Rmax; Rt += 128)
-      if ((P->is_f32 ? sweep2_lds_bytes<float>(m, Rt) : sweep2_lds_bytes<int8_t>(m, Rt)) <= (size_t)160 * 1024) R2 = Rt;
+      if ((P->is_f32 ? sweep2_lds_bytes<float>(m, Rt) : sweep2_lds_bytes<int8_t>(m, Rt)) <= (size_t)160 * 1024 &&
+          (P->is_f32 || (size_t)m * Rt <= S2I_TILE_BYTES_MAX)) R2 = Rt;   // (an int8 tile must fit its movers' registers)
     if (!(sv && sv[0] == '1') && R2 > 0 && (n + R2 - 1) / R2 + 1 + 6 <= 256) Rpick = R2;
   }
   int K = nwg > 0 ? nwg : (int)((n + Rpick - 1) / Rpick);
@@ -1090,6 +1091,7 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
     P->nfeed = std::min(6, std::max(2, (K + 39) / 40 + 1));   // K = 40: 2, K = 79: 3, K >= 161: 6
     if (const char *nf = getenv("BWGR_NFEED")) { const int v = atoi(nf); if (v >= 1 && v <= 6) P->nfeed = v; }   // experiments
     if (P->lds2_bytes > (size_t)160 * 1024 || K + 1 + P->nfeed > 256) P->sweep_version = 1;
+    if (!P->is_f32 && (size_t)m * R > S2I_TILE_BYTES_MAX) P->sweep_version = 1;
   }
   P->x_bytes = (size_t)P->ld * (size_t)p * (P->is_f32 ? 4 : 1);
   P->gram_bytes = (size_t)P->nblocks * m * m * (P->is_f32 ? 8 : 4);   // per Gram array (diagonal blocks; off-diagonal blocks)
@@ -1125,8 +1127,8 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipMalloc(&P->dgran, sizeof(unsigned long long) * S2_NSLOT * SW_MAXM));
   PCHK(hipMalloc(&P->ps.blocks, sizeof(StageBuf) * (size_t)P->nblocks));
 #ifdef BWGR_STAMPS
-  PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 64));
-  PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 64));
+  PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 256));
+  PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 256));
 #endif
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<int8_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<int8_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1164,9 +1166,9 @@ extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int
 
 #ifdef BWGR_STAMPS
 // diagnostic build only: cumulative per-phase s_memtime ticks of workgroup 0 (not part of include/bwgr.h)
-extern "C" int bwgr_debug_stamps(bwgr_panel *P, unsigned long long out[64]) {
-  HIPCHK(d2h(P->stream, out, P->stamps, sizeof(unsigned long long) * 64));
-  HIPCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 64));
+extern "C" int bwgr_debug_stamps(bwgr_panel *P, unsigned long long out[256]) {
+  HIPCHK(d2h(P->stream, out, P->stamps, sizeof(unsigned long long) * 256));
+  HIPCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 256));
   return BWGR_OK;
 }
 #endif
@@ -1195,8 +1197,8 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   PCHK(hipMalloc(&P->qpart, sizeof(double) * S2_NSLOT * ((size_t)K + 1) * SW_MAXM));
   PCHK(hipMalloc(&P->dgran, sizeof(unsigned long long) * S2_NSLOT * SW_MAXM));
 #ifdef BWGR_STAMPS
-  PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 64));
-  PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 64));
+  PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 256));
+  PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 256));
 #endif
   PCHK(hipStreamCreateWithFlags(&P->own_stream, hipStreamNonBlocking));
 #undef PCHK

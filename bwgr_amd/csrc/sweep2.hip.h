@@ -85,16 +85,20 @@ __device__ __forceinline__ void s2_put_q(double *slot, double v, int b) {
 #define S2_TILE_COMMIT(dstp, mB_) do { XT *dst_ = (dstp); const int cpr_ = R / PER; const int tot_ = (mB_) * cpr_; \
     const float rcpr_ = 1.0f / (float)cpr_; __builtin_amdgcn_s_waitcnt(0x0F70); BWGR_TILE_EACH(S2_COMMIT1) } while (0)
 
-// int8 streamer: the tile moves belong to waves 2-7 (384 threads, six chunks each) so that waves 0-1, which poll the delta
-// granules, never have a tile load in flight: the vmcnt counter is in order, and a poll behind tile loads waits for them
-#define S2I_TILE_EACH(X) X(0, tp0) X(1, tp1) X(2, tp2) X(3, tp3) X(4, tp4) X(5, tp5)
-#define S2I_ISSUE1(u, name) { const int c_ = (tid - 128) + (u) * (SW_THREADS - 128); if (c_ < tot_) name = src_[c_]; }
-#define S2I_TILE_ISSUE(j0_, mB_) do { if (tid >= 128) { const int tot_ = (mB_) * (R / PER); __builtin_amdgcn_s_waitcnt(0x0F70); \
+// int8 streamer: the tile moves belong to waves 4-7 (256 threads, eight chunks each).  Waves 0-1 poll the delta granules and
+// must never have a tile load in flight (the vmcnt counter is in order: a poll behind tile loads waits for them); waves 0-3
+// carry the e update and the digit split, so with the movers kept apart the commit runs beside the e update and the
+// ~600 cycles of load issue beside the e digits, instead of both in front of the e-update barrier
+#define S2I_MOVERS 256
+static constexpr size_t S2I_TILE_BYTES_MAX = (size_t)8 * 16 * (SW_THREADS - S2I_MOVERS);   // eight 16-byte chunks per mover thread
+#define S2I_TILE_EACH(X) X(0, tp0) X(1, tp1) X(2, tp2) X(3, tp3) X(4, tp4) X(5, tp5) X(6, tp6) X(7, tp7)
+#define S2I_ISSUE1(u, name) { const int c_ = (tid - S2I_MOVERS) + (u) * (SW_THREADS - S2I_MOVERS); if (c_ < tot_) name = src_[c_]; }
+#define S2I_TILE_ISSUE(j0_, mB_) do { if (tid >= S2I_MOVERS) { const int tot_ = (mB_) * (R / PER); __builtin_amdgcn_s_waitcnt(0x0F70); \
     const uint4 *src_ = reinterpret_cast<const uint4 *>(X + (size_t)(j0_) * R); S2I_TILE_EACH(S2I_ISSUE1) } } while (0)
-#define S2I_COMMIT1(u, name) { const int c_ = (tid - 128) + (u) * (SW_THREADS - 128); if (c_ < tot_) { \
+#define S2I_COMMIT1(u, name) { const int c_ = (tid - S2I_MOVERS) + (u) * (SW_THREADS - S2I_MOVERS); if (c_ < tot_) { \
     const int jj_ = (int)(((float)c_ + 0.5f) * rcpr_), ii_ = c_ - jj_ * cpr_; \
     *reinterpret_cast<uint4 *>((dst_) + (size_t)jj_ * Rp + ii_ * PER) = name; } }
-#define S2I_TILE_COMMIT(dstp, mB_) do { if (tid >= 128) { XT *dst_ = (dstp); const int cpr_ = R / PER; const int tot_ = (mB_) * cpr_; \
+#define S2I_TILE_COMMIT(dstp, mB_) do { if (tid >= S2I_MOVERS) { XT *dst_ = (dstp); const int cpr_ = R / PER; const int tot_ = (mB_) * cpr_; \
     const float rcpr_ = 1.0f / (float)cpr_; __builtin_amdgcn_s_waitcnt(0x0F70); S2I_TILE_EACH(S2I_COMMIT1) } } while (0)
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -326,7 +330,7 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
   auto blk_j0 = [&](int b) { return (a.blk_begin + b) * m; };
   auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
 
-  uint4 tp0 = make_uint4(0, 0, 0, 0), tp1 = tp0, tp2 = tp0, tp3 = tp0, tp4 = tp0, tp5 = tp0;
+  uint4 tp0 = make_uint4(0, 0, 0, 0), tp1 = tp0, tp2 = tp0, tp3 = tp0, tp4 = tp0, tp5 = tp0, tp6 = tp0, tp7 = tp0;
   for (int i = tid; i < 4 * Rp; i += SW_THREADS) reinterpret_cast<uint32_t *>(edig_s)[i] = 0u;
   for (int i = tid; i < 4 * S2_DP; i += SW_THREADS) reinterpret_cast<uint32_t *>(ddig_s)[i] = 0u;
   if (tid < 16) ctl_s[tid] = 0u;
@@ -335,6 +339,9 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
   __syncthreads();
   S2STAMP_DECL;
   S2WALL_DECL;
+#ifdef BWGR_STAMPS
+  unsigned long long wseen = 0, wq = 0;   // per-streamer wall-clock sums: delta_i seen, q_{i+L} stored
+#endif
 
   // digits of the e slab relative to the maximum exponent field recorded in ctl_s[2 + epar]; returns 1/S
   auto e_digits = [&](int epar) -> double {
@@ -376,6 +383,9 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
       rowp[0] = make_uint4(0, 0, 0, 0); rowp[1] = make_uint4(0, 0, 0, 0); rowp[2] = make_uint4(0, 0, 0, 0);
     }
     S2WALL(2, wg == 0 && tid == 0 && b >= a.lag);
+#ifdef BWGR_STAMPS
+    if (tid == 0 && b >= a.lag) wq += (unsigned long long)wall_clock64();
+#endif
     S2WALL(6, wg == 0 && tid == 0 && b == 100 + a.lag);
     S2MINMAX(56, 57, tid == 128 && b == 100 + a.lag);
   };
@@ -428,10 +438,17 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     S2STAMP(11);
     __syncthreads();
     S2WALL(1, wg == 0 && tid == 0 && i + L < nb);
+#ifdef BWGR_STAMPS
+    if (tid == 0 && i + L < nb) wseen += (unsigned long long)wall_clock64();
+#endif
     S2WALL(4, wg == 0 && tid == 0 && i == 100);
     S2MINMAX(58, 59, tid == 0 && i == 100);
     S2WALL(5, wg == 0 && tid == 0 && i == 101);
     if (ctl_s[8]) { if (tid == 0) a.sc->error = 1u; return; }
+    // first request for delta_{i+1}, a whole iteration ahead of its use: a streamer that runs behind the sequencer (the ones
+    // that set the pace) finds it there already, and the load's latency -- ~2 us on a CU whose memory queue also carries the
+    // tile stream -- is off its iteration; the others ask again after the update (below)
+    if (tid < SW_MAXM && i + 1 < nb) pre = (tid < blk_m(i + 1)) ? ld_agent_raw64(a.dgran + (size_t)((i + 1) % S2_NSLOT) * SW_MAXM + tid) : 0ull;
     const double invSd = pow2_field(851 + (int)ctl_s[par]);
     S2STAMP(1);
     S2STAMP(2);
@@ -490,11 +507,16 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
     // tile(i)), and the loads of tile(i+L+1) go out at once: they must have landed before the next iteration's poll (the
     // vmcnt counter is in order, so a poll behind 32 KB of tile loads pays for them; issued after the publish they cost
     // 10 % of the sweep)
+#ifdef BWGR_STAMPS
+    unsigned long long w4t = 0; if (wg == 0 && tid == 256 && i == 100) w4t = wall_clock64();
+#endif
     if (i + L < nb) S2I_TILE_COMMIT(S2I_TILE(i + L), blk_m(i + L));
+#ifdef BWGR_STAMPS
+    if (wg == 0 && tid == 256 && i == 100) wl2[8] += (wall_clock64() - w4t);
+#endif
     // early request for delta_{i+1} (older than the tile loads below, so the in-order vmcnt lets it be consumed first)
-    if (tid < SW_MAXM && i + 1 < nb) pre = (tid < blk_m(i + 1)) ? ld_agent_raw64(a.dgran + (size_t)((i + 1) % S2_NSLOT) * SW_MAXM + tid) : 0ull;
+    if (tid < SW_MAXM && i + 1 < nb && tid < blk_m(i + 1) && !s2_dgranule_is(pre, i + 1)) pre = ld_agent_raw64(a.dgran + (size_t)((i + 1) % S2_NSLOT) * SW_MAXM + tid);
     S2STAMP(9);
-    if (i + L + 1 < nb) S2I_TILE_ISSUE(blk_j0(i + L + 1), blk_m(i + L + 1));
     S2STAMP(0);
     {
       uint32_t ex = 0u;
@@ -512,6 +534,14 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
       if (lane == 0) atomicMax(&ctl_s[2 + par], ex);
     }
     __syncthreads();
+#ifdef BWGR_STAMPS
+    if (wg == 0 && tid == 256 && i == 100) wl2[15] += (wall_clock64() - w4t);
+#endif
+    // the loads of tile(i+L+1) go out behind the barrier, under the e digits (waves 0-3)
+    if (i + L + 1 < nb) S2I_TILE_ISSUE(blk_j0(i + L + 1), blk_m(i + L + 1));
+#ifdef BWGR_STAMPS
+    if (wg == 0 && tid == 256 && i == 100) wl2[8] += (wall_clock64() - w4t) << 32;
+#endif
     S2STAMP(5);
     if (i + L < nb) {
       const double invSe = e_digits(par);
@@ -524,6 +554,9 @@ __device__ __forceinline__ void s2_streamer_i8(const SweepArgs &a) {
   }
   if (wg == 0) S2STAMP_FLUSH(0);
   S2WALL_FLUSH;
+#ifdef BWGR_STAMPS
+  if (tid == 0 && a.stamps) { a.stamps[64 + wg] += wseen; a.stamps[128 + wg] += wq; }
+#endif
   __syncthreads();
   for (int i = tid; i < R; i += SW_THREADS) a.e[row0 + i] = e_s[i];
 }

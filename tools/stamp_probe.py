@@ -21,7 +21,7 @@ for key in sys.argv[1:] or ["c2", "c4s"]:
     P = bwgr_amd.Panel(X, n=n); del X
     ch = bwgr_amd.Chain(P, model, y, it=4, bi=0, pi=pi, seed=1)
     ch.run(1); ch.sync()
-    out = (C.c_ulonglong * 64)(); _lib.lib().bwgr_debug_stamps(P._h, out)
+    out = (C.c_ulonglong * 256)(); _lib.lib().bwgr_debug_stamps(P._h, out)
     ch.run(3); ch.sync()
     _lib.lib().bwgr_debug_stamps(P._h, out)
     v = np.array(list(out), float); nblk = 3 * ((p + P.block - 1) // P.block)
@@ -34,7 +34,7 @@ for key in sys.argv[1:] or ["c2", "c4s"]:
         if pi:   # selection models: lag-3 pipeline with the q feeder (wall clock, 100 MHz)
             print("   means (us): delta_i stored -> seen by streamer 0 %.2f -> streamer 0 stores q_{i+lag} %.2f -> feeder puts the sum %.2f -> sequencer has it %.2f"
                   % (hw[1] - hw[0], hw[2] - hw[0], hw[3] - hw[0], hw[10] - hw[0]))
-            one = (C.c_ulonglong * 64)(); ch2 = bwgr_amd.Chain(P, model, y, it=2, bi=0, pi=pi, seed=2)
+            one = (C.c_ulonglong * 256)(); ch2 = bwgr_amd.Chain(P, model, y, it=2, bi=0, pi=pi, seed=2)
             ch2.run(1); ch2.sync(); _lib.lib().bwgr_debug_stamps(P._h, one); ch2.run(1); ch2.sync(); _lib.lib().bwgr_debug_stamps(P._h, one); ch2.close()
             oo = [int(x) for x in list(one)]; o = oo[32:48]; t0 = o[7]
             print("   one sweep, around block 100 (us after the sequencer stores delta_100): streamer 0 sees delta_100 %.2f, stores q_{100+lag} %.2f, sees delta_101 %.2f; "
@@ -45,6 +45,13 @@ for key in sys.argv[1:] or ["c2", "c4s"]:
                   % ((mm(58) - t0) / 100.0, (oo[59] - t0) / 100.0, (mm(56) - t0) / 100.0, (oo[57] - t0) / 100.0))
             print("   sequencer helper phase for block 100+lag (us after it starts, i.e. after the barrier of block 98+lag): waves 1-5: Gram/constant stores done %.2f, next "
                   "loads issued %.2f;  wave 7: sum of q polled %.2f; wave 6: cross terms done %.2f; wave 7: state of block 98+lag stored %.2f;  barrier of block 99+lag at %.2f)" % tuple((x - oo[48]) / 100.0 for x in (oo[49], oo[50], oo[52], oo[53], oo[54], oo[55])))
+            nn = nblk - 3 * lag
+            seen = [(v[64 + w] / nn - v[32] / nn) / 100.0 for w in range(P.nwg)]   # mean (delta_i seen by w) - (delta_i stored)
+            work = [(v[128 + w] - v[64 + w]) / nn / 100.0 for w in range(P.nwg)]    # mean (q_{i+lag} stored) - (delta_i seen)
+            print("   per streamer, mean us: delta_i stored -> seen:", " ".join("%.2f" % x for x in seen))
+            print("   per streamer, mean us: seen -> q_{i+lag} stored:", " ".join("%.2f" % x for x in work))
+            print("   streamer 0, wave 4, block 100 (us after the update barrier): tile commit done %.2f, next tile's loads issued %.2f (behind the e-update barrier, passed at %.2f)"
+                  % ((o[8] & 0xFFFFFFFF) / 100.0, (o[8] >> 32) / 100.0, o[15] / 100.0))
     else:
         for nm, x in zip(names, v): print("   %-50s %9.0f ticks/block" % (nm, x / nblk))
     ms, nl = ch.sweep_ms(); print("   sweep ms", ms)
