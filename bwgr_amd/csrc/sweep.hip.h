@@ -112,7 +112,8 @@ template <typename XT> __host__ __device__ inline int tile_rp(int R) { return R 
 
 struct StageBuf {               // per-block per-marker constants, lane = marker
   float b0[SW_MAXM], xxb0[SW_MAXM], b2[SW_MAXM], drej[SW_MAXM];
-  double rden[SW_MAXM], sdz1[SW_MAXM], u[SW_MAXM], chi[SW_MAXM];
+  double rden[SW_MAXM], sdz1[SW_MAXM], chi[SW_MAXM];
+  float tacc[SW_MAXM], trej[SW_MAXM];   // selection models: the uniform turned into thresholds on C*(|e2|^2-|e1|^2), see lane_accept
 };
 
 template <typename XT> __host__ __device__ inline size_t sweep_lds_bytes(int m, int R) {
@@ -215,7 +216,27 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
       st.b2[t] = b2;
       st.drej[t] = sel ? (b2 - b0) : 0.0f;   // the step a marker takes when it is NOT included
     } else if (piece == 2) {
-      st.u[t] = sel ? rng_uniform(a.rng, mk, a.iter, RNG_U, 0) : 0.0;
+      const double uj = sel ? rng_uniform(a.rng, mk, a.iter, RNG_U, 0) : 0.0;
+      // The Bernoulli step accepts iff u < pj with pj a float function of x = C*(|e2|^2 - |e1|^2):
+      //   pj = 1/(1 + odds*expf(x))  or (BayesDpi)  min(1, (1-pi)*expf(-x)).
+      // Both are decreasing in x, so u maps to a threshold on x.  pj's float evaluation is within a relative 1e-6 of the exact
+      // function; x below tacc is therefore a certain accept, x above trej a certain reject, and only the sliver between them
+      // (about one decision in 10^5) needs pj itself -- the exponential and the division leave the recurrence's dependent chain.
+      float ta = -INFINITY, tr = INFINITY;
+      if (sel && uj > 0.0) {
+        const double eta = 1e-6, ua = uj * (1.0 + eta), ur = uj * (1.0 - eta);
+        if (a.flags & SWF_MH) {
+          const double omp = (double)(1.0f - sc.pi);
+          if (omp > 0.0) { ta = (float)log(omp / ua); tr = (float)log(omp / ur); }
+        } else if (sc.odds > 0.0f) {
+          const double lo = log((double)sc.odds);
+          if (ua < 1.0) ta = (float)(log1p(-ua) - log(ua) - lo);
+          tr = (float)(log1p(-ur) - log(ur) - lo);
+        }
+        ta = nextafterf(ta, -INFINITY); tr = nextafterf(tr, INFINITY);   // conservative after the rounding to float
+        if (!(ta < tr)) { ta = -INFINITY; tr = INFINITY; }
+      }
+      st.tacc[t] = ta; st.trej[t] = tr;
     } else {
       st.chi[t] = (a.flags & SWF_VB_VEC) ? rng_chisq(a.rng, (double)dfp1, mk, a.iter, RNG_CHI) : 1.0;
     }
@@ -290,7 +311,9 @@ __device__ __forceinline__ void put_gram4(GT *gram_s, double *gdiag_s, int m, in
 // what marker t does given its current r: the in-model draw b1 and (SELECT) the inclusion decision
 struct LaneConst {
   float b0, xxb0, b2, drej;
-  double rden, sdz1, u, gjj;
+  double rden, sdz1, gjj;
+  float tacc, trej;   // the Bernoulli step's uniform as thresholds (k_prestage); the uniform itself is re-derived when needed
+  uint32_t mk;        // global marker id (RNG counter word)
 };
 // The conditional mean stays in fp64 (wide contract): 2 dependent fp64 ops instead of the
 // cvt/add/cvt/mul/cvt/cvt/add chain that the reference's float rounding points would force on the serial path.
@@ -333,12 +356,10 @@ __device__ __forceinline__ float lane_em(double r, const LaneConst &c, int flags
   const bool keep = pos ? (G > 0.0) : (G < 0.0);
   return (float)(keep ? G + half : half);
 }
-__device__ __forceinline__ bool lane_accept(double r, float b1, const LaneConst &c, int flags, float Cc, float odds,
-                                            float one_minus_pi) {
-  const float d1f = b1 - c.b0;
-  const float d2f = (flags & SWF_ALT_B2) ? (c.b2 - c.b0) : (0.0f - c.b0);
-  const double D1 = (double)d1f, D2 = (double)d2f;
-  const double diffd = 2.0 * r * (D1 - D2) + c.gjj * (D2 * D2 - D1 * D1);   // |e2|^2 - |e1|^2, e_k = e - x d_k
+// the Bernoulli step's literal form, u < pj: reached only when some lane's x falls between its two thresholds (about one
+// decision in 10^5).  Not inlined, so that the Philox block that re-derives the uniform stays out of the recurrence's code.
+__device__ __attribute__((noinline)) bool lane_accept_exact(double diffd, uint32_t mk, int flags, float Cc, float odds, float one_minus_pi,
+                                                            Rng rng, uint32_t iter) {
   float pj;
   if (flags & SWF_MH) {
     const float diff = (float)(-diffd);
@@ -349,7 +370,19 @@ __device__ __forceinline__ bool lane_accept(double r, float b1, const LaneConst 
     const float LR = odds * expf(Cc * diff);
     pj = 1.0f / (1.0f + LR);
   }
-  return c.u < (double)pj;
+  return rng_uniform(rng, mk, iter, RNG_U, 0) < (double)pj;   // the same uniform k_prestage drew
+}
+__device__ __forceinline__ bool lane_accept(double r, float b1, const LaneConst &c, int flags, float Cc, float odds,
+                                            float one_minus_pi, const Rng &rng, uint32_t iter) {
+  const float d1f = b1 - c.b0;
+  const float d2f = (flags & SWF_ALT_B2) ? (c.b2 - c.b0) : (0.0f - c.b0);
+  const double D1 = (double)d1f, D2 = (double)d2f;
+  const double diffd = 2.0 * r * (D1 - D2) + c.gjj * (D2 * D2 - D1 * D1);   // |e2|^2 - |e1|^2, e_k = e - x d_k
+  const float x = Cc * (float)diffd;                  // the argument of the exponential (BayesDpi: its negative, exactly)
+  const bool sure_acc = x < c.tacc, sure_rej = x > c.trej;
+  if (__builtin_expect(__ballot(!(sure_acc || sure_rej)) == 0ull, 1)) return sure_acc;   // every lane decided by its thresholds
+  const bool exact = lane_accept_exact(diffd, c.mk, flags, Cc, odds, one_minus_pi, rng, iter);
+  return sure_acc ? true : (sure_rej ? false : exact);
 }
 
 template <typename XT, bool SELECT>
@@ -579,7 +612,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
         lc[q].b0 = live ? st.b0[t] : 0.0f; lc[q].xxb0 = live ? st.xxb0[t] : 0.0f;
         lc[q].b2 = live ? st.b2[t] : 0.0f; lc[q].drej = live ? st.drej[t] : 0.0f;
         lc[q].rden = live ? st.rden[t] : 1.0; lc[q].sdz1 = live ? st.sdz1[t] : 0.0;
-        lc[q].u = live ? st.u[t] : 2.0; lc[q].gjj = live ? gdiag_s[t] : 0.0;
+        lc[q].gjj = live ? gdiag_s[t] : 0.0; lc[q].mk = a.marker0 + (uint32_t)(j0 + t);
+        lc[q].tacc = live ? st.tacc[t] : -INFINITY; lc[q].trej = live ? st.trej[t] : -INFINITY;   // dead lanes: certain reject
       }
       unsigned long long accmask[2] = {0ull, 0ull};
 #pragma unroll
@@ -609,7 +643,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
             int front = 0;
             while (front < cnt) {
               const float b1 = lane_b1(r[q], lc[q]);
-              const bool acc = lane_accept(r[q], b1, lc[q], a.flags, Cc, odds, one_minus_pi);
+              const bool acc = lane_accept(r[q], b1, lc[q], a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
               const unsigned long long bal = __ballot(acc && lane >= front && lane < cnt);
               if (bal == 0ull) break;
               const int js = __ffsll((long long)bal) - 1;

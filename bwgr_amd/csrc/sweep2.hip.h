@@ -779,7 +779,8 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
         lc[q].b0 = live ? st.b0[t] : 0.0f; lc[q].xxb0 = live ? st.xxb0[t] : 0.0f;
         lc[q].b2 = live ? st.b2[t] : 0.0f; lc[q].drej = live ? st.drej[t] : 0.0f;
         lc[q].rden = live ? st.rden[t] : 1.0; lc[q].sdz1 = live ? st.sdz1[t] : 0.0;
-        lc[q].u = live ? st.u[t] : 2.0; lc[q].gjj = live ? sb.gjj[t] : 0.0;
+        lc[q].gjj = live ? sb.gjj[t] : 0.0; lc[q].mk = a.marker0 + (uint32_t)(j0 + t);
+        lc[q].tacc = live ? st.tacc[t] : -INFINITY; lc[q].trej = live ? st.trej[t] : -INFINITY;   // dead lanes: certain reject
       }
       S2STAMP(5);
       // affine models: the recurrence's variable, the un-rounded draw t = (r + xx*b0)*rden + sd*z
@@ -877,7 +878,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
             int front = 0;
             while (front < cnt) {
               const float b1 = lane_b1(r[q], lc[q]);
-              const bool acc = lane_accept(r[q], b1, lc[q], a.flags, Cc, odds, one_minus_pi);
+              const bool acc = lane_accept(r[q], b1, lc[q], a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
               const unsigned long long bal = __ballot(acc && lane >= front && lane < cnt);
               if (bal == 0ull) break;
               const int js = __ffsll((long long)bal) - 1;
@@ -1340,14 +1341,14 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       double r[2];
       LaneConst lc[2];
       {   // all loads unconditional (the buffers hold SW_MAXM entries) and issued before the first use; dead lanes masked after
-        double spc[2], rd[2], sz[2], uu[2], gj[2], ch[2];
-        float fb0[2], fxx[2], fb2[2], fdr[2];
+        double spc[2], rd[2], sz[2], gj[2], ch[2];
+        float fb0[2], fxx[2], fb2[2], fdr[2], fta[2], ftr[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int t = 64 * q + lane;
           spc[q] = sb.spec[t]; gj[q] = sb.gjj[t];
           fb0[q] = st.b0[t]; fxx[q] = st.xxb0[t]; fb2[q] = st.b2[t]; fdr[q] = st.drej[t];
-          rd[q] = st.rden[t]; sz[q] = st.sdz1[t]; uu[q] = st.u[t]; ch[q] = st.chi[t];
+          rd[q] = st.rden[t]; sz[q] = st.sdz1[t]; ch[q] = st.chi[t]; fta[q] = st.tacc[t]; ftr[q] = st.trej[t];
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -1356,7 +1357,8 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
           lc[q].b0 = live ? fb0[q] : 0.0f; lc[q].xxb0 = live ? fxx[q] : 0.0f;
           lc[q].b2 = live ? fb2[q] : 0.0f; lc[q].drej = live ? fdr[q] : 0.0f;
           lc[q].rden = live ? rd[q] : 1.0; lc[q].sdz1 = live ? sz[q] : 0.0;
-          lc[q].u = live ? uu[q] : 2.0; lc[q].gjj = live ? gj[q] : 0.0;
+          lc[q].gjj = live ? gj[q] : 0.0; lc[q].mk = a.marker0 + (uint32_t)((a.blk_begin + b) * m + 64 * q + lane);
+          lc[q].tacc = live ? fta[q] : -INFINITY; lc[q].trej = live ? ftr[q] : -INFINITY;   // dead lanes: certain reject
           chi[q] = live ? ch[q] : 1.0;
         }
       }
@@ -1369,7 +1371,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
           int front = 0;
           while (front < cnt) {   // exact speculative rounds: all lanes assume "nobody before me is accepted"
             const float b1 = lane_b1(r[q], lc[q]);
-            const bool acc = lane_accept(r[q], b1, lc[q], a.flags, Cc, odds, one_minus_pi);
+            const bool acc = lane_accept(r[q], b1, lc[q], a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
             const unsigned long long bal = __ballot(acc && lane >= front && lane < cnt);
             if (bal == 0ull) break;
             const int js = __ffsll((long long)bal) - 1;
