@@ -47,12 +47,14 @@ static constexpr int S2_NSLOT = 4;   // ring depth of the q / delta buffers (2 w
 
 template <typename XT> __host__ __device__ inline size_t s2_seq_lds_bytes(int m);
 __host__ __device__ inline size_t s2i_lds_bytes(int m, int R, int lag = 3);
+__host__ __device__ inline size_t s2_seq16_lds_bytes(int m);   // (defined with s2_sequencer_sel16)
 template <typename XT> __host__ __device__ inline size_t sweep2_lds_bytes(int m, int R) {
   size_t streamer = (size_t)3 * m * tile_rp<XT>(R) * sizeof(XT);
   streamer = (streamer + 15) & ~(size_t)15;
   streamer += (size_t)R * sizeof(double) + SW_MAXM * sizeof(double) + (size_t)(SW_THREADS / 64) * SW_MAXM * sizeof(double) + 64;
   if (sizeof(XT) == 1) streamer = s2i_lds_bytes(m, R, 3);
-  const size_t seq = s2_seq_lds_bytes<XT>(m);
+  size_t seq = s2_seq_lds_bytes<XT>(m);
+  if (sizeof(XT) == 1 && s2_seq16_lds_bytes(m) > seq) seq = s2_seq16_lds_bytes(m);   // small blocks: the 16-bit sequencer's fixed arrays outweigh its Gram buffers
   return streamer > seq ? streamer : seq;
 }
 
@@ -1117,6 +1119,7 @@ __host__ __device__ inline size_t s2_seq16_lds_bytes(int m) {
   s += (size_t)2 * 3 * SW_MAXM * sizeof(float);                        // state of a block [parity]
   s += (size_t)2 * SW_MAXM * sizeof(double);                           // lag-3 cross term [parity]
   s += (size_t)4 * SW_MAXM * (sizeof(double) + sizeof(int));           // accepted lists, ring of four blocks
+  s += (size_t)8 * SW_MAXM * sizeof(double);                           // dense blocks: per-wave partial sums
   return s + 64;
 }
 __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
@@ -1139,6 +1142,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
   // r0_{b+1} from wave 0's registers and, through these lists, the cross terms of blocks b+2 and b+3)
   double *acc_corr2 = reinterpret_cast<double *>(smem + off); off += (size_t)4 * SW_MAXM * sizeof(double);
   int *acc_k2 = reinterpret_cast<int *>(smem + off); off += (size_t)4 * SW_MAXM * sizeof(int);
+  double *dpost = reinterpret_cast<double *>(smem + off); off += (size_t)8 * SW_MAXM * sizeof(double);   // dense blocks: per-wave partial sums of the distance-1 term
   int *ctrl_s = reinterpret_cast<int *>(smem + off);   // [0] ok flag, [4 + (b & 3)] number of accepted markers of block b
 #define Q16_GP(i_) (gp_base + (size_t)((i_) & 1) * gp_elems)
 #define Q16_GX(i_) (gx_base + (size_t)((i_) & 1) * m * m)
@@ -1433,9 +1437,32 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
     S2ONE(55, tid == 0 && b == 99 + L);
     S2STAMP(2);
     if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
+    // Dense inclusion (BayesCpi / BayesDpi keep about half the markers in the model): the distance-1 term -- one row of Gx_{b+1}
+    // per accepted marker of block b -- is 250 cycles per marker as a loop of wave 0's; above 24 accepted markers all eight
+    // waves take every eighth list entry and wave 0 adds the eight partial sums behind one more barrier.
+    const int naccb = ctrl_s[4 + (b & 3)];
+    const bool dense = have_next && naccb > 24;
+    if (dense) {
+      const int *lk = acc_k2 + (size_t)(b & 3) * SW_MAXM;
+      const double *lcf = acc_corr2 + (size_t)(b & 3) * SW_MAXM;
+      const GT *gxn = Q16_GX(b + 1);
+      const int ja = min(lane, m - 1), jb = min(64 + lane, m - 1);
+      double xa = 0.0, xb = 0.0;
+      for (int idx = wave; idx < naccb; idx += 8) {
+        const int k = lk[idx];
+        const double cf = lcf[idx];
+        const GT *row = gxn + (size_t)k * m;
+        xa = fma((double)row[ja], cf, xa);
+        xb = fma((double)row[jb], cf, xb);
+      }
+      dpost[(size_t)wave * SW_MAXM + lane] = xa;
+      dpost[(size_t)wave * SW_MAXM + 64 + lane] = xb;
+      __syncthreads();
+    }
     if (wave == 0 && have_next) {
-      // r0_{b+1} = sum_w q - Gx' drej_b (precomputed) - what block b's accepted markers changed beyond drej - lag-3 term,
-      // for this lane's two markers; the accepted markers come from the masks (no list reads), their Gx rows from LDS
+      // r0_{b+1} = sum_w q - Gx' drej_b (precomputed) - what block b's accepted markers changed beyond drej - the cross terms of
+      // distance 2 .. L-1, for this lane's two markers; sparse blocks: the accepted markers come from the masks (no list
+      // reads), their Gx rows from LDS
       const double *ps = Q16_QS(b + 1);
       const double *cr = carry2 + (size_t)((b + 1) & 1) * SW_MAXM;
       const GT *gxn = Q16_GX(b + 1);
@@ -1443,17 +1470,24 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       const bool l0 = lane < mBn, l1 = 64 + lane < mBn;
       double r0 = l0 ? ps[lane] - sn.xspec[lane] : 0.0, r1 = l1 ? ps[64 + lane] - sn.xspec[64 + lane] : 0.0;
       if (L > 2) { r0 -= l0 ? cr[lane] : 0.0; r1 -= l1 ? cr[64 + lane] : 0.0; }
+      if (dense) {
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        unsigned long long mk = q ? am1 : am0;
-        while (mk) {
-          const int js = __ffsll((long long)mk) - 1;
-          mk &= mk - 1ull;
-          const double corr = (double)readlane_f32(corr_own[q], js) - (double)readlane_f32(drej_own[q], js);
-          const GT *row = gxn + (size_t)(64 * q + js) * m;
-          const GT ga = row[lane], gb = row[min(64 + lane, m - 1)];
-          r0 = fma(-(double)ga, corr, r0);
-          r1 = fma(-(double)gb, corr, r1);
+        for (int w = 0; w < 8; ++w) { s0 += dpost[(size_t)w * SW_MAXM + lane]; s1 += dpost[(size_t)w * SW_MAXM + 64 + lane]; }
+        r0 -= s0; r1 -= s1;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          unsigned long long mk = q ? am1 : am0;
+          while (mk) {
+            const int js = __ffsll((long long)mk) - 1;
+            mk &= mk - 1ull;
+            const double corr = (double)readlane_f32(corr_own[q], js) - (double)readlane_f32(drej_own[q], js);
+            const GT *row = gxn + (size_t)(64 * q + js) * m;
+            const GT ga = row[lane], gb = row[min(64 + lane, m - 1)];
+            r0 = fma(-(double)ga, corr, r0);
+            r1 = fma(-(double)gb, corr, r1);
+          }
         }
       }
       rnext[0] = l0 ? r0 : 0.0; rnext[1] = l1 ? r1 : 0.0;
