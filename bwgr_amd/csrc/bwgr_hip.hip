@@ -471,6 +471,36 @@ __global__ __launch_bounds__(256) void k_gemv_part(const XT *X, int64_t ld, int 
   double *o = part + (int64_t)c * ld + i0;
   o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
 }
+// int8 panels: 16 rows per thread (one 16-byte load per marker), four markers' loads in flight, no data-dependent branch --
+// the 4-rows-per-thread loop above with its skip of zero coefficients waited for every load and ran at 1.1 TB/s
+template <typename CT>
+__global__ __launch_bounds__(256) void k_gemv_part_i8(const int8_t *X, int64_t ld, int R, int p, const CT *coef, int cols_per_chunk, double *part) {
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  if (i0 >= ld) return;
+  const int c = blockIdx.y;
+  const int ja = c * cols_per_chunk, jb = min(p, ja + cols_per_chunk);
+  const int8_t *base = X + xoff(i0, 0, R, p);          // marker j of this slab: base + j*R (R is a multiple of 128)
+  double acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.0;
+#define GEMV_ADD(w_, cj_, k0_) { \
+    acc[(k0_) + 0] = fma((double)(int)(int8_t)((w_) & 0xFF), cj_, acc[(k0_) + 0]); acc[(k0_) + 1] = fma((double)(int)(int8_t)(((w_) >> 8) & 0xFF), cj_, acc[(k0_) + 1]); \
+    acc[(k0_) + 2] = fma((double)(int)(int8_t)(((w_) >> 16) & 0xFF), cj_, acc[(k0_) + 2]); acc[(k0_) + 3] = fma((double)((int)(w_) >> 24), cj_, acc[(k0_) + 3]); }
+#define GEMV_COL(v_, cj_) { GEMV_ADD((v_).x, cj_, 0) GEMV_ADD((v_).y, cj_, 4) GEMV_ADD((v_).z, cj_, 8) GEMV_ADD((v_).w, cj_, 12) }
+  int j = ja;
+  for (; j + 4 <= jb; j += 4) {
+    const uint4 v0 = *reinterpret_cast<const uint4 *>(base + (size_t)j * R), v1 = *reinterpret_cast<const uint4 *>(base + (size_t)(j + 1) * R);
+    const uint4 v2 = *reinterpret_cast<const uint4 *>(base + (size_t)(j + 2) * R), v3 = *reinterpret_cast<const uint4 *>(base + (size_t)(j + 3) * R);
+    const double c0 = (double)coef[j], c1 = (double)coef[j + 1], c2 = (double)coef[j + 2], c3 = (double)coef[j + 3];
+    GEMV_COL(v0, c0) GEMV_COL(v1, c1) GEMV_COL(v2, c2) GEMV_COL(v3, c3)
+  }
+  for (; j < jb; ++j) { const uint4 v0 = *reinterpret_cast<const uint4 *>(base + (size_t)j * R); const double c0 = (double)coef[j]; GEMV_COL(v0, c0) }
+#undef GEMV_COL
+#undef GEMV_ADD
+  double *o = part + (int64_t)c * ld + i0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) o[k] = acc[k];
+}
 __global__ void k_hat_finish(const double *part, int64_t ld, int nchunks, int n, float MU, float *hat) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1482,16 +1512,27 @@ extern "C" int bwgr_chain_state(bwgr_chain *C, float *b, float *d, float *e, flo
   return BWGR_OK;
 }
 
+// column chunks of the two-stage GEMV: enough workgroups to fill the chip at 16 rows per thread (int8) or 4 (float)
+static int gemv_chunks(const bwgr_panel *P) { return (int)std::min<int64_t>(P->is_f32 ? 64 : 512, std::max<int64_t>(1, P->p / 512)); }
+template <typename CT>
+static void gemv_launch(bwgr_panel *P, const CT *coef_dev, int nchunks, int cpc, double *part) {
+  if (P->is_f32) {
+    dim3 grid((unsigned)((P->ld / 4 + 255) / 256), (unsigned)nchunks);
+    hipLaunchKernelGGL((k_gemv_part<float, CT>), grid, dim3(256), 0, P->stream, (const float *)P->X, P->ld, P->R, (int)P->p, coef_dev, cpc, part);
+  } else {
+    dim3 grid((unsigned)((P->ld / 16 + 255) / 256), (unsigned)nchunks);
+    hipLaunchKernelGGL((k_gemv_part_i8<CT>), grid, dim3(256), 0, P->stream, (const int8_t *)P->X, P->ld, P->R, (int)P->p, coef_dev, cpc, part);
+  }
+}
+
 // hat = X*B + MU   (src/Rcpp20260726ai.cpp:629-630), fp64 accumulation, deterministic two-stage
 template <typename CT>
 static int gemv_hat(bwgr_panel *P, const CT *coef_dev, float MU, float *hat_dev) {
-  const int nchunks = (int)std::min<int64_t>(64, std::max<int64_t>(1, P->p / 512));
+  const int nchunks = gemv_chunks(P);
   const int cpc = (int)((P->p + nchunks - 1) / nchunks);
   double *part = nullptr;
   HIPCHK(hipMalloc(&part, sizeof(double) * (size_t)nchunks * P->ld));
-  dim3 grid((unsigned)((P->ld / 4 + 255) / 256), (unsigned)nchunks);
-  if (P->is_f32) hipLaunchKernelGGL((k_gemv_part<float, CT>), grid, dim3(256), 0, P->stream, (const float *)P->X, P->ld, P->R, (int)P->p, coef_dev, cpc, part);
-  else hipLaunchKernelGGL((k_gemv_part<int8_t, CT>), grid, dim3(256), 0, P->stream, (const int8_t *)P->X, P->ld, P->R, (int)P->p, coef_dev, cpc, part);
+  gemv_launch<CT>(P, coef_dev, nchunks, cpc, part);
   hipLaunchKernelGGL(k_hat_finish, dim3((unsigned)((P->n + 255) / 256)), dim3(256), 0, P->stream, part, P->ld, nchunks, (int)P->n, MU, hat_dev);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(P->stream));
@@ -1697,13 +1738,11 @@ extern "C" int bwgr_sample_rows(uint64_t seed, uint32_t iter, int64_t n, int64_t
 // X * coef (fp64 partial products per column chunk); caller finishes.  Returns nchunks and the device buffer.
 template <typename CT>
 static int gemv_parts(bwgr_panel *P, const CT *coef_dev, double **part_out, int *nchunks_out) {
-  const int nchunks = (int)std::min<int64_t>(64, std::max<int64_t>(1, P->p / 512));
+  const int nchunks = gemv_chunks(P);
   const int cpc = (int)((P->p + nchunks - 1) / nchunks);
   double *part = *part_out;
   if (!part) HIPCHK(hipMalloc(&part, sizeof(double) * (size_t)nchunks * P->ld));
-  dim3 grid((unsigned)((P->ld / 4 + 255) / 256), (unsigned)nchunks);
-  if (P->is_f32) hipLaunchKernelGGL((k_gemv_part<float, CT>), grid, dim3(256), 0, P->stream, (const float *)P->X, P->ld, P->R, (int)P->p, coef_dev, cpc, part);
-  else hipLaunchKernelGGL((k_gemv_part<int8_t, CT>), grid, dim3(256), 0, P->stream, (const int8_t *)P->X, P->ld, P->R, (int)P->p, coef_dev, cpc, part);
+  gemv_launch<CT>(P, coef_dev, nchunks, cpc, part);
   HIPCHK(hipGetLastError());
   *part_out = part; *nchunks_out = nchunks;
   return BWGR_OK;
