@@ -155,6 +155,57 @@ __global__ __launch_bounds__(256) void k_gram_i8(const int8_t *X, int64_t ld, in
     for (int c = 0; c < TJ; ++c) g[(size_t)(tj + 16 * a) * m + (tk + 16 * c)] = acc[a][c];
 }
 
+// m = 128: the same blocks on the matrix cores.  out[blk][i][j] = X_{(blk-dist)m+i} . X_{blk*m+j} (dist = 0: the diagonal block),
+// exact in the int32 accumulators.  One workgroup of four waves per block; wave w owns the 64 x 64 quadrant (4 x 4 tiles of
+// 16 x 16); v_mfma_i32_16x16x64_i8 takes, per lane (m16, grp), the 16 bytes of marker 16t + m16 at rows 64kk + 16grp .. +15 for
+// both operands -- straight from the slab-major panel, whose markers are contiguous along the rows -- and returns
+// out[16ti + 4grp + reg][16tj + m16].  Per 64 rows a wave issues 8 loads and 16 MFMAs (the sdot4 kernels above ran at
+// 0.75 TB/s: one dword per thread per load and an LDS round trip).
+__global__ __launch_bounds__(256) void k_gram_mfma_i8(const int8_t *X, int64_t ld, int R, int p, int32_t *out, int dist) {
+  constexpr int m = 128;
+  const int blk = blockIdx.x + dist, ia0 = (blk - dist) * m, jb0 = blk * m;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m16 = lane & 15, grp = lane >> 4;
+  const int ti0 = 4 * (wave >> 1), tj0 = 4 * (wave & 1);
+  s2_v4i acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = s2_v4i{0, 0, 0, 0};
+  // markers past the panel (last block) are read at a clamped column and zeroed
+  int ca[4], cb[4]; bool oka[4], okb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ja = ia0 + 16 * (ti0 + t) + m16, jb = jb0 + 16 * (tj0 + t) + m16;
+    oka[t] = ja < p; okb[t] = jb < p; ca[t] = min(ja, p - 1); cb[t] = min(jb, p - 1);
+  }
+  const s2_v4i zero = {0, 0, 0, 0};
+  for (int64_t r0 = 0; r0 < ld; r0 += 64) {
+    const int64_t sl = r0 / R;
+    const size_t roff = (size_t)(r0 - sl * R) + 16 * grp;
+    const int8_t *sb = X + (size_t)sl * p * R + roff;       // slab base + row offset; marker j adds j*R
+    s2_v4i av[4], bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      av[t] = *reinterpret_cast<const s2_v4i *>(sb + (size_t)ca[t] * R);
+      bv[t] = *reinterpret_cast<const s2_v4i *>(sb + (size_t)cb[t] * R);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { av[t] = oka[t] ? av[t] : zero; bv[t] = okb[t] ? bv[t] : zero; }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[a], bv[c], acc[a][c], 0, 0, 0);
+  }
+  int32_t *g = out + (size_t)blk * m * m;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        g[(size_t)(16 * (ti0 + a) + 4 * grp + reg) * m + 16 * (tj0 + c) + m16] = acc[a][c][reg];
+}
+
 // off-diagonal blocks for the pipelined sweep: gramx[blk][k][j] = X_{(blk-dist)m+k} . X_{blk*m+j}, blk >= dist (dist = 1, 2)
 template <int TJ>
 __global__ __launch_bounds__(256) void k_gramx_i8(const int8_t *X, int64_t ld, int R, int p, int m, int32_t *gramx, int dist) {
@@ -1014,7 +1065,8 @@ static int panel_build_gram(bwgr_panel *P) {
   } else {
     const size_t lds = (size_t)m * 33 * sizeof(int32_t);
     int32_t *g = (int32_t *)P->gram; const int8_t *X = (const int8_t *)P->X;
-    switch (TJ) {
+    if (m == 128) hipLaunchKernelGGL(k_gram_mfma_i8, dim3(P->nblocks), dim3(256), 0, P->stream, X, P->ld, P->R, p, g, 0);
+    else switch (TJ) {
       case 1: hipLaunchKernelGGL(k_gram_i8<1>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
       case 2: hipLaunchKernelGGL(k_gram_i8<2>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
       case 3: hipLaunchKernelGGL(k_gram_i8<3>, dim3(P->nblocks), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g); break;
@@ -1041,7 +1093,8 @@ static int panel_build_gram(bwgr_panel *P) {
     } else {
       const size_t lds = (size_t)2 * m * 33 * sizeof(int32_t);
       int32_t *g = (int32_t *)(dist == 1 ? P->gramx : dist == 2 ? P->gramx2 : P->gramx3); const int8_t *X = (const int8_t *)P->X;
-      switch (TJ) {
+      if (m == 128) hipLaunchKernelGGL(k_gram_mfma_i8, dim3(nbx), dim3(256), 0, P->stream, X, P->ld, P->R, p, g, dist);
+      else switch (TJ) {
         case 1: hipLaunchKernelGGL(k_gramx_i8<1>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
         case 2: hipLaunchKernelGGL(k_gramx_i8<2>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
         case 3: hipLaunchKernelGGL(k_gramx_i8<3>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
