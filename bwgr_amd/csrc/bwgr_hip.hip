@@ -8,6 +8,7 @@
 #include <math.h>
 #include <vector>
 #include <random>
+#include <chrono>
 #include <algorithm>
 #include "../../include/bwgr.h"
 #include "rng.hip.h"
@@ -2320,8 +2321,9 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
     h0.odds = h.Pi0; h0.lam = h.Lmb1; h0.Sb = h.cxx;                                 // Pi0; Lmb1; emBL's cxx (k_prestage)
     ECHK(hipMemcpyAsync(sc, &h0, sizeof(h0), hipMemcpyHostToDevice, st));
   }
-  std::vector<int> order((size_t)p);
+  std::vector<int> order((size_t)p), order_next;
   for (int64_t j = 0; j < p; ++j) order[(size_t)j] = (int)j;
+  if (shuffled) std::shuffle(order.begin(), order.end(), std::mt19937(0));            // sweep 0's order
   if (!shuffled) ECHK(hipMemcpyAsync(ordd, order.data(), sizeof(int32_t) * p, hipMemcpyHostToDevice, st));
   const int cps = (int)((size_t)P->R * (P->is_f32 ? 4 : 1) / 16);
   uint32_t flags = SWF_LAM_VEC;
@@ -2331,9 +2333,14 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
   if (model == BWGR_EM_BL) flags |= SWF_EM_BL;
   if (lasso) flags |= SWF_EM_LASSO;
   int numit = 0;
+  const bool emdbg = getenv("BWGR_EM_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int i = 0; i < maxit; ++i) {
+    const double t_0 = now();
     if (shuffled) {
-      std::shuffle(order.begin(), order.end(), std::mt19937(i));                     // :103, :277, :331, :491 ... -- the reference's own call
+      // order = sweep i's marker order.  std::shuffle(order.begin(), order.end(), std::mt19937(i)) -- :103, :277, :331, :491 ...,
+      // the reference's own call -- was made for sweep 0 before the loop and is made for sweep i+1 below, while the GPU
+      // runs sweep i (10-15 ms of host time per sweep at p = 10^6)
       ECHK(hipMemcpyAsync(ordd, order.data(), sizeof(int32_t) * p, hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(k_permute_cols, dim3(8192), dim3(256), 0, st, (const uint4 *)P->X, (uint4 *)Q->X, ordd, p, P->K, cps);
     }
@@ -2357,11 +2364,15 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
     hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(1024), 0, st, t);
     ECHK(hipGetLastError());
     ++numit;
-    // the order vector is reused by the next shuffle: the upload must have been consumed; the convergence test needs cnv
+    const double t_1 = now();
+    if (shuffled && i + 1 < maxit) { order_next = order; std::shuffle(order_next.begin(), order_next.end(), std::mt19937(i + 1)); }
+    const double t_2 = now();
+    // the convergence test needs cnv (and the sweep's status word)
     ChainScalars hc;
     ECHK(hipMemcpyAsync(&h, std_, sizeof(h), hipMemcpyDeviceToHost, st));
     ECHK(hipMemcpyAsync(&hc, sc, sizeof(hc), hipMemcpyDeviceToHost, st));
     ECHK(hipStreamSynchronize(st));
+    if (emdbg) fprintf(stderr, "em sweep %d: launches %.2f ms, host shuffle %.2f ms, wait %.2f ms\n", i, t_1 - t_0, t_2 - t_1, now() - t_2);
     if (hc.error) return done(fail(BWGR_ETIMEOUT, "em: a workgroup exchange timed out inside the sweep kernel"));
     if (lasso) {   // Lmb from the sweep's yx and b: the reference's own sequential float loop, :1487-1490
       yxh.resize((size_t)p); bh.resize((size_t)p);
@@ -2376,6 +2387,7 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
       ECHK(hipStreamSynchronize(st));
     }
     if (conv && h.cnv < tol) break;                                                  // :296, :452, :510, :1492
+    if (shuffled) order.swap(order_next);
   }
   float h2;
   if (model == BWGR_EM_ML) {
