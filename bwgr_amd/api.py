@@ -176,6 +176,14 @@ class Chain:
     def sweep_blocks(self, lo, hi):
         check(_lib.lib().bwgr_chain_sweep_blocks(self._h, int(lo), int(hi)))
 
+    def round_sweep(self, lo, hi, delta):
+        """Exchange round, first half (bwgr_chain_round_sweep): delta (torch float64 CUDA tensor of panel.ld entries) receives
+        e - e_before after sweeping blocks [lo, hi)."""
+        check(_lib.lib().bwgr_chain_round_sweep(self._h, int(lo), int(hi), C.c_void_p(delta.data_ptr())))
+
+    def round_apply(self, delta):
+        check(_lib.lib().bwgr_chain_round_apply(self._h, C.c_void_p(delta.data_ptr())))
+
     def get_sums(self):
         s = np.zeros(2, np.float64)
         check(_lib.lib().bwgr_chain_get_sums(self._h, _dp(s)))

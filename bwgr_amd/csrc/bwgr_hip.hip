@@ -889,6 +889,7 @@ struct bwgr_chain {
   int64_t marker0 = 0, p_total = 0;   // sharding: global id of local marker 0, markers over all ranks
   float MSx_eff = 0;                  // MSx over all ranks
   bool e_owned = true;
+  double *e0 = nullptr;               // residual at the start of the current exchange round (sharded stepping)
   int flags_extra = 0;                // two-effect BayesB2: SWF_ALT_B2 (the likelihood comparison uses the drawn alternative)
   std::vector<hipEvent_t> ev;  // pairs around each sweep launch since the last query
   float ms_acc = 0; int launch_acc = 0;
@@ -1420,7 +1421,7 @@ extern "C" int bwgr_chain_destroy(bwgr_chain *C) {
   if (!C) return BWGR_OK;
   (void)hipSetDevice(C->P->device);
   for (hipEvent_t ev : C->ev) hipEventDestroy(ev);
-  hipFree(C->y); if (C->e_owned) hipFree(C->e); hipFree(C->b); hipFree(C->d); hipFree(C->vb); hipFree(C->lam);
+  hipFree(C->e0); hipFree(C->y); if (C->e_owned) hipFree(C->e); hipFree(C->b); hipFree(C->d); hipFree(C->vb); hipFree(C->lam);
   hipFree(C->B); hipFree(C->D); hipFree(C->VB); hipFree(C->sc);
   delete C;
   return BWGR_OK;
@@ -1492,6 +1493,42 @@ extern "C" int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end
   HIPCHK(hipEventRecord(e1, P->stream));
   C->ev.push_back(e0); C->ev.push_back(e1);
   if (C->ev.size() >= 4096) CHK(bwgr_chain_sweep_ms(C, nullptr, nullptr));   // bound the number of live events
+  return BWGR_OK;
+}
+
+namespace {
+__global__ void k_round_delta(const double *__restrict__ e, const double *__restrict__ e0, double *__restrict__ delta, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) delta[i] = e[i] - e0[i];
+}
+__global__ void k_round_apply(double *__restrict__ e, const double *__restrict__ e0, const double *__restrict__ delta, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) e[i] = e0[i] + delta[i];
+}
+}  // namespace
+
+// One exchange round of the marker-sharded sampler in two calls (the same steps a caller can take with sweep_blocks and
+// its own vector arithmetic; here they cost two small launches instead of three framework operations per round):
+//   round_sweep: remember e, sweep the blocks [blk_begin, blk_end) (an empty range sweeps nothing), delta = e - e_before
+//   <caller: all-reduce(sum) delta over the ranks>
+//   round_apply: e = e_before + delta
+// delta_dev: ld doubles on the chain's device (the panel's padded row count).
+extern "C" int bwgr_chain_round_sweep(bwgr_chain *C, int blk_begin, int blk_end, double *delta_dev) {
+  if (!C || !delta_dev) return fail(BWGR_EINVAL, "round_sweep: null pointer");
+  bwgr_panel *P = C->P;
+  HIPCHK(hipSetDevice(P->device));
+  if (!C->e0) HIPCHK(hipMalloc(&C->e0, sizeof(double) * P->ld));
+  HIPCHK(hipMemcpyAsync(C->e0, C->e, sizeof(double) * P->ld, hipMemcpyDeviceToDevice, P->stream));
+  if (blk_begin < blk_end) CHK(bwgr_chain_sweep_blocks(C, blk_begin, blk_end));
+  hipLaunchKernelGGL(k_round_delta, dim3(64), dim3(256), 0, P->stream, C->e, C->e0, delta_dev, P->ld);
+  HIPCHK(hipGetLastError());
+  return BWGR_OK;
+}
+extern "C" int bwgr_chain_round_apply(bwgr_chain *C, const double *delta_dev) {
+  if (!C || !delta_dev) return fail(BWGR_EINVAL, "round_apply: null pointer");
+  if (!C->e0) return fail(BWGR_EINVAL, "round_apply: no round_sweep before it");
+  bwgr_panel *P = C->P;
+  HIPCHK(hipSetDevice(P->device));
+  hipLaunchKernelGGL(k_round_apply, dim3(64), dim3(256), 0, P->stream, C->e, C->e0, delta_dev, P->ld);
+  HIPCHK(hipGetLastError());
   return BWGR_OK;
 }
 
