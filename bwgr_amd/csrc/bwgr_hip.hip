@@ -867,6 +867,7 @@ struct bwgr_panel {
   double *xpart = nullptr, *qpart = nullptr;
   unsigned long long *dgran = nullptr;
   uint32_t *xflags = nullptr;
+  unsigned char *xchg = nullptr; size_t xchg_bytes = 0;   // xflags | dgran | qpart in one allocation: one memset per launch
   size_t lds_bytes = 0, lds2_bytes = 0;
   int sweep_version = 2;   // 2: streamer/sequencer pipeline (k_sweep2); 1: replicated recurrence (k_sweep)
   unsigned long long *stamps = nullptr;   // diagnostic build only
@@ -929,12 +930,24 @@ template <typename XT> static int max_slab_rows(int m) {
   return best;
 }
 
+// the words the workgroups poll (flags, delta granules, q words and the feeders' sums) live in one allocation
+static hipError_t alloc_exchange(bwgr_panel *P) {
+  const size_t K = (size_t)P->K;
+  const size_t fb = (sizeof(uint32_t) * (K + 1) * SW_FLAG_STRIDE + 255) & ~(size_t)255;
+  const size_t gb = (sizeof(unsigned long long) * S2_NSLOT * SW_MAXM + 255) & ~(size_t)255;
+  const size_t qb = sizeof(double) * S2_NSLOT * (K + 1) * SW_MAXM;
+  P->xchg_bytes = fb + gb + qb;
+  hipError_t e = hipMalloc(&P->xchg, P->xchg_bytes);
+  if (e != hipSuccess) return e;
+  P->xflags = reinterpret_cast<uint32_t *>(P->xchg);
+  P->dgran = reinterpret_cast<unsigned long long *>(P->xchg + fb);
+  P->qpart = reinterpret_cast<double *>(P->xchg + fb + gb);
+  return hipSuccess;
+}
 // polled words are zeroed before every launch (epochs count within a launch)
 static int reset_exchange(bwgr_panel *P) {
   if (P->sweep_version == 2) {
-    HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
-    HIPCHK(hipMemsetAsync(P->dgran, 0, sizeof(unsigned long long) * S2_NSLOT * SW_MAXM, P->stream));
-    HIPCHK(hipMemsetAsync(P->qpart, 0, sizeof(double) * S2_NSLOT * ((size_t)P->K + 1) * SW_MAXM, P->stream));   // + the feeder's sums
+    HIPCHK(hipMemsetAsync(P->xchg, 0, P->xchg_bytes, P->stream));
   } else if (P->K > 1) {
     HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
   }
@@ -1055,7 +1068,7 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
     P->parent->nclones--;
   }
   // the scratch a sweep writes: speculative cross terms, pre-staged constants, exchange words
-  hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->xpart); hipFree(P->qpart); hipFree(P->dgran); hipFree(P->xflags); hipFree(P->stamps);
+  hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->xpart); hipFree(P->xchg); hipFree(P->stamps);
   if (P->own_stream) hipStreamDestroy(P->own_stream);
   delete P;
   return BWGR_OK;
@@ -1239,9 +1252,7 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipMalloc(&P->vx, sizeof(float) * p));
   PCHK(hipMalloc(&P->msx_dev, sizeof(float)));
   PCHK(hipMalloc(&P->xpart, sizeof(double) * 2 * (size_t)K * SW_MAXM));
-  PCHK(hipMalloc(&P->xflags, sizeof(uint32_t) * ((size_t)K + 1) * SW_FLAG_STRIDE));
-  PCHK(hipMalloc(&P->qpart, sizeof(double) * S2_NSLOT * ((size_t)K + 1) * SW_MAXM));
-  PCHK(hipMalloc(&P->dgran, sizeof(unsigned long long) * S2_NSLOT * SW_MAXM));
+  PCHK(alloc_exchange(P));
   PCHK(hipMalloc(&P->ps.blocks, sizeof(StageBuf) * (size_t)P->nblocks));
 #ifdef BWGR_STAMPS
   PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 256));
@@ -1300,7 +1311,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   HIPCHK(hipStreamSynchronize(root->stream));   // the shared arrays are complete
   bwgr_panel *P = new bwgr_panel(*root);
   P->parent = root; P->nclones = 0; P->own_stream = nullptr; P->stream = nullptr;
-  P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->stamps = nullptr;
+  P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->xchg = nullptr; P->stamps = nullptr;
   root->nclones++;
   auto bail = [&](int code) { bwgr_panel_destroy(P); return code; };
 #define PCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return bail(fail(BWGR_EHIP, "%s failed: %s", #x, hipGetErrorString(e_))); } while (0)
@@ -1310,9 +1321,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   PCHK(hipMalloc(&P->ps.spec, sizeof(SpecBuf) * (size_t)P->nblocks));
   PCHK(hipMalloc(&P->ps.blocks, sizeof(StageBuf) * (size_t)P->nblocks));
   PCHK(hipMalloc(&P->xpart, sizeof(double) * 2 * (size_t)K * SW_MAXM));
-  PCHK(hipMalloc(&P->xflags, sizeof(uint32_t) * ((size_t)K + 1) * SW_FLAG_STRIDE));
-  PCHK(hipMalloc(&P->qpart, sizeof(double) * S2_NSLOT * ((size_t)K + 1) * SW_MAXM));
-  PCHK(hipMalloc(&P->dgran, sizeof(unsigned long long) * S2_NSLOT * SW_MAXM));
+  PCHK(alloc_exchange(P));
 #ifdef BWGR_STAMPS
   PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 256));
   PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 256));
