@@ -872,6 +872,7 @@ struct bwgr_panel {
   int sweep_version = 2;   // 2: streamer/sequencer pipeline (k_sweep2); 1: replicated recurrence (k_sweep)
   unsigned long long *stamps = nullptr;   // diagnostic build only
   PreStage ps = {};
+  const void *ps_owner = nullptr; int ps_iter = -1;   // whose sweep constants the scratch holds (a chain pre-stages a whole iteration once)
   int gram_maxdist = 3;           // panel_build_gram stops at this block distance (the EM scratch panel needs 1)
   bwgr_panel *parent = nullptr;   // a clone shares the parent's read-only arrays (X, Gram, xx, vx) and owns only the scratch
   int nclones = 0;
@@ -1012,6 +1013,7 @@ static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
 static int launch_sweep(bwgr_panel *P, SweepArgs &a) {
   choose_lag(P, a);
   CHK(reset_exchange(P));
+  P->ps_owner = nullptr;   // the scratch is about to hold this sweep's constants, nobody's iteration
   launch_prestage(P, a);
   launch_sweep_kernel(P, a);
   HIPCHK(hipGetLastError());
@@ -1310,7 +1312,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   HIPCHK(hipSetDevice(root->device));
   HIPCHK(hipStreamSynchronize(root->stream));   // the shared arrays are complete
   bwgr_panel *P = new bwgr_panel(*root);
-  P->parent = root; P->nclones = 0; P->own_stream = nullptr; P->stream = nullptr;
+  P->parent = root; P->nclones = 0; P->own_stream = nullptr; P->stream = nullptr; P->ps_owner = nullptr; P->ps_iter = -1;
   P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->xchg = nullptr; P->stamps = nullptr;
   root->nclones++;
   auto bail = [&](int code) { bwgr_panel_destroy(P); return code; };
@@ -1428,6 +1430,7 @@ static bool has_d(int model) { return model == BWGR_BAYESB || model == BWGR_BAYE
 
 extern "C" int bwgr_chain_destroy(bwgr_chain *C) {
   if (!C) return BWGR_OK;
+  if (C->P && C->P->ps_owner == C) C->P->ps_owner = nullptr;   // (a later chain may be allocated at this address)
   (void)hipSetDevice(C->P->device);
   for (hipEvent_t ev : C->ev) hipEventDestroy(ev);
   hipFree(C->e0); hipFree(C->y); if (C->e_owned) hipFree(C->e); hipFree(C->b); hipFree(C->d); hipFree(C->vb); hipFree(C->lam);
@@ -1495,7 +1498,14 @@ extern "C" int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   choose_lag(P, a);
   CHK(reset_exchange(P));
-  launch_prestage(P, a);
+  // the per-marker constants and speculative terms of an iteration depend on the state at its start only (a block's b is
+  // untouched until the block is swept), so a chain that sweeps its panel in several ranges -- the exchange rounds of the
+  // marker-sharded sampler -- pre-stages all of them with the first range
+  if (P->ps_owner != C || P->ps_iter != C->done) {
+    SweepArgs all = a; all.blk_begin = 0; all.blk_end = (int)P->nblocks;
+    launch_prestage(P, all);
+    P->ps_owner = C; P->ps_iter = C->done;
+  }
   HIPCHK(hipEventRecord(e0, P->stream));
   launch_sweep_kernel(P, a);
   HIPCHK(hipGetLastError());
