@@ -43,6 +43,8 @@ def lib():
     L.bwgr_chain_sweep_blocks.argtypes = [vp, i32, i32]
     L.bwgr_chain_round_sweep.argtypes = [vp, i32, i32, vp]
     L.bwgr_chain_round_apply.argtypes = [vp, vp]
+    L.bwgr_chain_get_sums_dev.argtypes = [vp, vp]
+    L.bwgr_chain_end_iteration_dev.argtypes = [vp, vp]
     L.bwgr_chain_get_sums.argtypes = [vp, c_d]
     L.bwgr_chain_end_iteration.argtypes = [vp, c_d]
     L.bwgr_chain_destroy.argtypes = [vp]
@@ -77,7 +79,7 @@ def device_count():
 
 EXPORTS = ["bwgr_abi_version", "bwgr_last_error", "bwgr_device_count", "bwgr_panel_create", "bwgr_panel_destroy",
            "bwgr_panel_set_stream", "bwgr_panel_info", "bwgr_panel_pipeline", "bwgr_panel_clone", "bwgr_em", "bwgr_em_order", "bwgr_panel_max_concurrent", "bwgr_panel_stats", "bwgr_kmup", "bwgr_chain_create",
-           "bwgr_chain_create_sharded", "bwgr_chain_sweep_blocks", "bwgr_chain_round_sweep", "bwgr_chain_round_apply", "bwgr_chain_get_sums", "bwgr_chain_end_iteration",
+           "bwgr_chain_create_sharded", "bwgr_chain_sweep_blocks", "bwgr_chain_round_sweep", "bwgr_chain_round_apply", "bwgr_chain_get_sums_dev", "bwgr_chain_end_iteration_dev", "bwgr_chain_get_sums", "bwgr_chain_end_iteration",
            "bwgr_chain_destroy", "bwgr_chain_run", "bwgr_chain_sync", "bwgr_chain_iterations", "bwgr_chain_result",
            "bwgr_chain_state", "bwgr_chain_sweep_ms", "bwgr_bayes", "bwgr_bayes2", "bwgr_wgr", "bwgr_wgr_ex", "bwgr_synth_genotypes",
            "bwgr_debug_variates", "bwgr_sample_rows"]

@@ -184,6 +184,13 @@ class Chain:
     def round_apply(self, delta):
         check(_lib.lib().bwgr_chain_round_apply(self._h, C.c_void_p(delta.data_ptr())))
 
+    def get_sums_dev(self, t):
+        """{sum d, sum b^2} of the blocks swept so far into t (torch float64 CUDA tensor, 2 entries): no host round trip."""
+        check(_lib.lib().bwgr_chain_get_sums_dev(self._h, C.c_void_p(t.data_ptr())))
+
+    def end_iteration_dev(self, t):
+        check(_lib.lib().bwgr_chain_end_iteration_dev(self._h, C.c_void_p(t.data_ptr())))
+
     def get_sums(self):
         s = np.zeros(2, np.float64)
         check(_lib.lib().bwgr_chain_get_sums(self._h, _dp(s)))

@@ -1582,6 +1582,27 @@ extern "C" int bwgr_chain_end_iteration(bwgr_chain *C, const double sums_total[2
   return BWGR_OK;
 }
 
+namespace {
+__global__ void k_get_sums_dev(const ChainScalars *sc, double *out2) { out2[0] = sc->sum_d; out2[1] = sc->sum_b2; }
+__global__ void k_set_sums_dev(ChainScalars *sc, const double *in2) { sc->sum_d = in2[0]; sc->sum_b2 = in2[1]; }
+}  // namespace
+// device-side forms of get_sums / end_iteration(sums_total) for the sharded sampler: the two sums stay on the device (the
+// caller all-reduces sums_dev, two doubles, in place), so an iteration needs no host round trip
+extern "C" int bwgr_chain_get_sums_dev(bwgr_chain *C, double *sums_dev) {
+  if (!C || !sums_dev) return fail(BWGR_EINVAL, "null pointer");
+  HIPCHK(hipSetDevice(C->P->device));
+  hipLaunchKernelGGL(k_get_sums_dev, dim3(1), dim3(1), 0, C->P->stream, C->sc, sums_dev);
+  HIPCHK(hipGetLastError());
+  return BWGR_OK;
+}
+extern "C" int bwgr_chain_end_iteration_dev(bwgr_chain *C, const double *sums_total_dev) {
+  if (!C || !sums_total_dev) return fail(BWGR_EINVAL, "null pointer");
+  HIPCHK(hipSetDevice(C->P->device));
+  hipLaunchKernelGGL(k_set_sums_dev, dim3(1), dim3(1), 0, C->P->stream, C->sc, sums_total_dev);
+  HIPCHK(hipGetLastError());
+  return bwgr_chain_end_iteration(C, nullptr);
+}
+
 extern "C" int bwgr_chain_run(bwgr_chain *C, int iters) {
   if (!C) return fail(BWGR_EINVAL, "null chain");
   if (iters < 0 || C->done + iters > C->iit) return fail(BWGR_EINVAL, "chain_run: %d more iterations would exceed it=%d (done %d)", iters, C->iit, C->done);

@@ -57,10 +57,18 @@ class HipShardEngine:
 
     def sums(self):
         import torch
-        return torch.as_tensor(self.chain.get_sums(), device=self.e.device)
+        if not hasattr(self, "_sums"):
+            self._sums = torch.zeros(2, dtype=torch.float64, device=self.e.device)
+        self.chain.get_sums_dev(self._sums)   # stays on the device: the all-reduce and end_iteration take it from there
+        return self._sums
 
     def end_iteration(self, sums_total):
-        self.chain.end_iteration(None if sums_total is None else sums_total.detach().cpu().numpy())
+        if sums_total is None:
+            self.chain.end_iteration(None)
+        elif sums_total.is_cuda:
+            self.chain.end_iteration_dev(sums_total)
+        else:
+            self.chain.end_iteration(sums_total.detach().cpu().numpy())
 
 
 def sync_rounds(nblocks_local, blocks_per_sync, world):

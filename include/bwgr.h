@@ -136,6 +136,9 @@ int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end);
 /* one exchange round in two calls: round_sweep remembers e, sweeps [blk_begin, blk_end) (empty range: nothing) and writes
  * delta = e - e_before to delta_dev (ld doubles, device); the caller all-reduces delta; round_apply sets e = e_before + delta */
 int bwgr_chain_round_sweep(bwgr_chain *C, int blk_begin, int blk_end, double *delta_dev);
+/* device-side forms of get_sums / end_iteration(sums_total): sums_dev = two doubles on the chain's device, all-reduced in place */
+int bwgr_chain_get_sums_dev(bwgr_chain *C, double *sums_dev);
+int bwgr_chain_end_iteration_dev(bwgr_chain *C, const double *sums_total_dev);
 int bwgr_chain_round_apply(bwgr_chain *C, const double *delta_dev);
 int bwgr_chain_get_sums(bwgr_chain *C, double sums[2]);              /* {sum d, sum b^2} of this rank's sweep */
 int bwgr_chain_end_iteration(bwgr_chain *C, const double sums_total[2]); /* NULL: use this rank's own sums */
