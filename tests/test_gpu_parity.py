@@ -533,3 +533,30 @@ def test_em_family_tpod_defaults(tpod, model):
     from oracle import oracle as O
     X, y = tpod["gen"], tpod["y"]
     _em_check(model, getattr(bwgr_amd, model)(y, X), O.em(model, y, X), tol=2e-6 if model in ("emBC", "emBCpi") else TOL)
+
+
+def test_exchange_rounds_with_one_shard_are_the_plain_chain(tpod):
+    """The sharded sampler's device-side round API (bwgr_chain_round_sweep / round_apply, get_sums_dev / end_iteration_dev)
+    with a single shard and an identity 'all-reduce' must reproduce bwgr_chain_run bit for bit."""
+    import bwgr_amd
+    from bwgr_amd.dist import HipShardEngine
+    X, y = tpod["gen"], tpod["y"].astype(np.float32)
+    for model, pi in (("BayesB", 0.9), ("BayesRR", 0.0), ("BayesCpi", 0.0)):
+        P = bwgr_amd.Panel(X, block=16)
+        msx = P.stats()[2]
+        eng = HipShardEngine(P, model, y, 5, 1, pi, 5.0, 0.5, 77, 0, P.p, msx)
+        for _ in range(5):
+            for lo in range(0, eng.nblocks, 7):
+                d = eng.round_sweep(lo, min(eng.nblocks, lo + 7))
+                eng.round_apply(d)                       # one rank: the all-reduce is the identity
+            d = eng.round_sweep(eng.nblocks, eng.nblocks)  # a rank that has run out of blocks still takes part in the round
+            eng.round_apply(d)
+            s = eng.sums()
+            assert s.is_cuda
+            eng.end_iteration(s)
+        got = eng.chain.state(); eng.chain.close()
+        ref_chain = bwgr_amd.Chain(P, model, y, it=5, bi=1, pi=pi, seed=77)
+        ref_chain.run(5); ref = ref_chain.state(); ref_chain.close(); P.close()
+        for k in ("b", "d", "e", "vb"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg="%s %s" % (model, k))
+        assert got["ve"] == ref["ve"] and got["mu"] == ref["mu"]
