@@ -2013,7 +2013,7 @@ extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int t
         WCHK(hipMemcpyAsync(use_d, use_h.data(), sizeof(int) * (size_t)nbag, hipMemcpyHostToDevice, P->stream));
         if (P->is_f32) hipLaunchKernelGGL(k_gather_rows<float>, dim3(4096), dim3(256), 0, P->stream, (const float *)P->X, P->R, use_d, (int)nbag, (float *)PB->X, PB->R, PB->ld, P->p);
         else if (P->ld <= 64 * 1024) {   // a column fits the LDS: stage, pick, write in 16-byte pieces
-          const int mpw = (int)std::max<int64_t>(1, std::min<int64_t>(8, (64 * 1024) / P->ld));
+          const int mpw = (int)std::max<int64_t>(1, std::min<int64_t>(8, (32 * 1024) / P->ld));   // ~30 KB of LDS per workgroup: five of them per CU
           hipLaunchKernelGGL(k_gather_rows_i8, dim3((unsigned)((P->p + mpw - 1) / mpw)), dim3(256), (size_t)mpw * P->ld, P->stream, (const int8_t *)P->X, P->R, P->ld,
                              use_d, (int)nbag, (int8_t *)PB->X, PB->R, PB->ld, P->p, mpw);
         } else hipLaunchKernelGGL(k_gather_rows<int8_t>, dim3(4096), dim3(256), 0, P->stream, (const int8_t *)P->X, P->R, use_d, (int)nbag, (int8_t *)PB->X, PB->R, PB->ld, P->p);
