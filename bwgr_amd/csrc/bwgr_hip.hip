@@ -180,22 +180,30 @@ __global__ __launch_bounds__(256) void k_gram_mfma_i8(const int8_t *X, int64_t l
     oka[t] = ja < p; okb[t] = jb < p; ca[t] = min(ja, p - 1); cb[t] = min(jb, p - 1);
   }
   const s2_v4i zero = {0, 0, 0, 0};
-  for (int64_t r0 = 0; r0 < ld; r0 += 64) {
+  // software pipeline: the operands of step k+1 are requested before the sixteen MFMAs of step k
+  auto load_step = [&](int64_t r0, s2_v4i (&av)[4], s2_v4i (&bv)[4]) {
     const int64_t sl = r0 / R;
     const size_t roff = (size_t)(r0 - sl * R) + 16 * grp;
     const int8_t *sb = X + (size_t)sl * p * R + roff;       // slab base + row offset; marker j adds j*R
-    s2_v4i av[4], bv[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       av[t] = *reinterpret_cast<const s2_v4i *>(sb + (size_t)ca[t] * R);
       bv[t] = *reinterpret_cast<const s2_v4i *>(sb + (size_t)cb[t] * R);
     }
+  };
+  s2_v4i av[4], bv[4], an[4], bn[4];
+  load_step(0, av, bv);
+  for (int64_t r0 = 0; r0 < ld; r0 += 64) {
+    const bool more = r0 + 64 < ld;
+    load_step(more ? r0 + 64 : r0, an, bn);                 // (the last step reloads its own operands: harmless)
 #pragma unroll
     for (int t = 0; t < 4; ++t) { av[t] = oka[t] ? av[t] : zero; bv[t] = okb[t] ? bv[t] : zero; }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[a], bv[c], acc[a][c], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { av[t] = an[t]; bv[t] = bn[t]; }
   }
   int32_t *g = out + (size_t)blk * m * m;
 #pragma unroll
