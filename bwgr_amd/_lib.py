@@ -38,6 +38,7 @@ def lib():
     L.bwgr_panel_pipeline.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.bwgr_panel_stats.argtypes = [vp, c_f, c_f, c_f]
     L.bwgr_kmup.argtypes = [vp, c_f, c_f, c_f, c_f, c_f, f32, f32, u64, u32, i32]
+    L.bwgr_kmup2.argtypes = [vp, C.POINTER(i32), i64, c_f, c_f, c_f, c_f, c_f, c_f, f32, f32, u64, u32, i32]
     L.bwgr_chain_create.argtypes = [C.POINTER(vp), vp, i32, vp, i32, f32, f32, f32, f32, f32, u64, i32]
     L.bwgr_chain_create_sharded.argtypes = [C.POINTER(vp), vp, i32, vp, i32, f32, f32, f32, f32, f32, u64, i32, i64, i64, f32, vp]
     L.bwgr_chain_sweep_blocks.argtypes = [vp, i32, i32]
@@ -60,6 +61,7 @@ def lib():
     L.bwgr_wgr_ex.argtypes = [vp, c_d, i32, i32, i32, i32, i32, f64, f64, f64, u64, i32, c_d, c_d, i64, f64, i32] + [c_d] * 9
     L.bwgr_synth_genotypes.argtypes = [vp, i64, i64, i64, i64, u64, vp, i32, vp]
     L.bwgr_debug_variates.argtypes = [i32, u64, i32, f64, u32, u32, u32, i32, c_d]
+    L.bwgr_debug_withhold.argtypes = [vp, i32]
     L.bwgr_device_count.argtypes = [C.POINTER(i32)]
     L.bwgr_sample_rows.argtypes = [u64, u32, i64, i64, i32, C.POINTER(i32)]
     _lib = L
@@ -78,8 +80,8 @@ def device_count():
 
 
 EXPORTS = ["bwgr_abi_version", "bwgr_last_error", "bwgr_device_count", "bwgr_panel_create", "bwgr_panel_destroy",
-           "bwgr_panel_set_stream", "bwgr_panel_info", "bwgr_panel_pipeline", "bwgr_panel_clone", "bwgr_em", "bwgr_em_order", "bwgr_panel_max_concurrent", "bwgr_panel_stats", "bwgr_kmup", "bwgr_chain_create",
+           "bwgr_panel_set_stream", "bwgr_panel_info", "bwgr_panel_pipeline", "bwgr_panel_clone", "bwgr_em", "bwgr_em_order", "bwgr_panel_max_concurrent", "bwgr_panel_stats", "bwgr_kmup", "bwgr_kmup2", "bwgr_chain_create",
            "bwgr_chain_create_sharded", "bwgr_chain_sweep_blocks", "bwgr_chain_round_sweep", "bwgr_chain_round_apply", "bwgr_chain_get_sums_dev", "bwgr_chain_end_iteration_dev", "bwgr_chain_get_sums", "bwgr_chain_end_iteration",
            "bwgr_chain_destroy", "bwgr_chain_run", "bwgr_chain_sync", "bwgr_chain_iterations", "bwgr_chain_result",
            "bwgr_chain_state", "bwgr_chain_sweep_ms", "bwgr_bayes", "bwgr_bayes2", "bwgr_wgr", "bwgr_wgr_ex", "bwgr_synth_genotypes",
-           "bwgr_debug_variates", "bwgr_sample_rows"]
+           "bwgr_debug_variates", "bwgr_debug_withhold", "bwgr_sample_rows"]

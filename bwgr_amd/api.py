@@ -63,10 +63,12 @@ class Panel:
             assert X.ndim == 2, "X must be n x p"
             n, p = X.shape
             if X.dtype != np.int8:
+                fits = bool(X.size == 0 or (X.min() >= -128 and X.max() <= 127))   # a wider integer must not wrap
                 if as_int8 is None:
-                    as_int8 = bool(np.issubdtype(X.dtype, np.integer) or
-                                   (X.size and np.all(X == np.rint(X)) and np.abs(X).max() <= 127))
+                    as_int8 = fits and bool(np.issubdtype(X.dtype, np.integer) or (X.size and np.all(X == np.rint(X))))
                 if as_int8:
+                    if not fits or not (np.issubdtype(X.dtype, np.integer) or np.all(X == np.rint(X))):
+                        raise ValueError("Panel(as_int8=True): X holds values outside -128..127 or non-integers")
                     X = X.astype(np.int8)
                 elif X.dtype not in (np.float32, np.float64):
                     X = X.astype(np.float64)
@@ -118,7 +120,7 @@ class Panel:
         if self._h:
             for q in list(getattr(self, "_clones", ())):
                 q.close()
-            _lib.lib().bwgr_panel_destroy(self._h)
+            check(_lib.lib().bwgr_panel_destroy(self._h))   # refuses while chains or clones are alive: the handle stays valid
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -568,6 +570,24 @@ def KMUP(X, b, d, xx, e, L, Ve, pi, *, seed=None, it=0, rng_mode=0, **panel_kw):
         assert b.size == P.p and d.size == P.p and xx.size == P.p and L.size == P.p and e.size == P.n
         check(_lib.lib().bwgr_kmup(P._h, _fp(b), _fp(d), _fp(xx), _fp(e), _fp(L), float(Ve), float(pi),
                                     C.c_uint64(_seed(seed)), C.c_uint32(int(it)), int(rng_mode)))
+        return {"b": b, "d": d, "e": e}
+    finally:
+        if own:
+            P.close()
+
+
+def KMUP2(X, Use, b, d, xx, E, L, Ve, pi, *, seed=None, it=0, rng_mode=0, **panel_kw):
+    """One Gibbs sweep on the row subsample Use (0-based, as wgr passes it: sort(sample(n, n*bag, rp)) - 1, R/wgr.R:68);
+    returns list(b=, d=, e=) like src/Rcpp20260726ai.cpp:76 (e: the subsample's residuals).  Inputs are not modified."""
+    P, own = _as_panel(X, **panel_kw)
+    try:
+        use = np.ascontiguousarray(np.asarray(Use), np.int32)
+        b = np.array(b, np.float32); d = np.array(d, np.float32); E = np.ascontiguousarray(E, np.float32)
+        xx = np.ascontiguousarray(xx, np.float32); L = np.ascontiguousarray(L, np.float32)
+        assert b.size == P.p and d.size == P.p and xx.size == P.p and L.size == P.p and E.size == P.n
+        e = np.zeros(use.size, np.float32)
+        check(_lib.lib().bwgr_kmup2(P._h, use.ctypes.data_as(C.POINTER(C.c_int)), int(use.size), _fp(b), _fp(d), _fp(xx), _fp(E),
+                                     _fp(e), _fp(L), float(Ve), float(pi), C.c_uint64(_seed(seed)), C.c_uint32(int(it)), int(rng_mode)))
         return {"b": b, "d": d, "e": e}
     finally:
         if own:

@@ -1,12 +1,13 @@
 """Build libbwgr_hip.so in-tree for gfx950 with hipcc (cross-compiles without a GPU)."""
+import glob
 import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(_HERE, "libbwgr_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("bwgr_hip.hip",)]
-DEPS = SOURCES + [os.path.join(_HERE, "csrc", f) for f in ("sweep.hip.h", "rng.hip.h")] + [
-    os.path.join(_HERE, "..", "include", "bwgr.h")]
+# every file under csrc/ (the kernels live in headers that bwgr_hip.hip includes) plus the public header
+DEPS = sorted(glob.glob(os.path.join(_HERE, "csrc", "*"))) + [os.path.join(_HERE, "..", "include", "bwgr.h")]
 # -ffp-contract=off: scalar float arithmetic must round exactly where the reference's does;
 # fused multiply-adds are written explicitly (fma / __fmul_rn / __fsub_rn) where intended.
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",

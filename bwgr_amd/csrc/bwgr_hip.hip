@@ -884,6 +884,8 @@ struct bwgr_panel {
   int gram_maxdist = 3;           // panel_build_gram stops at this block distance (the EM scratch panel needs 1)
   bwgr_panel *parent = nullptr;   // a clone shares the parent's read-only arrays (X, Gram, xx, vx) and owns only the scratch
   int nclones = 0;
+  int nchains = 0;                // live chains on this handle: panel_destroy refuses while any is alive
+  int debug_withhold = 0;         // test hook: the next sweeps run with slab workgroup 0 missing (bwgr_debug_withhold)
   hipStream_t own_stream = nullptr;
 };
 
@@ -977,6 +979,7 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a) {
 
 static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
   SweepArgs a = a_in;
+  if (P->debug_withhold) a.flags |= SWF_DEBUG_WITHHOLD;
   const bool sel = (a.flags & SWF_SELECT) != 0;
   // streamers, sequencer, and for the selection models the q feeders (the affine recurrence is compute-bound: its
   // sequencer gathers q itself under the recurrence, and a feeder hop in its lag-2 chain measured 15 % slower)
@@ -1071,6 +1074,7 @@ static int upload(bwgr_panel *P, const void *X, int memloc, int64_t ldx) {
 extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   if (!P) return BWGR_OK;
   if (P->nclones > 0) return fail(BWGR_EINVAL, "panel_destroy: %d clone(s) of this panel are still alive", P->nclones);
+  if (P->nchains > 0) return fail(BWGR_EINVAL, "panel_destroy: %d chain(s) on this panel are still alive (destroy them first)", P->nchains);
   (void)hipSetDevice(P->device);
   if (!P->parent) {
     hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->gramx3); hipFree(P->gramp16); hipFree(P->gramx16); hipFree(P->gram16_bad); hipFree(P->gramp); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev);
@@ -1320,7 +1324,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   HIPCHK(hipSetDevice(root->device));
   HIPCHK(hipStreamSynchronize(root->stream));   // the shared arrays are complete
   bwgr_panel *P = new bwgr_panel(*root);
-  P->parent = root; P->nclones = 0; P->own_stream = nullptr; P->stream = nullptr; P->ps_owner = nullptr; P->ps_iter = -1;
+  P->parent = root; P->nclones = 0; P->nchains = 0; P->own_stream = nullptr; P->stream = nullptr; P->ps_owner = nullptr; P->ps_iter = -1;
   P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->xchg = nullptr; P->stamps = nullptr;
   root->nclones++;
   auto bail = [&](int code) { bwgr_panel_destroy(P); return code; };
@@ -1352,6 +1356,14 @@ extern "C" int bwgr_panel_max_concurrent(const bwgr_panel *P, int selection, int
   // one sweep workgroup per CU even where the LDS would admit two (small blocks): measured, sharing a CU costs more than it adds
   *count = std::max(1, prop.multiProcessorCount / wgs);
   if (const char *ov = getenv("BWGR_MAX_CONCURRENT")) { const int v = atoi(ov); if (v > 0) *count = v; }   // experiments
+  return BWGR_OK;
+}
+
+// Test hook for the abort path: while on != 0 every sweep launched on this panel runs with slab workgroup 0 absent, so the
+// workgroups that wait for it spin to their wall-clock bound, raise the shared abort word and the launch reports BWGR_ETIMEOUT.
+extern "C" int bwgr_debug_withhold(bwgr_panel *P, int on) {
+  if (!P) return fail(BWGR_EINVAL, "null panel");
+  P->debug_withhold = on ? 1 : 0;
   return BWGR_OK;
 }
 
@@ -1392,42 +1404,109 @@ extern "C" int bwgr_panel_stats(bwgr_panel *P, float *xx, float *vx, float *MSx)
 // ------------------------------------------------------------------------------------------------
 // KMUP
 // ------------------------------------------------------------------------------------------------
+// device buffers of one call, released on every exit path
+namespace {
+struct DevBufs {
+  std::vector<void *> v;
+  ~DevBufs() { for (void *q : v) hipFree(q); }
+  template <typename T> T *get(size_t count) {
+    void *q = nullptr;
+    if (hipMalloc(&q, sizeof(T) * (count ? count : 1)) != hipSuccess) return nullptr;
+    v.push_back(q);
+    return reinterpret_cast<T *>(q);
+  }
+};
+}  // namespace
+
+// row gather of the resident panel P into the subsample panel PB (rows use_d[0..nbag), device array); KMUP2's H = X(Use, j)
+static void launch_gather_rows(bwgr_panel *P, bwgr_panel *PB, const int *use_d, int64_t nbag) {
+  if (P->is_f32) hipLaunchKernelGGL(k_gather_rows<float>, dim3(4096), dim3(256), 0, P->stream, (const float *)P->X, P->R, use_d, (int)nbag, (float *)PB->X, PB->R, PB->ld, P->p);
+  else if (P->ld <= 64 * 1024) {   // a column fits the LDS: stage, pick, write in 16-byte pieces
+    const int mpw = (int)std::max<int64_t>(1, std::min<int64_t>(8, (32 * 1024) / P->ld));   // ~30 KB of LDS per workgroup: five of them per CU
+    hipLaunchKernelGGL(k_gather_rows_i8, dim3((unsigned)((P->p + mpw - 1) / mpw)), dim3(256), (size_t)mpw * P->ld, P->stream, (const int8_t *)P->X, P->R, P->ld,
+                       use_d, (int)nbag, (int8_t *)PB->X, PB->R, PB->ld, P->p, mpw);
+  } else hipLaunchKernelGGL(k_gather_rows<int8_t>, dim3(4096), dim3(256), 0, P->stream, (const int8_t *)P->X, P->R, use_d, (int)nbag, (int8_t *)PB->X, PB->R, PB->ld, P->p);
+}
+
+// one sweep over panel PS with host-side b, d, xx, L and a device residual e64 (ld doubles, padding zero); KMUP and KMUP2
+static int kmup_sweep(bwgr_panel *PS, float *b, float *d, const float *xx, const float *L, double *e64, float Ve, float pi, float bg,
+                      int kmup2, uint64_t seed, uint32_t iter, int rng_mode, const char *who) {
+  DevBufs bufs;
+  const size_t p = (size_t)PS->p, pb = sizeof(float) * p;
+  float *db = bufs.get<float>(p), *dd = bufs.get<float>(p), *dxx = bufs.get<float>(p), *dL = bufs.get<float>(p), *dvb = bufs.get<float>(p);
+  ChainScalars *sc = bufs.get<ChainScalars>(1);
+  if (!db || !dd || !dxx || !dL || !dvb || !sc) return fail(BWGR_ENOMEM, "%s: device allocation failed", who);
+  HIPCHK(hipMemcpyAsync(db, b, pb, hipMemcpyHostToDevice, PS->stream));
+  HIPCHK(hipMemcpyAsync(dd, d, pb, hipMemcpyHostToDevice, PS->stream));
+  HIPCHK(hipMemcpyAsync(dxx, xx, pb, hipMemcpyHostToDevice, PS->stream));
+  HIPCHK(hipMemcpyAsync(dL, L, pb, hipMemcpyHostToDevice, PS->stream));
+  ChainScalars h; memset(&h, 0, sizeof(h));
+  h.ve = Ve; h.pi = pi; h.C = -0.5f / sqrtf(Ve); h.odds = pi / (1.0f - pi); h.dfp1 = 1.0f; h.bg = bg;
+  HIPCHK(hipMemcpyAsync(sc, &h, sizeof(h), hipMemcpyHostToDevice, PS->stream));
+  SweepArgs a; memset(&a, 0, sizeof(a));
+  fill_panel_args(PS, a);
+  a.flags = SWF_LAM_VEC | (pi > 0 ? (SWF_SELECT | SWF_ALT_B2) : 0) | (kmup2 ? SWF_KMUP2 : 0);
+  a.e = e64; a.b = db; a.d = dd; a.vb = dvb; a.xx = dxx; a.lam = dL; a.sc = sc;
+  a.iter = iter; a.rng = make_rng(seed, rng_mode);
+  CHK(launch_sweep(PS, a));
+  HIPCHK(hipMemcpyAsync(b, db, pb, hipMemcpyDeviceToHost, PS->stream));
+  HIPCHK(hipMemcpyAsync(d, dd, pb, hipMemcpyDeviceToHost, PS->stream));
+  HIPCHK(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, PS->stream));
+  HIPCHK(hipStreamSynchronize(PS->stream));
+  if (h.error) return fail(BWGR_ETIMEOUT, "%s: a workgroup exchange timed out inside the sweep kernel", who);
+  return BWGR_OK;
+}
+
 extern "C" int bwgr_kmup(bwgr_panel *P, float *b, float *d, const float *xx, float *e, const float *L, float Ve,
                          float pi, uint64_t seed, uint32_t iter, int rng_mode) {
   if (!P || !b || !d || !xx || !e || !L) return fail(BWGR_EINVAL, "kmup: null pointer");
   HIPCHK(hipSetDevice(P->device));
-  const size_t pb = sizeof(float) * P->p;
-  float *db = nullptr, *dd = nullptr, *dxx = nullptr, *dL = nullptr, *de = nullptr, *dvb = nullptr;
-  double *de64 = nullptr;
-  ChainScalars *sc = nullptr;
-  HIPCHK(hipMalloc(&db, pb)); HIPCHK(hipMalloc(&dd, pb)); HIPCHK(hipMalloc(&dxx, pb)); HIPCHK(hipMalloc(&dL, pb)); HIPCHK(hipMalloc(&dvb, pb));
-  HIPCHK(hipMalloc(&de, sizeof(float) * P->n)); HIPCHK(hipMalloc(&de64, sizeof(double) * P->ld)); HIPCHK(hipMalloc(&sc, sizeof(ChainScalars)));
-  HIPCHK(hipMemcpyAsync(db, b, pb, hipMemcpyHostToDevice, P->stream));
-  HIPCHK(hipMemcpyAsync(dd, d, pb, hipMemcpyHostToDevice, P->stream));
-  HIPCHK(hipMemcpyAsync(dxx, xx, pb, hipMemcpyHostToDevice, P->stream));
-  HIPCHK(hipMemcpyAsync(dL, L, pb, hipMemcpyHostToDevice, P->stream));
+  DevBufs bufs;
+  float *de = bufs.get<float>((size_t)P->n);
+  double *de64 = bufs.get<double>((size_t)P->ld);
+  if (!de || !de64) return fail(BWGR_ENOMEM, "kmup: device allocation failed");
   HIPCHK(hipMemcpyAsync(de, e, sizeof(float) * P->n, hipMemcpyHostToDevice, P->stream));
   hipLaunchKernelGGL(k_f2d, dim3(64), dim3(256), 0, P->stream, de, de64, P->n, P->ld);
-  ChainScalars h; memset(&h, 0, sizeof(h));
-  h.ve = Ve; h.pi = pi; h.C = -0.5f / sqrtf(Ve); h.odds = pi / (1.0f - pi); h.dfp1 = 1.0f;
-  HIPCHK(hipMemcpyAsync(sc, &h, sizeof(h), hipMemcpyHostToDevice, P->stream));
-  SweepArgs a; memset(&a, 0, sizeof(a));
-  fill_panel_args(P, a);
-  a.flags = SWF_LAM_VEC | (pi > 0 ? (SWF_SELECT | SWF_ALT_B2) : 0);
-  a.e = de64; a.b = db; a.d = dd; a.vb = dvb; a.xx = dxx; a.lam = dL; a.sc = sc;
-  a.iter = iter; a.rng = make_rng(seed, rng_mode);
-  int rc = launch_sweep(P, a);
-  if (rc == BWGR_OK) {
-    HIPCHK(hipMemcpyAsync(b, db, pb, hipMemcpyDeviceToHost, P->stream));
-    HIPCHK(hipMemcpyAsync(d, dd, pb, hipMemcpyDeviceToHost, P->stream));
-    hipLaunchKernelGGL(k_d2f, dim3(64), dim3(256), 0, P->stream, de64, de, P->n);
-    HIPCHK(hipMemcpyAsync(e, de, sizeof(float) * P->n, hipMemcpyDeviceToHost, P->stream));
-    HIPCHK(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, P->stream));
-    HIPCHK(hipStreamSynchronize(P->stream));
-    if (h.error) rc = fail(BWGR_ETIMEOUT, "kmup: a workgroup exchange timed out inside the sweep kernel");
-  }
-  hipFree(db); hipFree(dd); hipFree(dxx); hipFree(dL); hipFree(de); hipFree(de64); hipFree(dvb); hipFree(sc);
-  return rc;
+  CHK(kmup_sweep(P, b, d, xx, L, de64, Ve, pi, 0.0f, 0, seed, iter, rng_mode, "kmup"));
+  hipLaunchKernelGGL(k_d2f, dim3(64), dim3(256), 0, P->stream, de64, de, P->n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(d2h(P->stream, e, de, sizeof(float) * P->n));
+  return BWGR_OK;
+}
+
+// KMUP2(X,Use,b,d,xx,E,L,Ve,pi), src/Rcpp20260726ai.cpp:41-77: the sweep on the row subsample Use (0-based, nuse entries, in
+// the caller's order, repeats allowed) of the resident panel.  The rows are gathered into a subsample panel on the device, its
+// Gram blocks built, and the sweep runs with KMUP2's conditional mean (numerator + b0, denominator xx*bg + L, bg = n0/nuse).
+// e_out receives the nuse residuals of the subsample (:76); E (n0 entries) is not modified.
+extern "C" int bwgr_kmup2(bwgr_panel *P, const int *Use, int64_t nuse, float *b, float *d, const float *xx, const float *E,
+                          float *e_out, const float *L, float Ve, float pi, uint64_t seed, uint32_t iter, int rng_mode) {
+  if (!P || !Use || !b || !d || !xx || !E || !e_out || !L) return fail(BWGR_EINVAL, "kmup2: null pointer");
+  if (nuse < 2 || nuse > 0x7FFFFF00ll) return fail(BWGR_EINVAL, "kmup2: need 2 <= length(Use) < 2^31 (got %lld)", (long long)nuse);
+  for (int64_t k = 0; k < nuse; ++k)
+    if (Use[k] < 0 || Use[k] >= P->n) return fail(BWGR_EINVAL, "kmup2: Use[%lld] = %d is outside 0..%lld", (long long)k, Use[k], (long long)P->n - 1);
+  HIPCHK(hipSetDevice(P->device));
+  bwgr_panel *PB = nullptr;
+  CHK(panel_alloc(&PB, P->is_f32, nuse, P->p, P->device, P->m, 0));
+  PB->stream = P->stream;
+  struct Drop { bwgr_panel *q; ~Drop() { if (q) bwgr_panel_destroy(q); } } drop{PB};
+  DevBufs bufs;
+  int *use_d = bufs.get<int>((size_t)nuse);
+  float *dE = bufs.get<float>((size_t)P->n), *deo = bufs.get<float>((size_t)nuse);
+  double *dE64 = bufs.get<double>((size_t)P->n), *e64 = bufs.get<double>((size_t)PB->ld);
+  if (!use_d || !dE || !deo || !dE64 || !e64) return fail(BWGR_ENOMEM, "kmup2: device allocation failed");
+  HIPCHK(hipMemcpyAsync(use_d, Use, sizeof(int) * (size_t)nuse, hipMemcpyHostToDevice, P->stream));
+  HIPCHK(hipMemcpyAsync(dE, E, sizeof(float) * P->n, hipMemcpyHostToDevice, P->stream));
+  launch_gather_rows(P, PB, use_d, nuse);
+  HIPCHK(hipGetLastError());
+  CHK(panel_build_gram(PB));
+  hipLaunchKernelGGL(k_f2d, dim3(64), dim3(256), 0, P->stream, dE, dE64, P->n, P->n);
+  hipLaunchKernelGGL(k_gather_e, dim3(64), dim3(256), 0, P->stream, dE64, use_d, (int)nuse, PB->ld, e64);   // e0[k] = E[Use[k]], :49-53
+  HIPCHK(hipGetLastError());
+  CHK(kmup_sweep(PB, b, d, xx, L, e64, Ve, pi, (float)P->n / (float)nuse, 1, seed, iter, rng_mode, "kmup2"));
+  hipLaunchKernelGGL(k_d2f, dim3(64), dim3(256), 0, P->stream, e64, deo, nuse);
+  HIPCHK(hipGetLastError());
+  HIPCHK(d2h(P->stream, e_out, deo, sizeof(float) * (size_t)nuse));
+  return BWGR_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1439,7 +1518,7 @@ static bool has_d(int model) { return model == BWGR_BAYESB || model == BWGR_BAYE
 extern "C" int bwgr_chain_destroy(bwgr_chain *C) {
   if (!C) return BWGR_OK;
   if (C->P && C->P->ps_owner == C) C->P->ps_owner = nullptr;   // (a later chain may be allocated at this address)
-  (void)hipSetDevice(C->P->device);
+  if (C->P) { C->P->nchains--; (void)hipSetDevice(C->P->device); }
   for (hipEvent_t ev : C->ev) hipEventDestroy(ev);
   hipFree(C->e0); hipFree(C->y); if (C->e_owned) hipFree(C->e); hipFree(C->b); hipFree(C->d); hipFree(C->vb); hipFree(C->lam);
   hipFree(C->B); hipFree(C->D); hipFree(C->VB); hipFree(C->sc);
@@ -1456,7 +1535,7 @@ extern "C" int bwgr_chain_create_sharded(bwgr_chain **out, bwgr_panel *P, int mo
   if (marker0 < 0 || p_total < marker0 + P->p || p_total > 0xFFFFFFF0ll) return fail(BWGR_EINVAL, "chain_create: bad shard [%lld,+%lld) of %lld", (long long)marker0, (long long)P->p, (long long)p_total);
   HIPCHK(hipSetDevice(P->device));
   bwgr_chain *C = new bwgr_chain();
-  C->P = P; C->model = model; C->itf = it; C->bif = bi; C->iit = (int)it; C->ibi = (int)bi;
+  C->P = P; P->nchains++; C->model = model; C->itf = it; C->bif = bi; C->iit = (int)it; C->ibi = (int)bi;
   C->pi = pi; C->df = df; C->R2 = R2; C->seed = seed; C->rng_mode = rng_mode;
   C->marker0 = marker0; C->p_total = p_total; C->MSx_eff = MSx_total;
   C->Phi = MSx_total * (1 - R2) / R2;
@@ -1720,8 +1799,9 @@ extern "C" int bwgr_chain_result(bwgr_chain *C, float *mu, float *b, float *d, f
   const size_t pb = sizeof(float) * P->p;
   const bool per = per_marker_vb(C->model);
   const float MCMC = C->itf - C->bif;                                              // :626
+  DevBufs bufs;
   float *pval_dev = nullptr;
-  if (pval) HIPCHK(hipMalloc(&pval_dev, pb));
+  if (pval && !(pval_dev = bufs.get<float>((size_t)P->p))) return fail(BWGR_ENOMEM, "chain_result: device allocation failed");
   if (!C->finalized) {
     hipLaunchKernelGGL(k_final_markers, dim3(1024), dim3(256), 0, P->stream, C->B, C->D, C->VB, pval_dev, (int)P->p, MCMC, per ? 1 : 0);
     HIPCHK(hipGetLastError());
@@ -1755,7 +1835,7 @@ extern "C" int bwgr_chain_result(bwgr_chain *C, float *mu, float *b, float *d, f
   if (b) HIPCHK(d2h(P->stream, b, C->B, pb));
   if (d) HIPCHK(d2h(P->stream, d, C->D, pb));
   if (vb) { if (per) HIPCHK(d2h(P->stream, vb, C->VB, pb)); else vb[0] = VBs; }
-  if (pval) { HIPCHK(d2h(P->stream, pval, pval_dev, pb)); hipFree(pval_dev); }
+  if (pval) HIPCHK(d2h(P->stream, pval, pval_dev, pb));
   if (hat) {
     float *hat_dev = nullptr;
     HIPCHK(hipMalloc(&hat_dev, sizeof(float) * P->n));
@@ -1936,6 +2016,8 @@ extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int t
   if (bagging && !(bag > 0.0)) return fail(BWGR_EINVAL, "wgr: bag must be > 0");
   const int64_t nbag = bagging ? (int64_t)((double)P->n * bag) : P->n;
   if (bagging && nbag < 2) return fail(BWGR_EINVAL, "wgr: n*bag < 2");
+  // sample(n, n*bag, FALSE) cannot take more than the population (R errors out, R/wgr.R:68)
+  if (bagging && !rp && nbag > P->n) return fail(BWGR_EINVAL, "wgr: bag > 1 needs rp = TRUE (cannot take %lld of %lld rows without replacement)", (long long)nbag, (long long)P->n);
   if (bagging) df = df / (bag * bag);                                              // R/wgr.R:20
   if (it < 1 || bi < 0 || th < 1) return fail(BWGR_EINVAL, "wgr: need it >= 1, bi >= 0, th >= 1");
   if (de) iv = 1;                                                                  // R/wgr.R:9
@@ -2019,12 +2101,7 @@ extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int t
       if (bagging) {                                                               // R/wgr.R:68 + KMUP2's gathers
         bag_rows(seed, itx, n, nbag, rp, use_h);
         WCHK(hipMemcpyAsync(use_d, use_h.data(), sizeof(int) * (size_t)nbag, hipMemcpyHostToDevice, P->stream));
-        if (P->is_f32) hipLaunchKernelGGL(k_gather_rows<float>, dim3(4096), dim3(256), 0, P->stream, (const float *)P->X, P->R, use_d, (int)nbag, (float *)PB->X, PB->R, PB->ld, P->p);
-        else if (P->ld <= 64 * 1024) {   // a column fits the LDS: stage, pick, write in 16-byte pieces
-          const int mpw = (int)std::max<int64_t>(1, std::min<int64_t>(8, (32 * 1024) / P->ld));   // ~30 KB of LDS per workgroup: five of them per CU
-          hipLaunchKernelGGL(k_gather_rows_i8, dim3((unsigned)((P->p + mpw - 1) / mpw)), dim3(256), (size_t)mpw * P->ld, P->stream, (const int8_t *)P->X, P->R, P->ld,
-                             use_d, (int)nbag, (int8_t *)PB->X, PB->R, PB->ld, P->p, mpw);
-        } else hipLaunchKernelGGL(k_gather_rows<int8_t>, dim3(4096), dim3(256), 0, P->stream, (const int8_t *)P->X, P->R, use_d, (int)nbag, (int8_t *)PB->X, PB->R, PB->ld, P->p);
+        launch_gather_rows(P, PB, use_d, nbag);
         rc = panel_build_gram(PB);                                                  // syncs the stream (use_h stays valid)
         if (rc != BWGR_OK) goto done;
         hipLaunchKernelGGL(k_gather_e, dim3(64), dim3(256), 0, P->stream, eR, use_d, (int)nbag, ldmax, e64);

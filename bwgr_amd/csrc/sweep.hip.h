@@ -46,7 +46,8 @@ enum : int {
   SWF_EM_EN = 256,    // emEN: soft threshold (OLS -/+ Lmb1)/(Lmb2 + xx), clamped at 0 (:433-438); Lmb1 rides in sc->lam
   SWF_EM_BL = 512,    // emBL: G + Half_L2 (:379-387); Lmb1 in sc->lam, 1/(xx + cxx) in the sdz1 slot (cxx in sc->Sb)
   SWF_EM_LASSO = 1024, // lasso: yx = (e + x b0).x, soft threshold (yx -/+ Lmb)/xx clamped at 0 (:1477-1485); Lmb in sc->lam; yx_j leaves in d[j]
-  SWF_EM_ANY = SWF_EM_SEL | SWF_EM_EN | SWF_EM_BL | SWF_EM_LASSO
+  SWF_EM_ANY = SWF_EM_SEL | SWF_EM_EN | SWF_EM_BL | SWF_EM_LASSO,
+  SWF_DEBUG_WITHHOLD = 1 << 20   // test hook (bwgr_debug_withhold): slab workgroup 0 leaves at once, so every wait on it must time out
 };
 
 // scalars produced on the device by the per-iteration tail kernel (or filled by the host for KMUP)
@@ -398,6 +399,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(const SweepArgs a) {
   const int m = a.m, R = a.R, K = a.K;
   const int Rp = tile_rp<XT>(R);
   const int row0 = wg * R;
+  if ((a.flags & SWF_DEBUG_WITHHOLD) && wg == 0 && K > 1) return;
 
   // ---- LDS carve (every offset a multiple of 16 B) ----
   size_t off = 0;

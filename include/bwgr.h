@@ -93,6 +93,15 @@ int bwgr_panel_stats(bwgr_panel *P, float *xx, float *vx, float *MSx);
 int bwgr_kmup(bwgr_panel *P, float *b, float *d, const float *xx, float *e, const float *L, float Ve, float pi,
               uint64_t seed, uint32_t iter, int rng_mode);
 
+/* ---- KMUP2: the same sweep on a row subsample -----------------------------------------------------
+ * Replaces SEXP KMUP2(X,Use,b,d,xx,E,L,Ve,pi), src/Rcpp20260726ai.cpp:41-77 / _bWGR_KMUP2,
+ * src/RcppExports.cpp:34-50 (R/RcppExports.R:8-10).  Use: nuse 0-based row ids of the resident panel (wgr passes
+ * sort(sample(n, n*bag, rp)) - 1, R/wgr.R:68); b, d (p) in/out; xx, L (p) and E (the panel's n rows) inputs; e_out
+ * receives the nuse residuals of the subsample (:76).  Reference quirks kept: the conditional mean's numerator adds b0,
+ * not xx*b0, and the denominator is xx*bg + L with bg = n/nuse (:47, :59). */
+int bwgr_kmup2(bwgr_panel *P, const int *Use, int64_t nuse, float *b, float *d, const float *xx, const float *E,
+               float *e_out, const float *L, float Ve, float pi, uint64_t seed, uint32_t iter, int rng_mode);
+
 /* ---- fused chains: BayesA/B/C/L/RR/Cpi/Dpi ---------------------------------------------------------
  * Replaces SEXP Bayes*(y, X, it, bi, [pi,] df, R2), src/Rcpp20260726ai.cpp:589-987 /
  * _bWGR_BayesA.._bWGR_BayesDpi, src/RcppExports.cpp:177-290.  y: n floats (host or device per
@@ -218,6 +227,10 @@ int bwgr_synth_genotypes(void *Xdev, int64_t n, int64_t p, int64_t ldx, int64_t 
  * out[i] for marker = marker0 + i. */
 int bwgr_debug_variates(int device, uint64_t seed, int kind, double nu, uint32_t marker0, uint32_t iter,
                         uint32_t purpose, int count, double *out_host);
+/* abort-path hook: while on != 0, sweeps launched on this panel run with slab workgroup 0 absent; every workgroup that waits
+ * for it reaches its wall-clock bound (4 s), the shared abort word ends the launch and the call reports BWGR_ETIMEOUT.  The
+ * panel stays usable: switch the hook off and launch again. */
+int bwgr_debug_withhold(bwgr_panel *P, int on);
 
 #ifdef __cplusplus
 }

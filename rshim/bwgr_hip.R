@@ -7,6 +7,7 @@
 .bwgr_iter <- local({ i <- -1L; function() { i <<- i + 1L; i } })   # iteration word of the RNG counter for bare KMUP calls
 
 KMUP <- function(X, b, d, xx, e, L, Ve, pi) .Call("bwgrhip_KMUP", .bwgr_panel(X), as.double(b), as.double(d), as.double(xx), as.double(e), as.double(L), as.double(Ve), as.double(pi), .bwgr_iter())
+KMUP2 <- function(X, Use, b, d, xx, E, L, Ve, pi) .Call("bwgrhip_KMUP2", .bwgr_panel(X), as.double(Use), as.double(b), as.double(d), as.double(xx), as.double(E), as.double(L), as.double(Ve), as.double(pi), .bwgr_iter())
 
 .bwgr_fused <- function(model, y, X, it, bi, pi, df, R2) .Call("bwgrhip_Bayes", as.integer(model), as.double(y), .bwgr_panel(X), as.double(it), as.double(bi), as.double(pi), as.double(df), as.double(R2))
 BayesA   <- function(y, X, it = 1500, bi = 500, df = 5, R2 = 0.5) .bwgr_fused(0L, y, X, it, bi, 0, df, R2)
@@ -31,15 +32,26 @@ wgr <- function(y, X, it = 1500, bi = 500, th = 1, bag = 1, rp = FALSE, iv = FAL
     imp <- function(x) { x[is.na(x)] <- mean(x, na.rm = TRUE); x[is.nan(x)] <- 0; x }
     X <- apply(X, 2, imp)
   }
-  if (anyNA(y)) { mis <- which(is.na(y)); y <- y[-mis]; X <- X[-mis, ] }   # R/wgr.R:34-39
-  U <- V <- NULL
-  if (!is.null(eigK)) {                  # R/wgr.R:23-27; rows of missing y were dropped from U above in bWGR too
+  gen0 <- X; mis <- integer(0)           # R/wgr.R:10: predictions are returned for every row of gen0
+  if (anyNA(y)) { mis <- which(is.na(y)); y <- y[-mis]; X <- X[-mis, , drop = FALSE] }   # R/wgr.R:34-39
+  U <- U0 <- V <- NULL
+  if (!is.null(eigK)) {                  # R/wgr.R:23-27; the rows of missing y are dropped from U for the sweeps (:37)
     V <- eigK$values; pk <- which.max((cumsum(V) / length(V)) > VarK)
-    U <- eigK$vectors[, 1:pk, drop = FALSE]; V <- V[1:pk]
-    if (exists("mis")) U <- U[-mis, , drop = FALSE]
+    U0 <- eigK$vectors[, 1:pk, drop = FALSE]; V <- V[1:pk]
+    U <- if (length(mis)) U0[-mis, , drop = FALSE] else U0
   }
-  .Call("bwgrhip_wgr", as.double(y), .bwgr_panel(X), as.integer(it), as.integer(bi), as.integer(th), as.logical(iv), as.logical(de),
-        as.double(pi), as.double(df), as.double(R2), U, V, as.double(bag), as.logical(rp))
+  fit <- .Call("bwgrhip_wgr", as.double(y), .bwgr_panel(X), as.integer(it), as.integer(bi), as.integer(th), as.logical(iv), as.logical(de),
+               as.double(pi), as.double(df), as.double(R2), U, V, as.double(bag), as.logical(rp))
+  if (length(mis)) {                     # R/wgr.R:146-153: HAT = B0 + gen0 %*% B (+ U0 %*% H) over ALL rows, missing-y rows included
+    hat <- matrix(0, nrow(gen0), 1); hat[-mis, 1] <- fit$hat
+    hat[mis, 1] <- fit$mu + gen0[mis, , drop = FALSE] %*% fit$b
+    if (!is.null(U0)) {
+      H <- qr.solve(U, fit$u)            # u = U %*% H on the swept rows; H recovered for the rows that were left out
+      poly <- U0 %*% H; hat[mis, 1] <- hat[mis, 1] + poly[mis]; fit$u <- poly
+    }
+    fit$hat <- hat
+  }
+  fit
 }
 
 # EM / Gauss-Seidel family, R/RcppExports.R (emRR, emBA, emBB, emBC, emBCpi, emDE, emBL, emEN, emML): same names, argument

@@ -6,6 +6,7 @@
  *
  * It replaces the Rcpp-generated glue for the hot path:
  *     _bWGR_KMUP      src/RcppExports.cpp:16-31      -> bwgrhip_KMUP     (8 args)
+ *     _bWGR_KMUP2     src/RcppExports.cpp:34-50      -> bwgrhip_KMUP2    (9 args)
  *     _bWGR_BayesA..  src/RcppExports.cpp:177-290    -> bwgrhip_Bayes    (model + 7 args)
  * and adds bwgrhip_wgr (R/wgr.R:2-169 as one device-resident call) plus panel handles so that X is staged in HBM
  * once instead of being converted SEXP -> Eigen::MatrixXf on every call (src/RcppExports.cpp:20).
@@ -251,8 +252,27 @@ SEXP bwgrhip_wgr(SEXP y, SEXP panel, SEXP it, SEXP bi, SEXP th, SEXP iv, SEXP de
   return out;
 }
 
+/* KMUP2(X,Use,b,d,xx,E,L,Ve,pi) -> list(b=,d=,e=)     src/Rcpp20260726ai.cpp:41-77; Use holds 0-based row ids (R/wgr.R:68) */
+SEXP bwgrhip_KMUP2(SEXP panel, SEXP Use, SEXP b, SEXP d, SEXP xx, SEXP E, SEXP L, SEXP Ve, SEXP pi, SEXP iter) {
+  bwgr_panel *P = panel_of(panel);
+  int64_t info[8]; chk(bwgr_panel_info(P, info));
+  const R_xlen_t n0 = info[0], p = info[1], n = XLENGTH(Use);
+  if (XLENGTH(b) != p || XLENGTH(d) != p || XLENGTH(xx) != p || XLENGTH(L) != p || XLENGTH(E) != n0) Rf_error("KMUP2: length mismatch");
+  int *use = (int *)R_alloc((size_t)n, sizeof(int));
+  const double *ud = REAL(Use);                            /* the reference takes Use as a float vector and truncates, :50 */
+  for (R_xlen_t k = 0; k < n; k++) use[k] = (int)ud[k];
+  float *fb = to_float(b, p), *fd = to_float(d, p), *fxx = to_float(xx, p), *fE = to_float(E, n0), *fL = to_float(L, p);
+  float *fe = (float *)R_alloc((size_t)n, sizeof(float));
+  chk(bwgr_kmup2(P, use, (int64_t)n, fb, fd, fxx, fE, fe, fL, (float)Rf_asReal(Ve), (float)Rf_asReal(pi), seed_from_R(), (uint32_t)Rf_asInteger(iter), BWGR_RNG_PHILOX));
+  const char *nm[] = {"b", "d", "e"};
+  SEXP out = PROTECT(named_list(3, nm));
+  SET_VECTOR_ELT(out, 0, from_float(fb, p)); SET_VECTOR_ELT(out, 1, from_float(fd, p)); SET_VECTOR_ELT(out, 2, from_float(fe, n));
+  UNPROTECT(1);
+  return out;
+}
+
 static const R_CallMethodDef CallEntries[] = {   /* as src/RcppExports.cpp:1152-1228 registers _bWGR_* */
-  {"bwgrhip_panel", (DL_FUNC)&bwgrhip_panel, 2}, {"bwgrhip_KMUP", (DL_FUNC)&bwgrhip_KMUP, 9},
+  {"bwgrhip_panel", (DL_FUNC)&bwgrhip_panel, 2}, {"bwgrhip_KMUP", (DL_FUNC)&bwgrhip_KMUP, 9}, {"bwgrhip_KMUP2", (DL_FUNC)&bwgrhip_KMUP2, 10},
   {"bwgrhip_Bayes", (DL_FUNC)&bwgrhip_Bayes, 8}, {"bwgrhip_Bayes2", (DL_FUNC)&bwgrhip_Bayes2, 9},
   {"bwgrhip_wgr", (DL_FUNC)&bwgrhip_wgr, 14}, {"bwgrhip_em", (DL_FUNC)&bwgrhip_em, 7}, {NULL, NULL, 0}};
 

@@ -57,6 +57,7 @@ def test_host_mirror_signatures_match_reference():
                 if p.kind == inspect.Parameter.POSITIONAL_OR_KEYWORD]
     E = inspect.Parameter.empty
     assert pos(B.KMUP) == [("X", E), ("b", E), ("d", E), ("xx", E), ("e", E), ("L", E), ("Ve", E), ("pi", E)]
+    assert pos(B.KMUP2) == [("X", E), ("Use", E), ("b", E), ("d", E), ("xx", E), ("E", E), ("L", E), ("Ve", E), ("pi", E)]   # R/RcppExports.R:8
     for f in (B.BayesA, B.BayesL, B.BayesRR, B.BayesCpi, B.BayesDpi):
         assert pos(f) == [("y", E), ("X", E), ("it", 1500), ("bi", 500), ("df", 5), ("R2", 0.5)]
     for f in (B.BayesB, B.BayesC):

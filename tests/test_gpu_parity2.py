@@ -1,0 +1,248 @@
+"""GPU parity tests, second file: the configurations and boundary entries round 1 left uncovered.
+
+* KMUP2 as a standalone entry (src/Rcpp20260726ai.cpp:41-77)
+* n > 16 383 (the 16-bit Gram copies can no longer be taken for granted), many slab workgroups, > 2 q feeders: the shape of
+  BASELINE config 5 (n = 50 000, BayesCpi) at a p the oracle finishes in seconds
+* full-size BASELINE config 2 (5 000 x 50 000 BayesA) against the oracle
+* the GPU against the oracle's FLOAT-FAITHFUL flavour (the restatement of the reference's own types), with the bound
+  that is actually measured
+* the abort path (bounded spins -> BWGR_ETIMEOUT -> the panel stays usable)
+"""
+import numpy as np
+import pytest
+
+from conftest import scaled_err, synth_small
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+ALL_MODELS = ["BayesA", "BayesB", "BayesC", "BayesL", "BayesRR", "BayesCpi", "BayesDpi"]
+
+
+def _rel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-300)
+
+
+@pytest.mark.parametrize("pi", [0.0, 0.3])
+@pytest.mark.parametrize("repeats", [False, True])
+def test_kmup2_tpod(tpod, pi, repeats):
+    """KMUP2(X,Use,b,d,xx,E,L,Ve,pi): the sweep on a row subsample, with the reference's `+ b0` numerator and
+    `xx*bg + L` denominator (:47, :59); Use as wgr passes it (sorted, 0-based; with rp = TRUE rows repeat)."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = tpod["gen"], tpod["y"]
+    n, p = X.shape
+    rs = np.random.RandomState(9)
+    use = np.sort(rs.choice(n, 120, replace=repeats)).astype(np.int32)
+    xx = (X.astype(np.float64) ** 2).sum(0) * (120.0 / n)        # wgr passes colSums(X^2) * bag
+    b = rs.normal(size=p) * 0.01
+    d = np.ones(p)
+    E = y - y.mean() - X.astype(np.float64) @ b
+    L = np.full(p, 120.0) * rs.uniform(0.5, 2.0, p)
+    g = bwgr_amd.KMUP2(X, use, b, d, xx, E, L, 0.03, pi, seed=78, it=4)
+    o = O.kmup2(X, use, b, d, xx, E, L, 0.03, pi, seed=78, it=4)
+    assert g["e"].shape == (120,)
+    assert scaled_err(g["b"], o["b"]) < TOL and scaled_err(g["e"], o["e"]) < TOL
+    assert np.array_equal(g["d"], o["d"])
+
+
+def test_kmup2_rejects_rows_outside_the_panel(tpod):
+    import bwgr_amd
+    X = tpod["gen"]; n, p = X.shape
+    z = np.zeros(p)
+    with pytest.raises(bwgr_amd.BwgrError):
+        bwgr_amd.KMUP2(X, [0, 1, n], z, z + 1, z + 1, np.zeros(n), z + 1, 1.0, 0.0, seed=1)
+
+
+def test_wgr_bag_above_one_needs_replacement(tpod):
+    """sample(n, n*bag, FALSE) with bag > 1 is an error in R (R/wgr.R:68); the library must refuse it before touching memory."""
+    import bwgr_amd
+    with pytest.raises(bwgr_amd.BwgrError):
+        bwgr_amd.wgr(tpod["y"], tpod["gen"], it=3, bi=1, bag=1.5, rp=False, seed=1)
+    g = bwgr_amd.wgr(tpod["y"], tpod["gen"], it=3, bi=1, bag=1.5, rp=True, seed=1)    # with replacement it is legal
+    assert np.isfinite(g["hat"]).all()
+
+
+def test_panel_refuses_integers_that_do_not_fit_int8(tpod):
+    import bwgr_amd
+    X = tpod["gen"].astype(np.int32).copy(); X[3, 5] = 200
+    with pytest.raises(ValueError):
+        bwgr_amd.Panel(X, as_int8=True)
+    P = bwgr_amd.Panel(X)                       # default: staged as float32, value kept
+    xx, _, _ = P.stats()
+    assert xx[5] == np.float32((X[:, 5].astype(np.float64) ** 2).sum())
+    P.close()
+
+
+def test_panel_destroy_waits_for_its_chains(tpod):
+    import bwgr_amd
+    P = bwgr_amd.Panel(tpod["gen"])
+    ch = bwgr_amd.Chain(P, "BayesRR", tpod["y"], it=2, bi=0, seed=1)
+    with pytest.raises(bwgr_amd.BwgrError):
+        P.close()                                # a chain is alive: refused, handle still valid
+    ch.run(2); ch.sync(); ch.close()
+    P.close()
+
+
+@pytest.mark.parametrize("model", ["BayesCpi", "BayesB"])
+@pytest.mark.parametrize("n,p,env", [(20000, 640, {}), (50000, 384, {}), (50000, 384, {"BWGR_GRAM16": "0"})])
+def test_large_n_against_oracle(model, n, p, env, monkeypatch):
+    """BASELINE config 5's shape (n = 50 000, BayesCpi: dense inclusion) and n = 20 000, at a p the oracle finishes in seconds:
+    79-196 slab workgroups, 3-6 q feeders, more than nine of them for the first time; 16-bit and 32-bit Gram staging."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = synth_small(n, p, seed=n // 100 + p)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    P = bwgr_amd.Panel(X)
+    pipe = P.pipeline(True)
+    assert P.nwg >= 79 and pipe["generation"] >= 2 and pipe["feeders"] >= 3, (P.nwg, pipe)
+    if env:
+        assert pipe["gram_bits"] == 32
+    ch = bwgr_amd.Chain(P, model, y, it=3, bi=0, pi=0.9, seed=5)
+    ch.run(3)
+    st = ch.state()
+    ch.close(); P.close()
+    o = O.bayes(model, y, X, it=3, bi=0, pi=0.9, seed=5)["last"]
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
+    assert np.array_equal(st["d"], o["d"])
+
+
+def test_gram_entries_beyond_16_bits_fall_back_naturally():
+    """Markers fixed at 2 over 20 000 rows: X_j'X_k = 80 000 > 65 535, so the device-side range check must fail and the
+    32-bit staging take over by itself (no environment switch)."""
+    import bwgr_amd
+    from oracle import oracle as O
+    n, p = 20000, 256
+    X, y = synth_small(n, p, seed=31)
+    X = np.array(X); X[:, 10] = 2; X[:, 11] = 2; X[:, 140] = 2
+    X = np.asfortranarray(X)
+    P = bwgr_amd.Panel(X)
+    assert P.pipeline(True)["gram_bits"] == 32
+    ch = bwgr_amd.Chain(P, "BayesB", y, it=3, bi=0, pi=0.8, seed=6)
+    ch.run(3)
+    st = ch.state()
+    ch.close(); P.close()
+    o = O.bayes("BayesB", y, X, it=3, bi=0, pi=0.8, seed=6)["last"]
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and np.array_equal(st["d"], o["d"])
+
+
+def test_full_size_c2_against_oracle():
+    """BASELINE config 2 at full size: synthetic 5 000 x 50 000 int8, BayesA, two iterations against the oracle
+    (src/Rcpp20260726ai.cpp:589-635); the oracle takes about a second per iteration."""
+    import bwgr_amd
+    from bwgr_amd import synth
+    from oracle import oracle as O
+    n, p = 5000, 50000
+    Xd = synth.genotypes(n, p)
+    y = synth.scale_phenotype(synth.phenotype(Xd, n))
+    P = bwgr_amd.Panel(Xd, n=n)
+    ch = bwgr_amd.Chain(P, "BayesA", y, it=2, bi=0, seed=synth.SEED)
+    ch.run(2)
+    st = ch.state()
+    ch.close(); P.close()
+    Xh = np.asfortranarray(Xd[:, :n].cpu().numpy().T.astype(np.float32))
+    o = O.bayes("BayesA", y.cpu().numpy(), Xh, it=2, bi=0, seed=synth.SEED)["last"]
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
+
+
+def test_c3_size_properties():
+    """BASELINE config 3 (n = 10 000 x p = 500 000, BayesB pi = 0.99): residual identity against an independent fp64 product
+    and the inclusion rate, after three iterations (the oracle cannot run this size)."""
+    import torch
+    import bwgr_amd
+    from bwgr_amd import synth
+    n, p = 10000, 500000
+    X = synth.genotypes(n, p)
+    y = synth.scale_phenotype(synth.phenotype(X, n))
+    P = bwgr_amd.Panel(X, n=n)
+    ch = bwgr_amd.Chain(P, "BayesB", y, it=3, bi=0, pi=0.99, seed=synth.SEED)
+    ch.run(3)
+    st = ch.state()
+    ch.close(); P.close()
+    b = torch.from_numpy(st["b"]).to(X.device).double()
+    xb = torch.zeros(n, dtype=torch.float64, device=X.device)
+    for j0 in range(0, p, 50000):
+        xb += X[j0:j0 + 50000, :n].double().T @ b[j0:j0 + 50000]
+    e_ref = (y.double() - st["mu"] - xb).cpu().numpy()
+    assert np.abs(e_ref - st["e"]).max() < 2e-5 * np.abs(e_ref).max()
+    assert 0.003 < st["d"].mean() < 0.05
+
+
+# Distance of the GPU chain from the oracle's FLOAT-FAITHFUL flavour ("f": float residual, float accumulators in eight
+# interleaved partial sums like Eigen's packet reduction, norms rounded to float before subtraction -- the reference's own
+# types).  That flavour's results depend on the summation order at the 1e-6 level, which is why the parity target is the wide
+# flavour; the bounds below are the measured distances with a margin of about two, and they are what "identical to the
+# reference" can mean for this path: the north-star's 1e-6 holds against the widened restatement only.
+FAITHFUL_BOUND = {"b": 2e-5, "e": 2e-5, "scalar": 2e-5}
+
+
+@pytest.mark.parametrize("model", ALL_MODELS)
+@pytest.mark.parametrize("data", ["tpod", "synth"])
+def test_distance_to_the_float_faithful_flavour(tpod, model, data):
+    import bwgr_amd
+    from oracle import oracle as O
+    if data == "tpod":
+        X, y = tpod["gen"], tpod["y"]
+    else:
+        X, y = synth_small(600, 500, seed=3)
+    P = bwgr_amd.Panel(X)
+    ch = bwgr_amd.Chain(P, model, y, it=10, bi=2, pi=0.9, seed=21)
+    ch.run(10)
+    st = ch.state()
+    ch.close(); P.close()
+    f = O.bayes(model, y, X, it=10, bi=2, pi=0.9, seed=21, flavour="f")["last"]
+    w = O.bayes(model, y, X, it=10, bi=2, pi=0.9, seed=21, flavour="w")["last"]
+    same_decisions = np.array_equal(f["d"], w["d"])
+    eb, ee, ev = scaled_err(st["b"], f["b"]), scaled_err(st["e"], f["e"]), _rel(st["ve"], f["ve"])
+    print("faithful-distance %s/%s: b %.2e e %.2e ve %.2e (wide: b %.2e e %.2e) decisions_equal=%s" % (
+        model, data, eb, ee, ev, scaled_err(st["b"], w["b"]), scaled_err(st["e"], w["e"]), same_decisions))
+    assert scaled_err(st["b"], w["b"]) < TOL and scaled_err(st["e"], w["e"]) < TOL
+    if same_decisions:   # a flipped inclusion decision (the float flavour's norm cancellation) forks the chains: nothing to bound
+        assert eb < FAITHFUL_BOUND["b"] and ee < FAITHFUL_BOUND["e"] and ev < FAITHFUL_BOUND["scalar"]
+
+
+@pytest.mark.parametrize("pi", [0.0, 0.3])
+def test_kmup_distance_to_the_float_faithful_flavour(tpod, pi):
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = tpod["gen"], tpod["y"]
+    n, p = X.shape
+    rs = np.random.RandomState(5)
+    xx = (X.astype(np.float64) ** 2).sum(0)
+    b = rs.normal(size=p) * 0.01
+    e = y - y.mean() - X.astype(np.float64) @ b
+    L = np.full(p, 120.0) * rs.uniform(0.5, 2.0, p)
+    g = bwgr_amd.KMUP(X, b, np.ones(p), xx, e, L, 0.03, pi, seed=77, it=3)
+    f = O.kmup(X, b, np.ones(p), xx, e, L, 0.03, pi, seed=77, it=3, flavour="f")
+    eb, ee = scaled_err(g["b"], f["b"]), scaled_err(g["e"], f["e"])
+    print("faithful-distance KMUP pi=%.1f: b %.2e e %.2e decisions_equal=%s" % (pi, eb, ee, np.array_equal(g["d"], f["d"])))
+    if np.array_equal(g["d"], f["d"]):
+        assert eb < FAITHFUL_BOUND["b"] and ee < FAITHFUL_BOUND["e"]
+
+
+def test_abort_path_reports_a_timeout_and_the_panel_survives():
+    """One slab workgroup withheld (bwgr_debug_withhold): every workgroup that waits for it must reach its wall-clock bound,
+    the shared abort word must end the launch, bwgr_chain_sync must return BWGR_ETIMEOUT, and the next launch on the same
+    panel must succeed and give the oracle's chain."""
+    import ctypes as C
+    import time
+    import bwgr_amd
+    from bwgr_amd import _lib
+    from oracle import oracle as O
+    X, y = synth_small(700, 600, seed=4)
+    P = bwgr_amd.Panel(X, block=64, nwg=3)
+    _lib.check(_lib.lib().bwgr_debug_withhold(P._h, 1))
+    ch = bwgr_amd.Chain(P, "BayesB", y, it=2, bi=0, pi=0.8, seed=2)
+    t0 = time.time()
+    ch.run(1)
+    with pytest.raises(bwgr_amd.BwgrError) as ei:
+        ch.sync()
+    assert ei.value.code == 4 and time.time() - t0 < 30.0          # BWGR_ETIMEOUT, within the 4 s bound (+ slack)
+    ch.close()
+    _lib.check(_lib.lib().bwgr_debug_withhold(P._h, 0))
+    ch = bwgr_amd.Chain(P, "BayesB", y, it=4, bi=0, pi=0.8, seed=2)
+    ch.run(4)
+    st = ch.state()
+    ch.close(); P.close()
+    o = O.bayes("BayesB", y, X, it=4, bi=0, pi=0.8, seed=2)["last"]
+    assert scaled_err(st["b"], o["b"]) < TOL and np.array_equal(st["d"], o["d"])
