@@ -1,6 +1,7 @@
 """ctypes binding of libbwgr_hip.so (include/bwgr.h).  Fails loudly: there is no CPU fallback."""
 import ctypes as C
 import os
+import sys
 
 from . import build as _build
 
@@ -24,6 +25,13 @@ def lib():
     if not os.path.exists(path):
         raise ImportError("libbwgr_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `python -m bwgr_amd.build`); bwgr_amd has no CPU fallback")
+    # PyTorch (device memory for bench inputs, torch.distributed) bundles its own HIP runtime; if this library loads the system
+    # one first, torch later finds "No HIP GPUs".  Loading torch first lets both share one runtime.  BWGR_PRELOAD_TORCH=0 skips it.
+    if "torch" not in sys.modules and os.environ.get("BWGR_PRELOAD_TORCH", "1") != "0":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(path)
     L.bwgr_last_error.restype = C.c_char_p
     vp, i64, u64, u32, i32, f32, f64 = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_int, C.c_float, C.c_double

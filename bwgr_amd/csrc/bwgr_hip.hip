@@ -13,7 +13,7 @@
 #include "../../include/bwgr.h"
 #include "rng.hip.h"
 #include "sweep.hip.h"
-#include "sweep2.hip.h"
+#include "sweep3.hip.h"
 #include <stdlib.h>
 
 using namespace bwgr;
@@ -29,6 +29,11 @@ static int fail(int code, const char *fmt, ...) {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(BWGR_EHIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 #define CHK(x) do { int r_ = (x); if (r_ != BWGR_OK) return r_; } while (0)
 
+// the status a sweep kernel left in ChainScalars::error
+static int sweep_error(uint32_t code, const char *who) {
+  if (code == 2u) return fail(BWGR_ERANGE, "%s: the residual left the fixed-point range of the sweep (it grew more than eightfold within one sweep); the chain state is invalid", who);
+  return fail(BWGR_ETIMEOUT, "%s: a workgroup exchange timed out inside the sweep kernel (the chain state is invalid)", who);
+}
 extern "C" const char *bwgr_last_error(void) { return g_err; }
 extern "C" int bwgr_abi_version(void) { return BWGR_ABI_VERSION; }
 extern "C" int bwgr_device_count(int *count) {
@@ -340,6 +345,19 @@ __global__ void k_gram_pack(const GT *gram, GT *gramp, int m, int pstride, int64
 
 // 16-bit copies of the packed and the distance-1 cross Gram blocks for the k_sweep2 sequencer (half the bytes through its
 // CU per block); *bad is set when an entry does not fit, and the sequencer then stages the 32-bit arrays
+// largest |x| of an int8 panel (k_sweep3's integer sums are sized by it)
+__global__ void k_absmax_i8(const int8_t *X, size_t count, int *out) {
+  int mx = 0;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < count; i += (size_t)gridDim.x * blockDim.x * 16) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(X + i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const int x = (int)(int8_t)(w[q] >> (8 * c)); mx = max(mx, x < 0 ? -x : x); }
+  }
+  atomicMax(out, mx);
+}
 __global__ void k_gram_narrow(const int32_t *src, uint16_t *dst, int64_t count, int *bad) {
   int any = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
@@ -886,6 +904,18 @@ struct bwgr_panel {
   int nclones = 0;
   int nchains = 0;                // live chains on this handle: panel_destroy refuses while any is alive
   int debug_withhold = 0;         // test hook: the next sweeps run with slab workgroup 0 missing (bwgr_debug_withhold)
+  // k_sweep3 (selection models on int8 panels, sweep3.hip.h)
+  bool want3 = false;             // build what k_sweep3 needs with the panel (off for the per-iteration scratch panels of bagging and the EM family)
+  bool e3_ready = false;
+  int e3_D = 0;                   // fold-in lag in blocks; cross Gram arrays reach D-1 blocks back
+  int K3 = 0, R3 = 0, sub3 = 0;   // streamer workgroups, rows of each, streamers per slab
+  void *g3x[S3_MAXD] = {};        // g3x[d-1]: cross Gram blocks of distance d in the element type k_sweep3 reads (aliases the older arrays where they fit)
+  bool g3own[S3_MAXD] = {};       // allocated here (not an alias)
+  int xmax = 0;                   // largest |x| of an int8 panel
+  int *xmax_dev = nullptr;
+  unsigned long long *qsum3 = nullptr, *lists3 = nullptr;   // per handle (clones have their own)
+  uint32_t epoch3 = 0;
+  size_t lds3_bytes = 0;
   hipStream_t own_stream = nullptr;
 };
 
@@ -957,7 +987,7 @@ static hipError_t alloc_exchange(bwgr_panel *P) {
 }
 // polled words are zeroed before every launch (epochs count within a launch)
 static int reset_exchange(bwgr_panel *P) {
-  if (P->sweep_version == 2) {
+  if (P->sweep_version >= 2) {
     HIPCHK(hipMemsetAsync(P->xchg, 0, P->xchg_bytes, P->stream));
   } else if (P->K > 1) {
     HIPCHK(hipMemsetAsync(P->xflags, 0, sizeof(uint32_t) * ((size_t)P->K + 1) * SW_FLAG_STRIDE, P->stream));
@@ -965,11 +995,106 @@ static int reset_exchange(bwgr_panel *P) {
   return BWGR_OK;
 }
 
+static void launch_gramx_i8(bwgr_panel *P, int32_t *g, int dist);
+// ---- k_sweep3 (sweep3.hip.h): which launches take it, and what it needs beside the panel ----
+static int sweep3_lag(const bwgr_panel *P) { return P->e3_D; }
+static bool use_sweep3(const bwgr_panel *P, int flags) {
+  return P->sweep_version == 3 && P->e3_ready && (flags & SWF_SELECT) != 0 && (flags & SWF_EM_ANY) == 0;
+}
+// geometry, scratch and attributes (every handle: panels and clones)
+static int sweep3_alloc_scratch(bwgr_panel *P) {
+  HIPCHK(hipMalloc(&P->qsum3, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)P->nblocks));
+  HIPCHK(hipMalloc(&P->lists3, sizeof(unsigned long long) * S3_LSTRIDE * (size_t)P->nblocks));
+  HIPCHK(hipMemsetAsync(P->lists3, 0, sizeof(unsigned long long) * S3_LSTRIDE * (size_t)P->nblocks, P->stream));
+  return BWGR_OK;
+}
+// the cross Gram arrays of distance 2 .. D-1 in the element type of the 16-bit (or, failing that, 32-bit) staging
+static int sweep3_build(bwgr_panel *P) {
+  P->e3_ready = false;
+  if (P->is_f32 || !P->want3 || P->sweep_version != 3) return BWGR_OK;
+  const int m = P->m;
+  int R3 = (P->R % 256 == 0) ? 256 : 128;
+  if (const char *rv = getenv("BWGR_R3")) { const int v = atoi(rv); if ((v == 64 || v == 128 || v == 256) && P->R % v == 0) R3 = v; }
+  const int sub = P->R / R3, K3 = P->K * sub;
+  int D = 12;
+  if (const char *dv = getenv("BWGR_D3")) { const int v = atoi(dv); if (v >= 1 && v <= S3_MAXD) D = v; }
+  D = (int)std::min<int64_t>(D, std::max<int64_t>(1, P->nblocks));
+  const size_t lds = std::max(s3_streamer_lds(R3), s3_seq_lds(D));
+  // the slab dots are summed as integers: sum over all rows of |x| * 128 per digit, four digits of 8 bits, 8 bits of arrival count
+  if (K3 > 255 || K3 + 1 > 256 || lds > (size_t)160 * 1024 || (int64_t)P->ld * std::max(P->xmax, 1) >= (1ll << 23) || (size_t)m * R3 > (size_t)4 * 16 * SW_THREADS) {
+    P->sweep_version = 2;
+    return BWGR_OK;
+  }
+  P->R3 = R3; P->sub3 = sub; P->K3 = K3; P->e3_D = D; P->lds3_bytes = lds;
+  const size_t blk_elems = (size_t)P->nblocks * m * m;
+  const bool g16 = P->gram16;
+  int32_t *tmp = nullptr;
+  for (int d = 1; d < D; ++d) {
+    if (P->nblocks <= d) { P->g3x[d - 1] = nullptr; continue; }
+    if (d == 1) { P->g3x[0] = g16 ? (void *)P->gramx16 : P->gramx; continue; }
+    if (!g16 && d == 2 && P->gramx2) { P->g3x[1] = P->gramx2; continue; }
+    if (!g16 && d == 3 && P->gramx3) { P->g3x[2] = P->gramx3; continue; }
+    void *arr = nullptr;
+    HIPCHK(hipMalloc(&arr, blk_elems * (g16 ? 2 : 4)));
+    P->g3x[d - 1] = arr; P->g3own[d - 1] = true;
+    if (g16) {
+      const int32_t *src;
+      if (d == 2 && P->gramx2) src = (const int32_t *)P->gramx2;
+      else if (d == 3 && P->gramx3) src = (const int32_t *)P->gramx3;
+      else {
+        if (!tmp) HIPCHK(hipMalloc(&tmp, blk_elems * 4));
+        launch_gramx_i8(P, tmp, d);
+        src = tmp;
+      }
+      hipLaunchKernelGGL(k_gram_narrow, dim3(2048), dim3(256), 0, P->stream, src + (size_t)d * m * m, (uint16_t *)arr + (size_t)d * m * m, (int64_t)(P->nblocks - d) * m * m, P->gram16_bad);
+    } else launch_gramx_i8(P, (int32_t *)arr, d);
+    HIPCHK(hipGetLastError());
+  }
+  int bad = 0;
+  if (g16) HIPCHK(hipMemcpyAsync(&bad, P->gram16_bad, sizeof(int), hipMemcpyDeviceToHost, P->stream));
+  HIPCHK(hipStreamSynchronize(P->stream));
+  if (tmp) hipFree(tmp);
+  if (bad) {   // an entry of a far block left the 16-bit range although the near blocks fit: rare; leave the panel to k_sweep2
+    for (int d = 1; d < S3_MAXD; ++d) if (P->g3own[d - 1]) { hipFree(P->g3x[d - 1]); P->g3x[d - 1] = nullptr; P->g3own[d - 1] = false; }
+    P->sweep_version = 2;
+    return BWGR_OK;
+  }
+  CHK(sweep3_alloc_scratch(P));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<int32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  P->e3_ready = true;
+  return BWGR_OK;
+}
+static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
+  Sweep3Args A;
+  memset(&A, 0, sizeof(A));
+  A.a = a;
+  const bwgr_panel *root = P->parent ? P->parent : P;
+  for (int d = 0; d < S3_MAXD; ++d) A.gx[d] = root->g3x[d];
+  A.gp = root->gram16 ? (const void *)root->gramp16 : root->gramp;
+  A.D = P->e3_D; A.K3 = P->K3; A.R3 = P->R3; A.sub = P->sub3; A.g16 = root->gram16 ? 1 : 0;
+  A.qsum = P->qsum3; A.lists = P->lists3;
+  P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1;
+  A.epoch = P->epoch3;
+  (void)hipMemsetAsync(P->qsum3 + (size_t)a.blk_begin * 2 * SW_MAXM, 0, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
+  const dim3 grid(P->K3 + 1), blk(SW_THREADS);
+  if (A.g16) hipLaunchKernelGGL(k_sweep3<uint16_t>, grid, blk, P->lds3_bytes, P->stream, A);
+  else hipLaunchKernelGGL(k_sweep3<int32_t>, grid, blk, P->lds3_bytes, P->stream, A);
+}
+
 static void launch_prestage(bwgr_panel *P, const SweepArgs &a) {
   const int j0 = a.blk_begin * a.m, j1 = (int)std::min<int64_t>(P->p, (int64_t)a.blk_end * a.m);
   const int64_t tasks = 4ll * (j1 - j0);
+  const bool s3 = use_sweep3(P, a.flags);
+  if (s3) hipLaunchKernelGGL(k_escale_reset, dim3(1), dim3(1), 0, P->stream, a.sc);
   hipLaunchKernelGGL(k_prestage, dim3((unsigned)std::min<int64_t>(4096, (tasks + 255) / 256)), dim3(256), 0, P->stream, a, j0, j1);
-  if (P->sweep_version == 2) {
+  if (s3) {   // the sweep's fixed-point scale, then the in-block speculative terms on that grid
+    int xbits = 0; while ((1 << xbits) < std::max(1, (P->parent ? P->parent : P)->xmax)) ++xbits;
+    hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, xbits);
+    hipLaunchKernelGGL(k_spec3, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin);
+    return;
+  }
+  if (P->sweep_version >= 2) {
     const int sel = (a.flags & SWF_SELECT) ? 1 : 0;
     const unsigned nb = (unsigned)(a.blk_end - a.blk_begin);
     if (P->is_f32) hipLaunchKernelGGL(k_spec<double>, dim3(nb), dim3(128), 0, P->stream, a, a.blk_begin, sel);
@@ -980,11 +1105,12 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a) {
 static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
   SweepArgs a = a_in;
   if (P->debug_withhold) a.flags |= SWF_DEBUG_WITHHOLD;
+  if (use_sweep3(P, a.flags)) { launch_sweep3(P, a); return; }
   const bool sel = (a.flags & SWF_SELECT) != 0;
   // streamers, sequencer, and for the selection models the q feeders (the affine recurrence is compute-bound: its
   // sequencer gathers q itself under the recurrence, and a feeder hop in its lag-2 chain measured 15 % slower)
-  a.nfeed = (P->sweep_version == 2 && sel) ? P->nfeed : 0;
-  if (P->sweep_version == 2) {
+  a.nfeed = (P->sweep_version >= 2 && sel) ? P->nfeed : 0;
+  if (P->sweep_version >= 2) {
     const dim3 grid(P->K + 1 + a.nfeed), blk(SW_THREADS);
     if (P->is_f32) {
       if (sel) hipLaunchKernelGGL((k_sweep2<float, true>), grid, blk, P->lds2_bytes, P->stream, a);
@@ -1015,7 +1141,7 @@ static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
   // depth 4 where the panel has the third cross Gram array (int8, 16-bit staging), else 3; BWGR_LAG=2|3 caps it (A/B tests)
   const int cap = (lv && lv[0] >= '2' && lv[0] <= '4') ? lv[0] - '0' : 4;
   int lag = 2;
-  if (P->sweep_version == 2 && (a.flags & SWF_SELECT)) {
+  if (P->sweep_version >= 2 && (a.flags & SWF_SELECT)) {
     if (P->gramx2) lag = 3;   // fp32 panels too (generic streamer and sequencer)
     if (!P->is_f32 && P->gramx3 && P->gram16 && P->lag4_ok) lag = 4;   // only the 16-bit / single-barrier sequencer knows the third cross term
   }
@@ -1077,11 +1203,14 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   if (P->nchains > 0) return fail(BWGR_EINVAL, "panel_destroy: %d chain(s) on this panel are still alive (destroy them first)", P->nchains);
   (void)hipSetDevice(P->device);
   if (!P->parent) {
+    for (int d = 0; d < S3_MAXD; ++d) if (P->g3own[d]) hipFree(P->g3x[d]);
+    hipFree(P->xmax_dev);
     hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->gramx3); hipFree(P->gramp16); hipFree(P->gramx16); hipFree(P->gram16_bad); hipFree(P->gramp); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev);
   } else {
     P->parent->nclones--;
   }
   // the scratch a sweep writes: speculative cross terms, pre-staged constants, exchange words
+  hipFree(P->qsum3); hipFree(P->lists3);
   hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->xpart); hipFree(P->xchg); hipFree(P->stamps);
   if (P->own_stream) hipStreamDestroy(P->own_stream);
   delete P;
@@ -1107,7 +1236,41 @@ static int panel_setup(bwgr_panel *P) {
     HIPCHK(hipStreamSynchronize(P->stream));
     HIPCHK(hipFree(part));
   }
-  return panel_build_gram(P);
+  if (!P->is_f32) {
+    if (!P->xmax_dev) HIPCHK(hipMalloc(&P->xmax_dev, sizeof(int)));
+    HIPCHK(hipMemsetAsync(P->xmax_dev, 0, sizeof(int), P->stream));
+    hipLaunchKernelGGL(k_absmax_i8, dim3(2048), dim3(256), 0, P->stream, (const int8_t *)P->X, P->x_bytes, P->xmax_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&P->xmax, P->xmax_dev, sizeof(int), hipMemcpyDeviceToHost, P->stream));
+    HIPCHK(hipStreamSynchronize(P->stream));
+  }
+  CHK(panel_build_gram(P));
+  // the trajectory engine for the selection models (int8 panels that asked for it; BWGR_SWEEP=2 keeps k_sweep2)
+  const char *sv = getenv("BWGR_SWEEP");
+  if (P->want3 && !P->is_f32 && P->sweep_version == 2 && !(sv && sv[0] == '2')) {
+    P->sweep_version = 3;
+    CHK(sweep3_build(P));
+  }
+  return BWGR_OK;
+}
+
+// cross Gram blocks X_{b-dist}' X_b of an int8 panel, b = dist .. nblocks-1, into g[b][m][m] (int32, exact)
+static void launch_gramx_i8(bwgr_panel *P, int32_t *g, int dist) {
+  const int p = (int)P->p, m = P->m, TJ = m / 16;
+  const unsigned nbx = (unsigned)(P->nblocks - dist);
+  const size_t lds = (size_t)2 * m * 33 * sizeof(int32_t);
+  const int8_t *X = (const int8_t *)P->X;
+  if (m == 128) hipLaunchKernelGGL(k_gram_mfma_i8, dim3(nbx), dim3(256), 0, P->stream, X, P->ld, P->R, p, g, dist);
+  else switch (TJ) {
+    case 1: hipLaunchKernelGGL(k_gramx_i8<1>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+    case 2: hipLaunchKernelGGL(k_gramx_i8<2>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+    case 3: hipLaunchKernelGGL(k_gramx_i8<3>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+    case 4: hipLaunchKernelGGL(k_gramx_i8<4>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+    case 5: hipLaunchKernelGGL(k_gramx_i8<5>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+    case 6: hipLaunchKernelGGL(k_gramx_i8<6>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+    case 7: hipLaunchKernelGGL(k_gramx_i8<7>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+    default: hipLaunchKernelGGL(k_gramx_i8<8>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
+  }
 }
 
 // diagonal, off-diagonal and packed Gram blocks of the resident X
@@ -1152,19 +1315,7 @@ static int panel_build_gram(bwgr_panel *P) {
         default: hipLaunchKernelGGL(k_gramx_f32<4>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
       }
     } else {
-      const size_t lds = (size_t)2 * m * 33 * sizeof(int32_t);
-      int32_t *g = (int32_t *)(dist == 1 ? P->gramx : dist == 2 ? P->gramx2 : P->gramx3); const int8_t *X = (const int8_t *)P->X;
-      if (m == 128) hipLaunchKernelGGL(k_gram_mfma_i8, dim3(nbx), dim3(256), 0, P->stream, X, P->ld, P->R, p, g, dist);
-      else switch (TJ) {
-        case 1: hipLaunchKernelGGL(k_gramx_i8<1>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
-        case 2: hipLaunchKernelGGL(k_gramx_i8<2>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
-        case 3: hipLaunchKernelGGL(k_gramx_i8<3>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
-        case 4: hipLaunchKernelGGL(k_gramx_i8<4>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
-        case 5: hipLaunchKernelGGL(k_gramx_i8<5>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
-        case 6: hipLaunchKernelGGL(k_gramx_i8<6>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
-        case 7: hipLaunchKernelGGL(k_gramx_i8<7>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
-        default: hipLaunchKernelGGL(k_gramx_i8<8>, dim3(nbx), dim3(256), lds, P->stream, X, P->ld, P->R, p, m, g, dist); break;
-      }
+      launch_gramx_i8(P, (int32_t *)(dist == 1 ? P->gramx : dist == 2 ? P->gramx2 : P->gramx3), dist);
     }
     HIPCHK(hipGetLastError());
   }
@@ -1245,18 +1396,18 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipMalloc(&P->X, P->x_bytes));
   PCHK(hipMalloc(&P->gram, P->gram_bytes));
   PCHK(hipMalloc(&P->gramx, P->gram_bytes));
-  if (P->sweep_version == 2 && P->nblocks > 2) {   // distance-2 blocks: the selection models' lag-3 pipeline
+  if (P->sweep_version >= 2 && P->nblocks > 2) {   // distance-2 blocks: the selection models' lag-3 pipeline
     PCHK(hipMalloc(&P->gramx2, P->gram_bytes));
     PCHK(hipMalloc(&P->xspec2, sizeof(double) * (size_t)P->nblocks * SW_MAXM));
   }
   const char *lagenv = getenv("BWGR_LAG");
-  if (P->sweep_version == 2 && !P->is_f32 && P->nblocks > 3 && P->lag4_ok && !(lagenv && (lagenv[0] == '2' || lagenv[0] == '3'))) {   // distance-3 blocks: the lag-4 pipeline
+  if (P->sweep_version >= 2 && !P->is_f32 && P->nblocks > 3 && P->lag4_ok && !(lagenv && (lagenv[0] == '2' || lagenv[0] == '3'))) {   // distance-3 blocks: the lag-4 pipeline
     PCHK(hipMalloc(&P->gramx3, P->gram_bytes));
     PCHK(hipMalloc(&P->xspec3, sizeof(double) * (size_t)P->nblocks * SW_MAXM));
   }
   P->pstride = ((m * (m - 1) / 2 + 7) / 8) * 8;
   PCHK(hipMalloc(&P->gramp, (size_t)P->nblocks * std::max(P->pstride, 8) * (P->is_f32 ? 8 : 4)));
-  if (!P->is_f32 && P->sweep_version == 2) {
+  if (!P->is_f32 && P->sweep_version >= 2) {
     PCHK(hipMalloc(&P->gramp16, (size_t)P->nblocks * std::max(P->pstride, 8) * 2));
     PCHK(hipMalloc(&P->gramx16, (size_t)P->nblocks * m * m * 2));
     PCHK(hipMalloc(&P->gram16_bad, sizeof(int)));
@@ -1296,6 +1447,7 @@ extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int
   if (memloc != BWGR_HOST && memloc != BWGR_DEVICE) return fail(BWGR_EINVAL, "panel_create: bad memloc %d", memloc);
   bwgr_panel *P = nullptr;
   CHK(panel_alloc(&P, xtype != BWGR_X_I8, n, p, device, block, nwg));
+  P->want3 = true;
   int rc;
   if (xtype == BWGR_X_I8) rc = upload<int8_t, int8_t>(P, X, memloc, ldx);
   else if (xtype == BWGR_X_F32) rc = upload<float, float>(P, X, memloc, ldx);
@@ -1325,6 +1477,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   HIPCHK(hipStreamSynchronize(root->stream));   // the shared arrays are complete
   bwgr_panel *P = new bwgr_panel(*root);
   P->parent = root; P->nclones = 0; P->nchains = 0; P->own_stream = nullptr; P->stream = nullptr; P->ps_owner = nullptr; P->ps_iter = -1;
+  P->qsum3 = P->lists3 = nullptr; P->epoch3 = 0; P->xmax_dev = nullptr;
   P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->xchg = nullptr; P->stamps = nullptr;
   root->nclones++;
   auto bail = [&](int code) { bwgr_panel_destroy(P); return code; };
@@ -1343,6 +1496,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   PCHK(hipStreamCreateWithFlags(&P->own_stream, hipStreamNonBlocking));
 #undef PCHK
   P->stream = P->own_stream;
+  if (P->e3_ready) { int rc3 = sweep3_alloc_scratch(P); if (rc3 != BWGR_OK) return bail(rc3); HIPCHK(hipStreamSynchronize(P->stream)); }
   *out = P;
   return BWGR_OK;
 }
@@ -1352,7 +1506,7 @@ extern "C" int bwgr_panel_max_concurrent(const bwgr_panel *P, int selection, int
   if (!P || !count) return fail(BWGR_EINVAL, "null pointer");
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, P->device));
-  const int wgs = P->K + 1 + ((P->sweep_version == 2 && selection) ? P->nfeed : 0);
+  const int wgs = (selection && P->sweep_version == 3 && P->e3_ready) ? P->K3 + 1 : P->K + 1 + ((P->sweep_version >= 2 && selection) ? P->nfeed : 0);
   // one sweep workgroup per CU even where the LDS would admit two (small blocks): measured, sharing a CU costs more than it adds
   *count = std::max(1, prop.multiProcessorCount / wgs);
   if (const char *ov = getenv("BWGR_MAX_CONCURRENT")) { const int v = atoi(ov); if (v > 0) *count = v; }   // experiments
@@ -1385,9 +1539,10 @@ extern "C" int bwgr_panel_pipeline(const bwgr_panel *P, int selection, int info[
   SweepArgs a{};
   a.flags = selection ? SWF_SELECT : 0u;
   choose_lag(P, a);
-  info[0] = P->sweep_version;
-  info[1] = a.lag;
-  info[2] = (P->sweep_version == 2 && selection) ? P->nfeed : 0;
+  const bool s3 = selection && P->sweep_version == 3 && P->e3_ready;
+  info[0] = s3 ? 3 : std::min(P->sweep_version, 2);
+  info[1] = s3 ? P->e3_D : a.lag;
+  info[2] = s3 ? 0 : ((P->sweep_version >= 2 && selection) ? P->nfeed : 0);
   info[3] = P->is_f32 ? 0 : (P->gram16 ? 16 : 32);
   return BWGR_OK;
 }
@@ -1453,7 +1608,7 @@ static int kmup_sweep(bwgr_panel *PS, float *b, float *d, const float *xx, const
   HIPCHK(hipMemcpyAsync(d, dd, pb, hipMemcpyDeviceToHost, PS->stream));
   HIPCHK(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, PS->stream));
   HIPCHK(hipStreamSynchronize(PS->stream));
-  if (h.error) return fail(BWGR_ETIMEOUT, "%s: a workgroup exchange timed out inside the sweep kernel", who);
+  if (h.error) return sweep_error(h.error, who);
   return BWGR_OK;
 }
 
@@ -1644,7 +1799,7 @@ extern "C" int bwgr_chain_get_sums(bwgr_chain *C, double sums[2]) {
   ChainScalars h;
   HIPCHK(hipMemcpyAsync(&h, C->sc, sizeof(h), hipMemcpyDeviceToHost, C->P->stream));
   HIPCHK(hipStreamSynchronize(C->P->stream));
-  if (h.error) return fail(BWGR_ETIMEOUT, "a workgroup exchange timed out inside the sweep kernel (chain state is invalid)");
+  if (h.error) return sweep_error(h.error, "chain");
   sums[0] = h.sum_d; sums[1] = h.sum_b2;
   return BWGR_OK;
 }
@@ -1706,7 +1861,7 @@ extern "C" int bwgr_chain_sync(bwgr_chain *C) {
   HIPCHK(hipStreamSynchronize(C->P->stream));
   ChainScalars h;
   HIPCHK(d2h(C->P->stream, &h, C->sc, sizeof(h)));
-  if (h.error) return fail(BWGR_ETIMEOUT, "a workgroup exchange timed out inside the sweep kernel (chain state is invalid)");
+  if (h.error) return sweep_error(h.error, "chain");
   return BWGR_OK;
 }
 
@@ -2132,7 +2287,7 @@ extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int t
     WCHK(hipMemcpyAsync(&h, ws, sizeof(h), hipMemcpyDeviceToHost, P->stream));
     WCHK(hipMemcpyAsync(&hc, sc, sizeof(hc), hipMemcpyDeviceToHost, P->stream));
     WCHK(hipStreamSynchronize(P->stream));
-    if (hc.error) { rc = fail(BWGR_ETIMEOUT, "wgr: a workgroup exchange timed out inside the sweep kernel"); goto done; }
+    if (hc.error) { rc = sweep_error(hc.error, "wgr"); goto done; }
     const double B0 = h.B0 / mc;
     rc = gemv_parts<double>(P, B, &gpart, &nchunks);                               // HAT = B0 + gen0 %*% B, R/wgr.R:152
     if (rc != BWGR_OK) goto done;
@@ -2365,7 +2520,7 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
   const bool soft = (model == BWGR_EM_BB || model == BWGR_EM_BC || model == BWGR_EM_BCPI);
   const bool lasso = (model == BWGR_EM_LASSO);
   const bool nonaffine = soft || lasso || model == BWGR_EM_BL || model == BWGR_EM_EN;
-  if (nonaffine && P->sweep_version != 2) return fail(BWGR_EINVAL, "em: this member needs the pipelined sweep engine (k_sweep2), which this panel's geometry does not fit");
+  if (nonaffine && P->sweep_version < 2) return fail(BWGR_EINVAL, "em: this member needs the pipelined sweep engine (k_sweep2), which this panel's geometry does not fit");
   HIPCHK(hipSetDevice(P->device));
   const int64_t p = P->p, n = P->n;
   const bool conv = (model == BWGR_EM_DE || model == BWGR_EM_ML || model == BWGR_EM_EN || lasso);
@@ -2385,7 +2540,7 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
   int rc = BWGR_OK;
   auto done = [&](int code) { (void)hipStreamSynchronize(st); for (void *q : owned) hipFree(q); if (Q) bwgr_panel_destroy(Q); return code; };
 #define ECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return done(fail(BWGR_EHIP, "%s failed: %s", #x, hipGetErrorString(e_))); } while (0)
-  if (Q && (Q->K != P->K || Q->R != P->R || Q->m != P->m || Q->sweep_version != P->sweep_version)) return done(fail(BWGR_EINVAL, "em: scratch panel geometry differs"));
+  if (Q && (Q->K != P->K || Q->R != P->R || Q->m != P->m || std::min(Q->sweep_version, 2) != std::min(P->sweep_version, 2))) return done(fail(BWGR_EINVAL, "em: scratch panel geometry differs"));
   bwgr_panel *S = Q ? Q : P;                                                          // the panel the sweeps run on
   const size_t pb = sizeof(float) * (size_t)p;
   float *yd = nullptr, *bd = nullptr, *bcd = nullptr, *dd = nullptr, *lamd = nullptr, *vbd = nullptr, *xxd = nullptr, *Dd = nullptr;
@@ -2535,7 +2690,7 @@ extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float
     ECHK(hipMemcpyAsync(&hc, sc, sizeof(hc), hipMemcpyDeviceToHost, st));
     ECHK(hipStreamSynchronize(st));
     if (emdbg) fprintf(stderr, "em sweep %d: launches %.2f ms, host shuffle %.2f ms, wait %.2f ms\n", i, t_1 - t_0, t_2 - t_1, now() - t_2);
-    if (hc.error) return done(fail(BWGR_ETIMEOUT, "em: a workgroup exchange timed out inside the sweep kernel"));
+    if (hc.error) return done(sweep_error(hc.error, "em"));
     if (lasso) {   // Lmb from the sweep's yx and b: the reference's own sequential float loop, :1487-1490
       yxh.resize((size_t)p); bh.resize((size_t)p);
       ECHK(d2h(st, yxh.data(), dd, pb)); ECHK(d2h(st, bh.data(), bd, pb));

@@ -57,8 +57,10 @@ struct ChainScalars {
   float mu, dfp1, vy, MSx;
   float MU, VE, VBs, Pi;        // posterior sums
   double sum_d, sum_b2;         // written by the sweep (marker order, fp64)
-  uint32_t error;               // non-zero: an exchange gave up
+  uint32_t error;               // 1: an exchange gave up; 2: the fixed-point residual of k_sweep3 left its range
   float bg;                     // KMUP2: n0/n of the row subsample
+  int e3_sh;                    // k_sweep3: the sweep's fixed-point scale, e_fixed = e * 2^e3_sh (k_escale)
+  uint32_t e3_dex;              // k_sweep3: largest float exponent field among this sweep's rejected steps (k_prestage -> k_escale)
 };
 
 // per-marker constants of one sweep, produced chip-wide by k_prestage before the sweep kernel starts (they depend on
@@ -193,6 +195,9 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
   const ChainScalars &sc = *a.sc;
   const float ve = sc.ve, lam_common = sc.lam, dfp1 = sc.dfp1;
   const int64_t nm = j_end - j_begin;
+  __shared__ uint32_t dex_s;   // largest float exponent field of the rejected steps this workgroup staged
+  if (threadIdx.x == 0) dex_s = 0u;
+  __syncthreads();
   for (int64_t task = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; task < 4 * nm; task += (int64_t)gridDim.x * blockDim.x) {
     const int piece = (int)(task / nm);
     const int j = j_begin + (int)(task - (int64_t)piece * nm);
@@ -215,7 +220,9 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
     } else if (piece == 1) {
       const float b2 = sel ? (float)((double)0.0f + (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z2, 0)) : 0.0f;
       st.b2[t] = b2;
-      st.drej[t] = sel ? (b2 - b0) : 0.0f;   // the step a marker takes when it is NOT included
+      const float drej = sel ? (b2 - b0) : 0.0f;   // the step a marker takes when it is NOT included
+      st.drej[t] = drej;
+      if (sel) atomicMax(&dex_s, (__float_as_uint(drej) >> 23) & 0xFFu);   // k_sweep3 sizes its fixed-point grid by the largest step
     } else if (piece == 2) {
       const double uj = sel ? rng_uniform(a.rng, mk, a.iter, RNG_U, 0) : 0.0;
       // The Bernoulli step accepts iff u < pj with pj a float function of x = C*(|e2|^2 - |e1|^2):
@@ -242,6 +249,8 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
       st.chi[t] = (a.flags & SWF_VB_VEC) ? rng_chisq(a.rng, (double)dfp1, mk, a.iter, RNG_CHI) : 1.0;
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0 && dex_s != 0u) atomicMax(&a.sc->e3_dex, dex_s);
 }
 // k_spec: the r-independent speculative terms of every block of a sweep (one workgroup of 128 threads per block,
 // thread = marker j; Gram rows are read coalesced across j; fixed summation order k ascending)

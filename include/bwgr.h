@@ -33,7 +33,9 @@ enum bwgr_status {
   BWGR_EHIP = 2,     /* a HIP runtime call failed */
   BWGR_ENOMEM = 3,
   BWGR_ETIMEOUT = 4, /* an in-kernel workgroup exchange gave up (bounded spin) */
-  BWGR_ENODEV = 5    /* no usable GPU */
+  BWGR_ENODEV = 5,   /* no usable GPU */
+  BWGR_ERANGE = 6    /* the residual grew more than eightfold within one sweep (the fixed-point range of the selection
+                        models' sweep engine): the chain has diverged; its state is invalid */
 };
 enum bwgr_xtype { BWGR_X_I8 = 0, BWGR_X_F32 = 1, BWGR_X_F64 = 2 }; /* F64 (an R numeric matrix) is narrowed
                                                                      to float on upload, as the Rcpp glue does

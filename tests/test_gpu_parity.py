@@ -265,9 +265,14 @@ def test_both_sweep_engines_give_the_same_chain(model, monkeypatch):
 
 
 @pytest.mark.parametrize("model", ["BayesB", "BayesDpi", "BayesC"])
-@pytest.mark.parametrize("env", [{}, {"BWGR_LAG": "3"}, {"BWGR_LAG": "2"}, {"BWGR_GRAM16": "0"}, {"BWGR_GRAM16": "0", "BWGR_LAG": "2"}])
+@pytest.mark.parametrize("env", [{"BWGR_SWEEP": "2"}, {"BWGR_SWEEP": "2", "BWGR_LAG": "3"}, {"BWGR_SWEEP": "2", "BWGR_LAG": "2"},
+                                 {"BWGR_SWEEP": "2", "BWGR_GRAM16": "0"}, {"BWGR_SWEEP": "2", "BWGR_GRAM16": "0", "BWGR_LAG": "2"},
+                                 {}, {"BWGR_D3": "1"}, {"BWGR_D3": "2"}, {"BWGR_D3": "5"}, {"BWGR_R3": "64"}, {"BWGR_R3": "128", "BWGR_D3": "3"},
+                                 {"BWGR_GRAM16": "0"}, {"BWGR_GRAM16": "0", "BWGR_D3": "4"}])
 def test_selection_pipeline_variants_give_the_same_chain(model, env, monkeypatch):
-    """Selection models run k_sweep2 in one of five schedules: 16-bit Gram staging with the single-barrier sequencer and
+    """Selection models on int8 panels run the trajectory engine k_sweep3 by default (sweep3.hip.h: streamers on the all-rejected
+    trajectory in fixed point, included markers folded in D blocks later, Gram rows on demand; D = 1 .. 12, 64 / 128 / 256 rows per
+    streamer, 16- or 32-bit Gram entries), or -- BWGR_SWEEP=2 -- k_sweep2 in one of five schedules: 16-bit Gram staging with the single-barrier sequencer and
     the q feeders (default when every Gram entry fits 16 bits) at lag 4 (default), 3 or 2, or 32-bit staging with the
     generic sequencer at lag 3 or 2.  All are the same blocked algebra; several blocks and a ragged last one so that the distance-1
     and distance-2 cross terms, the first blocks of a launch and the tail are all exercised."""
@@ -402,11 +407,13 @@ def test_wgr_missing_phenotypes_are_dropped_and_predicted(tpod):
 
 
 def test_full_size_properties_c4(monkeypatch):
-    """BASELINE config 4 (n = 10 000 x p = 1 000 000 int8, BayesB pi = 0.99; 40 streamers, 7 813 blocks, ragged last block) is
+    """BASELINE config 4 (n = 10 000 x p = 1 000 000 int8, BayesB pi = 0.99; 40 slabs, 7 813 blocks, ragged last block) is
     far too large for the oracle; checked through size-independent properties instead:
     (1) residual identity  e == y - mu - X b  after three iterations, X b formed by an independent fp64 torch product;
-    (2) the two sweep engines (pipelined k_sweep2 with MFMA streamers / lag 3 / feeders vs the replicated-recurrence
-        k_sweep with fp64-FMA slab loops) give the same chain: inclusion indicators bit-equal, effects to 1e-9;
+    (2) the three sweep engines -- the trajectory engine k_sweep3 (default: fixed-point residual, included markers folded in
+        twelve blocks later, Gram rows on demand), the pipelined k_sweep2 (MFMA streamers in fp64, lag 4, feeders) and the
+        replicated-recurrence k_sweep (fp64-FMA slab loops) -- give the same chain: inclusion indicators bit-equal, effects to
+        1e-9 between the two fp64 engines and to 1e-6 for the fixed-point one;
     (3) the inclusion rate sits near 1 - pi."""
     import torch
     import bwgr_amd
@@ -415,24 +422,27 @@ def test_full_size_properties_c4(monkeypatch):
     X = synth.genotypes(n, p)                     # (p, ld) int8 on the GPU, marker-major
     y = synth.scale_phenotype(synth.phenotype(X, n))
     out = {}
-    for v in ("2", "1"):
+    for v in ("3", "2", "1"):
         monkeypatch.setenv("BWGR_SWEEP", v)
         P = bwgr_amd.Panel(X, n=n)
+        assert P.pipeline(True)["generation"] == int(v)
         ch = bwgr_amd.Chain(P, "BayesB", y, it=3, bi=0, pi=0.99, seed=synth.SEED)
         ch.run(3)
         out[v] = ch.state()
         ch.close(); P.close()
-    st = out["2"]
-    b = torch.from_numpy(st["b"]).to(X.device).double()
-    xb = torch.zeros(n, dtype=torch.float64, device=X.device)
-    step = 50000
-    for j0 in range(0, p, step):
-        xb += X[j0:j0 + step, :n].double().T @ b[j0:j0 + step]
-    e_ref = (y.double() - st["mu"] - xb).cpu().numpy()
-    assert np.abs(e_ref - st["e"]).max() < 2e-5 * np.abs(e_ref).max()      # st["e"] is the fp64 residual narrowed to float
-    assert np.array_equal(out["1"]["d"], out["2"]["d"])
+    for v in ("3", "2"):
+        st = out[v]
+        b = torch.from_numpy(st["b"]).to(X.device).double()
+        xb = torch.zeros(n, dtype=torch.float64, device=X.device)
+        step = 50000
+        for j0 in range(0, p, step):
+            xb += X[j0:j0 + step, :n].double().T @ b[j0:j0 + step]
+        e_ref = (y.double() - st["mu"] - xb).cpu().numpy()
+        assert np.abs(e_ref - st["e"]).max() < 2e-5 * np.abs(e_ref).max(), v     # st["e"] is the fp64 residual narrowed to float
+    assert np.array_equal(out["1"]["d"], out["2"]["d"]) and np.array_equal(out["3"]["d"], out["2"]["d"])
     assert scaled_err(out["1"]["b"], out["2"]["b"]) < 1e-9
-    assert 0.003 < st["d"].mean() < 0.05
+    assert scaled_err(out["3"]["b"], out["2"]["b"]) < 1e-6 and scaled_err(out["3"]["e"], out["2"]["e"]) < 1e-6
+    assert 0.003 < out["3"]["d"].mean() < 0.05
 
 
 def test_fit_many_runs_the_same_chains_side_by_side():

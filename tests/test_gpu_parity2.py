@@ -84,10 +84,13 @@ def test_panel_destroy_waits_for_its_chains(tpod):
 
 
 @pytest.mark.parametrize("model", ["BayesCpi", "BayesB"])
-@pytest.mark.parametrize("n,p,env", [(20000, 640, {}), (50000, 384, {}), (50000, 384, {"BWGR_GRAM16": "0"})])
+@pytest.mark.parametrize("n,p,env", [(20000, 640, {}), (50000, 384, {}), (50000, 384, {"BWGR_GRAM16": "0"}),
+                                     (20000, 640, {"BWGR_SWEEP": "2"}), (50000, 384, {"BWGR_SWEEP": "2"}),
+                                     (50000, 384, {"BWGR_SWEEP": "2", "BWGR_GRAM16": "0"})])
 def test_large_n_against_oracle(model, n, p, env, monkeypatch):
     """BASELINE config 5's shape (n = 50 000, BayesCpi: dense inclusion) and n = 20 000, at a p the oracle finishes in seconds:
-    79-196 slab workgroups, 3-6 q feeders, more than nine of them for the first time; 16-bit and 32-bit Gram staging."""
+    79-196 slab workgroups (more than nine for the first time); the trajectory engine (k_sweep3, default) and k_sweep2 with its
+    3-6 q feeders; 16-bit and 32-bit Gram entries."""
     import bwgr_amd
     from oracle import oracle as O
     X, y = synth_small(n, p, seed=n // 100 + p)
@@ -95,8 +98,12 @@ def test_large_n_against_oracle(model, n, p, env, monkeypatch):
         monkeypatch.setenv(k, v)
     P = bwgr_amd.Panel(X)
     pipe = P.pipeline(True)
-    assert P.nwg >= 79 and pipe["generation"] >= 2 and pipe["feeders"] >= 3, (P.nwg, pipe)
-    if env:
+    assert P.nwg >= 79, (P.nwg, pipe)
+    if env.get("BWGR_SWEEP") == "2":
+        assert pipe["generation"] == 2 and pipe["feeders"] >= 3, pipe
+    else:
+        assert pipe["generation"] == 3 and pipe["lag"] >= 2, pipe
+    if "BWGR_GRAM16" in env:
         assert pipe["gram_bits"] == 32
     ch = bwgr_amd.Chain(P, model, y, it=3, bi=0, pi=0.9, seed=5)
     ch.run(3)
@@ -173,7 +180,9 @@ def test_c3_size_properties():
 # types).  That flavour's results depend on the summation order at the 1e-6 level, which is why the parity target is the wide
 # flavour; the bounds below are the measured distances with a margin of about two, and they are what "identical to the
 # reference" can mean for this path: the north-star's 1e-6 holds against the widened restatement only.
-FAITHFUL_BOUND = {"b": 2e-5, "e": 2e-5, "scalar": 2e-5}
+# measured on MI355X (round 2, ten iterations, tpod and a 600 x 500 synthetic panel, all seven samplers and KMUP):
+# b <= 8.0e-7, e <= 1.9e-6, ve <= 5.6e-7, inclusion decisions equal everywhere
+FAITHFUL_BOUND = {"b": 2e-6, "e": 4e-6, "scalar": 2e-6}
 
 
 @pytest.mark.parametrize("model", ALL_MODELS)
