@@ -163,26 +163,29 @@ def main():
     alg_bytes = float(n) * float(p) * 1.0      # every genotype byte read once per sweep
     # HBM traffic per launch comes from separate rocprofv3 --pmc passes (it cannot be read inside this process); the
     # corrected figure is committed under profiles/ and quoted only for the workload it was measured on
-    traffic = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_c4.json")))
-        if pm["workload"] == args.workload and pm["n"] == n and pm["p"] == p:
-            traffic = pm["traffic_bytes_per_launch"]
-    except Exception:
-        pass
-    achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
     pl = P.pipeline(bool(pi))
+    kernel = {3: "k_sweep3<uint16>", 2: "k_sweep2<int8>", 1: "k_sweep<int8>"}[pl["generation"]]
+    traffic, traffic_source = None, None
+    for name in ("r02_pmc_c4.json", "r01_pmc_c4.json"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if pm["workload"] == args.workload and pm["n"] == n and pm["p"] == p and pm.get("kernel", "k_sweep2<int8>").split("<")[0] == kernel.split("<")[0]:
+                traffic, traffic_source = pm["traffic_bytes_per_launch"], "profiles/%s (an earlier rocprofv3 --pmc pass of this kernel, not measured in this run)" % name
+                break
+        except Exception:
+            pass
+    achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
     out = {
         "metric": "MCMC iter/sec (full marker sweep)", "value": K / elapsed, "unit": "iter/s", "n_gpus": 1,
         "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32 scalars, f64 residual/accumulation, int8 genotypes", "data": "synthetic",
-        "config": {"workload": "%s: synthetic n=%d x p=%d int8, %s%s, exact chain (blocked sweep, block=%d, %d slab "
-                               "workgroups x %d rows + 1 sequencer%s)" % (args.workload, n, p, model,
+        "config": {"workload": "%s: synthetic n=%d x p=%d int8, %s%s, exact chain (blocked sweep, block=%d, %d slabs "
+                               "x %d rows + 1 sequencer%s)" % (args.workload, n, p, model,
                                                           " pi=%.2f (1%% in model)" % pi if pi else "", P.block, P.nwg, P.slab_rows,
-                                                          (" + %d q feeders" % pl["feeders"] if pl["feeders"] else "") + ", lag-%d pipeline" % pl["lag"]),
+                                                          (" + %d q feeders" % pl["feeders"] if pl["feeders"] else "") + ", engine generation %d, lag %d blocks" % (pl["generation"], pl["lag"])),
                    "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_sweep2<int8>" if os.environ.get("BWGR_SWEEP", "2") != "1" else "k_sweep<int8>",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel,
                      "kernel_ms": sweep_ms, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes},
         "setup_s": setup_s,
         "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d": float(st["d"].mean())},

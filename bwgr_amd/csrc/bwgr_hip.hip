@@ -1017,8 +1017,9 @@ static int sweep3_build(bwgr_panel *P) {
   if (const char *rv = getenv("BWGR_R3")) { const int v = atoi(rv); if ((v == 64 || v == 128 || v == 256) && P->R % v == 0) R3 = v; }
   const int sub = P->R / R3, K3 = P->K * sub;
   int D = 12;
-  if (const char *dv = getenv("BWGR_D3")) { const int v = atoi(dv); if (v >= 1 && v <= S3_MAXD) D = v; }
-  D = (int)std::min<int64_t>(D, std::max<int64_t>(1, P->nblocks));
+  // (at least 2: a block's list leaves the sequencer while the next block is in its rounds)
+  if (const char *dv = getenv("BWGR_D3")) { const int v = atoi(dv); if (v >= 2 && v <= S3_MAXD) D = v; }
+  D = (int)std::min<int64_t>(D, std::max<int64_t>(2, P->nblocks));
   const size_t lds = std::max(s3_streamer_lds(R3), s3_seq_lds(D));
   // the slab dots are summed as integers: sum over all rows of |x| * 128 per digit, four digits of 8 bits, 8 bits of arrival count
   if (K3 > 255 || K3 + 1 > 256 || lds > (size_t)160 * 1024 || (int64_t)P->ld * std::max(P->xmax, 1) >= (1ll << 23) || (size_t)m * R3 > (size_t)4 * 16 * SW_THREADS) {
@@ -1076,6 +1077,7 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
   A.qsum = P->qsum3; A.lists = P->lists3;
   P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1;
   A.epoch = P->epoch3;
+  if (const char *dv = getenv("BWGR_DBG3")) A.dbg = atoi(dv);
   (void)hipMemsetAsync(P->qsum3 + (size_t)a.blk_begin * 2 * SW_MAXM, 0, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
   const dim3 grid(P->K3 + 1), blk(SW_THREADS);
   if (A.g16) hipLaunchKernelGGL(k_sweep3<uint16_t>, grid, blk, P->lds3_bytes, P->stream, A);

@@ -249,6 +249,17 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
       st.chi[t] = (a.flags & SWF_VB_VEC) ? rng_chisq(a.rng, (double)dfp1, mk, a.iter, RNG_CHI) : 1.0;
     }
   }
+  // the unused entries of a ragged last block: constants with which a lane rejects for certain and changes nothing (k_sweep3's
+  // recurrence wave runs without dead-lane masks)
+  if (blockIdx.x == 0 && j_end > j_begin) {
+    const int blkL = (j_end - 1) / a.m;
+    StageBuf &st = a.ps.blocks[blkL];
+    for (int t = j_end - blkL * a.m + (int)threadIdx.x; t < SW_MAXM; t += (int)blockDim.x) {
+      st.b0[t] = 0.0f; st.xxb0[t] = 0.0f; st.b2[t] = 0.0f; st.drej[t] = 0.0f;
+      st.rden[t] = 0.0; st.sdz1[t] = 0.0; st.chi[t] = 1.0;
+      st.tacc[t] = -INFINITY; st.trej[t] = -INFINITY;
+    }
+  }
   __syncthreads();
   if (threadIdx.x == 0 && dex_s != 0u) atomicMax(&a.sc->e3_dex, dex_s);
 }

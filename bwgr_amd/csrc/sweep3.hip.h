@@ -25,9 +25,22 @@
 
 namespace bwgr {
 
+#ifdef BWGR_STAMPS
+// diagnostic build: per-phase s_memtime sums of streamer 0's first update wave (stamps[0..7]) and first dots wave (8..15), of the
+// sequencer's wave 0 (16..23) and of its helper waves (24..31), flushed once at the end
+#define S3ST_DECL unsigned long long ph3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl3 = __builtin_amdgcn_s_memtime()
+#define S3ST(k, cond) do { if (cond) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph3[k] += t_ - tl3; tl3 = t_; } } while (0)
+#define S3ST_FLUSH(base, cond) do { if ((cond) && a.stamps) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&a.stamps[(base) + k_], ph3[k_]); } while (0)
+#else
+#define S3ST_DECL do { } while (0)
+#define S3ST(k, cond) do { } while (0)
+#define S3ST_FLUSH(base, cond) do { } while (0)
+#endif
+
 static constexpr int S3_MAXD = 16;                    // deepest fold-in lag, blocks
 static constexpr int S3_LSTRIDE = 2 * SW_MAXM + 2;    // 8-byte words of one block's list: header, two per entry, one spare
 static constexpr int S3_ND = 7;                       // signed base-256 digits of the fixed-point residual and steps (|q| < 2^55)
+static constexpr int S3_RING = S3_MAXD * SW_MAXM;     // flat ring of included markers in the sequencer's LDS (a power of two)
 static constexpr int S3_OS = 12;                      // dwords per row of the int32 recombination scratch (8 used; b128 reads conflict-free)
 
 struct Sweep3Args {
@@ -40,6 +53,7 @@ struct Sweep3Args {
   unsigned long long *qsum;      // [nblocks][SW_MAXM][2] {low digits, high digits} << 8 | arrivals; zero before the launch
   unsigned long long *lists;     // [nblocks][S3_LSTRIDE] epoch-tagged words
   uint32_t epoch;                // this launch's tag (24 bits, never 0)
+  int dbg;                       // experiment switches (BWGR_DBG3): 1 lazy q poll, 2 no L2 touches
 };
 
 // ---- fixed-point scale of one sweep.  With 2^k above both the largest |e_i| at the start of the sweep and the largest step
@@ -94,6 +108,15 @@ __global__ __launch_bounds__(128) void k_spec3(const SweepArgs a, int blk_begin)
   sp.spec[j] = (s0 + s1) + (s2 + s3); sp.xspec[j] = 0.0; sp.gjj[j] = gjj;
 }
 
+// The seven signed base-256 digits of q (|q| < 2^55) as bytes: adding 0x80 to each of the seven low bytes turns the signed digits
+// into the plain bytes of the sum (q + sum 128 * 256^n = sum (d_n + 128) 256^n), and d_n = byte_n - 128 = byte_n ^ 0x80 as int8.
+__device__ __forceinline__ void s3_put_digits7(long long q, int8_t *dst, int stride) {
+  const unsigned long long u = ((unsigned long long)q + 0x0080808080808080ull) ^ 0x0080808080808080ull;
+  const uint32_t lo = (uint32_t)u, hi = (uint32_t)(u >> 32);
+  dst[0] = (int8_t)lo; dst[stride] = (int8_t)(lo >> 8); dst[2 * stride] = (int8_t)(lo >> 16); dst[3 * stride] = (int8_t)(lo >> 24);
+  dst[4 * stride] = (int8_t)hi; dst[5 * stride] = (int8_t)(hi >> 8); dst[6 * stride] = (int8_t)(hi >> 16);
+}
+
 // list words
 __device__ __forceinline__ unsigned long long s3_hdr(uint32_t epoch, int count) { return ((unsigned long long)epoch << 40) | (0xFFull << 32) | (unsigned long long)(uint32_t)count; }
 __device__ __forceinline__ bool s3_epoch_is(unsigned long long w, uint32_t epoch) { return (uint32_t)(w >> 40) == epoch; }
@@ -102,13 +125,15 @@ typedef unsigned int s3_u4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline size_t s3_streamer_lds(int R3) {
   const size_t Rp = (size_t)R3 + 16;
-  return 2 * (size_t)SW_MAXM * Rp + 2 * 16 * Rp + 2 * 16 * (size_t)S2_DP + (size_t)64 * S3_OS * 4 * 4 + (size_t)8 * 16 * S3_OS * 4 + 64;
+  return 2 * (size_t)SW_MAXM * Rp + 2 * 16 * Rp + 2 * 16 * (size_t)S2_DP + (size_t)64 * S3_OS * 4 * 4 + (size_t)8 * 32 * S3_OS * 4 + 64;
 }
 __host__ __device__ inline size_t s3_seq_lds(int D) {
   size_t s = 2 * sizeof(StageBuf) + 2 * 2 * SW_MAXM * sizeof(double);            // constants, spec + gjj
   s += 2 * SW_MAXM * sizeof(double) + 2 * 3 * SW_MAXM * sizeof(double);          // q sums, far-field partial sums (three waves)
   s += 2 * 3 * SW_MAXM * sizeof(float);                                          // state of a block
-  s += (size_t)D * SW_MAXM * (sizeof(double) + sizeof(long long) + sizeof(int)); // lists of the last D blocks
+  (void)D;
+  s += (size_t)S3_RING * (sizeof(double) + sizeof(long long) + sizeof(int));       // the included markers of the last D blocks
+  s += (size_t)2 * 3 * 16 * SW_MAXM * 4;                                           // far-field rows in flight (sized for 32-bit entries)
   return s + 256;
 }
 
@@ -136,7 +161,7 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
   int8_t *edig0 = reinterpret_cast<int8_t *>(smem + off); off += (size_t)2 * 16 * Rp;     // [parity][n][row]
   int8_t *ddig0 = reinterpret_cast<int8_t *>(smem + off); off += (size_t)2 * 16 * S2_DP;  // [parity][n][marker]
   int *outu = reinterpret_cast<int *>(smem + off); off += (size_t)64 * S3_OS * 4 * 4;     // [update wave][row 64][n]
-  int *outd = reinterpret_cast<int *>(smem + off); off += (size_t)8 * 16 * S3_OS * 4;     // [wave][marker 16][n]
+  int *outd = reinterpret_cast<int *>(smem + off); off += (size_t)8 * 32 * S3_OS * 4;     // [wave][marker 32][n]
   uint32_t *ctl_s = reinterpret_cast<uint32_t *>(smem + off);                            // [0] failure, [1] overflow
   const int sh = a.sc->e3_sh;
   const double S = s3_pow2(sh), invS = s3_pow2(-sh);
@@ -151,7 +176,9 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
   if (upd) e_own = __double2ll_rn(a.e[row0 + 64 * wave + lane] * S);
 
   // tile moves: four 16-byte chunks per thread, all loads unconditional (clamped), stores guarded
-  s3_u4 tp0 = {0, 0, 0, 0}, tp1 = tp0, tp2 = tp0, tp3 = tp0;
+  // two tiles in flight in two register sets (tile t travels in set t & 1): with one, a tile had a single block period to
+  // arrive, and under load an HBM round trip on a streaming CU is longer than that -- the period could not drop below it
+  s3_u4 ta0 = {0, 0, 0, 0}, ta1 = ta0, ta2 = ta0, ta3 = ta0, tb0 = ta0, tb1 = ta0, tb2 = ta0, tb3 = ta0;
 #define S3_TILE_EACH(X) X(0, tp0) X(1, tp1) X(2, tp2) X(3, tp3)
 #define S3_ISSUE1(u, name) { const int cc_ = min(tid + (u) * SW_THREADS, tot_ - 1); const int jj_ = min(cc_ >> cprs, mBt_ - 1), ii_ = cc_ & ((1 << cprs) - 1); \
     name = __builtin_nontemporal_load(reinterpret_cast<const s3_u4 *>(Xs + (size_t)(j0t_ + jj_) * R + ii_ * 16)); }
@@ -214,48 +241,63 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
     return 1;
   };
 
-  // ---- prologue ----
-  S3_TILE_ISSUE(0);
-  S3_TILE_COMMIT(0);
-  if (nb > 1) S3_TILE_ISSUE(1);
-  float drej_pre = (tid < SW_MAXM && tid < blk_m(0)) ? a.ps.blocks[a.blk_begin].drej[tid] : 0.0f;
+  // ---- prologue: tile 0 into LDS, tiles 1 and 2 in flight ----
+  {
+    s3_u4 &tp0 = ta0, &tp1 = ta1, &tp2 = ta2, &tp3 = ta3;
+    S3_TILE_ISSUE(0);
+    S3_TILE_COMMIT(0);
+    if (nb > 2) S3_TILE_ISSUE(2);
+  }
+  if (nb > 1) { s3_u4 &tp0 = tb0, &tp1 = tb1, &tp2 = tb2, &tp3 = tb3; S3_TILE_ISSUE(1); }
+  float drej_pre = a.ps.blocks[a.blk_begin].drej[tid & (SW_MAXM - 1)];   // (used by the last two waves)
   unsigned long long lpre = 0ull;
   __syncthreads();
+  S3ST_DECL;
+  const bool st_u = (w == 0 && tid == 0), st_d = (w == 0 && tid == 64 * NU);
 
-  for (int b = 0; b < nb; ++b) {
+  // one block; tp0..tp3: the register set of tile b+1 (committed here) and then of tile b+3 (requested here)
+  auto step = [&](int b, s3_u4 &tp0, s3_u4 &tp1, s3_u4 &tp2, s3_u4 &tp3) -> bool {
     const int mB = blk_m(b), par = b & 1;
+    S3ST(0, st_u || st_d);
     int8_t *tile = tile0 + (size_t)par * tile_b;
     int8_t *edig = edig0 + (size_t)par * 16 * Rp;
     int8_t *ddig = ddig0 + (size_t)par * 16 * S2_DP;
     // A: what the included markers of block b - D changed
     if (b >= D && upd) { if (!fold_list(b - D, lpre)) ctl_s[0] = 1u; }
+    S3ST(1, st_u);
     // B: digits of the residual rows and of this block's rejected steps
     if (upd) {
       if ((unsigned long long)(e_own + (1ll << 54)) >> 55) ctl_s[1] = 1u;       // left the 55-bit range
-      put_digits<S3_ND>(e_own, edig + 64 * wave + lane, Rp);
-    }
-    if (tid < SW_MAXM) {
+      s3_put_digits7(e_own, edig + 64 * wave + lane, Rp);
+    } else if (tid >= SW_THREADS - SW_MAXM) {                                    // the last two waves (never update waves)
       const double qd = rint((double)drej_pre * S);
       if (!(fabs(qd) < 18014398509481984.0)) ctl_s[1] = 1u;                      // 2^54
-      put_digits<S3_ND>((tid < mB) ? (long long)qd : 0ll, ddig + tid, S2_DP);
+      s3_put_digits7((long long)qd, ddig + (tid - (SW_THREADS - SW_MAXM)), S2_DP);   // (a ragged block's unused markers are staged as zero steps)
     }
+    S3ST(2, st_u);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (ctl_s[0]) { if (tid == 0) a.sc->error = 1u; return; }
-    // C: tile b+1 (in registers since the last iteration) lands in the other buffer, whose last reader was block b-1; the loads
-    // of tile b+2 go out; the list of block b+1-D and the rejected steps of block b+1 are requested
+    S3ST(3, st_u || st_d);
+    if (ctl_s[0]) { if (tid == 0) a.sc->error = 1u; return false; }
+    // C: tile b+1 (in registers for two iterations) lands in the other buffer, whose last reader was block b-1; the loads of
+    // tile b+3 go out into the registers just freed; the list of block b+1-D and the rejected steps of block b+1 are requested
     if (b + 1 < nb) S3_TILE_COMMIT(b + 1);
-    if (b + 2 < nb) S3_TILE_ISSUE(b + 2);
-    if (b + 1 < nb) {
-      drej_pre = (tid < SW_MAXM && tid < blk_m(b + 1)) ? a.ps.blocks[a.blk_begin + b + 1].drej[tid] : 0.0f;
-      if (b + 1 >= D) lpre = ld_agent_raw64(A.lists + (size_t)(a.blk_begin + b + 1 - D) * S3_LSTRIDE + lane);
+    S3ST(6, st_u || st_d);
+    {   // the small requests first (older than the tile loads on the in-order memory counter, so waiting for them does not wait
+        // for the tile), every one unconditional: a load under a branch makes the compiler drain the counter in front of it
+      const int bn1 = min(b + 1, nb - 1);
+      drej_pre = a.ps.blocks[a.blk_begin + bn1].drej[tid & (SW_MAXM - 1)];
+      lpre = ld_agent_raw64(A.lists + (size_t)(a.blk_begin + max(bn1 - D, 0)) * S3_LSTRIDE + lane);
     }
+    S3ST(7, st_u || st_d);
+    if (b + 3 < nb && !(A.dbg & 16)) S3_TILE_ISSUE(b + 3);
+    S3ST(4, st_u || st_d);
     if (upd) {
       // ---- slab update with the rejected steps: out[row][n] = sum_markers x[row][marker] * digit_n(drej[marker]) ----
       // lane (m16, grp): row quad 16 wave + m16 (rows 4 * that + k for accumulator k); k slots (dword u, byte q) of step s0 are the
       // markers s0 + 16 u + 4 grp + q (the interleave keeps the four lane groups on different LDS banks)
       const int rowoff = 4 * (16 * wave + m16);
       s2_v4i acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-      for (int s0 = 0; s0 < mB; s0 += 64) {
+      for (int s0 = 0; s0 < ((A.dbg & 256) ? 0 : mB); s0 += 64) {
         const int8_t *tp = tile + __mul24(s0 + 4 * grp, Rp) + rowoff;
         uint32_t c[4][4];
 #pragma unroll
@@ -296,33 +338,52 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
         v += ((long long)o1.x << 32) + ((long long)o1.y << 40) + ((long long)o1.z << 48);
         e_own -= v;
       }
+      S3ST(5, st_u);
     } else {
-      // ---- slab dots of block b against the digits of e: markers in groups of 16, group gm on wave NU + gm % ND ----
-      for (int gm = wave - NU; 16 * gm < m; gm += ND) {
-        const int8_t *ap = tile + (size_t)(16 * gm + m16) * Rp + 16 * grp;
+      // ---- slab dots of block b against the digits of e: markers in groups of 16, groups gm and gm + ND together on wave
+      // NU + gm (the two groups' MFMAs, LDS round trips and atomics overlap) ----
+      for (int gm = wave - NU; 16 * gm < m; gm += 2 * ND) {
+        const int gm2 = gm + ND;
+        const bool two = 16 * gm2 < m;
         const int8_t *bp = edig + (size_t)m16 * Rp + 16 * grp;
-        s2_v4i acc = {0, 0, 0, 0};
-        for (int r = 0; r < R3; r += 64)
-          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap + r), *reinterpret_cast<const s2_v4i *>(bp + r), acc, 0, 0, 0);
-        int *od = outd + (size_t)wave * 16 * S3_OS;
-        if (m16 < 8) {      // lane: digit n = m16 of markers 16 gm + 4 grp + reg
+        const int8_t *ap = tile + (size_t)(16 * gm + m16) * Rp + 16 * grp;
+        const int8_t *ap2 = tile + (size_t)(16 * (two ? gm2 : gm) + m16) * Rp + 16 * grp;
+        s2_v4i acc = {0, 0, 0, 0}, acc2 = acc;
+        for (int r = 0; r < ((A.dbg & 256) ? 0 : R3); r += 64) {
+          const s2_v4i bv = *reinterpret_cast<const s2_v4i *>(bp + r);
+          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap + r), bv, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap2 + r), bv, acc2, 0, 0, 0);
+        }
+        int *od = outd + (size_t)wave * 32 * S3_OS;
+        if (m16 < 8) {      // lane: digit n = m16 of markers 16 gm + 4 grp + reg (rows 0..15 of the scratch) and of group gm2 (rows 16..31)
           int *op = od + (size_t)(4 * grp) * S3_OS + m16;
           op[0] = acc[0]; op[S3_OS] = acc[1]; op[2 * S3_OS] = acc[2]; op[3 * S3_OS] = acc[3];
+          op[16 * S3_OS] = acc2[0]; op[17 * S3_OS] = acc2[1]; op[18 * S3_OS] = acc2[2]; op[19 * S3_OS] = acc2[3];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane < 16) {
+        if (lane < (two ? 32 : 16)) {
           const int4 o0 = *reinterpret_cast<const int4 *>(od + (size_t)lane * S3_OS);
           const int4 o1 = *reinterpret_cast<const int4 *>(od + (size_t)lane * S3_OS + 4);
           const long long lo = (long long)o0.x + ((long long)o0.y << 8) + ((long long)o0.z << 16);
           const long long hi = (long long)o0.w + ((long long)o1.x << 8) + ((long long)o1.y << 16) + ((long long)o1.z << 24);
-          unsigned long long *qs = A.qsum + ((size_t)(a.blk_begin + b) * SW_MAXM + 16 * gm + lane) * 2;
+          const int mk = 16 * ((lane < 16) ? gm : gm2) + (lane & 15);
+          unsigned long long *qs = A.qsum + ((size_t)(a.blk_begin + b) * SW_MAXM + mk) * 2;
+          if (!(A.dbg & 8)) {
           __hip_atomic_fetch_add((gu64_t *)qs, (unsigned long long)((lo << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_fetch_add((gu64_t *)(qs + 1), (unsigned long long)((hi << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch is read before the next group overwrites it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch is read before the next pass overwrites it
       }
+      S3ST(5, st_d);
     }
+    return true;
+  };
+  for (int b = 0; b < nb; b += 2) {
+    if (!step(b, tb0, tb1, tb2, tb3)) return;                     // b even: tile b+1 travels in set 1
+    if (b + 1 < nb && !step(b + 1, ta0, ta1, ta2, ta3)) return;
   }
+  S3ST_FLUSH(0, st_u); S3ST_FLUSH(8, st_d);
   // the lists of the last D blocks
   if (upd) for (int bs = max(0, nb - D); bs < nb; ++bs) {
     if (!fold_list(bs, 0ull)) { ctl_s[0] = 1u; break; }
@@ -353,11 +414,15 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   double *spec_s = reinterpret_cast<double *>(smem + off); off += (size_t)2 * 2 * SW_MAXM * sizeof(double);   // [parity][spec | gjj][marker]
   double *q_s = reinterpret_cast<double *>(smem + off); off += (size_t)2 * SW_MAXM * sizeof(double);
   double *far_s = reinterpret_cast<double *>(smem + off); off += (size_t)2 * 3 * SW_MAXM * sizeof(double);    // [parity][far wave][marker]
-  float *state_s = reinterpret_cast<float *>(smem + off); off += (size_t)2 * 3 * SW_MAXM * sizeof(float);    // [parity][b | d | vb][marker]
-  double *accC = reinterpret_cast<double *>(smem + off); off += (size_t)D * SW_MAXM * sizeof(double);         // lists of the last D blocks: what marker k changed beyond drej
-  long long *accQ = reinterpret_cast<long long *>(smem + off); off += (size_t)D * SW_MAXM * sizeof(long long);   // ... on the fixed-point grid
-  int *accK = reinterpret_cast<int *>(smem + off); off += (size_t)D * SW_MAXM * sizeof(int);
-  int *ctrl_s = reinterpret_cast<int *>(smem + off);   // [0] ok flag, [8 + b % D] number of included markers of block b
+  float *state_s = reinterpret_cast<float *>(smem + off); off += (size_t)2 * 3 * SW_MAXM * sizeof(float);    // [parity][b | d][marker]
+  double *accC = reinterpret_cast<double *>(smem + off); off += (size_t)S3_RING * sizeof(double);         // included markers of the last D blocks: what marker k changed beyond drej
+  float2 *accS = reinterpret_cast<float2 *>(smem + off); off += (size_t)S3_RING * sizeof(float2);          // ... as the two float steps {included, rejected}
+  int *accK = reinterpret_cast<int *>(smem + off); off += (size_t)S3_RING * sizeof(int);                    // k | source block << 8
+  unsigned char *rowf_s = smem + off; off += (size_t)2 * 3 * 16 * SW_MAXM * sizeof(GT);                     // far-field rows landing by LDS-DMA [parity][wave][row]
+  int *ctrl_s = reinterpret_cast<int *>(smem + off);   // [0] ok flag
+  int *pos_s = ctrl_s + 8;                             // [b & 31]: ring position where block b's entries begin
+  const unsigned char **gx_s = reinterpret_cast<const unsigned char **>(ctrl_s + 40);   // the cross Gram arrays' base addresses (a table in LDS: indexed per entry)
+  S3ST_DECL;
   const GT *gp_all = reinterpret_cast<const GT *>(A.gp);
   const float Cc = a.sc->C, odds = a.sc->odds, one_minus_pi = 1.0f - a.sc->pi, Sb = a.sc->Sb;
   const int sh = a.sc->e3_sh;
@@ -388,212 +453,331 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     const int t = tid - 128;
     *stage_dst(c, t) = sg0; *stage_dst(c, t + 128) = sg1; *stage_dst(c, t + 256) = sg2; *stage_dst(c, t + 384) = sg3;
   };
-  auto poll_q = [&](int c) -> int {   // wave 1: the K3 slab dots of block c, summed by the streamers' atomics; two markers per lane
+  // wave 1: the K3 slab dots of block c, summed by the streamers' atomics; two markers per lane.  The four words a lane needs are
+  // requested one phase ahead (pq_*): the streamers run blocks ahead of the sequencer, so in steady state the words are complete
+  // when they are first looked at and no memory round trip sits in the block period.
+  unsigned long long pq_l0 = 0ull, pq_h0 = 0ull, pq_l1 = 0ull, pq_h1 = 0ull;
+  auto poll_request = [&](int c) {   // unconditional loads (clamped block and marker)
+    const unsigned long long *g = A.qsum + (size_t)(a.blk_begin + min(c, nb - 1)) * SW_MAXM * 2;
+    pq_l0 = ld_agent_raw64(g + 2 * lane); pq_h0 = ld_agent_raw64(g + 2 * lane + 1);
+    pq_l1 = ld_agent_raw64(g + 2 * (64 + lane)); pq_h1 = ld_agent_raw64(g + 2 * (64 + lane) + 1);
+  };
+  auto poll_q = [&](int c) -> int {
     const int mBc = blk_m(c);
     const unsigned long long *g = A.qsum + (size_t)(a.blk_begin + c) * SW_MAXM * 2;
     const unsigned long long need = (unsigned long long)A.K3;
     const bool n0 = lane < mBc, n1 = 64 + lane < mBc;
     const uint64_t t0 = wall_clock64();
     unsigned spins = 0;
-    unsigned long long l0 = need, h0 = need, l1 = need, h1 = need;
+    unsigned long long l0 = n0 ? pq_l0 : need, h0 = n0 ? pq_h0 : need, l1 = n1 ? pq_l1 : need, h1 = n1 ? pq_h1 : need;
     for (;;) {
-      if (n0) { l0 = ld_agent_raw64(g + 2 * lane); h0 = ld_agent_raw64(g + 2 * lane + 1); }
-      if (n1) { l1 = ld_agent_raw64(g + 2 * (64 + lane)); h1 = ld_agent_raw64(g + 2 * (64 + lane) + 1); }
       if ((l0 & 0xFFull) == need && (h0 & 0xFFull) == need && (l1 & 0xFFull) == need && (h1 & 0xFFull) == need) break;
+      if (A.dbg & 8) break;   // (timing experiment only: the streamers publish nothing)
       if ((++spins & 63u) == 0u) {
         if (ld_agent_u32(abortw) != 0u) return 0;
         if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
       }
       __builtin_amdgcn_s_sleep(1);
+      if (n0) { l0 = ld_agent_raw64(g + 2 * lane); h0 = ld_agent_raw64(g + 2 * lane + 1); }
+      if (n1) { l1 = ld_agent_raw64(g + 2 * (64 + lane)); h1 = ld_agent_raw64(g + 2 * (64 + lane) + 1); }
     }
     double *qd = q_s + (size_t)(c & 1) * SW_MAXM;
     qd[lane] = n0 ? fma((double)((long long)h0 >> 8), 16777216.0, (double)((long long)l0 >> 8)) * invS : 0.0;
     qd[64 + lane] = n1 ? fma((double)((long long)h1 >> 8), 16777216.0, (double)((long long)l1 >> 8)) * invS : 0.0;
+    poll_request(c + 1);
     return 1;
   };
-  auto far_field = [&](int c, int hw) {   // waves 4-6: sum over the included markers of blocks c-D+1 .. c-2 of G_kj corr_k, lane = markers 2 lane, 2 lane + 1
-    const int blk = a.blk_begin + c;
-    const int t0 = min(2 * lane, m - 2);             // m is even
-    double s0 = 0.0, s1 = 0.0;
-    int idx = 0;
-    for (int d = 2; d < D && d <= c; ++d) {
-      const int sb = (c - d) % D;
-      const int cnt = ctrl_s[8 + sb];
-      const GT *gd = reinterpret_cast<const GT *>(A.gx[d - 1]) + (size_t)blk * m * m + t0;
-      const int *kk = accK + (size_t)sb * SW_MAXM;
-      const double *cc = accC + (size_t)sb * SW_MAXM;
-      int i = (3 + hw - idx % 3) % 3;                // this wave takes every third entry of the running list
-      idx += cnt;
-      for (; i < cnt; i += 24) {                     // eight rows in flight
-        GT g0[8], g1[8]; double cf[8];
+  // The included markers of all blocks live in one flat ring of D * SW_MAXM entries {k | source block << 8, corr, corr on the grid}
+  // (the entries of the last D blocks can never exceed it); pos_s[b & 31] is where block b's entries begin.
+  constexpr int ring = S3_RING;
+  static_assert((S3_RING & (S3_RING - 1)) == 0, "ring positions wrap with a mask");
+  // Waves 4-6, far field: sum over the included markers k of blocks c-D+1 .. c-3 of G_kj corr_k for destination block c (wave 0
+  // itself takes distances 1 and 2 as the markers appear).  Those rows are HBM misses about 2 us away on this CU, so the work is
+  // cut in two phases: far_issue(c) -- while wave 0 is two blocks short of c, when the last of those lists is final -- requests
+  // up to NFL rows per wave by LDS-DMA (no registers in flight, a dynamic number of rows, nothing else on these waves' memory
+  // counter); far_consume(c), one block period later, waits for them, multiplies and leaves the sum in LDS.  Every third entry
+  // of the flat list per wave; lane = the row's dword(s) lane (markers 2 lane, 2 lane + 1 for 16-bit entries; lane and 64 + lane
+  // for 32-bit ones).
+  constexpr int NFL = 16;
+  constexpr int NFW = 2;                            // far-field waves: 5 and 6 (wave 4 shares wave 0's SIMD and stays idle)
+  constexpr int ROWB = SW_MAXM * (int)sizeof(GT);   // bytes reserved per row (256 or 512)
+  constexpr int NPC = ROWB / 256;
+  int f_p0 = 0, f_cnt = 0, f_n = 0;
+  const int rowbytes = m * (int)sizeof(GT);
+  auto far_src = [&](int c, int sl) -> const unsigned char * {
+    const int kb = accK[sl];                         // k | (source block, relative) << 8
+    const int d = c - (kb >> 8);
+    return gx_s[d - 1] + ((size_t)(a.blk_begin + c) * m * m + (size_t)(kb & 0xFF) * m) * sizeof(GT);
+  };
+  auto far_add = [&](const uint32_t *row, double cf, double &s0, double &s1) {   // row: 64 or 128 dwords in LDS or registers' image
+    if constexpr (sizeof(GT) == 2) { const uint32_t v = row[lane]; s0 = fma((double)(v & 0xFFFFu), cf, s0); s1 = fma((double)(v >> 16), cf, s1); }
+    else { s0 = fma((double)(int)row[lane], cf, s0); s1 = fma((double)(int)row[64 + lane], cf, s1); }
+  };
+  // (Per entry the work is a handful of instructions: the entries' addresses and coefficients are formed by the lanes in
+  // parallel -- lane i = this wave's i-th entry -- and handed to the wave through readlane; a loop that chases accK -> gx_s ->
+  // address one entry at a time costs two dependent LDS latencies per entry.)
+  unsigned long long f_ptr = 0ull;   // lane i: source row of this wave's i-th entry
+  double f_cf = 0.0;                 // lane i: its coefficient
+  auto far_issue = [&](int c, int hw) {
+    f_cnt = 0; f_n = 0;
+    if (c < 3 || D < 4 || c >= nb || (A.dbg & 32)) return;
+    f_p0 = pos_s[max(c - D + 1, 0) & 31];
+    f_cnt = (pos_s[(c - 2) & 31] - f_p0) & (ring - 1);   // [f_p0, +f_cnt): blocks c-D+1 .. c-3
+    f_n = (f_cnt > hw) ? min(NFL, (f_cnt - hw + NFW - 1) / NFW) : 0;
+    {
+      const int sl = (f_p0 + hw + NFW * min(lane, max(f_n - 1, 0))) & (ring - 1);
+      f_ptr = (f_n > 0) ? (unsigned long long)far_src(c, sl) : 0ull;
+      f_cf = (lane < f_n) ? accC[sl] : 0.0;
+    }
+    unsigned char *dst = rowf_s + (size_t)(((c & 1) * 3 + hw) * NFL) * ROWB;
+    for (int n = 0; n < f_n; ++n) {
+      const unsigned char *src = reinterpret_cast<const unsigned char *>(
+          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f_ptr, n) |
+          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(f_ptr >> 32), n) << 32));
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int ii = min(i + 3 * u, cnt - 1);
-          const GT *row = gd + (size_t)kk[ii] * m;
-          g0[u] = row[0]; g1[u] = row[1];
-          cf[u] = (i + 3 * u < cnt) ? cc[ii] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { s0 = fma((double)g0[u], cf[u], s0); s1 = fma((double)g1[u], cf[u], s1); }
-      }
+      for (int pc = 0; pc < NPC; ++pc)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + min(lane * 4 + 256 * pc, rowbytes - 4)),
+                                         (__attribute__((address_space(3))) void *)(dst + (size_t)n * ROWB + 256 * pc), 4, 0, 0);
+    }
+  };
+  auto far_consume = [&](int c, int hw) {
+    double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows requested one phase ago
+    const unsigned char *src = rowf_s + (size_t)(((c & 1) * 3 + hw) * NFL) * ROWB;
+    int n = 0;
+    for (; n + 2 <= f_n; n += 2) {                      // two rows per trip: their LDS reads overlap
+      far_add(reinterpret_cast<const uint32_t *>(src + (size_t)n * ROWB), readlane_f64(f_cf, n), s0, s1);
+      far_add(reinterpret_cast<const uint32_t *>(src + (size_t)(n + 1) * ROWB), readlane_f64(f_cf, n + 1), t0, t1);
+    }
+    if (n < f_n) far_add(reinterpret_cast<const uint32_t *>(src + (size_t)n * ROWB), readlane_f64(f_cf, n), s0, s1);
+    s0 += t0; s1 += t1;
+    for (int i = hw + NFW * NFL; i < f_cnt; i += NFW) {     // more included markers than rows in flight (dense blocks): the rest in place
+      const int sl = (f_p0 + i) & (ring - 1);
+      const unsigned char *g = far_src(c, sl);
+      uint32_t v0 = *reinterpret_cast<const uint32_t *>(g + min(lane * 4, rowbytes - 4)), v1 = 0u;
+      if constexpr (sizeof(GT) == 4) v1 = *reinterpret_cast<const uint32_t *>(g + min(lane * 4 + 256, rowbytes - 4));
+      const double cf = accC[sl];
+      if constexpr (sizeof(GT) == 2) { s0 = fma((double)(v0 & 0xFFFFu), cf, s0); s1 = fma((double)(v0 >> 16), cf, s1); }
+      else { s0 = fma((double)(int)v0, cf, s0); s1 = fma((double)(int)v1, cf, s1); }
     }
     double *fd = far_s + ((size_t)(c & 1) * 3 + hw) * SW_MAXM;
-    if (2 * lane < m) { fd[2 * lane] = s0; fd[2 * lane + 1] = s1; }
+    if constexpr (sizeof(GT) == 2) { if (2 * lane < m) { fd[2 * lane] = s0; fd[2 * lane + 1] = s1; } }
+    else { fd[lane] = s0; fd[64 + lane] = s1; }
   };
-  auto store_state = [&](int c) {   // wave 7
-    const int j0c = (a.blk_begin + c) * m, mBc = blk_m(c);
-    const float *sp = state_s + (size_t)(c & 1) * 3 * SW_MAXM;
+  // wave 7: the Gram rows wave 0 may ask for PF blocks from now -- the packed diagonal block and the distance-1 cross block,
+  // 48 KB -- are touched (one dword per 128-byte line) so that they sit in this XCD's L2 when an included marker needs its row
+  constexpr int PF = 8;
+  uint32_t pf0 = 0u, pf1 = 0u, pf2 = 0u, pf3 = 0u, pf4 = 0u, pf5 = 0u;
+  auto touch = [&](int c) {
+    if (c >= nb || !(A.dbg & 2)) return;   // (off by default: measured slower at C4; BWGR_DBG3=2 turns the touches on)
+    const int blk = a.blk_begin + c;
+    const unsigned char *gpb = reinterpret_cast<const unsigned char *>(gp_all + (size_t)blk * pstride);
+    const size_t gpbytes = (size_t)pstride * sizeof(GT), gxbytes = (size_t)m * m * sizeof(GT);
+    const unsigned char *gxb = (D >= 2 && c >= 1) ? reinterpret_cast<const unsigned char *>(reinterpret_cast<const GT *>(A.gx[0]) + (size_t)blk * m * m) : gpb;
+    const size_t gxl = (D >= 2 && c >= 1) ? gxbytes : gpbytes;
+    // (the values are consumed one phase later, so the loads have a whole period to land)
+    asm volatile("" :: "v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3), "v"(pf4), "v"(pf5));
+    const size_t o = (size_t)lane * 128;
+    pf0 = *reinterpret_cast<const uint32_t *>(gpb + min(o, gpbytes - 4));
+    pf1 = *reinterpret_cast<const uint32_t *>(gpb + min(o + 8192, gpbytes - 4));
+    pf2 = *reinterpret_cast<const uint32_t *>(gxb + min(o, gxl - 4));
+    pf3 = *reinterpret_cast<const uint32_t *>(gxb + min(o + 8192, gxl - 4));
+    pf4 = *reinterpret_cast<const uint32_t *>(gxb + min(o + 16384, gxl - 4));
+    pf5 = *reinterpret_cast<const uint32_t *>(gxb + min(o + 24576, gxl - 4));
+  };
+  // wave 7: everything about a finished block that is off the chain -- its marker state (with the per-marker variance draw),
+  // the posterior sums, and its list for the streamers (the fixed-point corrections are formed here, one entry per lane)
+  double sum_d = 0.0, sum_b2 = 0.0;
+  auto finish_block = [&](int c) {
+    const int blk = a.blk_begin + c, j0c = blk * m, mBc = blk_m(c);
+    const float *sp = state_s + (size_t)(c & 1) * 2 * SW_MAXM;
+    const bool vbv = (a.flags & SWF_VB_VEC) != 0;
+    double ch0 = 1.0, ch1 = 1.0;
+    if (vbv) { ch0 = a.ps.blocks[blk].chi[min(lane, mBc - 1)]; ch1 = a.ps.blocks[blk].chi[min(64 + lane, mBc - 1)]; }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int t = lane + 64 * h;
       if (t < mBc) {
-        a.b[j0c + t] = sp[t];
-        a.d[j0c + t] = sp[SW_MAXM + t];
-        if (a.flags & SWF_VB_VEC) a.vb[j0c + t] = sp[2 * SW_MAXM + t];
+        const float bn = sp[t], dn = sp[SW_MAXM + t];
+        a.b[j0c + t] = bn;
+        a.d[j0c + t] = dn;
+        if (vbv) a.vb[j0c + t] = (float)((double)(Sb + bn * bn) / (h ? ch1 : ch0));
+        sum_d += (double)dn;
+        sum_b2 = fma((double)bn, (double)bn, sum_b2);
+      }
+    }
+    const int p0 = pos_s[c & 31], cnt = (pos_s[(c + 1) & 31] - p0) & (ring - 1);
+    unsigned long long *L = A.lists + (size_t)blk * S3_LSTRIDE;
+    for (int w0 = 0; w0 < 1 + 2 * cnt; w0 += 64) {
+      const int wi = w0 + lane;
+      if (wi < 1 + 2 * cnt) {
+        unsigned long long v;
+        if (wi == 0) v = s3_hdr(A.epoch, cnt);
+        else {
+          const int sl = (p0 + ((wi - 1) >> 1)) & (ring - 1);
+          const float2 st2 = accS[sl];                                    // {included step, rejected step}
+          const long long cq = (long long)rint((double)st2.x * S) - (long long)rint((double)st2.y * S);   // what the streamers fold in
+          v = ((wi - 1) & 1) ? (((unsigned long long)A.epoch << 40) | (0xEEull << 32) | ((unsigned long long)cq >> 32))
+                             : (((unsigned long long)A.epoch << 40) | ((unsigned long long)(uint32_t)(accK[sl] & 0xFF) << 32) | ((unsigned long long)cq & 0xFFFFFFFFull));
+        }
+        st_agent_raw64(L + wi, v);
       }
     }
   };
   auto helper_phase = [&](int c) {   // block c >= 1, while wave 0 runs block c-1
     if (wave == 1) { if (!poll_q(c)) ctrl_s[0] = 0; }
     else if (wave <= 3) { stage_commit(c); if (c + 1 < nb) stage_request(c + 1); }
-    else if (wave <= 6) far_field(c, wave - 4);
-    else if (c >= 2) store_state(c - 2);
+    else if (wave == 4) { }   // idle: the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots
+    else if (wave <= 6) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      S3ST(5, tid == 320);
+      far_consume(c, wave - 5);
+      S3ST(6, tid == 320);
+      far_issue(c + 1, wave - 5);
+      S3ST(7, tid == 320);
+    }
+    else { if (c >= 2) finish_block(c - 2); touch(c + PF); }
   };
 
   // ---- prologue: block 0 ----
-  if (tid < 64) ctrl_s[tid] = (tid == 0) ? 1 : 0;
+  if (tid < 40) ctrl_s[tid] = (tid == 0) ? 1 : 0;   // (pos_s: block 0's entries begin at ring position 0)
+  if (tid >= 64 && tid < 64 + S3_MAXD) gx_s[tid - 64] = reinterpret_cast<const unsigned char *>(A.gx[tid - 64]);
   __syncthreads();
-  if (wave == 1) { if (!poll_q(0)) ctrl_s[0] = 0; }
+  if (wave == 1) { poll_request(0); if (!poll_q(0)) ctrl_s[0] = 0; }
   else if (wave == 2 || wave == 3) { stage_request(0); stage_commit(0); if (nb > 1) stage_request(1); }
-  else if (wave >= 4 && wave <= 6) far_field(0, wave - 4);
+  else if (wave >= 5 && wave <= 6) { far_consume(0, wave - 5); far_issue(1, wave - 5); }
+  else if (wave == 7) { for (int c = 0; c < PF; ++c) touch(c); }
   __syncthreads();
   if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
 
-  double sum_d = 0.0, sum_b2 = 0.0;
-  double rnext[2] = {0.0, 0.0};     // wave 0: what block b's included markers change in block b+1 (distance 1), accumulated as they appear
+  const bool sq0 = (tid == 0), sq1 = (tid == 64), sq2 = (tid == 128), sq4 = (tid == 320);
+  const bool altb2 = (a.flags & SWF_ALT_B2) != 0;
+  // wave 0: what the included markers of block b change in blocks b+1 and b+2 (distances 1 and 2), accumulated as they appear
+  double rnext0 = 0.0, rnext1 = 0.0, rnxt20 = 0.0, rnxt21 = 0.0;
   for (int b = 0; b < nb; ++b) {
     const int mB = blk_m(b), blk = a.blk_begin + b;
     const bool have_next = (b + 1 < nb);
+    S3ST(0, sq0 || sq1 || sq2 || sq4);
     if (wave == 0) {
+      // Wave 0 is one long dependent chain, so everything here is counted in instructions.  Dead lanes of a ragged last block need
+      // no masks: k_prestage fills their constants so that they reject for certain, and their q, spec and far terms are zero.
       const StageBuf &st = stage[b & 1];
       const double *sps = spec_s + (size_t)(b & 1) * 2 * SW_MAXM;
       const double *qd = q_s + (size_t)(b & 1) * SW_MAXM;
       const double *fd = far_s + (size_t)(b & 1) * 3 * SW_MAXM;
-      const int sbk = b % D;
-      int *lk = accK + (size_t)sbk * SW_MAXM;
-      double *lc_ = accC + (size_t)sbk * SW_MAXM;
-      long long *lq = accQ + (size_t)sbk * SW_MAXM;
+      const int pos0 = pos_s[b & 31];
       const GT *gp = gp_all + (size_t)blk * pstride;
       const bool use1 = have_next && D >= 2;   // (D = 1: the streamers fold block b's list in before the dots of block b+1)
-      const GT *g1 = use1 ? reinterpret_cast<const GT *>(A.gx[0]) + (size_t)(blk + 1) * m * m : nullptr;
-      const int mBn = have_next ? blk_m(b + 1) : 0;
-      double r[2], chi[2];
-      LaneConst lc[2];
-      {
-        double spc[2], rd[2], sz[2], gj[2], ch[2], qq[2], f0[2], f1[2], f2[2];
-        float fb0[2], fxx[2], fb2[2], fdr[2], fta[2], ftr[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int t = 64 * q + lane;
-          spc[q] = sps[t]; gj[q] = sps[SW_MAXM + t]; qq[q] = qd[t]; f0[q] = fd[t]; f1[q] = fd[SW_MAXM + t]; f2[q] = fd[2 * SW_MAXM + t];
-          fb0[q] = st.b0[t]; fxx[q] = st.xxb0[t]; fb2[q] = st.b2[t]; fdr[q] = st.drej[t];
-          rd[q] = st.rden[t]; sz[q] = st.sdz1[t]; ch[q] = st.chi[t]; fta[q] = st.tacc[t]; ftr[q] = st.trej[t];
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const bool live = 64 * q + lane < mB;
-          r[q] = live ? (((qq[q] - spc[q]) - ((f0[q] + f1[q]) + f2[q])) + rnext[q]) : 0.0;
-          lc[q].b0 = live ? fb0[q] : 0.0f; lc[q].xxb0 = live ? fxx[q] : 0.0f;
-          lc[q].b2 = live ? fb2[q] : 0.0f; lc[q].drej = live ? fdr[q] : 0.0f;
-          lc[q].rden = live ? rd[q] : 1.0; lc[q].sdz1 = live ? sz[q] : 0.0;
-          lc[q].gjj = live ? gj[q] : 0.0; lc[q].mk = a.marker0 + (uint32_t)(blk * m + 64 * q + lane);
-          lc[q].tacc = live ? fta[q] : -INFINITY; lc[q].trej = live ? ftr[q] : -INFINITY;   // dead lanes: certain reject
-          chi[q] = live ? ch[q] : 1.0;
-        }
-      }
-      rnext[0] = 0.0; rnext[1] = 0.0;
-      unsigned long long accmask[2] = {0ull, 0ull};
+      const GT *g1 = use1 ? reinterpret_cast<const GT *>(A.gx[0]) + (size_t)(blk + 1) * m * m : gp;
+      const bool use2 = (b + 2 < nb) && D >= 3;
+      const GT *g2 = use2 ? reinterpret_cast<const GT *>(A.gx[1]) + (size_t)(blk + 2) * m * m : gp;
+      const int l0 = lane, l1 = 64 + lane;
+      const int l1c = min(l1, m - 1);
+      // constants of this lane's two markers
+      const float b0a = st.b0[l0], b0b = st.b0[l1], b2a = st.b2[l0], b2b = st.b2[l1], dra = st.drej[l0], drb = st.drej[l1];
+      const float taa = st.tacc[l0], tab = st.tacc[l1], tra = st.trej[l0], trb = st.trej[l1];
+      const double xba = (double)st.xxb0[l0], xbb = (double)st.xxb0[l1];
+      const double rda = st.rden[l0], rdb = st.rden[l1], sza = st.sdz1[l0], szb = st.sdz1[l1];
+      const double gja = sps[SW_MAXM + l0], gjb = sps[SW_MAXM + l1];
+      double r0 = ((qd[l0] - sps[l0]) - (fd[l0] + fd[SW_MAXM + l0])) + rnext0;
+      double r1 = ((qd[l1] - sps[l1]) - (fd[l1] + fd[SW_MAXM + l1])) + rnext1;
+      const double D2a = (double)((altb2 ? b2a : 0.0f) - b0a), D2b = (double)((altb2 ? b2b : 0.0f) - b0b);   // the alternative's step
+      const double D2sa = D2a * D2a, D2sb = D2b * D2b;
+      rnext0 = rnxt20; rnext1 = rnxt21; rnxt20 = 0.0; rnxt21 = 0.0;
+      S3ST(1, sq0);
+      unsigned long long am0 = 0ull, am1 = 0ull;
       int nacc = 0;
-      const int cnt0 = min(64, mB), cnt1 = max(0, mB - 64);
-      int front0 = 0, front1 = 0;
-      for (;;) {   // exact speculative rounds over both lane groups: every lane assumes "nobody before me is included"
-        const float b1a = lane_b1(r[0], lc[0]), b1b = lane_b1(r[1], lc[1]);
-        const bool aa = lane_accept(r[0], b1a, lc[0], a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
-        const bool ab = lane_accept(r[1], b1b, lc[1], a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
-        const unsigned long long bal0 = __ballot(aa && lane >= front0 && lane < cnt0);
-        const unsigned long long bal1 = __ballot(ab && lane >= front1 && lane < cnt1);
-        int g, js;
-        if (bal0) { g = 0; js = __ffsll((long long)bal0) - 1; front0 = js + 1; }
-        else if (bal1) { g = 1; js = __ffsll((long long)bal1) - 1; front0 = 64; front1 = js + 1; }   // group 0 is final: group 1's votes were valid
-        else break;
-        const int k = 64 * g + js;
-        const float dacc = g ? readlane_f32(b1b - lc[1].b0, js) : readlane_f32(b1a - lc[0].b0, js);
-        const float drj = g ? readlane_f32(lc[1].drej, js) : readlane_f32(lc[0].drej, js);
-        const long long cq = (long long)rint((double)dacc * S) - (long long)rint((double)drj * S);   // what the streamers will fold in
-        const double corr = (double)cq * invS;
-        // rows of marker k, on demand: packed diagonal block (entries for markers t > k) and the distance-1 cross block
-        const int pr = prow(k);
-        const int ta = lane, tb = min(64 + lane, m - 1);
-        const GT ga = gp[min(pr + max(ta - k - 1, 0), pstride - 1)], gb = gp[min(pr + max(tb - k - 1, 0), pstride - 1)];   // (the last row is empty)
-        GT xa = (GT)0, xb = (GT)0;
-        if (use1) { const GT *row = g1 + (size_t)k * m; xa = row[min(lane, m - 1)]; xb = row[tb]; }
-        r[0] = fma(-(double)((ta > k) ? ga : (GT)0), corr, r[0]);
-        r[1] = fma(-(double)((64 + lane > k && 64 + lane < m) ? gb : (GT)0), corr, r[1]);
-        rnext[0] = fma(-(double)xa, corr, rnext[0]);
-        rnext[1] = fma(-(double)xb, corr, rnext[1]);
-        accmask[g] |= (1ull << js);
-        if (lane == 0) { lk[nacc] = k; lc_[nacc] = corr; lq[nacc] = cq; }
-        ++nacc;
-      }
-      // outputs of the block
-      float *sp = state_s + (size_t)(b & 1) * 3 * SW_MAXM;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int t = 64 * q + lane;
-        if (t < mB) {
-          const float b1 = lane_b1(r[q], lc[q]);
-          const bool inc = ((accmask[q] >> lane) & 1ull) != 0ull;
-          const float bn = inc ? b1 : lc[q].b2;
-          const float dn = inc ? 1.0f : 0.0f;
-          sp[t] = bn; sp[SW_MAXM + t] = dn;
-          if (a.flags & SWF_VB_VEC) sp[2 * SW_MAXM + t] = (float)((double)(Sb + bn * bn) / chi[q]);
-          sum_d += (double)dn;
-          sum_b2 = fma((double)bn, (double)bn, sum_b2);
+      // One evaluation: the in-model draw b1 given r and whether the Bernoulli step includes the marker (the algebra of lane_b1 /
+      // lane_accept with the r-independent factors hoisted: 11 dependent operations).
+#define S3_EVAL(R_, XB_, RD_, SZ_, B0_, D2_, D2S_, GJ_, TA_, TR_, MKOFF_, D1F_, ACC_) { \
+        const float b1_ = (float)fma((R_) + (XB_), (RD_), (SZ_)); \
+        D1F_ = b1_ - (B0_); \
+        const double D1_ = (double)D1F_; \
+        const double diffd_ = fma((GJ_), (D2S_) - D1_ * D1_, (2.0 * (R_)) * (D1_ - (D2_)));   /* |e2|^2 - |e1|^2 */ \
+        const float x_ = Cc * (float)diffd_; \
+        const bool sa_ = x_ < (TA_), sr_ = x_ > (TR_); \
+        ACC_ = sa_; \
+        if (__builtin_expect(__ballot(!(sa_ || sr_)) != 0ull, 0)) { \
+          const bool ex_ = lane_accept_exact(diffd_, a.marker0 + (uint32_t)(blk * m + (MKOFF_) + lane), a.flags, Cc, odds, one_minus_pi, a.rng, a.iter); \
+          ACC_ = sa_ ? true : (sr_ ? false : ex_); \
+        } }
+      // An included marker k = KOFF_ + js: its step beyond the speculated one, corr = (b1 - b0) - drej (both floats, exact in
+      // fp64; the streamers fold in the same difference on the fixed-point grid, 2^-44 of the scale away), and its Gram rows, read
+      // on demand: the packed diagonal block for the later markers of this block, the distance-1 cross block for the next one.
+#define S3_INCLUDE(KOFF_, D1F_, DR_) { \
+        const int k_ = (KOFF_) + js; \
+        const int pr_ = prow(k_); \
+        GT ga_ = (GT)1, gb_ = (GT)1, xa_ = (GT)1, xb_ = (GT)1, ya_ = (GT)1, yb_ = (GT)1; \
+        if (!(A.dbg & 64)) { \
+        ga_ = gp[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gp[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)];   /* (the last row is empty) */ \
+        const GT *row_ = g1 + (size_t)k_ * m; \
+        xa_ = row_[min(l0, m - 1)]; xb_ = row_[l1c]; \
+        const GT *row2_ = g2 + (size_t)k_ * m; \
+        ya_ = row2_[min(l0, m - 1)]; yb_ = row2_[l1c]; } \
+        const float dacc_ = readlane_f32(D1F_, js), drj_ = readlane_f32(DR_, js); \
+        const double corr_ = (double)dacc_ - (double)drj_; \
+        if (lane == 0) { const int sl_ = (pos0 + nacc) & (ring - 1); accK[sl_] = k_ | (b << 8); accC[sl_] = corr_; accS[sl_] = make_float2(dacc_, drj_); } \
+        ++nacc; \
+        r0 = fma(-(double)((l0 > k_) ? ga_ : (GT)0), corr_, r0); \
+        r1 = fma(-(double)((l1 > k_ && l1 < m) ? gb_ : (GT)0), corr_, r1); \
+        if (use1) { rnext0 = fma(-(double)xa_, corr_, rnext0); rnext1 = fma(-(double)xb_, corr_, rnext1); } \
+        if (use2) { rnxt20 = fma(-(double)ya_, corr_, rnxt20); rnxt21 = fma(-(double)yb_, corr_, rnxt21); } }
+      // exact speculative rounds, first over markers 0..63, then 64..127: every lane assumes "nobody before me is included"
+      if (!(A.dbg & 128)) {
+        const int cnt0 = min(64, mB);
+        int front = 0;
+        for (;;) {
+          float d1f; bool acc;
+          S3_EVAL(r0, xba, rda, sza, b0a, D2a, D2sa, gja, taa, tra, 0, d1f, acc)
+          const unsigned long long bal = __ballot(acc && lane >= front && lane < cnt0);
+          if (bal == 0ull) break;
+          const int js = __ffsll((long long)bal) - 1;
+          front = js + 1;
+          am0 |= 1ull << js;
+          S3_INCLUDE(0, d1f, dra)
         }
       }
-      if (!use1) { rnext[0] = 0.0; rnext[1] = 0.0; }
-      else { if (!(lane < mBn)) rnext[0] = 0.0; if (!(64 + lane < mBn)) rnext[1] = 0.0; }
-      // the block's list for the streamers: header + two words per entry, one word per lane and pass
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // lane 0's list writes
+      if (mB > 64 && !(A.dbg & 128)) {
+        const int cnt1 = mB - 64;
+        int front = 0;
+        for (;;) {
+          float d1f; bool acc;
+          S3_EVAL(r1, xbb, rdb, szb, b0b, D2b, D2sb, gjb, tab, trb, 64, d1f, acc)
+          const unsigned long long bal = __ballot(acc && lane >= front && lane < cnt1);
+          if (bal == 0ull) break;
+          const int js = __ffsll((long long)bal) - 1;
+          front = js + 1;
+          am1 |= 1ull << js;
+          S3_INCLUDE(64, d1f, drb)
+        }
+      }
+#undef S3_EVAL
+#undef S3_INCLUDE
+      S3ST(2, sq0);
+      // the block's new effects (every lane's r is final for its own marker); the rest of the outputs is wave 7's
       {
-        unsigned long long *L = A.lists + (size_t)blk * S3_LSTRIDE;
-        for (int w0 = 0; w0 < 1 + 2 * nacc; w0 += 64) {
-          const int wi = w0 + lane;
-          if (wi < 1 + 2 * nacc) {
-            unsigned long long v;
-            if (wi == 0) v = s3_hdr(A.epoch, nacc);
-            else {
-              const int e = (wi - 1) >> 1;
-              const unsigned long long cqv = (unsigned long long)lq[e];
-              v = ((wi - 1) & 1) ? (((unsigned long long)A.epoch << 40) | (0xEEull << 32) | (cqv >> 32))
-                                 : (((unsigned long long)A.epoch << 40) | ((unsigned long long)(uint32_t)lk[e] << 32) | (cqv & 0xFFFFFFFFull));
-            }
-            st_agent_raw64(L + wi, v);
-          }
-        }
+        float *sp = state_s + (size_t)(b & 1) * 2 * SW_MAXM;
+        const float b1a = (float)fma(r0 + xba, rda, sza), b1b = (float)fma(r1 + xbb, rdb, szb);
+        const bool ia = ((am0 >> lane) & 1ull) != 0ull, ib = ((am1 >> lane) & 1ull) != 0ull;
+        sp[l0] = ia ? b1a : b2a; sp[l1] = ib ? b1b : b2b;
+        sp[SW_MAXM + l0] = ia ? 1.0f : 0.0f; sp[SW_MAXM + l1] = ib ? 1.0f : 0.0f;
       }
-      if (lane == 0) ctrl_s[8 + sbk] = nacc;
+      if (lane == 0) pos_s[(b + 1) & 31] = (pos0 + nacc) & (ring - 1);
+      S3ST(3, sq0);
     } else if (have_next) {
       helper_phase(b + 1);
+      S3ST(1, sq1 || sq2 || sq4);
     }
-    __syncthreads();   // block b's rounds are done, its list is in LDS; everything block b+1 needs from the helpers is in LDS
+    // block b's rounds are done, its list is in LDS; everything block b+1 needs from the helpers is in LDS.  (A bare barrier:
+    // __syncthreads() would drain the far-field rows that are meant to stay in flight across it.)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    S3ST(4, sq0 || sq1 || sq2 || sq4);
     if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
   }
-  if (wave == 7) {   // the state of the last two blocks is still in LDS
-    if (nb >= 2) store_state(nb - 2);
-    store_state(nb - 1);
-  }
-  if (wave == 0) {
+  S3ST_FLUSH(16, sq0); S3ST_FLUSH(24, sq1); S3ST_FLUSH(32, sq2); S3ST_FLUSH(40, sq4);
+  if (wave == 7) {   // the last two blocks
+    if (nb >= 2) finish_block(nb - 2);
+    finish_block(nb - 1);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { sum_d += __shfl_down(sum_d, o, 64); sum_b2 += __shfl_down(sum_b2, o, 64); }
     if (lane == 0) { a.sc->sum_d += sum_d; a.sc->sum_b2 += sum_b2; }

@@ -1,0 +1,43 @@
+"""Diagnostic: sweep time of k_sweep3 under the BWGR_DBG3 experiment switches (some of them break the chain on purpose:
+timing only) and under BWGR_D3 / BWGR_R3.  Usage: ab3_probe.py "VAR=val,VAR=val" ... (each argument one configuration)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, bwgr_amd
+from bwgr_amd import synth
+n, p = 10000, int(os.environ.get("AB_P", "200000"))
+model, pi = os.environ.get("AB_MODEL", "BayesB"), float(os.environ.get("AB_PI", "0.99"))
+X = synth.genotypes(n, p); y = synth.scale_phenotype(synth.phenotype(X, n))
+for cfg in sys.argv[1:] or [""]:
+    for kv in cfg.split(","):
+        if "=" in kv:
+            k, v = kv.split("="); os.environ[k] = v
+    P = bwgr_amd.Panel(X, n=n)
+    ch = bwgr_amd.Chain(P, model, y, it=6, bi=0, pi=pi, seed=1)
+    try:
+        ch.run(2); ch.sync()
+    except Exception as ex:
+        pass
+    try:
+        ch.sweep_ms()
+        ch.run(3)
+        try:
+            ch.sync()
+        except Exception:
+            pass
+        ms, nl = ch.sweep_ms()
+        nb = (p + P.block - 1) // P.block
+        st = None
+        try:
+            st = ch.state()
+        except Exception:
+            pass
+        print("%-40s sweep %8.3f ms  %6.3f us/block  mean_d %s  %s" % (cfg, ms, 1e3 * ms / nb, "%.4f" % st["d"].mean() if st else "n/a", P.pipeline(True)), flush=True)
+    finally:
+        try:
+            ch.close(); P.close()
+        except Exception:
+            pass
+    for kv in cfg.split(","):
+        if "=" in kv:
+            os.environ.pop(kv.split("=")[0], None)
