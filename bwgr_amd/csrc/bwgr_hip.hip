@@ -394,6 +394,7 @@ __global__ void k_chain_init(const InitArgs a) {
     sc.ve = vy; sc.vb = Sb; sc.lam = vy / Sb; sc.pi = pi;
     sc.Sb = Sb; sc.Se = (1 - a.R2) * a.df * vy; sc.C = -0.5f / sqrtf(vy); sc.odds = pi / (1.0f - pi);
     sc.mu = mu; sc.dfp1 = a.df + 1; sc.vy = vy; sc.MSx = a.MSx;
+    sc.inc_rate = 1.0f - pi;
     *a.sc = sc;
   }
 }
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(1024) void k_tail(const TailArgs a) {
     if (a.model == BWGR_BAYESDPI) pi = (float)(sc.sum_d / (double)a.p);
     sc.ve = ve; sc.vb = vb; sc.pi = pi; sc.Sb = Sb; sc.mu = mu;
     sc.C = -0.5f / sqrtf(ve);
+    sc.inc_rate = (float)(sc.sum_d / (double)a.p);
     sc.sum_d = 0.0; sc.sum_b2 = 0.0;
     if (a.accumulate) { sc.MU += mu; sc.VE += ve; sc.VBs += vb; sc.Pi += pi; }
   }
@@ -506,6 +508,7 @@ __global__ __launch_bounds__(1024) void k_tail2(const Tail2Args a) {
     }
     const float Cn = -0.5f / sqrtf(ve);
     s1.ve = ve; s2.ve = ve; s1.mu = mu; s2.mu = mu; s1.C = Cn; s2.C = Cn;
+    s1.inc_rate = (float)(s1.sum_d / (double)a.p1); s2.inc_rate = (float)(s2.sum_d / (double)a.p2);
     s1.sum_d = 0.0; s1.sum_b2 = 0.0; s2.sum_d = 0.0; s2.sum_b2 = 0.0;
     if (a.accumulate) { s1.MU += mu; s1.VE += ve; s1.VBs += s1.vb; s2.VBs += s2.vb; }
   }
@@ -658,6 +661,7 @@ __global__ void k_wgr_pre(const double *bR, const double *dR, const double *LR, 
     ChainScalars c; memset(&c, 0, sizeof(c));
     const float Ve = (float)ws->Ve;
     c.ve = Ve; c.pi = pi; c.C = -0.5f / sqrtf(Ve); c.odds = pi / (1.0f - pi); c.dfp1 = 1.0f;
+    c.inc_rate = 1.0f - pi;
     *sc = c;
   }
 }
@@ -916,6 +920,7 @@ struct bwgr_panel {
   unsigned long long *qsum3 = nullptr, *lists3 = nullptr;   // per handle (clones have their own)
   uint32_t epoch3 = 0;
   size_t lds3_bytes = 0;
+  float eng3_thr = 0.02f;         // k_sweep3 takes the sweeps whose chains hold fewer than this share of markers in the model (BWGR_ENG3_THR)
   hipStream_t own_stream = nullptr;
 };
 
@@ -1016,7 +1021,7 @@ static int sweep3_build(bwgr_panel *P) {
   int R3 = (P->R % 256 == 0) ? 256 : 128;
   if (const char *rv = getenv("BWGR_R3")) { const int v = atoi(rv); if ((v == 64 || v == 128 || v == 256) && P->R % v == 0) R3 = v; }
   const int sub = P->R / R3, K3 = P->K * sub;
-  int D = 12;
+  int D = 8;
   // (at least 2: a block's list leaves the sequencer while the next block is in its rounds)
   if (const char *dv = getenv("BWGR_D3")) { const int v = atoi(dv); if (v >= 2 && v <= S3_MAXD) D = v; }
   D = (int)std::min<int64_t>(D, std::max<int64_t>(2, P->nblocks));
@@ -1027,6 +1032,7 @@ static int sweep3_build(bwgr_panel *P) {
     return BWGR_OK;
   }
   P->R3 = R3; P->sub3 = sub; P->K3 = K3; P->e3_D = D; P->lds3_bytes = lds;
+  if (const char *tv = getenv("BWGR_ENG3_THR")) { const float v = (float)atof(tv); if (v > 0.0f) P->eng3_thr = v; }
   const size_t blk_elems = (size_t)P->nblocks * m * m;
   const bool g16 = P->gram16;
   int32_t *tmp = nullptr;
@@ -1078,23 +1084,35 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
   P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1;
   A.epoch = P->epoch3;
   if (const char *dv = getenv("BWGR_DBG3")) A.dbg = atoi(dv);
+  // one more workgroup, on the sequencer's XCD (workgroups with equal index mod 8 share an XCD), warms that XCD's L2 with the Gram
+  // rows the sequencer reads on demand; BWGR_PF3=1 switches it on
+  const char *pv = getenv("BWGR_PF3");
+  const bool pf_on = (pv && pv[0] == '1') && P->K3 + 2 <= 256;   // (measured: helps panels of few blocks' acceptance-heavy early sweeps, not C4; off by default)
+  A.pf = pf_on ? ((P->K3 + 2 > 8) ? 8 : P->K3 + 1) : -1;
   (void)hipMemsetAsync(P->qsum3 + (size_t)a.blk_begin * 2 * SW_MAXM, 0, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
-  const dim3 grid(P->K3 + 1), blk(SW_THREADS);
+  const dim3 grid(P->K3 + 1 + (pf_on ? 1 : 0)), blk(SW_THREADS);
   if (A.g16) hipLaunchKernelGGL(k_sweep3<uint16_t>, grid, blk, P->lds3_bytes, P->stream, A);
   else hipLaunchKernelGGL(k_sweep3<int32_t>, grid, blk, P->lds3_bytes, P->stream, A);
 }
 
-static void launch_prestage(bwgr_panel *P, const SweepArgs &a) {
+// The selection models' sweeps on a panel that has k_sweep3: the device picks the engine from the chain's current inclusion
+// rate (ChainScalars::inc_rate against the panel's threshold), so both engines' kernels are enqueued and one side leaves at once
+// (a few microseconds per iteration); a threshold >= 1 means k_sweep3 always and the other side is not enqueued at all.
+static float sweep3_gate(const bwgr_panel *P, int flags) { return use_sweep3(P, flags) ? (P->eng3_thr >= 1.0f ? INFINITY : P->eng3_thr) : 0.0f; }
+
+static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
+  SweepArgs a = a_in;
+  a.gate3 = sweep3_gate(P, a.flags);
   const int j0 = a.blk_begin * a.m, j1 = (int)std::min<int64_t>(P->p, (int64_t)a.blk_end * a.m);
   const int64_t tasks = 4ll * (j1 - j0);
-  const bool s3 = use_sweep3(P, a.flags);
+  const bool s3 = a.gate3 > 0.0f;
   if (s3) hipLaunchKernelGGL(k_escale_reset, dim3(1), dim3(1), 0, P->stream, a.sc);
   hipLaunchKernelGGL(k_prestage, dim3((unsigned)std::min<int64_t>(4096, (tasks + 255) / 256)), dim3(256), 0, P->stream, a, j0, j1);
   if (s3) {   // the sweep's fixed-point scale, then the in-block speculative terms on that grid
     int xbits = 0; while ((1 << xbits) < std::max(1, (P->parent ? P->parent : P)->xmax)) ++xbits;
-    hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, xbits);
+    hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, xbits, a.gate3);
     hipLaunchKernelGGL(k_spec3, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin);
-    return;
+    if (std::isinf(a.gate3)) return;
   }
   if (P->sweep_version >= 2) {
     const int sel = (a.flags & SWF_SELECT) ? 1 : 0;
@@ -1107,7 +1125,8 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a) {
 static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
   SweepArgs a = a_in;
   if (P->debug_withhold) a.flags |= SWF_DEBUG_WITHHOLD;
-  if (use_sweep3(P, a.flags)) { launch_sweep3(P, a); return; }
+  a.gate3 = sweep3_gate(P, a.flags);
+  if (a.gate3 > 0.0f) { launch_sweep3(P, a); if (std::isinf(a.gate3)) return; }
   const bool sel = (a.flags & SWF_SELECT) != 0;
   // streamers, sequencer, and for the selection models the q feeders (the affine recurrence is compute-bound: its
   // sequencer gathers q itself under the recurrence, and a feeder hop in its lag-2 chain measured 15 % slower)
@@ -1599,6 +1618,7 @@ static int kmup_sweep(bwgr_panel *PS, float *b, float *d, const float *xx, const
   HIPCHK(hipMemcpyAsync(dL, L, pb, hipMemcpyHostToDevice, PS->stream));
   ChainScalars h; memset(&h, 0, sizeof(h));
   h.ve = Ve; h.pi = pi; h.C = -0.5f / sqrtf(Ve); h.odds = pi / (1.0f - pi); h.dfp1 = 1.0f; h.bg = bg;
+  h.inc_rate = 1.0f - pi;
   HIPCHK(hipMemcpyAsync(sc, &h, sizeof(h), hipMemcpyHostToDevice, PS->stream));
   SweepArgs a; memset(&a, 0, sizeof(a));
   fill_panel_args(PS, a);

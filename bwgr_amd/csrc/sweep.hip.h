@@ -61,6 +61,8 @@ struct ChainScalars {
   float bg;                     // KMUP2: n0/n of the row subsample
   int e3_sh;                    // k_sweep3: the sweep's fixed-point scale, e_fixed = e * 2^e3_sh (k_escale)
   uint32_t e3_dex;              // k_sweep3: largest float exponent field among this sweep's rejected steps (k_prestage -> k_escale)
+  float inc_rate;               // share of markers in the model, as far as the chain knows (start: 1 - pi; then mean(d) of the last sweep):
+                                // picks the sweep engine of a selection model on the device (SweepArgs::gate3)
 };
 
 // per-marker constants of one sweep, produced chip-wide by k_prestage before the sweep kernel starts (they depend on
@@ -104,6 +106,8 @@ struct SweepArgs {
   unsigned long long *dgran;    // k_sweep2: [S2_NSLOT][SW_MAXM] {epoch, float delta} granules
   uint32_t *xflags;             // [K*SW_FLAG_STRIDE] epochs, then the abort word
   unsigned long long *stamps;   // diagnostic build only (-DBWGR_STAMPS): per-phase cycle sums of workgroup 0
+  float gate3;                  // > 0: both engines of the selection models are launched and the device picks one -- k_sweep3 (and its
+                                // k_escale / k_spec3) runs when sc->inc_rate < gate3, k_sweep2 (and k_spec) otherwise; 0: no gating
 };
 
 template <typename XT> struct XTraits;
@@ -249,15 +253,18 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
       st.chi[t] = (a.flags & SWF_VB_VEC) ? rng_chisq(a.rng, (double)dfp1, mk, a.iter, RNG_CHI) : 1.0;
     }
   }
-  // the unused entries of a ragged last block: constants with which a lane rejects for certain and changes nothing (k_sweep3's
-  // recurrence wave runs without dead-lane masks)
-  if (blockIdx.x == 0 && j_end > j_begin) {
-    const int blkL = (j_end - 1) / a.m;
-    StageBuf &st = a.ps.blocks[blkL];
-    for (int t = j_end - blkL * a.m + (int)threadIdx.x; t < SW_MAXM; t += (int)blockDim.x) {
-      st.b0[t] = 0.0f; st.xxb0[t] = 0.0f; st.b2[t] = 0.0f; st.drej[t] = 0.0f;
-      st.rden[t] = 0.0; st.sdz1[t] = 0.0; st.chi[t] = 1.0;
-      st.tacc[t] = -INFINITY; st.trej[t] = -INFINITY;
+  // the unused entries of every block (blocks narrower than SW_MAXM, the ragged last block): constants with which a lane rejects
+  // for certain and changes nothing (k_sweep3's recurrence wave runs without dead-lane masks, its streamers digitise all
+  // SW_MAXM steps of a block)
+  if (j_end > j_begin && (a.m < SW_MAXM || (j_end % a.m) != 0)) {
+    const int blk0 = j_begin / a.m, blk1 = (j_end - 1) / a.m;
+    for (int blk = blk0 + (int)blockIdx.x; blk <= blk1; blk += (int)gridDim.x) {
+      StageBuf &st = a.ps.blocks[blk];
+      for (int t = min(a.m, j_end - blk * a.m) + (int)threadIdx.x; t < SW_MAXM; t += (int)blockDim.x) {
+        st.b0[t] = 0.0f; st.xxb0[t] = 0.0f; st.b2[t] = 0.0f; st.drej[t] = 0.0f;
+        st.rden[t] = 0.0; st.sdz1[t] = 0.0; st.chi[t] = 1.0;
+        st.tacc[t] = -INFINITY; st.trej[t] = -INFINITY;
+      }
     }
   }
   __syncthreads();
@@ -267,6 +274,7 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
 // thread = marker j; Gram rows are read coalesced across j; fixed summation order k ascending)
 template <typename GT>
 __global__ __launch_bounds__(128) void k_spec(const SweepArgs a, int blk_begin, int select) {
+  if (a.gate3 > 0.0f && a.sc->inc_rate < a.gate3) return;   // this sweep is k_sweep3's
   const int blk = blk_begin + blockIdx.x, j = threadIdx.x, m = a.m;
   const int mB = min(m, a.p - blk * m);
   const GT *G = reinterpret_cast<const GT *>(a.gram) + (size_t)blk * m * m;

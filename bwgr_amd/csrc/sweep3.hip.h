@@ -29,7 +29,9 @@ namespace bwgr {
 // diagnostic build: per-phase s_memtime sums of streamer 0's first update wave (stamps[0..7]) and first dots wave (8..15), of the
 // sequencer's wave 0 (16..23) and of its helper waves (24..31), flushed once at the end
 #define S3ST_DECL unsigned long long ph3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl3 = __builtin_amdgcn_s_memtime()
-#define S3ST(k, cond) do { if (cond) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph3[k] += t_ - tl3; tl3 = t_; } } while (0)
+// (BWGR_STAMPS=2: only the stamps around the block barrier, slots 0 and 4 -- "busy" and "waiting" per role; a stamp costs a few
+// hundred cycles because it drains the wave's LDS / scalar counter, so the full set distorts the roles it measures)
+#define S3ST(k, cond) do { if ((BWGR_STAMPS != 2 || (k) == 0 || (k) == 1 || (k) == 4) && (cond)) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph3[k] += t_ - tl3; tl3 = t_; } } while (0)
 #define S3ST_FLUSH(base, cond) do { if ((cond) && a.stamps) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&a.stamps[(base) + k_], ph3[k_]); } while (0)
 #else
 #define S3ST_DECL do { } while (0)
@@ -53,7 +55,8 @@ struct Sweep3Args {
   unsigned long long *qsum;      // [nblocks][SW_MAXM][2] {low digits, high digits} << 8 | arrivals; zero before the launch
   unsigned long long *lists;     // [nblocks][S3_LSTRIDE] epoch-tagged words
   uint32_t epoch;                // this launch's tag (24 bits, never 0)
-  int dbg;                       // experiment switches (BWGR_DBG3): 1 lazy q poll, 2 no L2 touches
+  int dbg;                       // experiment switches (BWGR_DBG3)
+  int pf;                        // blockIdx of the prefetcher workgroup (shares the sequencer's XCD), or -1
 };
 
 // ---- fixed-point scale of one sweep.  With 2^k above both the largest |e_i| at the start of the sweep and the largest step
@@ -62,7 +65,8 @@ struct Sweep3Args {
 // and where p > n the steps themselves are larger than the residual), and a grid 2^-44 relative to that scale, far below the
 // last bit of a float step.  k_prestage leaves the largest exponent field of drej in sc->e3_dex (reset here after use). ----
 __global__ void k_escale_reset(ChainScalars *sc) { sc->e3_dex = 0u; }
-__global__ __launch_bounds__(1024) void k_escale(const double *e, int64_t ld, ChainScalars *sc, int xbits) {
+__global__ __launch_bounds__(1024) void k_escale(const double *e, int64_t ld, ChainScalars *sc, int xbits, float gate3) {
+  if (!(sc->inc_rate < gate3)) { if (threadIdx.x == 0) sc->e3_dex = 0u; return; }   // this sweep is k_sweep2's
   __shared__ uint32_t mx;
   if (threadIdx.x == 0) mx = 0u;
   __syncthreads();
@@ -84,6 +88,7 @@ __device__ __forceinline__ double s3_pow2(int k) { return __hiloint2double((1023
 // k_spec3: spec_j = sum_{k<j, same block} G_kj * drej_k with drej on the sweep's fixed-point grid (what the streamers apply),
 // and the Gram diagonal.  One workgroup of 128 threads per block, thread = marker j, four partial sums.
 __global__ __launch_bounds__(128) void k_spec3(const SweepArgs a, int blk_begin) {
+  if (!(a.sc->inc_rate < a.gate3)) return;   // this sweep is k_sweep2's
   const int blk = blk_begin + blockIdx.x, j = threadIdx.x, m = a.m;
   const int mB = min(m, a.p - blk * m);
   const int32_t *G = reinterpret_cast<const int32_t *>(a.gram) + (size_t)blk * m * m;
@@ -145,7 +150,7 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
   const SweepArgs &a = A.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m16 = lane & 15, grp = lane >> 4;
-  const int w = (int)blockIdx.x - 1;
+  const int w = (int)blockIdx.x - 1 - ((A.pf >= 0 && (int)blockIdx.x > A.pf) ? 1 : 0);
   const int m = a.m, R = a.R, R3 = A.R3, Rp = R3 + 16, D = A.D;
   const int slab = w / A.sub, hsub = w - slab * A.sub;
   const int nb = a.blk_end - a.blk_begin;
@@ -263,20 +268,26 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
     int8_t *edig = edig0 + (size_t)par * 16 * Rp;
     int8_t *ddig = ddig0 + (size_t)par * 16 * S2_DP;
     // A: what the included markers of block b - D changed
-    if (b >= D && upd) { if (!fold_list(b - D, lpre)) ctl_s[0] = 1u; }
+    if (b >= D && upd && !(A.dbg & 512)) { if (!fold_list(b - D, lpre)) ctl_s[0] = 1u; }
     S3ST(1, st_u);
     // B: digits of the residual rows and of this block's rejected steps
     if (upd) {
       if ((unsigned long long)(e_own + (1ll << 54)) >> 55) ctl_s[1] = 1u;       // left the 55-bit range
       s3_put_digits7(e_own, edig + 64 * wave + lane, Rp);
     } else if (tid >= SW_THREADS - SW_MAXM) {                                    // the last two waves (never update waves)
-      const double qd = rint((double)drej_pre * S);
+      const double qd = (tid - (SW_THREADS - SW_MAXM) < mB) ? rint((double)drej_pre * S) : 0.0;   // (unused markers: zero steps)
       if (!(fabs(qd) < 18014398509481984.0)) ctl_s[1] = 1u;                      // 2^54
-      s3_put_digits7((long long)qd, ddig + (tid - (SW_THREADS - SW_MAXM)), S2_DP);   // (a ragged block's unused markers are staged as zero steps)
+      s3_put_digits7((long long)qd, ddig + (tid - (SW_THREADS - SW_MAXM)), S2_DP);
     }
     S3ST(2, st_u);
+#if defined(BWGR_STAMPS) && BWGR_STAMPS == 2
+    S3ST(0, st_u || st_d);                      // lite: slot 0 = busy (barrier exit .. barrier entry), slot 4 = waiting at the barrier
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    S3ST(4, st_u || st_d);
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     S3ST(3, st_u || st_d);
+#endif
     if (ctl_s[0]) { if (tid == 0) a.sc->error = 1u; return false; }
     // C: tile b+1 (in registers for two iterations) lands in the other buffer, whose last reader was block b-1; the loads of
     // tile b+3 go out into the registers just freed; the list of block b+1-D and the rejected steps of block b+1 are requested
@@ -385,7 +396,7 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
   }
   S3ST_FLUSH(0, st_u); S3ST_FLUSH(8, st_d);
   // the lists of the last D blocks
-  if (upd) for (int bs = max(0, nb - D); bs < nb; ++bs) {
+  if (upd && !(A.dbg & 512)) for (int bs = max(0, nb - D); bs < nb; ++bs) {
     if (!fold_list(bs, 0ull)) { ctl_s[0] = 1u; break; }
   }
   if (upd && ((unsigned long long)(e_own + (1ll << 54)) >> 55)) ctl_s[1] = 1u;
@@ -588,12 +599,17 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   // wave 7: everything about a finished block that is off the chain -- its marker state (with the per-marker variance draw),
   // the posterior sums, and its list for the streamers (the fixed-point corrections are formed here, one entry per lane)
   double sum_d = 0.0, sum_b2 = 0.0;
+  double chn0 = 1.0, chn1 = 1.0;   // the chi-square variates of the block finish_block handles next, requested one phase ahead
+  auto chi_request = [&](int c) {   // (unconditional, clamped; a ragged block's unused entries are staged as 1)
+    const StageBuf &sb = a.ps.blocks[a.blk_begin + max(0, min(c, nb - 1))];
+    chn0 = sb.chi[lane]; chn1 = sb.chi[64 + lane];
+  };
   auto finish_block = [&](int c) {
     const int blk = a.blk_begin + c, j0c = blk * m, mBc = blk_m(c);
     const float *sp = state_s + (size_t)(c & 1) * 2 * SW_MAXM;
     const bool vbv = (a.flags & SWF_VB_VEC) != 0;
-    double ch0 = 1.0, ch1 = 1.0;
-    if (vbv) { ch0 = a.ps.blocks[blk].chi[min(lane, mBc - 1)]; ch1 = a.ps.blocks[blk].chi[min(64 + lane, mBc - 1)]; }
+    const double ch0 = chn0, ch1 = chn1;
+    chi_request(c + 1);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int t = lane + 64 * h;
@@ -625,8 +641,8 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     }
   };
   auto helper_phase = [&](int c) {   // block c >= 1, while wave 0 runs block c-1
-    if (wave == 1) { if (!poll_q(c)) ctrl_s[0] = 0; }
-    else if (wave <= 3) { stage_commit(c); if (c + 1 < nb) stage_request(c + 1); }
+    if (wave == 1) { if (!(A.dbg & 32768)) { if (!poll_q(c)) ctrl_s[0] = 0; } }
+    else if (wave <= 3) { if (!(A.dbg & 8192)) { stage_commit(c); if (c + 1 < nb) stage_request(c + 1); } }
     else if (wave == 4) { }   // idle: the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots
     else if (wave <= 6) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -636,7 +652,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       far_issue(c + 1, wave - 5);
       S3ST(7, tid == 320);
     }
-    else { if (c >= 2) finish_block(c - 2); touch(c + PF); }
+    else { if (c >= 2 && !(A.dbg & 4096)) finish_block(c - 2); touch(c + PF); }
   };
 
   // ---- prologue: block 0 ----
@@ -646,19 +662,20 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   if (wave == 1) { poll_request(0); if (!poll_q(0)) ctrl_s[0] = 0; }
   else if (wave == 2 || wave == 3) { stage_request(0); stage_commit(0); if (nb > 1) stage_request(1); }
   else if (wave >= 5 && wave <= 6) { far_consume(0, wave - 5); far_issue(1, wave - 5); }
-  else if (wave == 7) { for (int c = 0; c < PF; ++c) touch(c); }
+  else if (wave == 7) { for (int c = 0; c < PF; ++c) touch(c); chi_request(0); }
   __syncthreads();
   if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
 
   const bool sq0 = (tid == 0), sq1 = (tid == 64), sq2 = (tid == 128), sq4 = (tid == 320);
   const bool altb2 = (a.flags & SWF_ALT_B2) != 0;
+  if (wave == 0 && !(A.dbg & 1)) __builtin_amdgcn_s_setprio(3);   // the chain's wave goes first wherever it shares an issue port
   // wave 0: what the included markers of block b change in blocks b+1 and b+2 (distances 1 and 2), accumulated as they appear
   double rnext0 = 0.0, rnext1 = 0.0, rnxt20 = 0.0, rnxt21 = 0.0;
   for (int b = 0; b < nb; ++b) {
     const int mB = blk_m(b), blk = a.blk_begin + b;
     const bool have_next = (b + 1 < nb);
     S3ST(0, sq0 || sq1 || sq2 || sq4);
-    if (wave == 0) {
+    if (wave == 0 && !(A.dbg & 16384)) {
       // Wave 0 is one long dependent chain, so everything here is counted in instructions.  Dead lanes of a ragged last block need
       // no masks: k_prestage fills their constants so that they reject for certain, and their q, spec and far terms are zero.
       const StageBuf &st = stage[b & 1];
@@ -710,10 +727,10 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
         GT ga_ = (GT)1, gb_ = (GT)1, xa_ = (GT)1, xb_ = (GT)1, ya_ = (GT)1, yb_ = (GT)1; \
         if (!(A.dbg & 64)) { \
         ga_ = gp[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gp[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)];   /* (the last row is empty) */ \
-        const GT *row_ = g1 + (size_t)k_ * m; \
-        xa_ = row_[min(l0, m - 1)]; xb_ = row_[l1c]; \
-        const GT *row2_ = g2 + (size_t)k_ * m; \
-        ya_ = row2_[min(l0, m - 1)]; yb_ = row2_[l1c]; } \
+        const GT *row_ = g1 + (use1 ? (size_t)k_ * m : (size_t)0);   /* (without a next block: a harmless in-bounds read) */ \
+        xa_ = row_[use1 ? min(l0, m - 1) : 0]; xb_ = row_[use1 ? l1c : 0]; \
+        const GT *row2_ = g2 + (use2 ? (size_t)k_ * m : (size_t)0); \
+        ya_ = row2_[use2 ? min(l0, m - 1) : 0]; yb_ = row2_[use2 ? l1c : 0]; } \
         const float dacc_ = readlane_f32(D1F_, js), drj_ = readlane_f32(DR_, js); \
         const double corr_ = (double)dacc_ - (double)drj_; \
         if (lane == 0) { const int sl_ = (pos0 + nacc) & (ring - 1); accK[sl_] = k_ | (b << 8); accC[sl_] = corr_; accS[sl_] = make_float2(dacc_, drj_); } \
@@ -764,7 +781,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       }
       if (lane == 0) pos_s[(b + 1) & 31] = (pos0 + nacc) & (ring - 1);
       S3ST(3, sq0);
-    } else if (have_next) {
+    } else if (have_next && wave != 0) {
       helper_phase(b + 1);
       S3ST(1, sq1 || sq2 || sq4);
     }
@@ -784,11 +801,50 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// prefetcher: one workgroup on the sequencer's XCD (equal blockIdx mod 8) that walks a dozen blocks ahead of the sequencer and
+// touches one dword per 128-byte line of the Gram rows wave 0 may ask for on demand -- the packed diagonal block and the cross
+// blocks of distance 1 and 2, 80 KB per block -- so that those reads are L2 hits (a few hundred cycles) instead of HBM misses
+// (about 2 us on a loaded chip, on the chain's critical path).  Paced by the lists the sequencer publishes; speed only.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename GT>
+__device__ __forceinline__ void s3_prefetcher(const Sweep3Args &A) {
+  const SweepArgs &a = A.a;
+  const int tid = threadIdx.x, m = a.m, nb = a.blk_end - a.blk_begin;
+  constexpr int AHEAD = 12;
+  uint32_t *abortw = a.xflags + (size_t)a.K * SW_FLAG_STRIDE;
+  const size_t gpbytes = (size_t)a.pstride * sizeof(GT), gxbytes = (size_t)m * m * sizeof(GT);
+  uint32_t sink = 0u;
+  for (int c = 0; c < nb; ++c) {
+    if (c >= AHEAD) {   // wait (one lane polls) until the sequencer has published the list of block c - AHEAD
+      const unsigned long long *L = A.lists + (size_t)(a.blk_begin + c - AHEAD) * S3_LSTRIDE;
+      const uint64_t t0 = wall_clock64();
+      unsigned spins = 0;
+      for (;;) {
+        if (s3_epoch_is(ld_agent_raw64(L), A.epoch)) break;
+        if ((++spins & 63u) == 0u && (ld_agent_u32(abortw) != 0u || wall_clock64() - t0 > SW_TIMEOUT_TICKS)) return;
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    const int blk = a.blk_begin + c;
+    const unsigned char *gpb = reinterpret_cast<const unsigned char *>(A.gp) + (size_t)blk * gpbytes;
+    for (size_t o = (size_t)tid * 128; o < gpbytes; o += (size_t)SW_THREADS * 128) sink += *reinterpret_cast<const uint32_t *>(gpb + o);
+    for (int d = 1; d <= 2; ++d) {
+      if (d >= A.D || c + d >= nb) continue;
+      const unsigned char *gxb = reinterpret_cast<const unsigned char *>(A.gx[d - 1]) + (size_t)(blk + d) * gxbytes;
+      for (size_t o = (size_t)tid * 128; o < gxbytes; o += (size_t)SW_THREADS * 128) sink += *reinterpret_cast<const uint32_t *>(gxb + o);
+    }
+  }
+  if (sink == 0x9E3779B9u && a.stamps) a.stamps[255] = sink;   // (keeps the loads alive)
+}
+
 template <typename GT>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep3(const Sweep3Args A) {
-  if (blockIdx.x == 0) s3_sequencer<GT>(A);
-  else if ((A.a.flags & SWF_DEBUG_WITHHOLD) && blockIdx.x == 1) return;   // test hook: a streamer that never shows up
-  else s3_streamer(A);
+  if (!(A.a.sc->inc_rate < A.a.gate3)) return;   // this sweep is k_sweep2's (dense inclusion: every workgroup sees the same scalar)
+  if ((int)blockIdx.x == A.pf) { s3_prefetcher<GT>(A); return; }
+  if (blockIdx.x == 0) { if (!(A.dbg & 1024)) s3_sequencer<GT>(A); }
+  else if ((A.a.flags & SWF_DEBUG_WITHHOLD) && blockIdx.x == 1 && A.pf != 1) return;   // test hook: a streamer that never shows up
+  else if (!(A.dbg & 2048)) s3_streamer(A);
 }
 
 }  // namespace bwgr

@@ -170,9 +170,12 @@ def test_sharded_entry_points_world1_equals_run(tpod):
             b.sweep_blocks(lo, min(b.nblocks, lo + 5))
         b.end_iteration(None)
     sb = b.state()
-    for k in ("b", "d", "e", "vb"):
-        assert np.array_equal(sa[k], sb[k]), k
-    assert sa["ve"] == sb["ve"] and sa["mu"] == sb["mu"]
+    # Same chain; not always the same bits: k_sweep3 takes a launch's first blocks from slab dots that already hold the previous
+    # range's included markers, where the one-launch sweep subtracts their Gram rows in fp64 -- the same numbers to 1e-16
+    assert np.array_equal(sa["d"], sb["d"])
+    for k in ("b", "e", "vb"):
+        assert scaled_err(sa[k], sb[k]) < 1e-9, k
+    assert _rel(sa["ve"], sb["ve"]) < 1e-9 and _rel(sa["mu"], sb["mu"]) < 1e-9
     a.close(); b.close(); P.close()
 
 
@@ -547,7 +550,7 @@ def test_em_family_tpod_defaults(tpod, model):
 
 def test_exchange_rounds_with_one_shard_are_the_plain_chain(tpod):
     """The sharded sampler's device-side round API (bwgr_chain_round_sweep / round_apply, get_sums_dev / end_iteration_dev)
-    with a single shard and an identity 'all-reduce' must reproduce bwgr_chain_run bit for bit."""
+    with a single shard and an identity 'all-reduce' must reproduce bwgr_chain_run (same decisions, effects to 1e-9)."""
     import bwgr_amd
     from bwgr_amd.dist import HipShardEngine
     X, y = tpod["gen"], tpod["y"].astype(np.float32)
@@ -567,6 +570,7 @@ def test_exchange_rounds_with_one_shard_are_the_plain_chain(tpod):
         got = eng.chain.state(); eng.chain.close()
         ref_chain = bwgr_amd.Chain(P, model, y, it=5, bi=1, pi=pi, seed=77)
         ref_chain.run(5); ref = ref_chain.state(); ref_chain.close(); P.close()
-        for k in ("b", "d", "e", "vb"):
-            np.testing.assert_array_equal(got[k], ref[k], err_msg="%s %s" % (model, k))
-        assert got["ve"] == ref["ve"] and got["mu"] == ref["mu"]
+        np.testing.assert_array_equal(got["d"], ref["d"], err_msg=model)
+        for k in ("b", "e", "vb"):   # (to 1e-9, not bit for bit: see test_sharded_entry_points_world1_equals_run)
+            assert scaled_err(got[k], ref[k]) < 1e-9, (model, k)
+        assert _rel(got["ve"], ref["ve"]) < 1e-9 and _rel(got["mu"], ref["mu"]) < 1e-9

@@ -255,3 +255,23 @@ def test_abort_path_reports_a_timeout_and_the_panel_survives():
     ch.close(); P.close()
     o = O.bayes("BayesB", y, X, it=4, bi=0, pi=0.8, seed=2)["last"]
     assert scaled_err(st["b"], o["b"]) < TOL and np.array_equal(st["d"], o["d"])
+
+
+@pytest.mark.parametrize("model,pi", [("BayesB", 0.99), ("BayesB", 0.9), ("BayesC", 0.985), ("BayesCpi", 0.0)])
+def test_engine_choice_follows_the_inclusion_rate(model, pi, monkeypatch):
+    """With the default threshold (2 % of markers in the model) the device picks k_sweep3 or k_sweep2 sweep by sweep from the
+    chain's own inclusion rate; whichever runs, the chain is the oracle's.  BayesB pi = 0.99 stays on k_sweep3, pi = 0.9 and
+    BayesCpi on k_sweep2, BayesC pi = 0.985 wanders across the threshold."""
+    import bwgr_amd
+    from oracle import oracle as O
+    monkeypatch.setenv("BWGR_ENG3_THR", "0.02")
+    X, y = synth_small(500, 3000, seed=17, causal=0.01)
+    P = bwgr_amd.Panel(X)
+    assert P.pipeline(True)["generation"] == 3
+    ch = bwgr_amd.Chain(P, model, y, it=12, bi=2, pi=pi, seed=9)
+    ch.run(12)
+    st = ch.state()
+    ch.close(); P.close()
+    o = O.bayes(model, y, X, it=12, bi=2, pi=pi, seed=9)["last"]
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
+    assert np.array_equal(st["d"], o["d"])

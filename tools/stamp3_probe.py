@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT)
 from bwgr_amd import build as B
 so = os.path.join(ROOT, "gpurun_out", "libbwgr_hip_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DBWGR_STAMPS", "-o", so] + B.SOURCES)
+LITE = os.environ.get("STAMPS_LITE", "0") == "1"
+subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DBWGR_STAMPS=2" if LITE else "-DBWGR_STAMPS=1", "-o", so] + B.SOURCES)
 B.LIB = so
 import numpy as np, torch
 import bwgr_amd
