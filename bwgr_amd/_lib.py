@@ -70,6 +70,12 @@ def lib():
     L.bwgr_synth_genotypes.argtypes = [vp, i64, i64, i64, i64, u64, vp, i32, vp]
     L.bwgr_debug_variates.argtypes = [i32, u64, i32, f64, u32, u32, u32, i32, c_d]
     L.bwgr_debug_withhold.argtypes = [vp, i32]
+    L.bwgr_group_create.argtypes = [C.POINTER(vp), i32, C.POINTER(i32), vp, i32, i64, i64, i64, i32, c_f, i32, f32, f32, f32, f32, f32, u64, i32, i64]
+    L.bwgr_group_run.argtypes = [vp, i32]
+    L.bwgr_group_sync.argtypes = [vp]
+    L.bwgr_group_info.argtypes = [vp, C.POINTER(i64)]
+    L.bwgr_group_result.argtypes = [vp] + [c_f] * 10
+    L.bwgr_group_destroy.argtypes = [vp]
     L.bwgr_device_count.argtypes = [C.POINTER(i32)]
     L.bwgr_sample_rows.argtypes = [u64, u32, i64, i64, i32, C.POINTER(i32)]
     _lib = L
@@ -92,4 +98,5 @@ EXPORTS = ["bwgr_abi_version", "bwgr_last_error", "bwgr_device_count", "bwgr_pan
            "bwgr_chain_create_sharded", "bwgr_chain_sweep_blocks", "bwgr_chain_round_sweep", "bwgr_chain_round_apply", "bwgr_chain_get_sums_dev", "bwgr_chain_end_iteration_dev", "bwgr_chain_get_sums", "bwgr_chain_end_iteration",
            "bwgr_chain_destroy", "bwgr_chain_run", "bwgr_chain_sync", "bwgr_chain_iterations", "bwgr_chain_result",
            "bwgr_chain_state", "bwgr_chain_sweep_ms", "bwgr_bayes", "bwgr_bayes2", "bwgr_wgr", "bwgr_wgr_ex", "bwgr_synth_genotypes",
-           "bwgr_debug_variates", "bwgr_debug_withhold", "bwgr_sample_rows"]
+           "bwgr_debug_variates", "bwgr_debug_withhold", "bwgr_sample_rows", "bwgr_group_create", "bwgr_group_run", "bwgr_group_sync",
+           "bwgr_group_info", "bwgr_group_result", "bwgr_group_destroy"]

@@ -288,6 +288,73 @@ def BayesDpi(y, X, it=1500, bi=500, df=5, R2=0.5, *, seed=None, rng_mode=0, **kw
     return _fused("BayesDpi", y, X, it, bi, 0.0, df, R2, seed, rng_mode, **kw)
 
 
+class Group:
+    """One fused-sampler chain over several GPUs of this process (bwgr_group_*, include/bwgr.h): device g takes the g-th
+    block-aligned marker shard of the host matrix X, the residual is replicated and re-united by RCCL all-reduces at the
+    exchange rounds, one host thread drives everything.  devices=[d] is the plain exact chain on one GPU; more devices
+    run the partitioned sampler (statistical parity).  This is the path an R .Call takes to more than one GPU; the
+    benchmark's one-process-per-GPU driver is bwgr_amd/dist.py."""
+
+    def __init__(self, model, y, X, devices=(0,), it=1500, bi=500, pi=0.95, df=5.0, R2=0.5, seed=None, rng_mode=0, block=0,
+                 markers_per_sync=0):
+        X = np.asarray(X)
+        assert X.ndim == 2
+        if X.dtype != np.int8:
+            fits = bool(X.size == 0 or (X.min() >= -128 and X.max() <= 127))
+            if fits and (np.issubdtype(X.dtype, np.integer) or np.all(X == np.rint(X))):
+                X = X.astype(np.int8)
+            elif X.dtype not in (np.float32, np.float64):
+                X = X.astype(np.float64)
+        self._X = np.asfortranarray(X)
+        self.n, self.p = self._X.shape
+        self.model = model
+        self._y = np.ascontiguousarray(y, np.float32)
+        assert self._y.size == self.n
+        xtype = {np.dtype(np.int8): X_I8, np.dtype(np.float32): X_F32, np.dtype(np.float64): X_F64}[self._X.dtype]
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = C.c_void_p()
+        check(_lib.lib().bwgr_group_create(C.byref(self._h), len(devices), devs, self._X.ctypes.data_as(C.c_void_p), xtype, self.n,
+                                            self.p, self.n, int(block), _fp(self._y), MODELS[model], float(it), float(bi), float(pi),
+                                            float(df), float(R2), C.c_uint64(_seed(seed)), int(rng_mode), int(markers_per_sync)))
+
+    def info(self):
+        v = (C.c_int64 * 4)()
+        check(_lib.lib().bwgr_group_info(self._h, v))
+        return dict(zip(("devices", "rounds_per_sweep", "markers_per_round", "rccl"), (int(x) for x in v)))
+
+    def run(self, iters):
+        check(_lib.lib().bwgr_group_run(self._h, int(iters)))
+
+    def sync(self):
+        check(_lib.lib().bwgr_group_sync(self._h))
+
+    def result(self):
+        p, n, model = self.p, self.n, self.model
+        per = model in _PER_MARKER_VB
+        B = np.empty(p, np.float32); D = np.empty(p, np.float32); hat = np.empty(n, np.float32)
+        VB = np.empty(p if per else 1, np.float32); PV = np.empty(p, np.float32)
+        mu = C.c_float(); ve = C.c_float(); h2 = C.c_float(); msx = C.c_float(); Pi = C.c_float()
+        check(_lib.lib().bwgr_group_result(self._h, C.byref(mu), _fp(B), _fp(D), _fp(hat), _fp(VB), C.byref(ve), C.byref(h2),
+                                            C.byref(msx), C.byref(Pi), _fp(PV)))
+        vb = VB if per else float(VB[0])
+        if model in ("BayesA", "BayesL", "BayesRR"):
+            return {"mu": mu.value, "b": B, "hat": hat, "vb": vb, "ve": ve.value, "h2": h2.value, "MSx": msx.value}
+        if model in ("BayesB", "BayesC"):
+            return {"mu": mu.value, "b": B, "d": D, "hat": hat, "vb": vb, "ve": ve.value, "h2": h2.value, "MSx": msx.value}
+        return {"mu": mu.value, "b": B, "d": D, "pi": Pi.value, "hat": hat, "h2": h2.value, "vb": vb, "ve": ve.value, "PVAL": PV}
+
+    def close(self):
+        if self._h:
+            _lib.lib().bwgr_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _SELECTION = ("BayesB", "BayesC", "BayesCpi", "BayesDpi")
 _DEFAULT_PI = {"BayesB": 0.95, "BayesC": 0.95}
 

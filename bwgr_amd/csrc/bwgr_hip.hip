@@ -2341,6 +2341,202 @@ done:
 }
 
 // ------------------------------------------------------------------------------------------------
+// Multi-GPU inside the library (row e): bwgr_group_* -- one marker shard per device of this process, the residual replicated,
+// ONE host thread, one stream per device, RCCL all-reduces of the residual delta (n fp64) on those streams at the exchange
+// rounds.  This is what an R process (the reference's only host, R/wgr.R:2) needs in order to use more than one GPU through a
+// .Call; bwgr_amd/dist.py remains the torchrun driver of the benchmark (one process per GPU).  For G > 1 this is the
+// partitioned sampler of DESIGN.md section 8 (statistical parity); G = 1 is the plain exact chain.
+// RCCL is loaded with dlopen on first use, so single-GPU users never touch it.
+// ------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+namespace {
+typedef struct ncclComm *bwgr_ncclComm_t;
+struct RcclApi {
+  void *h = nullptr;
+  int (*CommInitAll)(bwgr_ncclComm_t *, int, const int *) = nullptr;
+  int (*CommDestroy)(bwgr_ncclComm_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, bwgr_ncclComm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+  if (g_rccl.h) return BWGR_OK;
+  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(BWGR_EHIP, "group: cannot load librccl.so (%s)", dlerror());
+  RcclApi a; a.h = h;
+  a.CommInitAll = (int (*)(bwgr_ncclComm_t *, int, const int *))dlsym(h, "ncclCommInitAll");
+  a.CommDestroy = (int (*)(bwgr_ncclComm_t))dlsym(h, "ncclCommDestroy");
+  a.AllReduce = (int (*)(const void *, void *, size_t, int, int, bwgr_ncclComm_t, hipStream_t))dlsym(h, "ncclAllReduce");
+  a.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+  a.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+  a.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+  if (!a.CommInitAll || !a.CommDestroy || !a.AllReduce || !a.GroupStart || !a.GroupEnd) return fail(BWGR_EHIP, "group: librccl.so lacks an expected symbol");
+  g_rccl = a;
+  return BWGR_OK;
+}
+constexpr int BWGR_NCCL_FLOAT64 = 8, BWGR_NCCL_SUM = 0;   // ncclFloat64, ncclSum (rccl.h)
+}  // namespace
+
+struct bwgr_group {
+  int G = 0;
+  int model = 0;
+  int64_t n = 0, p = 0;
+  int block = 0, bps = 1, rounds = 1;
+  std::vector<int> dev;
+  std::vector<int64_t> lo, hi;
+  std::vector<bwgr_panel *> P;
+  std::vector<bwgr_chain *> C;
+  std::vector<double *> delta, sums;
+  std::vector<bwgr_ncclComm_t> comm;
+  bool use_comm = false;
+  float MSx_total = 0;
+};
+
+extern "C" int bwgr_group_destroy(bwgr_group *Gp) {
+  if (!Gp) return BWGR_OK;
+  for (size_t g = 0; g < Gp->C.size(); ++g) if (Gp->C[g]) bwgr_chain_destroy(Gp->C[g]);
+  for (size_t g = 0; g < Gp->P.size(); ++g) {
+    if (g < Gp->dev.size()) (void)hipSetDevice(Gp->dev[g]);
+    if (g < Gp->delta.size()) hipFree(Gp->delta[g]);
+    if (g < Gp->sums.size()) hipFree(Gp->sums[g]);
+    if (Gp->P[g]) bwgr_panel_destroy(Gp->P[g]);
+  }
+  if (Gp->use_comm) for (bwgr_ncclComm_t c : Gp->comm) if (c) g_rccl.CommDestroy(c);
+  delete Gp;
+  return BWGR_OK;
+}
+
+// X: HOST matrix, column-major n x p (ldx >= n), any bwgr_xtype; y: n host floats.  Device g of `devices` stages the
+// block-aligned column shard [lo_g, hi_g) (as bwgr_amd/dist.py::shard_bounds) and runs the chain of that shard.
+// markers_per_sync: markers swept per device between two residual all-reduces (0: 131072 / ndev, the benchmark's default).
+extern "C" int bwgr_group_create(bwgr_group **out, int ndev, const int *devices, const void *X, int xtype, int64_t n, int64_t p,
+                                 int64_t ldx, int block, const float *y, int model, float it, float bi, float pi, float df, float R2,
+                                 uint64_t seed, int rng_mode, int64_t markers_per_sync) {
+  if (!out || !devices || !X || !y) return fail(BWGR_EINVAL, "group_create: null pointer");
+  *out = nullptr;
+  if (ndev < 1 || ndev > 64) return fail(BWGR_EINVAL, "group_create: ndev = %d", ndev);
+  if (xtype != BWGR_X_I8 && xtype != BWGR_X_F32 && xtype != BWGR_X_F64) return fail(BWGR_EINVAL, "group_create: bad xtype %d", xtype);
+  const int mmax = (xtype == BWGR_X_I8) ? SW_MAXM : 64;
+  const int m = block > 0 ? block : mmax;
+  const int64_t nblk = (p + m - 1) / m, per = (nblk + ndev - 1) / ndev;
+  if ((int64_t)(ndev - 1) * per * m >= p) return fail(BWGR_EINVAL, "group_create: p = %lld has only %lld blocks of %d markers: too few for %d devices", (long long)p, (long long)nblk, m, ndev);
+  bwgr_group *Gp = new bwgr_group();
+  Gp->G = ndev; Gp->model = model; Gp->n = n; Gp->p = p; Gp->block = m;
+  Gp->dev.assign(devices, devices + ndev);
+  Gp->P.assign(ndev, nullptr); Gp->C.assign(ndev, nullptr); Gp->delta.assign(ndev, nullptr); Gp->sums.assign(ndev, nullptr);
+  auto bail = [&](int code) { bwgr_group_destroy(Gp); return code; };
+  const size_t esz = (xtype == BWGR_X_I8) ? 1 : (xtype == BWGR_X_F32 ? 4 : 8);
+  double msx = 0.0;
+  for (int g = 0; g < ndev; ++g) {
+    const int64_t lo = std::min<int64_t>(p, (int64_t)g * per * m), hi = std::min<int64_t>(p, (int64_t)(g + 1) * per * m);
+    Gp->lo.push_back(lo); Gp->hi.push_back(hi);
+    int rc = bwgr_panel_create(&Gp->P[g], reinterpret_cast<const unsigned char *>(X) + (size_t)lo * (size_t)ldx * esz, xtype, BWGR_HOST, n, hi - lo, ldx, devices[g], m, 0);
+    if (rc != BWGR_OK) return bail(rc);
+    msx += (double)Gp->P[g]->MSx;
+  }
+  Gp->MSx_total = (float)msx;
+  for (int g = 0; g < ndev; ++g) {
+    int rc = bwgr_chain_create_sharded(&Gp->C[g], Gp->P[g], model, y, BWGR_HOST, it, bi, pi, df, R2, seed, rng_mode, Gp->lo[g], p, Gp->MSx_total, nullptr);
+    if (rc != BWGR_OK) return bail(rc);
+    if (hipSetDevice(devices[g]) != hipSuccess || hipMalloc(&Gp->delta[g], sizeof(double) * (size_t)Gp->P[g]->ld) != hipSuccess ||
+        hipMalloc(&Gp->sums[g], sizeof(double) * 2) != hipSuccess) return bail(fail(BWGR_ENOMEM, "group_create: device allocation failed"));
+    if (Gp->P[g]->ld != Gp->P[0]->ld) return bail(fail(BWGR_EINVAL, "group_create: shards disagree on the padded row count"));
+  }
+  const int64_t mps = markers_per_sync > 0 ? markers_per_sync : std::max<int64_t>(m, 131072 / ndev);
+  Gp->bps = (int)std::max<int64_t>(1, mps / m);
+  int64_t nbmax = 0;
+  for (int g = 0; g < ndev; ++g) nbmax = std::max<int64_t>(nbmax, Gp->P[g]->nblocks);
+  Gp->rounds = (int)((nbmax + Gp->bps - 1) / Gp->bps);
+  const char *fc = getenv("BWGR_GROUP_FORCE_COMM");   // (tests: exercise the RCCL path with a single device)
+  Gp->use_comm = ndev > 1 || (fc && fc[0] == '1');
+  if (Gp->use_comm) {
+    int rc = rccl_load();
+    if (rc != BWGR_OK) return bail(rc);
+    Gp->comm.assign(ndev, nullptr);
+    const int nr = g_rccl.CommInitAll(Gp->comm.data(), ndev, devices);
+    if (nr != 0) return bail(fail(BWGR_EHIP, "group_create: ncclCommInitAll failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(nr) : "?"));
+  }
+  *out = Gp;
+  return BWGR_OK;
+}
+
+static int group_allreduce(bwgr_group *Gp, std::vector<double *> &buf, size_t count) {
+  int nr = g_rccl.GroupStart();
+  for (int g = 0; g < Gp->G && nr == 0; ++g)
+    nr = g_rccl.AllReduce(buf[g], buf[g], count, BWGR_NCCL_FLOAT64, BWGR_NCCL_SUM, Gp->comm[g], Gp->P[g]->stream);
+  const int ne = g_rccl.GroupEnd();
+  if (nr == 0) nr = ne;
+  if (nr != 0) return fail(BWGR_EHIP, "group: ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(nr) : "?");
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_group_run(bwgr_group *Gp, int iters) {
+  if (!Gp) return fail(BWGR_EINVAL, "null group");
+  if (iters < 0) return fail(BWGR_EINVAL, "group_run: iters < 0");
+  if (!Gp->use_comm) return bwgr_chain_run(Gp->C[0], iters);   // one device: the plain exact chain
+  for (int k = 0; k < iters; ++k) {
+    for (int r = 0; r < Gp->rounds; ++r) {
+      for (int g = 0; g < Gp->G; ++g) {
+        const int nb = (int)Gp->P[g]->nblocks;
+        const int lo = std::min(nb, r * Gp->bps), hi = std::min(nb, (r + 1) * Gp->bps);   // (lo == hi: a device that has run out of blocks still takes part)
+        CHK(bwgr_chain_round_sweep(Gp->C[g], lo, hi, Gp->delta[g]));
+      }
+      CHK(group_allreduce(Gp, Gp->delta, (size_t)Gp->P[0]->ld));
+      for (int g = 0; g < Gp->G; ++g) CHK(bwgr_chain_round_apply(Gp->C[g], Gp->delta[g]));
+    }
+    for (int g = 0; g < Gp->G; ++g) CHK(bwgr_chain_get_sums_dev(Gp->C[g], Gp->sums[g]));
+    CHK(group_allreduce(Gp, Gp->sums, 2));
+    for (int g = 0; g < Gp->G; ++g) CHK(bwgr_chain_end_iteration_dev(Gp->C[g], Gp->sums[g]));
+  }
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_group_sync(bwgr_group *Gp) {
+  if (!Gp) return fail(BWGR_EINVAL, "null group");
+  for (int g = 0; g < Gp->G; ++g) CHK(bwgr_chain_sync(Gp->C[g]));
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_group_info(const bwgr_group *Gp, int64_t info[4]) {
+  if (!Gp || !info) return fail(BWGR_EINVAL, "null pointer");
+  info[0] = Gp->G; info[1] = Gp->rounds; info[2] = (int64_t)Gp->bps * Gp->block; info[3] = Gp->use_comm ? 1 : 0;
+  return BWGR_OK;
+}
+
+// the reference's return list over the whole panel (host outputs; any may be NULL): b, d, pval: p floats; vb: p floats for the
+// per-marker-variance models, else 1; hat: n floats
+extern "C" int bwgr_group_result(bwgr_group *Gp, float *mu, float *b, float *d, float *hat, float *vb, float *ve, float *h2,
+                                 float *MSx, float *pi_out, float *pval) {
+  if (!Gp) return fail(BWGR_EINVAL, "null group");
+  const bool per = per_marker_vb(Gp->model);
+  std::vector<float> hg(hat ? (size_t)Gp->n : 0), vbl;
+  float mu0 = 0, ve0 = 0, h20 = 0, msx0 = 0, pi0 = 0, vbs = 0;
+  double vg = 0.0;
+  if (hat) for (int64_t i = 0; i < Gp->n; ++i) hat[i] = 0.0f;
+  for (int g = 0; g < Gp->G; ++g) {
+    const int64_t lo = Gp->lo[g], pg = Gp->hi[g] - lo;
+    float mug, veg, h2g, msxg, pig;
+    vbl.assign(per ? (size_t)pg : 1, 0.0f);
+    CHK(bwgr_chain_result(Gp->C[g], &mug, b ? b + lo : nullptr, d ? d + lo : nullptr, hat ? hg.data() : nullptr, vbl.data(), &veg, &h2g,
+                          &msxg, &pig, pval ? pval + lo : nullptr));
+    if (g == 0) { mu0 = mug; ve0 = veg; h20 = h2g; msx0 = msxg; pi0 = pig; vbs = vbl[0]; }
+    if (per) { for (int64_t j = 0; j < pg; ++j) { vg += (double)vbl[(size_t)j]; if (vb) vb[lo + j] = vbl[(size_t)j]; } }
+    if (hat) for (int64_t i = 0; i < Gp->n; ++i) hat[i] += hg[(size_t)i] - mug;   // X_g B_g
+  }
+  if (hat) for (int64_t i = 0; i < Gp->n; ++i) hat[i] += mu0;
+  if (!per && vb) vb[0] = vbs;
+  if (mu) *mu = mu0;
+  if (ve) *ve = ve0;
+  if (h2) *h2 = per ? (float)(vg / (vg + (double)ve0)) : h20;   // (the common-variance models form vg from MSx over all shards already)
+  if (MSx) *MSx = msx0;
+  if (pi_out) *pi_out = pi0;
+  return BWGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // f4: EM / Gauss-Seidel family (emRR, emBA, emBB, emBC, emBCpi, emDE, emBL, emEN, emML), src/Rcpp20260726ai.cpp:80-521, :1502-1545
 //
 // Deterministic coordinate updates -- b_j = (X_j.e + xx_j b_j)/(xx_j + lambda_j), i.e. the affine sweep with the variates

@@ -31,7 +31,7 @@ namespace bwgr {
 #define S3ST_DECL unsigned long long ph3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl3 = __builtin_amdgcn_s_memtime()
 // (BWGR_STAMPS=2: only the stamps around the block barrier, slots 0 and 4 -- "busy" and "waiting" per role; a stamp costs a few
 // hundred cycles because it drains the wave's LDS / scalar counter, so the full set distorts the roles it measures)
-#define S3ST(k, cond) do { if ((BWGR_STAMPS != 2 || (k) == 0 || (k) == 1 || (k) == 4) && (cond)) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph3[k] += t_ - tl3; tl3 = t_; } } while (0)
+#define S3ST(k, cond) do { if ((BWGR_STAMPS == 1 || (BWGR_STAMPS == 2 && ((k) == 0 || (k) == 1 || (k) == 4)) || (BWGR_STAMPS == 3 && ((k) == 0 || (k) == 4) && blockIdx.x == 0 && threadIdx.x == 0)) && (cond)) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph3[k] += t_ - tl3; tl3 = t_; } } while (0)
 #define S3ST_FLUSH(base, cond) do { if ((cond) && a.stamps) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&a.stamps[(base) + k_], ph3[k_]); } while (0)
 #else
 #define S3ST_DECL do { } while (0)

@@ -224,6 +224,25 @@ int bwgr_em_order(int64_t p, int upto, int32_t *order);
 int bwgr_synth_genotypes(void *Xdev, int64_t n, int64_t p, int64_t ldx, int64_t col0, uint64_t seed, float *freq_dev,
                          int device, void *hip_stream);
 
+/* ---- multi-GPU inside the library ----------------------------------------------------------------
+ * (new; the reference is single-process, single-threaded R: R/wgr.R:2.)  One marker shard per device of THIS process, the
+ * residual replicated, RCCL all-reduces of the residual delta (n fp64) at the exchange rounds, one host thread: what an R
+ * .Call needs to use several GPUs.  G > 1 is the partitioned sampler of DESIGN.md section 8 (statistical parity, not the
+ * reference's chain); G = 1 is the exact chain.  X is a HOST matrix (column-major n x p, ldx >= n), y n host floats; device g
+ * of `devices` takes the block-aligned column shard g.  markers_per_sync: markers swept per device between two all-reduces
+ * (0: 131072 / ndev).  bwgr_group_result returns the Bayes* return list over the whole panel (b, d, pval: p floats; vb: p
+ * floats for BayesA/B/L/Dpi, else 1; hat: n floats).  info: {devices, exchange rounds per sweep, markers per round, RCCL in use}. */
+typedef struct bwgr_group bwgr_group;
+int bwgr_group_create(bwgr_group **out, int ndev, const int *devices, const void *X, int xtype, int64_t n, int64_t p, int64_t ldx,
+                      int block, const float *y, int model, float it, float bi, float pi, float df, float R2, uint64_t seed,
+                      int rng_mode, int64_t markers_per_sync);
+int bwgr_group_run(bwgr_group *G, int iters);
+int bwgr_group_sync(bwgr_group *G);
+int bwgr_group_info(const bwgr_group *G, int64_t info[4]);
+int bwgr_group_result(bwgr_group *G, float *mu, float *b, float *d, float *hat, float *vb, float *ve, float *h2, float *MSx,
+                      float *pi_out, float *pval);
+int bwgr_group_destroy(bwgr_group *G);
+
 /* ---- test hooks -----------------------------------------------------------------------------------
  * variates of the RNG contract computed on the device: kind 0 normal, 1 uniform, 2 chisq(nu);
  * out[i] for marker = marker0 + i. */

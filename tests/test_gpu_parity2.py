@@ -275,3 +275,28 @@ def test_engine_choice_follows_the_inclusion_rate(model, pi, monkeypatch):
     o = O.bayes(model, y, X, it=12, bi=2, pi=pi, seed=9)["last"]
     assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
     assert np.array_equal(st["d"], o["d"])
+
+
+@pytest.mark.parametrize("model,pi", [("BayesB", 0.9), ("BayesRR", 0.0)])
+def test_group_on_one_device_is_the_plain_chain(tpod, model, pi, monkeypatch):
+    """bwgr_group_* (multi-GPU inside the library) with one device: without RCCL it IS bwgr_chain_run; with the RCCL path forced
+    (a one-rank communicator, the exchange rounds and the in-place all-reduces of the residual delta and the iteration's sums)
+    it must give the same chain (same decisions, effects to 1e-9; the rounds start blocks from already folded slab dots)."""
+    import bwgr_amd
+    X, y = tpod["gen"], tpod["y"]
+    ref = getattr(bwgr_amd, model)(y, X, it=8, bi=2, **({"pi": pi} if model == "BayesB" else {}), seed=5, block=32)
+    for force in ("0", "1"):
+        monkeypatch.setenv("BWGR_GROUP_FORCE_COMM", force)
+        g = bwgr_amd.Group(model, y, X, devices=[0], it=8, bi=2, pi=pi, seed=5, block=32, markers_per_sync=96)
+        info = g.info()
+        assert info["devices"] == 1 and info["rccl"] == int(force) and (force == "0" or info["rounds_per_sweep"] == 4)
+        g.run(8); g.sync()
+        out = g.result(); g.close()
+        assert list(out) == list(ref)
+        for k in ref:
+            if k == "d":
+                assert np.array_equal(out[k], ref[k])
+            elif np.ndim(ref[k]):
+                assert scaled_err(out[k], ref[k]) < 1e-6, k
+            else:
+                assert _rel(out[k], ref[k]) < 1e-6, k

@@ -6,8 +6,8 @@ sys.path.insert(0, ROOT)
 from bwgr_amd import build as B
 so = os.path.join(ROOT, "gpurun_out", "libbwgr_hip_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-LITE = os.environ.get("STAMPS_LITE", "0") == "1"
-subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DBWGR_STAMPS=2" if LITE else "-DBWGR_STAMPS=1", "-o", so] + B.SOURCES)
+LITE = os.environ.get("STAMPS_LITE", "0")   # 0: every stamp; 1: busy / waiting per role; 2: only the sequencer's wave 0, busy / waiting
+subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DBWGR_STAMPS=%d" % (1 + int(LITE)), "-o", so] + B.SOURCES)
 B.LIB = so
 import numpy as np, torch
 import bwgr_amd
