@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--sync-every", type=int, default=0, help="markers per rank between residual all-reduces (N>1)")
     ap.add_argument("--chains", type=int, default=0, help="extra leg at N=1: this many chains side by side on the one "
                     "resident panel (0 = as many as fit the chip, 1 = skip the leg); reported as concurrent_chains")
+    ap.add_argument("--sharded", action="store_true", help="N > 1: the marker-sharded partitioned sampler (one chain over N GPUs, RCCL "
+                    "residual all-reduce) instead of N replica chains; statistically unsound on uncentred genotypes, see DESIGN.md section 8")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-slice", type=int, default=20000)
     args = ap.parse_args()
@@ -127,9 +129,55 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = local_rank
 
-    if world > 1 or os.environ.get("BWGR_FORCE_DIST"):   # BWGR_FORCE_DIST=1: rehearse the sharded leg with one rank
+    if (world > 1 and args.sharded) or os.environ.get("BWGR_FORCE_DIST"):   # BWGR_FORCE_DIST=1: rehearse the sharded leg with one rank
         from bwgr_amd import dist as bdist
         out = bdist.bench_sharded(args, n, p, model, pi, K, W, rank, world, dev)
+        if rank == 0:
+            print(json.dumps(out))
+        return
+    if world > 1:
+        # N replica chains: every rank stages the full panel (10 GB at C4) and runs the EXACT chain with its own seed; no data-path
+        # collective.  The sweep is a recurrence over the markers, so one exact chain does not shard (the
+        # partitioned sampler the north-star sketches overshoots on uncentred genotypes at every exchange window that would scale).
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        X = synth.genotypes(n, p, device=dev)
+        y = synth.scale_phenotype(synth.phenotype(X, n))
+        P = bwgr_amd.Panel(X, n=n, device=dev, block=args.block, nwg=args.nwg)
+        del X
+        torch.cuda.empty_cache()
+        ch = bwgr_amd.Chain(P, model, y, it=W + K, bi=W, pi=pi, df=5, R2=0.5, seed=synth.SEED + rank)
+        ch.run(W); ch.sync(); ch.sweep_ms()
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ch.run(K); ch.sync()
+        dist.barrier(); torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda:%d" % dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+        sweep_ms, launches = ch.sweep_ms()
+        st = ch.state()
+        pl = P.pipeline(bool(pi))
+        kernel = {3: "k_sweep3<uint16>", 2: "k_sweep2<int8>", 1: "k_sweep<int8>"}[pl["generation"]]
+        alg_bytes = float(n) * float(p)
+        achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+        out = {
+            "metric": "MCMC iter/sec (full marker sweep)", "value": world * K / elapsed, "unit": "iter/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 scalars, fixed-point / f64 residual, int8 genotypes", "data": "synthetic",
+            "config": {"workload": "%s: synthetic n=%d x p=%d int8, %s%s: %d replica chains, one exact chain per GPU on its own copy "
+                                   "of the panel (replicas only: no data-path collective; value = chain-iterations/s over all GPUs)"
+                                   % (args.workload, n, p, model, " pi=%.2f" % pi if pi else "", world),
+                       "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "traffic_source": None, "kernel": kernel + " (rank 0)", "kernel_ms": sweep_ms,
+                         "launches": launches, "algorithmic_bytes_per_launch": alg_bytes},
+            "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d": float(st["d"].mean())},
+        }
+        ch.close(); P.close()
+        dist.destroy_process_group()
         if rank == 0:
             print(json.dumps(out))
         return
@@ -177,8 +225,8 @@ def main():
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
     out = {
         "metric": "MCMC iter/sec (full marker sweep)", "value": K / elapsed, "unit": "iter/s", "n_gpus": 1,
-        "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32 scalars, f64 residual/accumulation, int8 genotypes", "data": "synthetic",
+        "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 scalars, fixed-point / f64 residual, int8 genotypes", "data": "synthetic",
         "config": {"workload": "%s: synthetic n=%d x p=%d int8, %s%s, exact chain (blocked sweep, block=%d, %d slabs "
                                "x %d rows + 1 sequencer%s)" % (args.workload, n, p, model,
                                                           " pi=%.2f (1%% in model)" % pi if pi else "", P.block, P.nwg, P.slab_rows,

@@ -300,3 +300,61 @@ def test_group_on_one_device_is_the_plain_chain(tpod, model, pi, monkeypatch):
                 assert scaled_err(out[k], ref[k]) < 1e-6, k
             else:
                 assert _rel(out[k], ref[k]) < 1e-6, k
+
+
+def test_partitioned_sampler_characterisation():
+    """The marker-sharded sampler is a different chain from the reference for more than one shard (every shard sweeps against a
+    residual that has not seen the other shards' updates since the last exchange round), so its parity can only be statistical.
+    This test pins what IS guaranteed and records what is not:
+      * one shard driven through the round API is the exact chain (asserted);
+      * several shards of a p >> n panel of uncentred genotypes are NOT a sound approximation at any exchange window: all
+        markers share the mean direction, every shard corrects the same stale residual mean, and the summed corrections
+        overshoot (measured on MI355X, n = 800 x p = 16 384, BayesB pi = 0.95, 150 kept iterations, exact chain ve = 1.45:
+        2 shards x 128 markers per round ve = 2.39, cor(hat) = 0.66; 2 x 512: 9.19, 0.50; 4 x 1024: 16.1).  The runs must
+        complete and stay finite; their statistics are printed, not asserted.  bench.py therefore scales over GPUs with replica
+        chains, and bwgr_amd/dist.py flags its own output (`statistically_sound`)."""
+    import os
+    import torch
+    import bwgr_amd
+    from bwgr_amd.dist import HipShardEngine, shard_bounds
+    from oracle import oracle as O
+    n, p, it, bi, pi = 800, 16384, 60, 10, 0.95
+    X, y = synth_small(n, p, seed=23, causal=0.01)
+    y = y.astype(np.float32)
+    msx = float(O.stats(X)[2])
+
+    def sharded(G, markers_per_round, seed):
+        spans = [shard_bounds(p, G, r, 128) for r in range(G)]
+        panels = [bwgr_amd.Panel(np.asfortranarray(X[:, lo:hi])) for lo, hi in spans]
+        engs = [HipShardEngine(panels[r], "BayesB", y, it, bi, pi, 5.0, 0.5, seed, spans[r][0], p, msx) for r in range(G)]
+        bps = max(1, markers_per_round // 128)
+        rounds = max((e.nblocks + bps - 1) // bps for e in engs)
+        for _ in range(it):
+            for r in range(rounds):
+                ds = [e.round_sweep(min(e.nblocks, r * bps), min(e.nblocks, (r + 1) * bps)) for e in engs]
+                total = torch.stack(ds).sum(0)
+                for e, dlt in zip(engs, ds):
+                    dlt.copy_(total); e.round_apply(dlt)
+            s_ = torch.stack([e.sums() for e in engs]).sum(0)
+            for e in engs:
+                e.sums().copy_(s_); e.end_iteration(e.sums())
+        res = [e.chain.result() for e in engs]
+        out = {"ve": res[0]["ve"], "mu": res[0]["mu"], "d": np.concatenate([r_["d"] for r_ in res]),
+               "b": np.concatenate([r_["b"] for r_ in res]), "hat": res[0]["mu"] + sum(r_["hat"] - r_["mu"] for r_ in res)}
+        for e in engs:
+            e.chain.close()
+        for P in panels:
+            P.close()
+        return out
+
+    a = bwgr_amd.BayesB(y, X, it=it, bi=bi, pi=pi, seed=31)
+    one = sharded(1, 1024, 31)
+    assert np.array_equal(one["d"], a["d"]) and scaled_err(one["b"], a["b"]) < 1e-6 and _rel(one["ve"], a["ve"]) < 1e-6
+    cases = ((2, 2048), (4, 1024))
+    if os.environ.get("SHARD_SCAN"):
+        cases = [(int(a_), int(b_)) for a_, b_ in (c.split(":") for c in os.environ["SHARD_SCAN"].split(","))]
+    for G, mpr in cases:
+        s_ = sharded(G, mpr, 31)
+        print("shards %d x %d markers per round: ve %.4f (exact %.4f), mean d %.4f (exact %.4f), cor(hat) %.5f" % (
+            G, mpr, s_["ve"], a["ve"], s_["d"].mean(), a["d"].mean(), np.corrcoef(s_["hat"], a["hat"])[0, 1]))
+        assert np.isfinite(s_["ve"]) and np.isfinite(s_["hat"]).all() and np.isfinite(s_["b"]).all()
