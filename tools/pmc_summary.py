@@ -31,10 +31,10 @@ def main():
     dfetch, dwrite, out, workload, n, p = sys.argv[1:7]
     n, p = int(n), int(p)
     fetch, write = load(dfetch, "FETCH_SIZE"), load(dwrite, "WRITE_SIZE")
-    sweep = [k for k in fetch if "k_sweep2" in k]
+    sweep = [k for k in fetch if "k_sweep3" in k] or [k for k in fetch if "k_sweep2" in k]
     if not sweep:
-        raise SystemExit("no k_sweep2 dispatch in %s (kernels: %s)" % (dfetch, sorted(fetch)[:8]))
-    sk = max(sweep, key=lambda k: fetch[k][1])
+        raise SystemExit("no k_sweep3 / k_sweep2 dispatch in %s (kernels: %s)" % (dfetch, sorted(fetch)[:8]))
+    sk = max(sweep, key=lambda k: fetch[k][0])   # (with the device-side engine choice both engines are dispatched; the idle one fetches nothing)
     calib = {k[:40]: fetch[k][0] for k in fetch if "k_gram_i8" in k or "k_gramx_i8" in k}
     gi = [fetch[k][0] for k in fetch if "k_gram_i8" in k]
     factor = None
@@ -48,7 +48,7 @@ def main():
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --no-cpu; tools/pmc_summary.py",
         "units": "FETCH_SIZE / WRITE_SIZE in KiB per launch (mean over %d launches, summed over XCDs)" % fetch[sk][1],
         "correction": "gfx950: FETCH_SIZE reports ~1/2 of the bytes of coalesced streaming reads (MI355X_MICROARCH.md, HBM); factor %.3f "
-                      "calibrated in the same run on k_gram_i8, which reads the padded panel once; WRITE_SIZE exact" % corr,
+                      "as the guide prescribes unless a kernel of known read volume calibrates it in the same run; WRITE_SIZE exact" % corr,
         "fetch_size_kib": fetch[sk][0], "write_size_kib": write.get(sk, (0.0, 0))[0],
         "calibration_fetch_size_kib": calib,
         "read_bytes_corrected": rd, "write_bytes": wr, "traffic_bytes_per_launch": rd + wr,
