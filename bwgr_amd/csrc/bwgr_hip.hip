@@ -14,6 +14,7 @@
 #include "rng.hip.h"
 #include "sweep.hip.h"
 #include "sweep3.hip.h"
+#include "sweep2w.hip.h"
 #include <stdlib.h>
 
 using namespace bwgr;
@@ -920,6 +921,12 @@ struct bwgr_panel {
   unsigned long long *qsum3 = nullptr, *lists3 = nullptr;   // per handle (clones have their own)
   uint32_t epoch3 = 0;
   size_t lds3_bytes = 0;
+  // the affine models' block solve as a triangular product (sweep2w.hip.h)
+  bool winv_on = true;            // BWGR_WINV=0: the serial recurrence of k_sweep2's sequencer instead
+  double *winv = nullptr;         // per handle: [nblocks][S2W_WDOUBLES], written by k_affine_inv before every affine sweep
+  unsigned char *gxt[S2W_MAXDIST] = {};   // the cross Gram blocks as the sequencer's MFMA operand (k_gx_planes); shared with clones
+  int winv_nd = 0;                // distances built = the deepest lag the affine sweeps can run, minus one
+  size_t ldsw_bytes = 0;
   float eng3_thr = 0.02f;         // k_sweep3 takes the sweeps whose chains hold fewer than this share of markers in the model (BWGR_ENG3_THR)
   hipStream_t own_stream = nullptr;
 };
@@ -1100,6 +1107,19 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
 // (a few microseconds per iteration); a threshold >= 1 means k_sweep3 always and the other side is not enqueued at all.
 static float sweep3_gate(const bwgr_panel *P, int flags) { return use_sweep3(P, flags) ? (P->eng3_thr >= 1.0f ? INFINITY : P->eng3_thr) : 0.0f; }
 
+// The affine sweeps of an int8 panel with 16-bit Gram staging run k_sweep2w: the block solve as a product with the inverse
+// k_affine_inv forms before the sweep (sweep2w.hip.h).
+static bool use_winv(const bwgr_panel *P, int flags) {
+  if (!P->winv_on || P->sweep_version < 2 || P->is_f32 || !P->gramp || P->winv_nd < 1) return false;
+  if (flags & (SWF_SELECT | SWF_EM_ANY | SWF_SERIAL)) return false;
+  return P->ldsw_bytes > 0 && P->ldsw_bytes <= (size_t)160 * 1024;
+}
+static int winv_alloc(bwgr_panel *P) {
+  if (P->winv) return BWGR_OK;
+  HIPCHK(hipMalloc(&P->winv, sizeof(double) * (size_t)S2W_WDOUBLES * (size_t)P->nblocks));
+  return BWGR_OK;
+}
+
 static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
   SweepArgs a = a_in;
   a.gate3 = sweep3_gate(P, a.flags);
@@ -1113,6 +1133,10 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
     hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, xbits, a.gate3);
     hipLaunchKernelGGL(k_spec3, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin);
     if (std::isinf(a.gate3)) return;
+  }
+  if (use_winv(P, a.flags) && P->winv) {
+    hipLaunchKernelGGL(k_affine_inv, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(256), S2W_INV_LDS, P->stream, a, P->winv, (a.flags & SWF_DELTA2) ? 2.0 : 1.0);
+    return;
   }
   if (P->sweep_version >= 2) {
     const int sel = (a.flags & SWF_SELECT) ? 1 : 0;
@@ -1131,6 +1155,17 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
   // streamers, sequencer, and for the selection models the q feeders (the affine recurrence is compute-bound: its
   // sequencer gathers q itself under the recurrence, and a feeder hop in its lag-2 chain measured 15 % slower)
   a.nfeed = (P->sweep_version >= 2 && sel) ? P->nfeed : 0;
+  if (use_winv(P, a.flags) && P->winv) {
+    S2WArgs A;
+    A.winv = P->winv; A.nd = a.lag - 1;
+    for (int d = 0; d < S2W_MAXDIST; ++d) A.gxt[d] = P->gxt[d < P->winv_nd ? d : 0];
+    A.npf = 4;      // measured at C2: 0 -> 540, 2 -> 636, 4 -> 685 iter/s (6 and 8 no better)
+    A.ahead = 5;
+    if (const char *pv = getenv("BWGR_WPF")) A.npf = std::max(0, std::min(8, atoi(pv)));
+    if (const char *pv = getenv("BWGR_WAHEAD")) A.ahead = std::max(1, atoi(pv));
+    hipLaunchKernelGGL(k_sweep2w, dim3(P->K + 1 + 8 * A.npf), dim3(S2W_THREADS), P->ldsw_bytes, P->stream, a, A);
+    return;
+  }
   if (P->sweep_version >= 2) {
     const dim3 grid(P->K + 1 + a.nfeed), blk(SW_THREADS);
     if (P->is_f32) {
@@ -1157,6 +1192,7 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
 }
 
 // selection models run the deeper pipelines (their cross terms are sparse); BWGR_LAG=2|3 caps the depth (A/B tests)
+static bool use_winv(const bwgr_panel *P, int flags);
 static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
   const char *lv = getenv("BWGR_LAG");
   // depth 4 where the panel has the third cross Gram array (int8, 16-bit staging), else 3; BWGR_LAG=2|3 caps it (A/B tests)
@@ -1167,9 +1203,14 @@ static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
     if (!P->is_f32 && P->gramx3 && P->gram16 && P->lag4_ok) lag = 4;   // only the 16-bit / single-barrier sequencer knows the third cross term
   }
   a.lag = lag < cap ? lag : cap;
+  if (use_winv(P, a.flags)) {   // the affine sweeps' product sequencer: as deep as the panel's cross Gram planes reach (BWGR_WLAG caps it)
+    a.lag = std::min(4, P->winv_nd + 1);
+    if (const char *wl = getenv("BWGR_WLAG")) if (wl[0] >= '2' && wl[0] <= '4') a.lag = std::min(a.lag, wl[0] - '0');
+  }
 }
 static int launch_sweep(bwgr_panel *P, SweepArgs &a) {
   choose_lag(P, a);
+  if (use_winv(P, a.flags)) CHK(winv_alloc(P));
   CHK(reset_exchange(P));
   P->ps_owner = nullptr;   // the scratch is about to hold this sweep's constants, nobody's iteration
   launch_prestage(P, a);
@@ -1226,12 +1267,13 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   if (!P->parent) {
     for (int d = 0; d < S3_MAXD; ++d) if (P->g3own[d]) hipFree(P->g3x[d]);
     hipFree(P->xmax_dev);
+    for (int d = 0; d < S2W_MAXDIST; ++d) hipFree(P->gxt[d]);
     hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->gramx3); hipFree(P->gramp16); hipFree(P->gramx16); hipFree(P->gram16_bad); hipFree(P->gramp); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev);
   } else {
     P->parent->nclones--;
   }
   // the scratch a sweep writes: speculative cross terms, pre-staged constants, exchange words
-  hipFree(P->qsum3); hipFree(P->lists3);
+  hipFree(P->qsum3); hipFree(P->lists3); hipFree(P->winv);
   hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->xpart); hipFree(P->xchg); hipFree(P->stamps);
   if (P->own_stream) hipStreamDestroy(P->own_stream);
   delete P;
@@ -1356,6 +1398,24 @@ static int panel_build_gram(bwgr_panel *P) {
     const char *gv = getenv("BWGR_GRAM16");   // BWGR_GRAM16=0 forces the 32-bit staging (A/B tests)
     P->gram16 = (bad == 0) && !(gv && gv[0] == '0');
   }
+  // the affine sweeps' sequencer (sweep2w.hip.h) takes the cross blocks as biased byte planes: built where every entry fits 16 bits
+  P->winv_nd = 0;
+  if (!P->is_f32 && P->gram16 && P->winv_on && m <= SW_MAXM) {
+    HIPCHK(hipMemsetAsync(P->gram16_bad, 0, sizeof(int), P->stream));
+    int nd = 0;
+    for (int dist = 1; dist <= S2W_MAXDIST; ++dist) {
+      const int32_t *src = (const int32_t *)(dist == 1 ? P->gramx : dist == 2 ? P->gramx2 : P->gramx3);
+      if (P->nblocks <= dist || dist > P->gram_maxdist || !src) break;
+      if (!P->gxt[dist - 1]) HIPCHK(hipMalloc(&P->gxt[dist - 1], (size_t)P->nblocks * S2W_PBYTES));
+      hipLaunchKernelGGL(k_gx_planes, dim3(4096), dim3(256), 0, P->stream, src, P->gxt[dist - 1], m, (int64_t)P->nblocks, dist, P->gram16_bad);
+      HIPCHK(hipGetLastError());
+      nd = dist;
+    }
+    int bad = 1;
+    HIPCHK(hipMemcpyAsync(&bad, P->gram16_bad, sizeof(int), hipMemcpyDeviceToHost, P->stream));
+    HIPCHK(hipStreamSynchronize(P->stream));
+    P->winv_nd = bad ? 0 : nd;
+  }
   HIPCHK(hipStreamSynchronize(P->stream));
   return BWGR_OK;
 }
@@ -1453,6 +1513,10 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<int8_t, true, uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2w), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_affine_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  if (!P->is_f32) P->ldsw_bytes = s2w_lds_bytes(m, R);
+  if (const char *wv = getenv("BWGR_WINV")) P->winv_on = !(wv[0] == '0');
 #undef PCHK
   (void)rc;
   *out = P;
@@ -1498,7 +1562,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   HIPCHK(hipStreamSynchronize(root->stream));   // the shared arrays are complete
   bwgr_panel *P = new bwgr_panel(*root);
   P->parent = root; P->nclones = 0; P->nchains = 0; P->own_stream = nullptr; P->stream = nullptr; P->ps_owner = nullptr; P->ps_iter = -1;
-  P->qsum3 = P->lists3 = nullptr; P->epoch3 = 0; P->xmax_dev = nullptr;
+  P->qsum3 = P->lists3 = nullptr; P->epoch3 = 0; P->xmax_dev = nullptr; P->winv = nullptr;
   P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->xchg = nullptr; P->stamps = nullptr;
   root->nclones++;
   auto bail = [&](int code) { bwgr_panel_destroy(P); return code; };
@@ -1761,6 +1825,7 @@ extern "C" int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   choose_lag(P, a);
+  if (use_winv(P, a.flags)) CHK(winv_alloc(P));
   CHK(reset_exchange(P));
   // the per-marker constants and speculative terms of an iteration depend on the state at its start only (a block's b is
   // untouched until the block is swept), so a chain that sweeps its panel in several ranges -- the exchange rounds of the
@@ -2285,7 +2350,7 @@ extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int t
         hipLaunchKernelGGL(k_set_bg, dim3(1), dim3(1), 0, P->stream, sc, (float)n / (float)nbag);
       }
       fill_panel_args(PS, a);
-      a.flags = SWF_LAM_VEC | (pi > 0 ? (SWF_SELECT | SWF_ALT_B2) : 0) | (bagging ? SWF_KMUP2 : 0);
+      a.flags = SWF_LAM_VEC | (pi > 0 ? (SWF_SELECT | SWF_ALT_B2) : 0) | (bagging ? SWF_KMUP2 : 0) | (de ? SWF_SERIAL : 0);
       a.e = e64; a.b = bf; a.d = dfl; a.vb = vbf; a.xx = xxf; a.lam = Lf; a.sc = sc; a.iter = itx; a.rng = rng;
       rc = launch_sweep(PS, a);                                                    // KMUP / KMUP2, R/wgr.R:85
       if (rc != BWGR_OK) goto done;

@@ -47,6 +47,8 @@ enum : int {
   SWF_EM_BL = 512,    // emBL: G + Half_L2 (:379-387); Lmb1 in sc->lam, 1/(xx + cxx) in the sdz1 slot (cxx in sc->Sb)
   SWF_EM_LASSO = 1024, // lasso: yx = (e + x b0).x, soft threshold (yx -/+ Lmb)/xx clamped at 0 (:1477-1485); Lmb in sc->lam; yx_j leaves in d[j]
   SWF_EM_ANY = SWF_EM_SEL | SWF_EM_EN | SWF_EM_BL | SWF_EM_LASSO,
+  SWF_SERIAL = 1 << 19,          // affine sweep that must keep the lane-ordered recurrence (wgr's de: Vb_j = |b_j| sqrt(Ve/MSx) feeds rounding-level
+                                 // differences of b back into the next sweep's shrinkage, amplified; R/wgr.R:118)
   SWF_DEBUG_WITHHOLD = 1 << 20   // test hook (bwgr_debug_withhold): slab workgroup 0 leaves at once, so every wait on it must time out
 };
 

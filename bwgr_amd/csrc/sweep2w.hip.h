@@ -1,0 +1,534 @@
+// bwgr_amd: the affine models' in-block solve as ONE triangular matrix-vector product per 128-marker block.
+//
+// The samplers without a Bernoulli draw (BayesRR, BayesA, BayesL, wgr / KMUP at pi = 0, the affine EM members) update marker
+// j of a block from  t_j = (r_j + xx_j b0_j) rden_j + sd_j z_j,  r_j = r0_j - sum_{k<j} G_jk delta_k,  delta_k = dscale (t_k - b0_k):
+// a lane-ordered recurrence of 128 dependent steps per block in k_sweep2's sequencer (sweep2.hip.h, ~106 cycles a step).
+// With  M = diag(dscale rden) G_L  (G_L the strict lower triangle of the block's Gram matrix) the un-rounded steps
+// d = t - b0 solve  (I + M) d = c - b0,  c_j = (r0_j + xx_j b0_j) rden_j + sd_j z_j,  so  d = W (c - b0)  with
+// W = (I + M)^-1  lower triangular.  rden is fixed during a sweep (the variances move between sweeps), hence:
+//
+//   k_affine_inv   one workgroup per block, the whole GPU, before the sweep: W by blocked forward substitution on 16 x 16
+//                  tiles in fp64, written in the order the sequencer's lanes read it (73.7 KB per block);
+//   s2_sequencer_winv   the sequencer of k_sweep2w: per block a dense cross term (r0 = q - Gx' delta_prev), the 128 x 128
+//                  triangular product out of registers (waves 0-3: nine tiles each, loaded a block ahead), outputs.
+//                  Waves 4-7 gather the streamers' slab dots of the next block and write the block's state.
+//
+// The one departure from the serial chain: the serial chain feeds the float-ROUNDED draw of marker k into the markers
+// behind it, the product feeds the un-rounded one (relative 2^-24 per term, random signs, no accept / reject behind it):
+// the chains agree to ~1e-7 relative per sweep and stay there (the sweep is a contraction), inside the 1e-6 the parity tests
+// allow; tests/test_gpu_parity2.py::test_affine_winv_* bound it over 200 iterations.  int8 panels with 16-bit Gram staging
+// only; everything else keeps the serial sequencer.
+// Reference for the recurrence being solved: /root/reference/src/Rcpp20260726ai.cpp:612-619 (BayesA), :833-838 (BayesRR),
+// :20-31 (KMUP, pi = 0).
+#pragma once
+#include "sweep2.hip.h"
+#include "sweep3.hip.h"
+
+namespace bwgr {
+
+static constexpr int S2W_WDOUBLES = 4 * 9 * 256;   // per block: four waves x nine 16 x 16 tiles
+static constexpr size_t S2W_INV_LDS = (size_t)(36 * 256 + 8 * 16 * 18 + 8 * 256 + SW_MAXM) * sizeof(double);
+// wave w holds block rows 7 - w (8 - w tiles) and w (w + 1 tiles): nine tiles each
+__host__ __device__ inline void s2w_tile_of(int w, int q, int &I, int &J) { if (q < 8 - w) { I = 7 - w; J = q; } else { I = w; J = q - (8 - w); } }
+
+// ------------------------------------------------------------------------------------------------------------------
+// W = (I + diag(scl) G_L)^-1 of every block
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_affine_inv(const SweepArgs a, double *winv, double dscale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *Wt = reinterpret_cast<double *>(smem);   // [36 * 256]: tile (I, J), J <= I, at I (I + 1) / 2 + J; element [r][c]
+  double *Gt = Wt + 36 * 256;                      // [8 * 16 * 18]: G tiles of one block row, [J][r][t], rows padded to 18
+  double *St = Gt + 8 * 16 * 18;                   // [8 * 256]
+  double *scl = St + 8 * 256;                      // [SW_MAXM]
+  const int tid = threadIdx.x;
+  const int blk = a.blk_begin + (int)blockIdx.x;
+  const int m = a.m, mB = min(m, a.p - blk * m);
+  const int32_t *gp = reinterpret_cast<const int32_t *>(a.gramp) + (size_t)blk * a.pstride;
+  auto prow = [&](int k) { return k * (m - 1) - k * (k - 1) / 2; };
+  auto gat = [&](int row, int col) -> double {   // G[row][col], col < row, both inside the block
+    return (col < row && row < mB) ? (double)gp[prow(col) + row - col - 1] : 0.0;
+  };
+  if (tid < SW_MAXM) scl[tid] = (tid < mB) ? dscale * a.ps.blocks[blk].rden[tid] : 0.0;
+  {   // the eight diagonal tiles
+    const int rr = tid & 15, tt = tid >> 4;
+    for (int I = 0; I < 8; ++I) Gt[(I * 16 + rr) * 18 + tt] = gat(16 * I + rr, 16 * I + tt);
+  }
+  __syncthreads();
+  if (tid < 128) {   // their inverses: one column per thread, forward substitution in registers
+    const int I = tid >> 4, c = tid & 15;
+    const double *g = Gt + (size_t)I * 16 * 18;
+    double w[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < r; ++t) acc = fma(g[r * 18 + t], w[t], acc);
+      w[r] = (r > c) ? -scl[16 * I + r] * acc : ((r == c) ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Wt[(I * (I + 1) / 2 + I) * 256 + r * 16 + c] = w[r];
+  }
+  __syncthreads();
+  const int r = tid >> 4, c = tid & 15;
+  for (int I = 1; I < 8; ++I) {
+    {   // G tiles (I, 0..I-1)
+      const int rr = tid & 15, tt = tid >> 4;
+      for (int J = 0; J < I; ++J) Gt[(J * 16 + rr) * 18 + tt] = gat(16 * I + rr, 16 * J + tt);
+    }
+    __syncthreads();
+    // S_IJ = diag(scl_I) sum_{K=J..I-1} G_IK W_KJ
+    for (int J = 0; J < I; ++J) {
+      double acc = 0.0;
+      for (int K = J; K < I; ++K) {
+        const double *g = Gt + (size_t)(K * 16 + r) * 18;
+        const double *wk = Wt + (size_t)(K * (K + 1) / 2 + J) * 256 + c;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc = fma(g[t], wk[t * 16], acc);
+      }
+      St[J * 256 + r * 16 + c] = scl[16 * I + r] * acc;
+    }
+    __syncthreads();
+    // W_IJ = -W_II S_IJ
+    {
+      const double *wd = Wt + (size_t)(I * (I + 1) / 2 + I) * 256 + r * 16;
+      for (int J = 0; J < I; ++J) {
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc = fma(wd[t], St[J * 256 + t * 16 + c], acc);
+        Wt[(size_t)(I * (I + 1) / 2 + J) * 256 + r * 16 + c] = -acc;
+      }
+    }
+    __syncthreads();
+  }
+  // out, in the sequencer's order: wave w, tile q, half h, lane l holds W[16 I + (l & 15)][16 J + 4 (l >> 4) + 2 h + {0, 1}]
+  double *dst = winv + (size_t)blk * S2W_WDOUBLES;
+  for (int o = tid; o < S2W_WDOUBLES; o += 256) {
+    const int w = o / 2304, rem = o - w * 2304, chunk = rem >> 1, e = rem & 1;
+    const int qh = chunk >> 6, l = chunk & 63, q = qh >> 1, h = qh & 1;
+    int I, J; s2w_tile_of(w, q, I, J);
+    dst[o] = Wt[(size_t)(I * (I + 1) / 2 + J) * 256 + (l & 15) * 16 + 4 * (l >> 4) + 2 * h + e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// cross Gram blocks as the sequencer's MFMA operand, in the order its lanes load them: per block 2048 pieces of 16 bytes,
+// piece ((w * 2 + plane) * 2 + ch) * 64 + lane = bytes k = 64 ch + 16 (lane >> 4) .. + 15 of row j = 16 w + (lane & 15) of
+// plane `plane`; byte k of row j of plane P = byte P of G[k][j] minus 128 (markers k of block b-dist against markers j of
+// block b; pad markers hold G = 0)
+// ------------------------------------------------------------------------------------------------------------------
+static constexpr int S2W_PBYTES = 2 * SW_MAXM * SW_MAXM;            // 32 768 per block and distance
+static constexpr int S2W_MAXDIST = 3;
+
+__global__ void k_gx_planes(const int32_t *src, unsigned char *dst, int m, int64_t nblocks, int dist, int *bad) {
+  const int64_t total = nblocks * (S2W_PBYTES / 16);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(t & 63), ch = (int)((t >> 6) & 1), plane = (int)((t >> 7) & 1), w = (int)((t >> 8) & 7);
+    const int64_t blk = t >> 11;
+    const int j = 16 * w + (l & 15), k0 = 64 * ch + 16 * (l >> 4);
+    uint32_t wd[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+    if (blk >= dist && j < m) {
+      const int32_t *g = src + (size_t)blk * m * m + j;
+      int nbad = 0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int k = k0 + u;
+        const int32_t v = (k < m) ? g[(size_t)k * m] : 0;
+        if (v < 0 || v > 65535) ++nbad;
+        const uint32_t byte = (((uint32_t)v >> (8 * plane)) & 0xFFu) ^ 0x80u;
+        wd[u >> 2] = (wd[u >> 2] & ~(0xFFu << (8 * (u & 3)))) | (byte << (8 * (u & 3)));
+      }
+      if (nbad && plane == 0) atomicAdd(bad, nbad);
+    }
+    reinterpret_cast<uint4 *>(dst)[t] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+  }
+}
+
+static constexpr int S2W_THREADS = 768;   // k_sweep2w's workgroups: twelve waves in the sequencer (the streamers use the first eight)
+static constexpr int S2W_DROW = 144;   // bytes per digit row in LDS (128 + 16: the four rows on different banks)
+struct S2WArgs {
+  const double *winv;                        // [nblocks][S2W_WDOUBLES]
+  const unsigned char *gxt[S2W_MAXDIST];     // gxt[d-1]: planes of the distance-d cross Gram blocks (missing distances repeat gxt[0])
+  int nd;                                    // distances in use = lag - 1
+  int ahead;                                 // blocks a prefetcher may run ahead of the sequencer
+  int npf;                                   // L2 prefetch workgroups (blockIdx K + 8, K + 16, ...: the sequencer's XCD)
+};
+
+__host__ __device__ inline size_t s2w_lds_bytes(int m, int R) {
+  size_t s = 3 * sizeof(StageBuf);
+  s += (size_t)(2 * 2 + 1 + 1 + 1 + 1) * SW_MAXM * sizeof(double);   // q parts [parity][2], cross, rhs, d, delta
+  s += (size_t)(4 * 4 + 1) * S2W_DROW;                                // delta digits of the last four blocks, a row of zeros
+  s += 256;
+  const size_t streamer = s2i_lds_bytes(m, R, 4);
+  return s > streamer ? s : streamer;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// sequencer
+// ------------------------------------------------------------------------------------------------------------------
+#define S2W_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef BWGR_STAMPS
+#define S2WSTAMP(k) do { if (tid == 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph2[k] += t_ - tl2; tl2 = t_; } } while (0)
+#define S2WSTAMP_FLUSH() do { if (tid == 512 && a.stamps) for (int k_ = 0; k_ < 8; ++k_) a.stamps[16 + k_] += ph2[k_]; } while (0)
+#define S2WSTAMP0(k) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph2[k] += t_ - tl2; tl2 = t_; } } while (0)
+#define S2WSTAMP0_FLUSH() do { if (tid == 0 && a.stamps) for (int k_ = 0; k_ < 8; ++k_) a.stamps[24 + k_] += ph2[k_]; } while (0)
+#else
+#define S2WSTAMP(k) do { } while (0)
+#define S2WSTAMP_FLUSH() do { } while (0)
+#define S2WSTAMP0(k) do { } while (0)
+#define S2WSTAMP0_FLUSH() do { } while (0)
+#endif
+// 16 bytes per lane from global memory straight into LDS at lds_base + 16 * lane.  Inline asm, not the builtin: hipcc tracks
+// the builtin's LDS writes and puts a vmcnt(0) in front of the next LDS access it cannot prove disjoint.  (M0 is not live in
+// compiled code around these: nothing else in the function uses it.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void s2w_dma16(const void *gsrc, unsigned char *lds_base) {
+  const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(la) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+// The K streamers' slab dots of one block, two halves of the streamers on two threads per marker.  The words are REQUESTED a
+// block before they are needed (with lag >= 3 the streamers are ahead and the words complete: no memory round trip in the
+// block period) and polled only if a tag is missing.
+static constexpr int S2W_QW = 16;   // words a polling thread requests early (K <= 32 streamers: all of them); the words beyond are polled when due
+struct S2WPoll {
+  unsigned long long v[S2W_QW];
+};
+__device__ __forceinline__ void s2w_q_request(const SweepArgs &a, int b, int part, int t, S2WPoll &P) {
+  const int K = a.K, wq = (K + 1) / 2;
+  const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(a.qpart + (size_t)(b % S2_NSLOT) * K * SW_MAXM) + (size_t)min(part * wq, K - 1) * SW_MAXM + t;
+  const int nw = min(wq, K - part * wq);   // (uniform)
+#pragma unroll
+  for (int u = 0; u < S2W_QW; ++u) P.v[u] = ld_agent_raw64(slot + (size_t)min(u, max(nw - 1, 0)) * SW_MAXM);   // (unconditional: repeats of the last word are L2 hits)
+}
+__device__ __forceinline__ int s2w_q_collect(const SweepArgs &a, int b, int part, int t, int mB, S2WPoll &P, double *dst) {
+  const int K = a.K, wq = (K + 1) / 2;
+  uint32_t *abortw = a.xflags + (size_t)K * SW_FLAG_STRIDE;
+  const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(a.qpart + (size_t)(b % S2_NSLOT) * K * SW_MAXM) + (size_t)min(part * wq, K - 1) * SW_MAXM + t;
+  const unsigned long long tag = s2_qtag(b);
+  const int nw = (t < mB) ? min(wq, K - part * wq) : 0;
+  const uint64_t t0 = wall_clock64();
+  unsigned spins = 0;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < S2W_QW; ++u) ok = ok && (u >= nw || (P.v[u] & 0xFFull) == tag);
+    if (__ballot(!ok) == 0ull) break;
+    if ((++spins & 63u) == 0u) {
+      if (ld_agent_u32(abortw) != 0u) return 0;
+      if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+    if (!ok) {
+#pragma unroll
+      for (int u = 0; u < S2W_QW; ++u) P.v[u] = ld_agent_raw64(slot + (size_t)min(u, max(nw - 1, 0)) * SW_MAXM);
+    }
+  }
+  double r = 0.0;
+#pragma unroll
+  for (int u = 0; u < S2W_QW; ++u) r += (u < nw) ? __longlong_as_double((long long)(P.v[u] & ~0xFFull)) : 0.0;
+  for (int u0 = S2W_QW; u0 < wq; u0 += 8) {   // more than 2 * S2W_QW streamers: the rest, eight words a round trip (uniform trip count)
+    unsigned long long v[8];
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { v[u] = (u0 + u < nw) ? ld_agent_raw64(slot + (size_t)(u0 + u) * SW_MAXM) : tag; ok = ok && ((v[u] & 0xFFull) == tag); }
+      if (__ballot(!ok) == 0ull) break;
+      if ((++spins & 63u) == 0u) {
+        if (ld_agent_u32(abortw) != 0u) return 0;
+        if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r += (u0 + u < nw) ? __longlong_as_double((long long)(v[u] & ~0xFFull)) : 0.0;
+  }
+  dst[t] = r;
+  return 1;
+}
+
+// Block c, in four phases between raw barriers (no memory-counter drain at a barrier):
+//   X  all eight waves: the cross terms  sum_{d=1..nd} G_d' delta_{c-d}  as int8 MFMA products -- two byte planes of the 16-bit
+//      Gram entries (LDS, by DMA) against the four balanced base-256 digits of the steps in block-common fixed point; wave w
+//      owns markers 16 w .. 16 w + 15
+//   R  threads 0-127:   r0 = q - cross, rhs = (r0 + xx b0) rden + sd z - b0
+//   M  waves 0-3:       d = W rhs out of registers; then the requests for block c+1: W (the same registers), the Gram planes
+//                       (single LDS copy: X has read block c's), and the constants of block c+2
+//      waves 4-7:       collect q_{c+1} (requested a block ago), request q_{c+2}
+//   O  wave 4:          b, d, vb, the delta granules for the streamers, the digits of this block's steps
+// Block c+1 begins with vmcnt(0) in waves 0-3: everything requested in M; the planes had the outputs' time only, so part of
+// their latency shows in the period (~2k cycles) -- the streamers' period is longer.
+__device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WArgs &A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = a.m, nb = a.blk_end - a.blk_begin, nd = A.nd;
+  size_t off = 0;
+  StageBuf *stage = reinterpret_cast<StageBuf *>(smem + off); off += 3 * sizeof(StageBuf);
+  double *q_s = reinterpret_cast<double *>(smem + off); off += (size_t)4 * SW_MAXM * sizeof(double);      // [parity][part][marker]
+    double *rhs_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
+  double *d_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);                  // the un-rounded steps
+  double *delta_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);              // what the residual gets (float values)
+  int8_t *ddig_s = reinterpret_cast<int8_t *>(smem + off); off += (size_t)(4 * 4 + 1) * S2W_DROW;        // [block & 3][digit 0..3][k]; then the zero row
+  int8_t *zrow_s = ddig_s + (size_t)4 * 4 * S2W_DROW;
+  double *bias_s = reinterpret_cast<double *>(smem + off); off += 4 * sizeof(double);                     // [block & 3]: 32896 * the sum of the block's fixed-point steps
+  double *scd_s = reinterpret_cast<double *>(smem + off); off += 4 * sizeof(double);                      // [block & 3]: 2^-(their binary point)
+  int *ctrl_s = reinterpret_cast<int *>(smem + off);
+  const float Sb = a.sc->Sb;
+  const double dscale = (a.flags & SWF_DELTA2) ? 2.0 : 1.0;
+  constexpr int NCH = (int)(sizeof(StageBuf) / 16), SPIECES = (NCH + 63) >> 6;
+  static_assert(sizeof(StageBuf) % 1024 == 0, "whole 1 KiB pieces");
+  auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
+
+  // ---- the requests of waves 0-3 ----
+  // W: ordinary loads, one defining site (inside the block loop): the compiler's own wait covers them
+  double2 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15, w16, w17;
+  auto issue_w = [&](int c) {   // 18 loads
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(A.winv + (size_t)(a.blk_begin + min(c, nb - 1)) * S2W_WDOUBLES) + (size_t)(wave - 4) * 2304 * 8 + (size_t)lane * 16;
+#define S2W_W1(i, name) name = *reinterpret_cast<const double2 *>(src + (size_t)(i) * 1024);
+    S2W_W1(0, w0) S2W_W1(1, w1) S2W_W1(2, w2) S2W_W1(3, w3) S2W_W1(4, w4) S2W_W1(5, w5) S2W_W1(6, w6) S2W_W1(7, w7) S2W_W1(8, w8)
+    S2W_W1(9, w9) S2W_W1(10, w10) S2W_W1(11, w11) S2W_W1(12, w12) S2W_W1(13, w13) S2W_W1(14, w14) S2W_W1(15, w15) S2W_W1(16, w16) S2W_W1(17, w17)
+#undef S2W_W1
+  };
+  // waves 0-3: the planes of the wave's 32 markers (two 16-marker tiles), block c, straight into the MFMA's operand registers
+  // (ordinary loads, requested right after block c-1's cross terms have read the registers: a block ahead).  Always all 24
+  // loads: the wait counts rely on it.
+  s2_v4i a1p0, a1p1, a1p2, a1p3, a2p0, a2p1, a2p2, a2p3, a3p0, a3p1, a3p2, a3p3;   // tile 0, distance d: {plane 0, plane 1} x {k < 64, k >= 64}
+  s2_v4i b1p0, b1p1, b1p2, b1p3, b2p0, b2p1, b2p2, b2p3, b3p0, b3p1, b3p2, b3p3;   // tile 1
+  auto issue_a = [&](int c) {
+    const size_t boff = (size_t)(a.blk_begin + min(c, nb - 1)) * S2W_PBYTES + (size_t)wave * 8192 + (size_t)lane * 16;
+#define S2W_A1(d_, o_, r0, r1, r2, r3) { const unsigned char *p_ = A.gxt[(d_) - 1] + boff + (o_); \
+      r0 = *reinterpret_cast<const s2_v4i *>(p_); r1 = *reinterpret_cast<const s2_v4i *>(p_ + 1024); \
+      r2 = *reinterpret_cast<const s2_v4i *>(p_ + 2048); r3 = *reinterpret_cast<const s2_v4i *>(p_ + 3072); }
+    S2W_A1(1, 0, a1p0, a1p1, a1p2, a1p3) S2W_A1(1, 4096, b1p0, b1p1, b1p2, b1p3)
+    S2W_A1(2, 0, a2p0, a2p1, a2p2, a2p3) S2W_A1(2, 4096, b2p0, b2p1, b2p2, b2p3)
+    S2W_A1(3, 0, a3p0, a3p1, a3p2, a3p3) S2W_A1(3, 4096, b3p0, b3p1, b3p2, b3p3)
+#undef S2W_A1
+  };
+  auto issue_stage = [&](int c) {   // the constants of block c: six pieces
+    const int cc = min(c, nb - 1);
+    const unsigned char *ssrc = reinterpret_cast<const unsigned char *>(a.ps.blocks + a.blk_begin + cc) + (size_t)lane * 16;
+    unsigned char *sl = reinterpret_cast<unsigned char *>(&stage[cc % 3]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int pc = min(wave + 4 * i, SPIECES - 1); s2w_dma16(ssrc + (size_t)pc * 1024, sl + (size_t)pc * 1024); }
+  };
+
+  // ---- prologue ----
+  if (tid == 0) ctrl_s[0] = 1;
+  if (tid < SW_MAXM) delta_s[tid] = 0.0;
+  for (int i = tid; i < (int)((4 * 4 + 1) * S2W_DROW / 4); i += S2W_THREADS) reinterpret_cast<uint32_t *>(ddig_s)[i] = 0u;
+  if (tid < 4) { bias_s[tid] = 0.0; scd_s[tid] = 1.0; }
+  if (wave < 4) { issue_stage(0); issue_stage(1); }
+  __syncthreads();
+  S2WPoll QP;
+  if (wave >= 8) {
+    const int gpart = (tid - 512) >> 7, gt = tid & 127;
+    s2w_q_request(a, 0, gpart, gt, QP);
+    if (!s2w_q_collect(a, 0, gpart, gt, blk_m(0), QP, q_s + (size_t)gpart * SW_MAXM)) ctrl_s[0] = 0;
+  }
+  double sum_d = 0.0, sum_b2 = 0.0;
+
+  // the phases every thread takes part in
+  // X + R fused (waves 0-3): wave w forms the cross terms of markers 32 w .. 32 w + 31 (two tiles of 16) and, on its lanes
+  // 0-15, their right-hand sides.  MFMA roles: A = the four digit rows of the steps (rows 4-15 zero), B = a byte plane of a
+  // tile's 16 Gram columns, so lane j < 16 ends up with the four digit sums of ITS marker in its four accumulator registers
+  // (no cross-lane step).
+  auto phase_xr = [&](int c, int mB) {
+    const int i16 = lane & 15, kg = lane >> 4;
+    double cross0 = 0.0, cross1 = 0.0;
+#define S2W_X1(CR, r0, r1, r2, r3) { \
+      s2_v4i acc0 = {0, 0, 0, 0}, acc1 = acc0; \
+      acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(dv0, r0, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(dv0, r2, acc1, 0, 0, 0); \
+      acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(dv1, r1, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(dv1, r3, acc1, 0, 0, 0); \
+      /* lane j < 16: acc_P[n] = sum_k digit_n[k] plane_P[marker j of the tile][k] */ \
+      const double t3 = fma(256.0, (double)acc1[3], (double)acc0[3]), t2 = fma(256.0, (double)acc1[2], (double)acc0[2]); \
+      const double t1 = fma(256.0, (double)acc1[1], (double)acc0[1]), t0 = fma(256.0, (double)acc1[0], (double)acc0[0]); \
+      const double val = fma(256.0, fma(256.0, fma(256.0, t3, t2), t1), t0); \
+      CR = fma(val + bias_, scd_, CR); }   /* (the planes are biased by 128: bias = (128 + 256 * 128) sum_k q_k; scd = 2^-sh) */
+#define S2W_XD(d_, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3) if (nd >= (d_) && c - (d_) >= 0) { \
+      const int slot = (c - (d_)) & 3; \
+      const int8_t *dg = (i16 < 4 ? ddig_s + (size_t)(slot * 4 + i16) * S2W_DROW : zrow_s) + 16 * kg; \
+      const s2_v4i dv0 = *reinterpret_cast<const s2_v4i *>(dg), dv1 = *reinterpret_cast<const s2_v4i *>(dg + 64); \
+      const double bias_ = bias_s[slot], scd_ = scd_s[slot]; \
+      S2W_X1(cross0, ra0, ra1, ra2, ra3) S2W_X1(cross1, rb0, rb1, rb2, rb3) }
+    S2W_XD(1, a1p0, a1p1, a1p2, a1p3, b1p0, b1p1, b1p2, b1p3)
+    S2W_XD(2, a2p0, a2p1, a2p2, a2p3, b2p0, b2p1, b2p2, b2p3)
+    S2W_XD(3, a3p0, a3p1, a3p2, a3p3, b3p0, b3p1, b3p2, b3p3)
+#undef S2W_XD
+#undef S2W_X1
+    if (lane < 16) {
+      const StageBuf &st = stage[c % 3];
+      const double *qq = q_s + (size_t)(c & 1) * 2 * SW_MAXM;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 32 * wave + 16 * u + lane;
+        double rhs = 0.0;
+        if (t < mB) {
+          const double r0 = (qq[t] + qq[SW_MAXM + t]) - (u ? cross1 : cross0);
+          rhs = fma(r0 + (double)st.xxb0[t], st.rden[t], st.sdz1[t]) - (double)st.b0[t];
+        }
+        rhs_s[t] = rhs;
+      }
+    }
+  };
+
+  if (wave < 4) {
+    // ================= waves 0-3: cross terms and right-hand sides =================
+    S2STAMP_DECL;
+    // (the loop starts at "block -1", which only issues requests: the plane registers then have ONE defining site, inside the
+    // loop, and the compiler needs no second register set to carry a prologue's values into it)
+#pragma clang loop unroll(disable)
+    for (int c = -1; c < nb; ++c) {
+      if (c >= 0) {
+        S2WSTAMP0(7);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the constants of blocks c, c+1 (DMA); everything in flight is a block old
+        S2WSTAMP0(0);
+        S2W_BAR();                                         // B0: + q_c, the digits of block c-1
+        S2WSTAMP0(1);
+        if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
+        phase_xr(c, blk_m(c));
+        S2WSTAMP0(2);
+        S2W_BAR();                                         // B2: rhs
+      }
+      issue_a(c + 1);       // (these waves sit in the memory pipeline's queue now, while waves 4-7 form the product)
+      issue_stage(c + 2);
+      if (c >= 0) {
+        S2WSTAMP0(3);
+        S2W_BAR();                                         // B3: d
+      }
+    }
+    S2WSTAMP0_FLUSH();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (wave < 8) {
+    // ================= waves 4-7: the product =================
+    const int wv = wave - 4, r16 = lane & 15, cq = lane >> 4;
+#pragma clang loop unroll(disable)
+    for (int c = -1; c < nb; ++c) {
+      double acc_hi = 0.0, acc_lo = 0.0;
+      if (c >= 0) {
+        S2W_BAR();                                         // B0
+        if (ctrl_s[0] == 0) return;
+        S2W_BAR();                                         // B2: rhs
+#define S2W_TILE(q, A_, B_) { const bool hi_ = (q) < 8 - wv; const int J_ = hi_ ? (q) : (q) - (8 - wv); \
+          const double2 x0_ = *reinterpret_cast<const double2 *>(rhs_s + 16 * J_ + 4 * cq), x1_ = *reinterpret_cast<const double2 *>(rhs_s + 16 * J_ + 4 * cq + 2); \
+          double t_ = A_.x * x0_.x; t_ = fma(A_.y, x0_.y, t_); t_ = fma(B_.x, x1_.x, t_); t_ = fma(B_.y, x1_.y, t_); \
+          if (hi_) acc_hi += t_; else acc_lo += t_; }
+        S2W_TILE(0, w0, w1) S2W_TILE(1, w2, w3) S2W_TILE(2, w4, w5) S2W_TILE(3, w6, w7) S2W_TILE(4, w8, w9)
+        S2W_TILE(5, w10, w11) S2W_TILE(6, w12, w13) S2W_TILE(7, w14, w15) S2W_TILE(8, w16, w17)
+#undef S2W_TILE
+        acc_hi += __shfl_xor(acc_hi, 16, 64); acc_hi += __shfl_xor(acc_hi, 32, 64);
+        acc_lo += __shfl_xor(acc_lo, 16, 64); acc_lo += __shfl_xor(acc_lo, 32, 64);
+        if (cq == 0) d_s[16 * (7 - wv) + r16] = acc_hi;
+        if (cq == 1) d_s[16 * wv + r16] = acc_lo;
+        S2W_BAR();                                         // B3: d
+      }
+      issue_w(c + 1);     // (into the registers just read; the wave waits in the memory pipeline's queue while wave 8 writes the outputs)
+    }
+  } else {
+    // ================= waves 8-11: the dots of the next block; wave 8: the outputs of this one =================
+    const int gpart = (tid - 512) >> 7, gt = tid & 127;
+    S2STAMP_DECL;
+    s2w_q_request(a, min(1, nb - 1), gpart, gt, QP);
+    for (int c = 0; c < nb; ++c) {
+      const int blk = a.blk_begin + c, j0 = blk * m;
+      const int mB = blk_m(c);
+      const bool have_next = c + 1 < nb;
+      S2WSTAMP(5);
+      S2W_BAR();                                          // B0
+      S2WSTAMP(0);
+      if (ctrl_s[0] == 0) return;
+      S2W_BAR();                                          // B2
+      S2WSTAMP(2);
+      if (have_next) { if (!s2w_q_collect(a, c + 1, gpart, gt, blk_m(c + 1), QP, q_s + (size_t)(((c + 1) & 1) * 2 + gpart) * SW_MAXM)) ctrl_s[0] = 0; }
+      s2w_q_request(a, min(c + 2, nb - 1), gpart, gt, QP);   // (every pass, the last ones too: the compiler's wait counts merge over all paths)
+      S2WSTAMP(3);
+      S2W_BAR();                                          // B3: d
+      S2WSTAMP(4);
+      if (wave == 8) {
+        const StageBuf &st = stage[c % 3];
+        unsigned long long *gslot = a.dgran + (size_t)(c % S2_NSLOT) * SW_MAXM;
+        float dl_own[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int t = 64 * q + lane;
+          float dl = 0.0f;
+          if (t < mB) {
+            const float b0 = st.b0[t];
+            const float bn = (float)(d_s[t] + (double)b0);
+            dl = (bn - b0) * (float)dscale;
+            a.b[j0 + t] = bn;
+            a.d[j0 + t] = 1.0f;
+            if (a.flags & SWF_VB_VEC) a.vb[j0 + t] = (float)((double)(Sb + bn * bn) / st.chi[t]);
+            sum_d += 1.0;
+            sum_b2 = fma((double)bn, (double)bn, sum_b2);
+          }
+          dl_own[q] = dl;
+          delta_s[t] = (double)dl;
+        }
+        const uint32_t exmax = wave_max_u32(max((__float_as_uint(dl_own[0]) >> 23) & 0xFFu, (__float_as_uint(dl_own[1]) >> 23) & 0xFFu));
+        if (lane < mB) st_agent_raw64(gslot + lane, s2_dgranule(c, exmax, dl_own[0]));
+        if (64 + lane < mB) st_agent_raw64(gslot + 64 + lane, s2_dgranule(c, exmax, dl_own[1]));
+        // the steps in block-common fixed point, |q| < 2^30, as four balanced base-256 digits: the next blocks' cross terms
+        const int sh = 156 - (int)exmax;
+        const double scq = __hiloint2double((1023 + sh) << 20, 0);
+        long long sq = 0;
+        int8_t *dg = ddig_s + (size_t)((c & 3) * 4) * S2W_DROW;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int t = 64 * q + lane;
+          const int qi = (int)rint((double)dl_own[q] * scq);
+          sq += qi;
+          const uint32_t u = ((uint32_t)qi + 0x00808080u) ^ 0x00808080u;
+          dg[t] = (int8_t)(u & 0xFFu); dg[S2W_DROW + t] = (int8_t)((u >> 8) & 0xFFu); dg[2 * S2W_DROW + t] = (int8_t)((u >> 16) & 0xFFu); dg[3 * S2W_DROW + t] = (int8_t)(u >> 24);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        if (lane == 0) { bias_s[c & 3] = 32896.0 * (double)sq; scd_s[c & 3] = __hiloint2double((1023 - sh) << 20, 0); }
+        if (lane == 0 && A.npf > 0) st_agent_u32(a.xflags + (size_t)a.K * SW_FLAG_STRIDE + 1, (uint32_t)(c + 1));   // progress, for the prefetchers
+      }
+    }
+    S2WSTAMP_FLUSH();
+    if (wave == 8) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { sum_d += __shfl_down(sum_d, o, 64); sum_b2 += __shfl_down(sum_b2, o, 64); }
+      if (lane == 0) { a.sc->sum_d += sum_d; a.sc->sum_b2 += sum_b2; }
+    }
+  }
+}
+#undef S2W_BAR
+
+// A prefetcher: a workgroup on the sequencer's XCD (workgroups go round-robin over the eight XCDs) that reads W and the Gram
+// planes of the blocks a little ahead of the sequencer, so that the sequencer's own loads -- 172 KB per block through ONE CU,
+// whose outstanding-miss capacity bounds it at ~40 GB/s from HBM -- find their lines in the XCD's L2.
+__device__ __forceinline__ void s2w_prefetcher(const SweepArgs &a, const S2WArgs &A, int i) {
+  const int tid = threadIdx.x, nb = a.blk_end - a.blk_begin;
+  const uint32_t *progw = a.xflags + (size_t)a.K * SW_FLAG_STRIDE + 1;
+  uint32_t *abortw = a.xflags + (size_t)a.K * SW_FLAG_STRIDE;
+  const int AHEAD = A.ahead;
+  uint32_t sink = 0u;
+  for (int c = i; c < nb; c += A.npf) {
+    const uint64_t t0 = wall_clock64();
+    while ((int)ld_agent_u32(progw) + AHEAD < c) {
+      if (ld_agent_u32(abortw) != 0u || wall_clock64() - t0 > SW_TIMEOUT_TICKS) return;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    const size_t blk = (size_t)(a.blk_begin + c);
+    const uint4 *w = reinterpret_cast<const uint4 *>(A.winv + blk * S2W_WDOUBLES);
+    for (int k = tid; k < S2W_WDOUBLES / 2; k += S2W_THREADS) sink ^= w[k].x;
+    for (int d = 0; d < A.nd; ++d) {
+      const uint4 *g = reinterpret_cast<const uint4 *>(A.gxt[d] + blk * S2W_PBYTES);
+      for (int k = tid; k < S2W_PBYTES / 16; k += S2W_THREADS) sink ^= g[k].x;
+    }
+  }
+  if (sink == 0x9E3779B9u && a.stamps) a.stamps[255] = sink;   // (keeps the loads)
+}
+
+__global__ __launch_bounds__(S2W_THREADS) void k_sweep2w(const SweepArgs a, const S2WArgs A) {
+  if ((int)blockIdx.x > a.K) { const int r = (int)blockIdx.x - a.K; if ((r & 7) == 0) s2w_prefetcher(a, A, (r >> 3) - 1); return; }
+  if ((int)blockIdx.x == a.K) s2_sequencer_winv(a, A);
+  else if (threadIdx.x >= SW_THREADS) return;                            // the streamers are eight waves (a wave that has ended leaves the barriers' count)
+  else if ((a.flags & SWF_DEBUG_WITHHOLD) && blockIdx.x == 0) return;   // test hook: a streamer that never shows up
+  else s2_streamer_i8(a);
+}
+
+}  // namespace bwgr

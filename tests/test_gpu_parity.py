@@ -264,7 +264,9 @@ def test_both_sweep_engines_give_the_same_chain(model, monkeypatch):
     o = O.bayes(model, y, X, it=8, bi=2, pi=0.9, seed=6)["last"]
     for v in ("1", "2"):
         assert scaled_err(out[v]["b"], o["b"]) < TOL and scaled_err(out[v]["e"], o["e"]) < TOL
-    assert scaled_err(out["1"]["b"], out["2"]["b"]) < 1e-9 and np.array_equal(out["1"]["d"], out["2"]["d"])
+    # (the affine models' default engine solves each block with a precomputed inverse, sweep2w.hip.h: it feeds the un-rounded
+    # draws forward, the replicated engine the float-rounded ones -- 1e-7, not 1e-9)
+    assert scaled_err(out["1"]["b"], out["2"]["b"]) < (2e-7 if model == "BayesRR" else 1e-9) and np.array_equal(out["1"]["d"], out["2"]["d"])
 
 
 @pytest.mark.parametrize("model", ["BayesB", "BayesDpi", "BayesC"])
