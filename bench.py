@@ -25,6 +25,7 @@ WORKLOADS = {
     "c2": (5000, 50000, "BayesA", 0.0),
     "c3": (10000, 500000, "BayesB", 0.99),
     "c4": (10000, 1000000, "BayesB", 0.99),
+    "c4a": (10000, 1000000, "BayesA", 0.0),    # (not a BASELINE config: C4's shape with an affine model, as wgr() runs by default)
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 

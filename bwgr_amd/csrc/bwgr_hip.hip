@@ -1625,7 +1625,8 @@ extern "C" int bwgr_panel_pipeline(const bwgr_panel *P, int selection, int info[
   a.flags = selection ? SWF_SELECT : 0u;
   choose_lag(P, a);
   const bool s3 = selection && P->sweep_version == 3 && P->e3_ready;
-  info[0] = s3 ? 3 : std::min(P->sweep_version, 2);
+  const bool w4 = !selection && use_winv(P, 0);
+  info[0] = s3 ? 3 : w4 ? 4 : std::min(P->sweep_version, 2);
   info[1] = s3 ? P->e3_D : a.lag;
   info[2] = s3 ? 0 : ((P->sweep_version >= 2 && selection) ? P->nfeed : 0);
   info[3] = P->is_f32 ? 0 : (P->gram16 ? 16 : 32);

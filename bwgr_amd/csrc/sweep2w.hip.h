@@ -191,7 +191,7 @@ __device__ __forceinline__ void s2w_dma16(const void *gsrc, unsigned char *lds_b
 // The K streamers' slab dots of one block, two halves of the streamers on two threads per marker.  The words are REQUESTED a
 // block before they are needed (with lag >= 3 the streamers are ahead and the words complete: no memory round trip in the
 // block period) and polled only if a tag is missing.
-static constexpr int S2W_QW = 16;   // words a polling thread requests early (K <= 32 streamers: all of them); the words beyond are polled when due
+static constexpr int S2W_QW = 16;   // words a polling thread requests early (K <= 32 streamers: all of them; 20 words spill registers); the words beyond are polled when due
 struct S2WPoll {
   unsigned long long v[S2W_QW];
 };

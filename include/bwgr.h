@@ -78,7 +78,8 @@ int bwgr_panel_max_concurrent(const bwgr_panel *P, int selection, int *count);
 /* geometry actually chosen: info[0]=n, [1]=p, [2]=ld (padded rows), [3]=block, [4]=nwg, [5]=slab rows,
  * [6]=bytes of X resident, [7]=bytes of Gram resident */
 int bwgr_panel_info(const bwgr_panel *P, int64_t info[8]);
-/* how a sweep over this panel is pipelined (no reference counterpart; reporting only): info[0]=kernel generation (1|2),
+/* how a sweep over this panel is pipelined (no reference counterpart; reporting only): info[0]=kernel generation (1 k_sweep,
+ * 2 k_sweep2, 3 k_sweep3 -- selection sweeps of sparse chains --, 4 k_sweep2w -- affine sweeps as a triangular product --),
  * [1]=pipeline depth in blocks (a block's dots lag the chain by this many blocks), [2]=q feeder workgroups,
  * [3]=bits of the Gram entries the sequencer stages (16|32; 0 for float panels).  selection != 0: BayesB/C/Cpi/Dpi-type
  * sweeps (inclusion indicators), else the affine ones (BayesA/L/RR). */

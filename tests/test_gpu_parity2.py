@@ -358,3 +358,69 @@ def test_partitioned_sampler_characterisation():
         print("shards %d x %d markers per round: ve %.4f (exact %.4f), mean d %.4f (exact %.4f), cor(hat) %.5f" % (
             G, mpr, s_["ve"], a["ve"], s_["d"].mean(), a["d"].mean(), np.corrcoef(s_["hat"], a["hat"])[0, 1]))
         assert np.isfinite(s_["ve"]) and np.isfinite(s_["hat"]).all() and np.isfinite(s_["b"]).all()
+
+
+# ---- affine sweeps as a triangular product (k_affine_inv + k_sweep2w, bwgr_amd/csrc/sweep2w.hip.h) ----
+@pytest.mark.parametrize("model", ["BayesA", "BayesRR"])
+def test_affine_winv_long_chain_stays_on_the_oracle(model):
+    """The product sequencer feeds the UN-rounded draws of a block forward (the serial recurrence and the oracle feed the
+    float-rounded ones): a rounding-level difference per sweep.  No accept / reject behind it, the sweep is a contraction:
+    200 iterations later the chain still sits on the oracle's to the same 1e-6 (reference recurrences:
+    /root/reference/src/Rcpp20260726ai.cpp:612-619 BayesA, :833-838 BayesRR)."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = synth_small(700, 1000, seed=23)
+    P = bwgr_amd.Panel(X)
+    assert P.pipeline(False)["generation"] == 4 and P.pipeline(False)["lag"] == 4
+    ch = bwgr_amd.Chain(P, model, y, it=200, bi=50, seed=4)
+    ch.run(200)
+    st = ch.state()
+    ch.close(); P.close()
+    o = O.bayes(model, y, X, it=200, bi=50, seed=4)["last"]
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
+
+
+@pytest.mark.parametrize("env", [{"BWGR_WINV": "0"}, {"BWGR_WLAG": "2"}, {"BWGR_WLAG": "3"}, {"BWGR_WPF": "0"}, {"BWGR_WPF": "1", "BWGR_WAHEAD": "2"}])
+def test_affine_winv_variants_agree(env, monkeypatch):
+    """The serial sequencer (BWGR_WINV=0), shallower pipelines (cross terms of one or two blocks back instead of three) and the
+    L2 prefetch workgroups switched off or down: the oracle's chain every time, and the default's to 2e-7 (bit for bit where only
+    the prefetch changed)."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = synth_small(900, 1300, seed=29)
+    out = {}
+    for name, e in (("default", {}), ("variant", env)):
+        for k in ("BWGR_WINV", "BWGR_WLAG", "BWGR_WPF", "BWGR_WAHEAD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in e.items():
+            monkeypatch.setenv(k, v)
+        P = bwgr_amd.Panel(X)
+        gen = P.pipeline(False)["generation"]
+        assert gen == (2 if e.get("BWGR_WINV") == "0" else 4)
+        ch = bwgr_amd.Chain(P, "BayesA", y, it=10, bi=2, seed=8)
+        ch.run(10)
+        out[name] = ch.state()
+        ch.close(); P.close()
+    o = O.bayes("BayesA", y, X, it=10, bi=2, seed=8)["last"]
+    for name in out:
+        assert scaled_err(out[name]["b"], o["b"]) < TOL and scaled_err(out[name]["e"], o["e"]) < TOL
+    # (another depth means other partial sums of the same numbers, and a float rounding of a draw flips here and there)
+    tol = 0.0 if set(env) <= {"BWGR_WPF", "BWGR_WAHEAD"} else 2e-7
+    assert scaled_err(out["default"]["b"], out["variant"]["b"]) <= tol
+
+
+def test_affine_winv_falls_back_on_signed_genotypes():
+    """Centred genotype codes {-1, 0, 1} give negative Gram entries: no 16-bit planes, the serial sequencer takes the affine
+    sweeps (and says so)."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = synth_small(400, 600, seed=31)
+    Xc = (X.astype(np.int16) - 1).astype(np.int8)
+    P = bwgr_amd.Panel(Xc)
+    assert P.pipeline(False)["generation"] == 2
+    ch = bwgr_amd.Chain(P, "BayesRR", y, it=6, bi=1, seed=3)
+    ch.run(6)
+    st = ch.state()
+    ch.close(); P.close()
+    o = O.bayes("BayesRR", y, Xc, it=6, bi=1, seed=3)["last"]
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL
