@@ -1135,7 +1135,7 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
     if (std::isinf(a.gate3)) return;
   }
   if (use_winv(P, a.flags) && P->winv) {
-    hipLaunchKernelGGL(k_affine_inv, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(256), S2W_INV_LDS, P->stream, a, P->winv, (a.flags & SWF_DELTA2) ? 2.0 : 1.0);
+    hipLaunchKernelGGL(k_affine_inv, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(512), S2W_INV_LDS, P->stream, a, P->winv, (a.flags & SWF_DELTA2) ? 2.0 : 1.0);
     return;
   }
   if (P->sweep_version >= 2) {

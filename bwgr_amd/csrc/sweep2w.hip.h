@@ -27,29 +27,32 @@
 namespace bwgr {
 
 static constexpr int S2W_WDOUBLES = 4 * 9 * 256;   // per block: four waves x nine 16 x 16 tiles
-static constexpr size_t S2W_INV_LDS = (size_t)(36 * 256 + 8 * 16 * 18 + 8 * 256 + SW_MAXM) * sizeof(double);
+static constexpr size_t S2W_INV_LDS = (size_t)(36 * 256 + 8 * 16 * 18 + 8 * 256 + SW_MAXM) * sizeof(double) + (size_t)(SW_MAXM * (SW_MAXM - 1) / 2) * sizeof(int32_t);
 // wave w holds block rows 7 - w (8 - w tiles) and w (w + 1 tiles): nine tiles each
 __host__ __device__ inline void s2w_tile_of(int w, int q, int &I, int &J) { if (q < 8 - w) { I = 7 - w; J = q; } else { I = w; J = q - (8 - w); } }
 
 // ------------------------------------------------------------------------------------------------------------------
 // W = (I + diag(scl) G_L)^-1 of every block
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_affine_inv(const SweepArgs a, double *winv, double dscale) {
+__global__ __launch_bounds__(512) void k_affine_inv(const SweepArgs a, double *winv, double dscale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *Wt = reinterpret_cast<double *>(smem);   // [36 * 256]: tile (I, J), J <= I, at I (I + 1) / 2 + J; element [r][c]
   double *Gt = Wt + 36 * 256;                      // [8 * 16 * 18]: G tiles of one block row, [J][r][t], rows padded to 18
   double *St = Gt + 8 * 16 * 18;                   // [8 * 256]
   double *scl = St + 8 * 256;                      // [SW_MAXM]
+  int32_t *gp_s = reinterpret_cast<int32_t *>(scl + SW_MAXM);   // the block's packed Gram rows (one coalesced pass over global memory)
   const int tid = threadIdx.x;
   const int blk = a.blk_begin + (int)blockIdx.x;
   const int m = a.m, mB = min(m, a.p - blk * m);
   const int32_t *gp = reinterpret_cast<const int32_t *>(a.gramp) + (size_t)blk * a.pstride;
   auto prow = [&](int k) { return k * (m - 1) - k * (k - 1) / 2; };
+  for (int i = tid; i < m * (m - 1) / 2; i += 512) gp_s[i] = gp[i];
   auto gat = [&](int row, int col) -> double {   // G[row][col], col < row, both inside the block
-    return (col < row && row < mB) ? (double)gp[prow(col) + row - col - 1] : 0.0;
+    return (col < row && row < mB) ? (double)gp_s[prow(col) + row - col - 1] : 0.0;
   };
   if (tid < SW_MAXM) scl[tid] = (tid < mB) ? dscale * a.ps.blocks[blk].rden[tid] : 0.0;
-  {   // the eight diagonal tiles
+  __syncthreads();
+  if (tid < 256) {   // the eight diagonal tiles
     const int rr = tid & 15, tt = tid >> 4;
     for (int I = 0; I < 8; ++I) Gt[(I * 16 + rr) * 18 + tt] = gat(16 * I + rr, 16 * I + tt);
   }
@@ -60,53 +63,59 @@ __global__ __launch_bounds__(256) void k_affine_inv(const SweepArgs a, double *w
     double w[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      double acc = 0.0;
+      double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-      for (int t = 0; t < r; ++t) acc = fma(g[r * 18 + t], w[t], acc);
-      w[r] = (r > c) ? -scl[16 * I + r] * acc : ((r == c) ? 1.0 : 0.0);
+      for (int t = 0; t + 1 < r; t += 2) { acc0 = fma(g[r * 18 + t], w[t], acc0); acc1 = fma(g[r * 18 + t + 1], w[t + 1], acc1); }
+      if (r & 1) acc0 = fma(g[r * 18 + r - 1], w[r - 1], acc0);
+      w[r] = (r > c) ? -scl[16 * I + r] * (acc0 + acc1) : ((r == c) ? 1.0 : 0.0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) Wt[(I * (I + 1) / 2 + I) * 256 + r * 16 + c] = w[r];
   }
   __syncthreads();
-  const int r = tid >> 4, c = tid & 15;
+  // block rows 1..7 on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15] of a
+  // k-step of four; result register v is D[(l >> 4) + 4 v][l & 15]): wave J forms the target tile (I, J), J < I
+  typedef double s2w_v4d __attribute__((ext_vector_type(4)));
+  const int lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   for (int I = 1; I < 8; ++I) {
-    {   // G tiles (I, 0..I-1)
-      const int rr = tid & 15, tt = tid >> 4;
-      for (int J = 0; J < I; ++J) Gt[(J * 16 + rr) * 18 + tt] = gat(16 * I + rr, 16 * J + tt);
+    for (int J = tid >> 8; J < I; J += 2) {   // G tiles (I, 0..I-1)
+      const int rr = tid & 15, tt = (tid >> 4) & 15;
+      Gt[(J * 16 + rr) * 18 + tt] = gat(16 * I + rr, 16 * J + tt);
     }
     __syncthreads();
-    // S_IJ = diag(scl_I) sum_{K=J..I-1} G_IK W_KJ
-    for (int J = 0; J < I; ++J) {
-      double acc = 0.0;
+    if (wv < I) {
+      const int J = wv;
+      // S_IJ = diag(scl_I) sum_{K=J..I-1} G_IK W_KJ
+      s2w_v4d acc = {0.0, 0.0, 0.0, 0.0};
       for (int K = J; K < I; ++K) {
-        const double *g = Gt + (size_t)(K * 16 + r) * 18;
-        const double *wk = Wt + (size_t)(K * (K + 1) / 2 + J) * 256 + c;
+        const double *g = Gt + (size_t)(K * 16 + l15) * 18 + l4;
+        const double *wk = Wt + (size_t)(K * (K + 1) / 2 + J) * 256 + l4 * 16 + l15;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) acc = fma(g[t], wk[t * 16], acc);
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(g[4 * s4], wk[64 * s4], acc, 0, 0, 0);
       }
-      St[J * 256 + r * 16 + c] = scl[16 * I + r] * acc;
-    }
-    __syncthreads();
-    // W_IJ = -W_II S_IJ
-    {
-      const double *wd = Wt + (size_t)(I * (I + 1) / 2 + I) * 256 + r * 16;
-      for (int J = 0; J < I; ++J) {
-        double acc = 0.0;
+      double *stj = St + J * 256;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) acc = fma(wd[t], St[J * 256 + t * 16 + c], acc);
-        Wt[(size_t)(I * (I + 1) / 2 + J) * 256 + r * 16 + c] = -acc;
-      }
+      for (int v = 0; v < 4; ++v) stj[(l4 + 4 * v) * 16 + l15] = scl[16 * I + l4 + 4 * v] * acc[v];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave wrote the tile, this wave reads it)
+      // W_IJ = -W_II S_IJ
+      s2w_v4d acc2 = {0.0, 0.0, 0.0, 0.0};
+      const double *wd = Wt + (size_t)(I * (I + 1) / 2 + I) * 256 + l15 * 16 + l4;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(wd[4 * s4], stj[(4 * s4 + l4) * 16 + l15], acc2, 0, 0, 0);
+      double *wo = Wt + (size_t)(I * (I + 1) / 2 + J) * 256;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) wo[(l4 + 4 * v) * 16 + l15] = -acc2[v];
     }
     __syncthreads();
   }
   // out, in the sequencer's order: wave w, tile q, half h, lane l holds W[16 I + (l & 15)][16 J + 4 (l >> 4) + 2 h + {0, 1}]
-  double *dst = winv + (size_t)blk * S2W_WDOUBLES;
-  for (int o = tid; o < S2W_WDOUBLES; o += 256) {
-    const int w = o / 2304, rem = o - w * 2304, chunk = rem >> 1, e = rem & 1;
+  double2 *dst = reinterpret_cast<double2 *>(winv + (size_t)blk * S2W_WDOUBLES);
+  for (int ch = tid; ch < S2W_WDOUBLES / 2; ch += 512) {
+    const int w = ch / 1152, chunk = ch - w * 1152;
     const int qh = chunk >> 6, l = chunk & 63, q = qh >> 1, h = qh & 1;
     int I, J; s2w_tile_of(w, q, I, J);
-    dst[o] = Wt[(size_t)(I * (I + 1) / 2 + J) * 256 + (l & 15) * 16 + 4 * (l >> 4) + 2 * h + e];
+    const double *src = Wt + (size_t)(I * (I + 1) / 2 + J) * 256 + (l & 15) * 16 + 4 * (l >> 4) + 2 * h;
+    dst[ch] = make_double2(src[0], src[1]);
   }
 }
 
