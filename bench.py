@@ -161,7 +161,7 @@ def main():
         sweep_ms, launches = ch.sweep_ms()
         st = ch.state()
         pl = P.pipeline(bool(pi))
-        kernel = {3: "k_sweep3<uint16>", 2: "k_sweep2<int8>", 1: "k_sweep<int8>"}[pl["generation"]]
+        kernel = {4: "k_sweep2w", 3: "k_sweep3<uint16>", 2: "k_sweep2<int8>", 1: "k_sweep<int8>"}[pl["generation"]]
         alg_bytes = float(n) * float(p)
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
         out = {
@@ -213,7 +213,7 @@ def main():
     # HBM traffic per launch comes from separate rocprofv3 --pmc passes (it cannot be read inside this process); the
     # corrected figure is committed under profiles/ and quoted only for the workload it was measured on
     pl = P.pipeline(bool(pi))
-    kernel = {3: "k_sweep3<uint16>", 2: "k_sweep2<int8>", 1: "k_sweep<int8>"}[pl["generation"]]
+    kernel = {4: "k_sweep2w", 3: "k_sweep3<uint16>", 2: "k_sweep2<int8>", 1: "k_sweep<int8>"}[pl["generation"]]
     traffic, traffic_source = None, None
     for name in ("r02_pmc_c4.json", "r01_pmc_c4.json"):
         try:

@@ -1110,7 +1110,7 @@ static float sweep3_gate(const bwgr_panel *P, int flags) { return use_sweep3(P, 
 // The affine sweeps of an int8 panel with 16-bit Gram staging run k_sweep2w: the block solve as a product with the inverse
 // k_affine_inv forms before the sweep (sweep2w.hip.h).
 static bool use_winv(const bwgr_panel *P, int flags) {
-  if (!P->winv_on || P->sweep_version < 2 || P->is_f32 || !P->gramp || P->winv_nd < 1) return false;
+  if (!P->winv_on || P->sweep_version < 2 || P->is_f32 || !P->gramp || P->winv_nd < 1 || P->K > 2 * (S2W_QW + S2W_QX)) return false;
   if (flags & (SWF_SELECT | SWF_EM_ANY | SWF_SERIAL)) return false;
   return P->ldsw_bytes > 0 && P->ldsw_bytes <= (size_t)160 * 1024;
 }

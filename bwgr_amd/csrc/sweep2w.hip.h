@@ -164,7 +164,7 @@ struct S2WArgs {
 
 __host__ __device__ inline size_t s2w_lds_bytes(int m, int R) {
   size_t s = 3 * sizeof(StageBuf);
-  s += (size_t)(2 * 2 + 1 + 1 + 1 + 1) * SW_MAXM * sizeof(double);   // q parts [parity][2], cross, rhs, d, delta
+  s += (size_t)(2 * 4 + 1 + 1 + 1 + 1) * SW_MAXM * sizeof(double);   // q parts [parity][4], cross, rhs, d, delta
   s += (size_t)(4 * 4 + 1) * S2W_DROW;                                // delta digits of the last four blocks, a row of zeros
   s += 256;
   const size_t streamer = s2i_lds_bytes(m, R, 4);
@@ -207,7 +207,7 @@ struct S2WPoll {
 __device__ __forceinline__ void s2w_q_request(const SweepArgs &a, int b, int part, int t, S2WPoll &P) {
   const int K = a.K, wq = (K + 1) / 2;
   const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(a.qpart + (size_t)(b % S2_NSLOT) * K * SW_MAXM) + (size_t)min(part * wq, K - 1) * SW_MAXM + t;
-  const int nw = min(wq, K - part * wq);   // (uniform)
+  const int nw = min(S2W_QW, min(wq, K - part * wq));   // (uniform)
 #pragma unroll
   for (int u = 0; u < S2W_QW; ++u) P.v[u] = ld_agent_raw64(slot + (size_t)min(u, max(nw - 1, 0)) * SW_MAXM);   // (unconditional: repeats of the last word are L2 hits)
 }
@@ -216,7 +216,7 @@ __device__ __forceinline__ int s2w_q_collect(const SweepArgs &a, int b, int part
   uint32_t *abortw = a.xflags + (size_t)K * SW_FLAG_STRIDE;
   const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(a.qpart + (size_t)(b % S2_NSLOT) * K * SW_MAXM) + (size_t)min(part * wq, K - 1) * SW_MAXM + t;
   const unsigned long long tag = s2_qtag(b);
-  const int nw = (t < mB) ? min(wq, K - part * wq) : 0;
+  const int nw = (t < mB) ? min(S2W_QW, min(wq, K - part * wq)) : 0;   // (the words beyond S2W_QW are the product waves': S2WPollX)
   const uint64_t t0 = wall_clock64();
   unsigned spins = 0;
   for (;;) {
@@ -237,22 +237,52 @@ __device__ __forceinline__ int s2w_q_collect(const SweepArgs &a, int b, int part
   double r = 0.0;
 #pragma unroll
   for (int u = 0; u < S2W_QW; ++u) r += (u < nw) ? __longlong_as_double((long long)(P.v[u] & ~0xFFull)) : 0.0;
-  for (int u0 = S2W_QW; u0 < wq; u0 += 8) {   // more than 2 * S2W_QW streamers: the rest, eight words a round trip (uniform trip count)
-    unsigned long long v[8];
-    for (;;) {
-      bool ok = true;
+  dst[t] = r;
+  return 1;
+}
+
+// With more than 2 * S2W_QW streamers (K = 40 at n = 10 000) the words S2W_QW .. of each half are the product waves' (waves 4-7,
+// 256 threads, the same two threads per marker): up to S2W_QX more words per thread, same early request.
+static constexpr int S2W_QX = 8;   // K <= 2 * (S2W_QW + S2W_QX) = 48 streamers
+struct S2WPollX {
+  unsigned long long v[S2W_QX];
+};
+__device__ __forceinline__ void s2w_qx_request(const SweepArgs &a, int b, int part, int t, S2WPollX &P) {
+  const int K = a.K, wq = (K + 1) / 2;
+  const int nx = min(wq, K - part * wq) - S2W_QW;   // (uniform)
+  if (nx <= 0) return;
+  const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(a.qpart + (size_t)(b % S2_NSLOT) * K * SW_MAXM) + (size_t)(part * wq + S2W_QW) * SW_MAXM + t;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { v[u] = (u0 + u < nw) ? ld_agent_raw64(slot + (size_t)(u0 + u) * SW_MAXM) : tag; ok = ok && ((v[u] & 0xFFull) == tag); }
-      if (__ballot(!ok) == 0ull) break;
-      if ((++spins & 63u) == 0u) {
-        if (ld_agent_u32(abortw) != 0u) return 0;
-        if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
-      }
-      __builtin_amdgcn_s_sleep(1);
+  for (int u = 0; u < S2W_QX; ++u) P.v[u] = ld_agent_raw64(slot + (size_t)min(u, nx - 1) * SW_MAXM);
+}
+__device__ __forceinline__ int s2w_qx_collect(const SweepArgs &a, int b, int part, int t, int mB, S2WPollX &P, double *dst) {
+  const int K = a.K, wq = (K + 1) / 2;
+  const int nxu = min(wq, K - part * wq) - S2W_QW;   // (uniform)
+  if (nxu <= 0) { dst[t] = 0.0; return 1; }
+  uint32_t *abortw = a.xflags + (size_t)K * SW_FLAG_STRIDE;
+  const unsigned long long *slot = reinterpret_cast<const unsigned long long *>(a.qpart + (size_t)(b % S2_NSLOT) * K * SW_MAXM) + (size_t)(part * wq + S2W_QW) * SW_MAXM + t;
+  const unsigned long long tag = s2_qtag(b);
+  const int nx = (t < mB) ? nxu : 0;
+  const uint64_t t0 = wall_clock64();
+  unsigned spins = 0;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < S2W_QX; ++u) ok = ok && (u >= nx || (P.v[u] & 0xFFull) == tag);
+    if (__ballot(!ok) == 0ull) break;
+    if ((++spins & 63u) == 0u) {
+      if (ld_agent_u32(abortw) != 0u) return 0;
+      if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
     }
+    __builtin_amdgcn_s_sleep(1);
+    if (!ok) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) r += (u0 + u < nw) ? __longlong_as_double((long long)(v[u] & ~0xFFull)) : 0.0;
+      for (int u = 0; u < S2W_QX; ++u) P.v[u] = ld_agent_raw64(slot + (size_t)min(u, nxu - 1) * SW_MAXM);
+    }
   }
+  double r = 0.0;
+#pragma unroll
+  for (int u = 0; u < S2W_QX; ++u) r += (u < nx) ? __longlong_as_double((long long)(P.v[u] & ~0xFFull)) : 0.0;
   dst[t] = r;
   return 1;
 }
@@ -274,7 +304,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
   const int m = a.m, nb = a.blk_end - a.blk_begin, nd = A.nd;
   size_t off = 0;
   StageBuf *stage = reinterpret_cast<StageBuf *>(smem + off); off += 3 * sizeof(StageBuf);
-  double *q_s = reinterpret_cast<double *>(smem + off); off += (size_t)4 * SW_MAXM * sizeof(double);      // [parity][part][marker]
+  double *q_s = reinterpret_cast<double *>(smem + off); off += (size_t)8 * SW_MAXM * sizeof(double);      // [parity][part 0..3][marker]
     double *rhs_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
   double *d_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);                  // the un-rounded steps
   double *delta_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);              // what the residual gets (float values)
@@ -334,6 +364,11 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
     const int gpart = (tid - 512) >> 7, gt = tid & 127;
     s2w_q_request(a, 0, gpart, gt, QP);
     if (!s2w_q_collect(a, 0, gpart, gt, blk_m(0), QP, q_s + (size_t)gpart * SW_MAXM)) ctrl_s[0] = 0;
+  } else if (wave >= 4) {   // block 0's words beyond the pollers' (their own registers: the loop's have one defining site)
+    const int xpart = (tid - 256) >> 7, xt = tid & 127;
+    S2WPollX Q0;
+    s2w_qx_request(a, 0, xpart, xt, Q0);
+    if (!s2w_qx_collect(a, 0, xpart, xt, blk_m(0), Q0, q_s + (size_t)(2 + xpart) * SW_MAXM)) ctrl_s[0] = 0;
   }
   double sum_d = 0.0, sum_b2 = 0.0;
 
@@ -367,13 +402,13 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
 #undef S2W_X1
     if (lane < 16) {
       const StageBuf &st = stage[c % 3];
-      const double *qq = q_s + (size_t)(c & 1) * 2 * SW_MAXM;
+      const double *qq = q_s + (size_t)(c & 1) * 4 * SW_MAXM;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int t = 32 * wave + 16 * u + lane;
         double rhs = 0.0;
         if (t < mB) {
-          const double r0 = (qq[t] + qq[SW_MAXM + t]) - (u ? cross1 : cross0);
+          const double r0 = ((qq[t] + qq[SW_MAXM + t]) + (qq[2 * SW_MAXM + t] + qq[3 * SW_MAXM + t])) - (u ? cross1 : cross0);
           rhs = fma(r0 + (double)st.xxb0[t], st.rden[t], st.sdz1[t]) - (double)st.b0[t];
         }
         rhs_s[t] = rhs;
@@ -411,6 +446,8 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
   } else if (wave < 8) {
     // ================= waves 4-7: the product =================
     const int wv = wave - 4, r16 = lane & 15, cq = lane >> 4;
+    const int xpart = (tid - 256) >> 7, xt = tid & 127;
+    S2WPollX QX;
 #pragma clang loop unroll(disable)
     for (int c = -1; c < nb; ++c) {
       double acc_hi = 0.0, acc_lo = 0.0;
@@ -429,9 +466,11 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         acc_lo += __shfl_xor(acc_lo, 16, 64); acc_lo += __shfl_xor(acc_lo, 32, 64);
         if (cq == 0) d_s[16 * (7 - wv) + r16] = acc_hi;
         if (cq == 1) d_s[16 * wv + r16] = acc_lo;
+        if (c + 1 < nb) { if (!s2w_qx_collect(a, c + 1, xpart, xt, blk_m(c + 1), QX, q_s + (size_t)(((c + 1) & 1) * 4 + 2 + xpart) * SW_MAXM)) ctrl_s[0] = 0; }
         S2W_BAR();                                         // B3: d
       }
       issue_w(c + 1);     // (into the registers just read; the wave waits in the memory pipeline's queue while wave 8 writes the outputs)
+      s2w_qx_request(a, min(c + 2, nb - 1), xpart, xt, QX);
     }
   } else {
     // ================= waves 8-11: the dots of the next block; wave 8: the outputs of this one =================
@@ -448,7 +487,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
       if (ctrl_s[0] == 0) return;
       S2W_BAR();                                          // B2
       S2WSTAMP(2);
-      if (have_next) { if (!s2w_q_collect(a, c + 1, gpart, gt, blk_m(c + 1), QP, q_s + (size_t)(((c + 1) & 1) * 2 + gpart) * SW_MAXM)) ctrl_s[0] = 0; }
+      if (have_next) { if (!s2w_q_collect(a, c + 1, gpart, gt, blk_m(c + 1), QP, q_s + (size_t)(((c + 1) & 1) * 4 + gpart) * SW_MAXM)) ctrl_s[0] = 0; }
       s2w_q_request(a, min(c + 2, nb - 1), gpart, gt, QP);   // (every pass, the last ones too: the compiler's wait counts merge over all paths)
       S2WSTAMP(3);
       S2W_BAR();                                          // B3: d

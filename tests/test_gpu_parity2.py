@@ -424,3 +424,19 @@ def test_affine_winv_falls_back_on_signed_genotypes():
     ch.close(); P.close()
     o = O.bayes("BayesRR", y, Xc, it=6, bi=1, seed=3)["last"]
     assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL
+
+
+def test_affine_winv_forty_slabs():
+    """n = 10 000 rows are 40 slab workgroups: more slab dots per marker than the four polling waves request early (2 x 16), the
+    rest are the product waves' (S2WPollX)."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = synth_small(10000, 700, seed=37)
+    P = bwgr_amd.Panel(X)
+    assert P.nwg == 40 and P.pipeline(False)["generation"] == 4
+    ch = bwgr_amd.Chain(P, "BayesA", y, it=5, bi=1, seed=12)
+    ch.run(5)
+    st = ch.state()
+    ch.close(); P.close()
+    o = O.bayes("BayesA", y, X, it=5, bi=1, seed=12)["last"]
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
