@@ -927,6 +927,8 @@ struct bwgr_panel {
   unsigned char *gxt[S2W_MAXDIST] = {};   // the cross Gram blocks as the sequencer's MFMA operand (k_gx_planes); shared with clones
   int winv_nd = 0;                // distances built = the deepest lag the affine sweeps can run, minus one
   size_t ldsw_bytes = 0;
+  float dense_thr = 1.0f;         // selection sweeps of chains with at least this share of markers in the model run the marker-by-marker recurrence
+                                  // (BWGR_DENSE_THR; >= 1, the default: never -- measured no faster than the rounds at any inclusion rate)
   float eng3_thr = 0.02f;         // k_sweep3 takes the sweeps whose chains hold fewer than this share of markers in the model (BWGR_ENG3_THR)
   hipStream_t own_stream = nullptr;
 };
@@ -1155,6 +1157,15 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
   // streamers, sequencer, and for the selection models the q feeders (the affine recurrence is compute-bound: its
   // sequencer gathers q itself under the recurrence, and a feeder hop in its lag-2 chain measured 15 % slower)
   a.nfeed = (P->sweep_version >= 2 && sel) ? P->nfeed : 0;
+  // the selection sweeps' twin for dense inclusion (int8 panels): the generic sequencer's marker-by-marker recurrence, two blocks
+  // deep; both launches are enqueued, the device runs the one whose regime the chain's last inclusion rate says it is
+  const bool twin = sel && P->sweep_version >= 2 && !P->is_f32 && P->dense_thr < 1.0f;
+  a.gate_dense = twin ? P->dense_thr : 0.0f;
+  if (twin) {
+    SweepArgs ad = a;
+    ad.flags |= SWF_DENSE; ad.lag = 2;
+    hipLaunchKernelGGL((k_sweep2<int8_t, true>), dim3(P->K + 1 + ad.nfeed), dim3(SW_THREADS), P->lds2_bytes, P->stream, ad);
+  }
   if (use_winv(P, a.flags) && P->winv) {
     S2WArgs A;
     A.winv = P->winv; A.nd = a.lag - 1;
@@ -1517,6 +1528,7 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_affine_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (!P->is_f32) P->ldsw_bytes = s2w_lds_bytes(m, R);
   if (const char *wv = getenv("BWGR_WINV")) P->winv_on = !(wv[0] == '0');
+  if (const char *dv = getenv("BWGR_DENSE_THR")) { const float v = (float)atof(dv); if (v >= 0.0f) P->dense_thr = std::max(v, 1e-9f); }   // (0: always)
 #undef PCHK
   (void)rc;
   *out = P;

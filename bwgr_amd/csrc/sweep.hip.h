@@ -47,6 +47,7 @@ enum : int {
   SWF_EM_BL = 512,    // emBL: G + Half_L2 (:379-387); Lmb1 in sc->lam, 1/(xx + cxx) in the sdz1 slot (cxx in sc->Sb)
   SWF_EM_LASSO = 1024, // lasso: yx = (e + x b0).x, soft threshold (yx -/+ Lmb)/xx clamped at 0 (:1477-1485); Lmb in sc->lam; yx_j leaves in d[j]
   SWF_EM_ANY = SWF_EM_SEL | SWF_EM_EN | SWF_EM_BL | SWF_EM_LASSO,
+  SWF_DENSE = 1 << 18,           // k_sweep2's generic sequencer: the selection models' in-block recurrence marker by marker (dense inclusion)
   SWF_SERIAL = 1 << 19,          // affine sweep that must keep the lane-ordered recurrence (wgr's de: Vb_j = |b_j| sqrt(Ve/MSx) feeds rounding-level
                                  // differences of b back into the next sweep's shrinkage, amplified; R/wgr.R:118)
   SWF_DEBUG_WITHHOLD = 1 << 20   // test hook (bwgr_debug_withhold): slab workgroup 0 leaves at once, so every wait on it must time out
@@ -108,6 +109,8 @@ struct SweepArgs {
   unsigned long long *dgran;    // k_sweep2: [S2_NSLOT][SW_MAXM] {epoch, float delta} granules
   uint32_t *xflags;             // [K*SW_FLAG_STRIDE] epochs, then the abort word
   unsigned long long *stamps;   // diagnostic build only (-DBWGR_STAMPS): per-phase cycle sums of workgroup 0
+  float gate_dense;             // > 0: the selection sweeps of k_sweep2 are enqueued twice -- speculative rounds (sparse inclusion) and the marker-by-marker
+                                // recurrence (SWF_DENSE, lag 2) -- and the device runs the one whose regime sc->inc_rate says it is; 0: no gating
   float gate3;                  // > 0: both engines of the selection models are launched and the device picks one -- k_sweep3 (and its
                                 // k_escale / k_spec3) runs when sc->inc_rate < gate3, k_sweep2 (and k_spec) otherwise; 0: no gating
 };

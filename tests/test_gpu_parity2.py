@@ -440,3 +440,24 @@ def test_affine_winv_forty_slabs():
     ch.close(); P.close()
     o = O.bayes("BayesA", y, X, it=5, bi=1, seed=12)["last"]
     assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
+
+
+@pytest.mark.parametrize("model,pi,thr", [("BayesCpi", 0.0, "0"), ("BayesDpi", 0.0, "0"), ("BayesB", 0.6, "0.3"), ("BayesC", 0.7, "0.25")])
+def test_dense_recurrence_is_the_same_chain(model, pi, thr, monkeypatch):
+    """BWGR_DENSE_THR (opt-in): selection sweeps of chains with that share of markers in the model run the generic sequencer's
+    marker-by-marker recurrence, two blocks deep, instead of the speculative rounds; the device switches sweep by sweep
+    (thresholds 0.3 / 0.25 sit where these chains' inclusion rates wander).  Same numbers in the same order: the oracle's chain,
+    identical decisions (/root/reference/src/Rcpp20260726ai.cpp:884-909 BayesCpi, :950-975 BayesDpi)."""
+    import bwgr_amd
+    from oracle import oracle as O
+    monkeypatch.setenv("BWGR_DENSE_THR", thr)
+    monkeypatch.setenv("BWGR_ENG3_THR", "0.02")
+    X, y = synth_small(600, 1500, seed=41)
+    P = bwgr_amd.Panel(X)
+    ch = bwgr_amd.Chain(P, model, y, it=10, bi=2, pi=pi, seed=6)
+    ch.run(10)
+    st = ch.state()
+    ch.close(); P.close()
+    o = O.bayes(model, y, X, it=10, bi=2, pi=pi, seed=6)["last"]
+    assert np.array_equal(st["d"], o["d"])
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
