@@ -925,6 +925,8 @@ struct bwgr_panel {
   bool winv_on = true;            // BWGR_WINV=0: the serial recurrence of k_sweep2's sequencer instead
   double *winv = nullptr;         // per handle: [nblocks][S2W_WDOUBLES], written by k_affine_inv before every affine sweep
   unsigned char *gxt[S2W_MAXDIST] = {};   // the cross Gram blocks as the sequencer's MFMA operand (k_gx_planes); shared with clones
+  unsigned long long *qsumw = nullptr;    // per handle: the fixed-point streamers' slab-dot sums [nblocks][SW_MAXM][2]
+  bool wfx_on = true;             // BWGR_WFX=0: k_sweep2's streamers under the product sequencer instead of the fixed-point ones
   int winv_nd = 0;                // distances built = the deepest lag the affine sweeps can run, minus one
   size_t ldsw_bytes = 0;
   float dense_thr = 1.0f;         // selection sweeps of chains with at least this share of markers in the model run the marker-by-marker recurrence
@@ -1116,9 +1118,12 @@ static bool use_winv(const bwgr_panel *P, int flags) {
   if (flags & (SWF_SELECT | SWF_EM_ANY | SWF_SERIAL)) return false;
   return P->ldsw_bytes > 0 && P->ldsw_bytes <= (size_t)160 * 1024;
 }
+// ... with its own streamers (s2w_streamer_fx: 128 rows each, fixed-point residual) where the slab count allows
+static bool use_wfx(const bwgr_panel *P) { return P->wfx_on && (P->R % S2W_FXR) == 0 && P->K * (P->R / S2W_FXR) <= 255; }
 static int winv_alloc(bwgr_panel *P) {
   if (P->winv) return BWGR_OK;
   HIPCHK(hipMalloc(&P->winv, sizeof(double) * (size_t)S2W_WDOUBLES * (size_t)P->nblocks));
+  HIPCHK(hipMalloc(&P->qsumw, sizeof(unsigned long long) * 4 * 2 * SW_MAXM * (size_t)P->nblocks));   // (up to four copies)
   return BWGR_OK;
 }
 
@@ -1137,6 +1142,10 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
     if (std::isinf(a.gate3)) return;
   }
   if (use_winv(P, a.flags) && P->winv) {
+    if (use_wfx(P)) {   // the sweep's fixed-point scale from the residual alone (the steps are not known before the sweep)
+      hipLaunchKernelGGL(k_escale_reset, dim3(1), dim3(1), 0, P->stream, a.sc);
+      hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, 0, INFINITY);
+    }
     hipLaunchKernelGGL(k_affine_inv, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(512), S2W_INV_LDS, P->stream, a, P->winv, (a.flags & SWF_DELTA2) ? 2.0 : 1.0);
     return;
   }
@@ -1174,7 +1183,12 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
     A.ahead = 5;
     if (const char *pv = getenv("BWGR_WPF")) A.npf = std::max(0, std::min(8, atoi(pv)));
     if (const char *pv = getenv("BWGR_WAHEAD")) A.ahead = std::max(1, atoi(pv));
-    hipLaunchKernelGGL(k_sweep2w, dim3(P->K + 1 + 8 * A.npf), dim3(S2W_THREADS), P->ldsw_bytes, P->stream, a, A);
+    A.fx = use_wfx(P) ? 1 : 0; A.qsum = P->qsumw; A.sub = P->R / S2W_FXR; A.K3 = P->K * A.sub;
+    A.nq = A.K3 > 48 ? 2 : 1;
+    if (const char *qv = getenv("BWGR_WNQ")) { const int v = atoi(qv); if (v == 1 || v == 2 || v == 4) A.nq = v; }
+    if (A.fx) (void)hipMemsetAsync(P->qsumw + (size_t)a.blk_begin * A.nq * 2 * SW_MAXM, 0, sizeof(unsigned long long) * A.nq * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
+    if (A.fx) hipLaunchKernelGGL(k_sweep2w<true>, dim3(A.K3 + 1 + 8 * A.npf), dim3(S2W_THREADS), P->ldsw_bytes, P->stream, a, A);
+    else hipLaunchKernelGGL(k_sweep2w<false>, dim3(P->K + 1 + 8 * A.npf), dim3(S2W_THREADS), P->ldsw_bytes, P->stream, a, A);
     return;
   }
   if (P->sweep_version >= 2) {
@@ -1284,7 +1298,7 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
     P->parent->nclones--;
   }
   // the scratch a sweep writes: speculative cross terms, pre-staged constants, exchange words
-  hipFree(P->qsum3); hipFree(P->lists3); hipFree(P->winv);
+  hipFree(P->qsum3); hipFree(P->lists3); hipFree(P->winv); hipFree(P->qsumw);
   hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->xpart); hipFree(P->xchg); hipFree(P->stamps);
   if (P->own_stream) hipStreamDestroy(P->own_stream);
   delete P;
@@ -1524,10 +1538,12 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<int8_t, true, uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2w), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2w<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2w<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_affine_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (!P->is_f32) P->ldsw_bytes = s2w_lds_bytes(m, R);
   if (const char *wv = getenv("BWGR_WINV")) P->winv_on = !(wv[0] == '0');
+  if (const char *wv = getenv("BWGR_WFX")) P->wfx_on = !(wv[0] == '0');
   if (const char *dv = getenv("BWGR_DENSE_THR")) { const float v = (float)atof(dv); if (v >= 0.0f) P->dense_thr = std::max(v, 1e-9f); }   // (0: always)
 #undef PCHK
   (void)rc;
@@ -1574,7 +1590,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   HIPCHK(hipStreamSynchronize(root->stream));   // the shared arrays are complete
   bwgr_panel *P = new bwgr_panel(*root);
   P->parent = root; P->nclones = 0; P->nchains = 0; P->own_stream = nullptr; P->stream = nullptr; P->ps_owner = nullptr; P->ps_iter = -1;
-  P->qsum3 = P->lists3 = nullptr; P->epoch3 = 0; P->xmax_dev = nullptr; P->winv = nullptr;
+  P->qsum3 = P->lists3 = nullptr; P->epoch3 = 0; P->xmax_dev = nullptr; P->winv = nullptr; P->qsumw = nullptr;
   P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->xchg = nullptr; P->stamps = nullptr;
   root->nclones++;
   auto bail = [&](int code) { bwgr_panel_destroy(P); return code; };

@@ -158,16 +158,22 @@ struct S2WArgs {
   const double *winv;                        // [nblocks][S2W_WDOUBLES]
   const unsigned char *gxt[S2W_MAXDIST];     // gxt[d-1]: planes of the distance-d cross Gram blocks (missing distances repeat gxt[0])
   int nd;                                    // distances in use = lag - 1
+  unsigned long long *qsum;                  // fixed-point streamers: [nblocks][SW_MAXM][2] slab-dot sums (integer atomics, low byte = count)
+  int fx;                                    // 1: the streamers are s2w_streamer_fx (K3 workgroups of 128 rows), 0: k_sweep2's (K of R rows)
+  int K3, sub;                               // streamer workgroups, streamers per slab
+  int nq;                                    // copies of the sums (1, 2 or 4; streamer w adds into copy w mod nq: fewer atomics queue on one word)
   int ahead;                                 // blocks a prefetcher may run ahead of the sequencer
   int npf;                                   // L2 prefetch workgroups (blockIdx K + 8, K + 16, ...: the sequencer's XCD)
 };
 
+__host__ __device__ inline size_t s2w_fx_lds(int L);
 __host__ __device__ inline size_t s2w_lds_bytes(int m, int R) {
   size_t s = 3 * sizeof(StageBuf);
   s += (size_t)(2 * 4 + 1 + 1 + 1 + 1) * SW_MAXM * sizeof(double);   // q parts [parity][4], cross, rhs, d, delta
   s += (size_t)(4 * 4 + 1) * S2W_DROW;                                // delta digits of the last four blocks, a row of zeros
   s += 256;
-  const size_t streamer = s2i_lds_bytes(m, R, 4);
+  size_t streamer = s2i_lds_bytes(m, R, 4);
+  if (s2w_fx_lds(4) > streamer) streamer = s2w_fx_lds(4);
   return s > streamer ? s : streamer;
 }
 
@@ -287,6 +293,36 @@ __device__ __forceinline__ int s2w_qx_collect(const SweepArgs &a, int b, int par
   return 1;
 }
 
+// fixed-point streamers (S2WArgs::fx): one self-counting word per marker and half (digits 0-2 / 3-6), whatever the number of streamers
+__device__ __forceinline__ unsigned long long s2w_qf_load(const S2WArgs &A, const unsigned long long *g) {   // the sum over the copies (counts add up in the low byte)
+  unsigned long long v = ld_agent_raw64(g);
+  if (A.nq > 1) v += ld_agent_raw64(g + 2 * SW_MAXM);
+  if (A.nq > 2) { v += ld_agent_raw64(g + 4 * SW_MAXM); v += ld_agent_raw64(g + 6 * SW_MAXM); }
+  return v;
+}
+__device__ __forceinline__ unsigned long long s2w_qf_request(const SweepArgs &a, const S2WArgs &A, int b, int part, int t) {
+  return s2w_qf_load(A, A.qsum + ((size_t)(a.blk_begin + b) * A.nq * SW_MAXM + t) * 2 + part);
+}
+__device__ __forceinline__ int s2w_qf_collect(const SweepArgs &a, const S2WArgs &A, int b, int part, int t, int mB, unsigned long long v, double invS, double *dst) {
+  uint32_t *abortw = a.xflags + (size_t)a.K * SW_FLAG_STRIDE;
+  const unsigned long long *g = A.qsum + ((size_t)(a.blk_begin + b) * A.nq * SW_MAXM + t) * 2 + part;
+  const unsigned long long need = (unsigned long long)A.K3;
+  const uint64_t t0 = wall_clock64();
+  unsigned spins = 0;
+  for (;;) {
+    const bool ok = (t >= mB) || ((v & 0xFFull) == need);
+    if (__ballot(!ok) == 0ull) break;
+    if ((++spins & 63u) == 0u) {
+      if (ld_agent_u32(abortw) != 0u) return 0;
+      if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+    if (!ok) v = s2w_qf_load(A, g);
+  }
+  dst[t] = (t < mB) ? (double)((long long)v >> 8) * (part ? 16777216.0 * invS : invS) : 0.0;
+  return 1;
+}
+
 // Block c, in four phases between raw barriers (no memory-counter drain at a barrier):
 //   X  all eight waves: the cross terms  sum_{d=1..nd} G_d' delta_{c-d}  as int8 MFMA products -- two byte planes of the 16-bit
 //      Gram entries (LDS, by DMA) against the four balanced base-256 digits of the steps in block-common fixed point; wave w
@@ -298,6 +334,7 @@ __device__ __forceinline__ int s2w_qx_collect(const SweepArgs &a, int b, int par
 //   O  wave 4:          b, d, vb, the delta granules for the streamers, the digits of this block's steps
 // Block c+1 begins with vmcnt(0) in waves 0-3: everything requested in M; the planes had the outputs' time only, so part of
 // their latency shows in the period (~2k cycles) -- the streamers' period is longer.
+template <bool FX>
 __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WArgs &A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -360,10 +397,20 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
   if (wave < 4) { issue_stage(0); issue_stage(1); }
   __syncthreads();
   S2WPoll QP;
+  constexpr bool fx = FX;
+  const double invSq = fx ? s3_pow2(-a.sc->e3_sh) : 1.0;
+  unsigned long long qf = 0ull;
   if (wave >= 8) {
     const int gpart = (tid - 512) >> 7, gt = tid & 127;
-    s2w_q_request(a, 0, gpart, gt, QP);
-    if (!s2w_q_collect(a, 0, gpart, gt, blk_m(0), QP, q_s + (size_t)gpart * SW_MAXM)) ctrl_s[0] = 0;
+    if constexpr (fx) {
+      qf = s2w_qf_request(a, A, 0, gpart, gt);
+      if (!s2w_qf_collect(a, A, 0, gpart, gt, blk_m(0), qf, invSq, q_s + (size_t)gpart * SW_MAXM)) ctrl_s[0] = 0;
+    } else {
+      s2w_q_request(a, 0, gpart, gt, QP);
+      if (!s2w_q_collect(a, 0, gpart, gt, blk_m(0), QP, q_s + (size_t)gpart * SW_MAXM)) ctrl_s[0] = 0;
+    }
+  } else if (wave >= 4 && fx) {   // (parts 2 and 3 stay zero)
+    q_s[(size_t)(2 + ((tid - 256) >> 7)) * SW_MAXM + (tid & 127)] = 0.0; q_s[(size_t)(6 + ((tid - 256) >> 7)) * SW_MAXM + (tid & 127)] = 0.0;
   } else if (wave >= 4) {   // block 0's words beyond the pollers' (their own registers: the loop's have one defining site)
     const int xpart = (tid - 256) >> 7, xt = tid & 127;
     S2WPollX Q0;
@@ -466,17 +513,17 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         acc_lo += __shfl_xor(acc_lo, 16, 64); acc_lo += __shfl_xor(acc_lo, 32, 64);
         if (cq == 0) d_s[16 * (7 - wv) + r16] = acc_hi;
         if (cq == 1) d_s[16 * wv + r16] = acc_lo;
-        if (c + 1 < nb) { if (!s2w_qx_collect(a, c + 1, xpart, xt, blk_m(c + 1), QX, q_s + (size_t)(((c + 1) & 1) * 4 + 2 + xpart) * SW_MAXM)) ctrl_s[0] = 0; }
+        if constexpr (!fx) if (c + 1 < nb) { if (!s2w_qx_collect(a, c + 1, xpart, xt, blk_m(c + 1), QX, q_s + (size_t)(((c + 1) & 1) * 4 + 2 + xpart) * SW_MAXM)) ctrl_s[0] = 0; }
         S2W_BAR();                                         // B3: d
       }
       issue_w(c + 1);     // (into the registers just read; the wave waits in the memory pipeline's queue while wave 8 writes the outputs)
-      s2w_qx_request(a, min(c + 2, nb - 1), xpart, xt, QX);
+      if constexpr (!fx) s2w_qx_request(a, min(c + 2, nb - 1), xpart, xt, QX);
     }
   } else {
     // ================= waves 8-11: the dots of the next block; wave 8: the outputs of this one =================
     const int gpart = (tid - 512) >> 7, gt = tid & 127;
     S2STAMP_DECL;
-    s2w_q_request(a, min(1, nb - 1), gpart, gt, QP);
+    if constexpr (fx) qf = s2w_qf_request(a, A, min(1, nb - 1), gpart, gt); else s2w_q_request(a, min(1, nb - 1), gpart, gt, QP);
     for (int c = 0; c < nb; ++c) {
       const int blk = a.blk_begin + c, j0 = blk * m;
       const int mB = blk_m(c);
@@ -487,8 +534,13 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
       if (ctrl_s[0] == 0) return;
       S2W_BAR();                                          // B2
       S2WSTAMP(2);
-      if (have_next) { if (!s2w_q_collect(a, c + 1, gpart, gt, blk_m(c + 1), QP, q_s + (size_t)(((c + 1) & 1) * 4 + gpart) * SW_MAXM)) ctrl_s[0] = 0; }
-      s2w_q_request(a, min(c + 2, nb - 1), gpart, gt, QP);   // (every pass, the last ones too: the compiler's wait counts merge over all paths)
+      if constexpr (fx) {
+        if (have_next) { if (!s2w_qf_collect(a, A, c + 1, gpart, gt, blk_m(c + 1), qf, invSq, q_s + (size_t)(((c + 1) & 1) * 4 + gpart) * SW_MAXM)) ctrl_s[0] = 0; }
+        qf = s2w_qf_request(a, A, min(c + 2, nb - 1), gpart, gt);
+      } else {
+        if (have_next) { if (!s2w_q_collect(a, c + 1, gpart, gt, blk_m(c + 1), QP, q_s + (size_t)(((c + 1) & 1) * 4 + gpart) * SW_MAXM)) ctrl_s[0] = 0; }
+        s2w_q_request(a, min(c + 2, nb - 1), gpart, gt, QP);   // (every pass, the last ones too: the compiler's wait counts merge over all paths)
+      }
       S2WSTAMP(3);
       S2W_BAR();                                          // B3: d
       S2WSTAMP(4);
@@ -545,6 +597,218 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
 }
 #undef S2W_BAR
 
+// ------------------------------------------------------------------------------------------------------------------
+// The affine sweeps' own streamers: k_sweep3's arithmetic (sweep3.hip.h: the residual rows as 55-bit fixed point in registers
+// on one per-sweep scale, the update's int32 MFMA accumulators added straight into them, the dots as exact integers summed by
+// self-counting 64-bit atomics -- one pair of words per marker for the sequencer instead of K) on k_sweep2's data flow: block j's
+// steps come from the sequencer (delta granules), the dots of block j + L are formed once they have been applied.
+//   waves 0-1 (update): poll delta_j, its digits, the update with tile j (a two-wave sync through an LDS counter in between),
+//                       the residual's digits; waves 2-7 (dots): the dots of block j + L against those digits, the atomics.
+// One workgroup barrier per block.  128 rows per workgroup (twice k_sweep2's workgroups): L + 1 tiles of 18 KB stay in LDS.
+// ------------------------------------------------------------------------------------------------------------------
+static constexpr int S2W_FXR = 128;
+__host__ __device__ inline size_t s2w_fx_lds(int L) {
+  const size_t Rp = S2W_FXR + 16;
+  return (size_t)(L + 1) * SW_MAXM * Rp + 2 * 16 * Rp + 2 * 16 * (size_t)S2_DP + (size_t)2 * 64 * S3_OS * 4 + (size_t)8 * 32 * S3_OS * 4 + 64;
+}
+__device__ __forceinline__ void s2w_streamer_fx(const SweepArgs &a, const S2WArgs &A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m16 = lane & 15, grp = lane >> 4;
+  const int w = (int)blockIdx.x;
+  constexpr int R3 = S2W_FXR, Rp = R3 + 16, NU = 2, ND = 6, cprs = 3;
+  const int m = a.m, R = a.R, L = a.lag, NR = L + 1;
+  const int slab = w / A.sub, hsub = w - slab * A.sub;
+  const int nb = a.blk_end - a.blk_begin;
+  const int8_t *Xs = reinterpret_cast<const int8_t *>(a.X) + (size_t)slab * a.p * R + (size_t)hsub * R3;   // marker j: Xs + j * R
+  const int64_t row0 = (int64_t)slab * R + (int64_t)hsub * R3;
+  uint32_t *abortw = a.xflags + (size_t)a.K * SW_FLAG_STRIDE;
+  const size_t tile_b = (size_t)SW_MAXM * Rp;
+  int8_t *tile0 = reinterpret_cast<int8_t *>(smem);
+  size_t off = (size_t)NR * tile_b;
+  int8_t *edig0 = reinterpret_cast<int8_t *>(smem + off); off += (size_t)2 * 16 * Rp;     // [parity][n][row]
+  int8_t *ddig0 = reinterpret_cast<int8_t *>(smem + off); off += (size_t)2 * 16 * S2_DP;  // [parity][n][marker]
+  int *outu = reinterpret_cast<int *>(smem + off); off += (size_t)2 * 64 * S3_OS * 4;     // [update wave][row 64][n]
+  int *outd = reinterpret_cast<int *>(smem + off); off += (size_t)8 * 32 * S3_OS * 4;     // [wave][marker 32][n]
+  uint32_t *ctl_s = reinterpret_cast<uint32_t *>(smem + off);                            // [0] failure, [1] overflow, [2] update waves' counter
+  const int sh = a.sc->e3_sh;
+  const double S = s3_pow2(sh), invS = s3_pow2(-sh);
+  auto blk_j0 = [&](int b) { return (a.blk_begin + b) * m; };
+  auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
+
+  for (int i = tid; i < (int)((2 * 16 * Rp + 2 * 16 * S2_DP) / 4); i += SW_THREADS) reinterpret_cast<uint32_t *>(edig0)[i] = 0u;   // (adjacent)
+  if (tid < 16) ctl_s[tid] = 0u;
+  long long e_own = 0;
+  const bool upd = wave < NU;
+  if (upd) e_own = __double2ll_rn(a.e[row0 + 64 * wave + lane] * S);
+
+  // tile moves: two 16-byte chunks per thread (1024 chunks per tile), loads unconditional (clamped), stores guarded; two tiles in
+  // flight in two register sets (tile t travels in set t & 1)
+  s3_u4 ta0 = {0, 0, 0, 0}, ta1 = ta0, tb0 = ta0, tb1 = ta0;
+#define S2F_ISSUE1(u, name) { const int cc_ = min(tid + (u) * SW_THREADS, tot_ - 1); const int jj_ = min(cc_ >> cprs, mBt_ - 1), ii_ = cc_ & ((1 << cprs) - 1); \
+    name = __builtin_nontemporal_load(reinterpret_cast<const s3_u4 *>(Xs + (size_t)(j0t_ + jj_) * R + ii_ * 16)); }
+#define S2F_TILE_ISSUE(b_, T0, T1) do { const int bb_ = min((b_), nb - 1); const int j0t_ = blk_j0(bb_), mBt_ = blk_m(bb_), tot_ = m << cprs; S2F_ISSUE1(0, T0) S2F_ISSUE1(1, T1) } while (0)
+#define S2F_COMMIT1(u, name) { const int c_ = tid + (u) * SW_THREADS; if (c_ < tot_) { const int jj_ = c_ >> cprs, ii_ = c_ & ((1 << cprs) - 1); \
+    *reinterpret_cast<s3_u4 *>(dst_ + (size_t)jj_ * Rp + ii_ * 16) = name; } }
+#define S2F_TILE_COMMIT(b_, T0, T1) do { int8_t *dst_ = tile0 + (size_t)((b_) % NR) * tile_b; const int tot_ = m << cprs; S2F_COMMIT1(0, T0) S2F_COMMIT1(1, T1) } while (0)
+
+  // the slab dots of block b against the residual digits in edig: markers in groups of 16, groups gm and gm + ND together
+  auto dots = [&](int b, const int8_t *edig) {
+    const int8_t *tile = tile0 + (size_t)(b % NR) * tile_b;
+    for (int gm = wave - NU; 16 * gm < m; gm += 2 * ND) {
+      const int gm2 = gm + ND;
+      const bool two = 16 * gm2 < m;
+      const int8_t *bp = edig + (size_t)m16 * Rp + 16 * grp;
+      const int8_t *ap = tile + (size_t)(16 * gm + m16) * Rp + 16 * grp;
+      const int8_t *ap2 = tile + (size_t)(16 * (two ? gm2 : gm) + m16) * Rp + 16 * grp;
+      s2_v4i acc = {0, 0, 0, 0}, acc2 = acc;
+#pragma unroll
+      for (int r = 0; r < R3; r += 64) {
+        const s2_v4i bv = *reinterpret_cast<const s2_v4i *>(bp + r);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap + r), bv, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap2 + r), bv, acc2, 0, 0, 0);
+      }
+      int *od = outd + (size_t)wave * 32 * S3_OS;
+      if (m16 < 8) {      // lane: digit n = m16 of markers 16 gm + 4 grp + reg (rows 0..15 of the scratch) and of group gm2 (rows 16..31)
+        int *op = od + (size_t)(4 * grp) * S3_OS + m16;
+        op[0] = acc[0]; op[S3_OS] = acc[1]; op[2 * S3_OS] = acc[2]; op[3 * S3_OS] = acc[3];
+        op[16 * S3_OS] = acc2[0]; op[17 * S3_OS] = acc2[1]; op[18 * S3_OS] = acc2[2]; op[19 * S3_OS] = acc2[3];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane < (two ? 32 : 16)) {
+        const int4 o0 = *reinterpret_cast<const int4 *>(od + (size_t)lane * S3_OS);
+        const int4 o1 = *reinterpret_cast<const int4 *>(od + (size_t)lane * S3_OS + 4);
+        const long long lo = (long long)o0.x + ((long long)o0.y << 8) + ((long long)o0.z << 16);
+        const long long hi = (long long)o0.w + ((long long)o1.x << 8) + ((long long)o1.y << 16) + ((long long)o1.z << 24);
+        const int mk = 16 * ((lane < 16) ? gm : gm2) + (lane & 15);
+        unsigned long long *qs = A.qsum + ((((size_t)(a.blk_begin + b) * A.nq + (w & (A.nq - 1))) * SW_MAXM + mk) * 2);
+        __hip_atomic_fetch_add((gu64_t *)qs, (unsigned long long)((lo << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add((gu64_t *)(qs + 1), (unsigned long long)((hi << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch is read before the next pass overwrites it
+    }
+  };
+
+  // ---- prologue: tiles 0 .. L into LDS, tiles L+1 and L+2 in flight; the dots of blocks 0 .. L-1 against the starting residual ----
+  for (int b = 0; b <= L && b < nb; ++b) { S2F_TILE_ISSUE(b, ta0, ta1); S2F_TILE_COMMIT(b, ta0, ta1); }
+  // (set of tile t is t & 1)
+  if ((L + 1) & 1) { S2F_TILE_ISSUE(L + 1, tb0, tb1); S2F_TILE_ISSUE(L + 2, ta0, ta1); }
+  else { S2F_TILE_ISSUE(L + 1, ta0, ta1); S2F_TILE_ISSUE(L + 2, tb0, tb1); }
+  if (upd) {
+    if ((unsigned long long)(e_own + (1ll << 54)) >> 55) ctl_s[1] = 1u;
+    s3_put_digits7(e_own, edig0 + (size_t)16 * Rp + 64 * wave + lane, Rp);      // parity 1: block 0 writes parity 0
+  }
+  unsigned long long pre = 0ull;   // early-requested granule of the next block's step (update waves: thread = marker)
+  if (upd) pre = ld_agent_raw64(a.dgran + tid);
+  __syncthreads();
+  if (!upd) for (int b = 0; b < L && b < nb; ++b) dots(b, edig0 + (size_t)16 * Rp);
+
+  // one block; T0, T1: the register set of tile j+L+1 (committed here) and then of tile j+L+3 (requested here)
+  auto step = [&](int j, s3_u4 &T0, s3_u4 &T1) -> bool {
+    const int mB = blk_m(j), par = j & 1;
+    int8_t *edig = edig0 + (size_t)par * 16 * Rp;
+    int8_t *ddig = ddig0 + (size_t)par * 16 * S2_DP;
+    if (upd) {
+      // the steps of block j: one granule per marker, polled by the thread that needs it
+      int bad = 0;
+      double qd = 0.0;
+      if (tid < mB) {
+        const unsigned long long *g = a.dgran + (size_t)(j % S2_NSLOT) * SW_MAXM + tid;
+        const uint64_t t0 = wall_clock64();
+        unsigned spins = 0;
+        unsigned long long v = pre;
+        for (;;) {
+          if (s2_dgranule_is(v, j)) break;
+          v = ld_agent_raw64(g);
+          if (s2_dgranule_is(v, j)) break;
+          if ((++spins & 63u) == 0u) {
+            if (ld_agent_u32(abortw) != 0u) { bad = 1; break; }
+            if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); bad = 1; break; }
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!bad) qd = rint((double)__uint_as_float((uint32_t)v) * S);
+      }
+      if (bad) ctl_s[0] = 1u;
+      if (!(fabs(qd) < 18014398509481984.0)) { ctl_s[1] = 1u; qd = 0.0; }       // 2^54
+      s3_put_digits7((long long)qd, ddig + tid, S2_DP);
+      // the two update waves need each other's digits: an LDS counter (no workgroup barrier: the dots waves are busy)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) atomicAdd(&ctl_s[2], 1u);
+      while (__hip_atomic_load(&ctl_s[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2u * (uint32_t)(j + 1)) __builtin_amdgcn_s_sleep(0);
+      // ---- slab update: out[row][n] = sum_markers x[row][marker] * digit_n(step[marker]) ----
+      const int8_t *tile = tile0 + (size_t)(j % NR) * tile_b;
+      const int rowoff = 4 * (16 * wave + m16);
+      s2_v4i acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+      for (int s0 = 0; s0 < mB; s0 += 64) {
+        const int8_t *tp = tile + __mul24(s0 + 4 * grp, Rp) + rowoff;
+        uint32_t c[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            c[u][q] = *reinterpret_cast<const uint32_t *>(tp + (16 * u + q) * Rp);
+        const int8_t *bp = ddig + (size_t)m16 * S2_DP + s0 + 4 * grp;
+        const s2_v4i bv = {*reinterpret_cast<const int *>(bp), *reinterpret_cast<const int *>(bp + 16),
+                           *reinterpret_cast<const int *>(bp + 32), *reinterpret_cast<const int *>(bp + 48)};
+        uint32_t rw[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t t0 = __builtin_amdgcn_perm(c[u][1], c[u][0], 0x05010400u), t1 = __builtin_amdgcn_perm(c[u][1], c[u][0], 0x07030602u);
+          const uint32_t t2 = __builtin_amdgcn_perm(c[u][3], c[u][2], 0x05010400u), t3 = __builtin_amdgcn_perm(c[u][3], c[u][2], 0x07030602u);
+          rw[0][u] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); rw[1][u] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+          rw[2][u] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); rw[3][u] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+        }
+        acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[0][0], (int)rw[0][1], (int)rw[0][2], (int)rw[0][3]}, bv, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[1][0], (int)rw[1][1], (int)rw[1][2], (int)rw[1][3]}, bv, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[2][0], (int)rw[2][1], (int)rw[2][2], (int)rw[2][3]}, bv, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[3][0], (int)rw[3][1], (int)rw[3][2], (int)rw[3][3]}, bv, acc3, 0, 0, 0);
+      }
+      int *ou = outu + (size_t)wave * 64 * S3_OS;
+      if (m16 < 8) {      // lane: digit n = m16; acc_k[reg] belongs to local row 4 (4 grp + reg) + k
+        int *op = ou + (size_t)(4 * (4 * grp)) * S3_OS + m16;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          op[(4 * reg + 0) * S3_OS] = acc0[reg]; op[(4 * reg + 1) * S3_OS] = acc1[reg];
+          op[(4 * reg + 2) * S3_OS] = acc2[reg]; op[(4 * reg + 3) * S3_OS] = acc3[reg];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes (in order; no other wave reads this scratch)
+      {
+        const int4 o0 = *reinterpret_cast<const int4 *>(ou + (size_t)lane * S3_OS);
+        const int4 o1 = *reinterpret_cast<const int4 *>(ou + (size_t)lane * S3_OS + 4);
+        long long v = (long long)o0.x + ((long long)o0.y << 8) + ((long long)o0.z << 16) + ((long long)o0.w << 24);
+        v += ((long long)o1.x << 32) + ((long long)o1.y << 40) + ((long long)o1.z << 48);
+        e_own -= v;
+      }
+      if ((unsigned long long)(e_own + (1ll << 54)) >> 55) ctl_s[1] = 1u;       // left the 55-bit range
+      s3_put_digits7(e_own, edig + 64 * wave + lane, Rp);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ctl_s[0]) { if (tid == 0) a.sc->error = 1u; return false; }
+    // tile j+L+1 (in registers for two iterations) lands in the slot of tile j, spent; the first request for the steps of block
+    // j+1 (older than the tile loads on the in-order memory counter); the loads of tile j+L+3 into the registers just freed
+    if (j + L + 1 < nb) S2F_TILE_COMMIT(j + L + 1, T0, T1);
+    if (upd) pre = ld_agent_raw64(a.dgran + (size_t)((j + 1) % S2_NSLOT) * SW_MAXM + tid);
+    S2F_TILE_ISSUE(j + L + 3, T0, T1);
+    if (!upd && j + L < nb) dots(j + L, edig);
+    return true;
+  };
+  // (tile j+L+1 travels in set (j+L+1) & 1)
+  for (int j = 0; j < nb; j += 2) {
+    if ((L + 1) & 1) { if (!step(j, tb0, tb1)) return; if (j + 1 < nb && !step(j + 1, ta0, ta1)) return; }
+    else { if (!step(j, ta0, ta1)) return; if (j + 1 < nb && !step(j + 1, tb0, tb1)) return; }
+  }
+  __syncthreads();
+  if (ctl_s[0]) { if (tid == 0) a.sc->error = 1u; return; }
+  if (ctl_s[1] && tid == 0) a.sc->error = 2u;
+  if (upd) a.e[row0 + 64 * wave + lane] = (double)e_own * invS;
+#undef S2F_ISSUE1
+#undef S2F_TILE_ISSUE
+#undef S2F_COMMIT1
+#undef S2F_TILE_COMMIT
+}
+
 // A prefetcher: a workgroup on the sequencer's XCD (workgroups go round-robin over the eight XCDs) that reads W and the Gram
 // planes of the blocks a little ahead of the sequencer, so that the sequencer's own loads -- 172 KB per block through ONE CU,
 // whose outstanding-miss capacity bounds it at ~40 GB/s from HBM -- find their lines in the XCD's L2.
@@ -571,11 +835,14 @@ __device__ __forceinline__ void s2w_prefetcher(const SweepArgs &a, const S2WArgs
   if (sink == 0x9E3779B9u && a.stamps) a.stamps[255] = sink;   // (keeps the loads)
 }
 
+template <bool FX>
 __global__ __launch_bounds__(S2W_THREADS) void k_sweep2w(const SweepArgs a, const S2WArgs A) {
-  if ((int)blockIdx.x > a.K) { const int r = (int)blockIdx.x - a.K; if ((r & 7) == 0) s2w_prefetcher(a, A, (r >> 3) - 1); return; }
-  if ((int)blockIdx.x == a.K) s2_sequencer_winv(a, A);
+  const int KS = FX ? A.K3 : a.K;   // streamer workgroups; then the sequencer; then every eighth workgroup a prefetcher
+  if ((int)blockIdx.x > KS) { const int r = (int)blockIdx.x - KS; if ((r & 7) == 0) s2w_prefetcher(a, A, (r >> 3) - 1); return; }
+  if ((int)blockIdx.x == KS) s2_sequencer_winv<FX>(a, A);
   else if (threadIdx.x >= SW_THREADS) return;                            // the streamers are eight waves (a wave that has ended leaves the barriers' count)
   else if ((a.flags & SWF_DEBUG_WITHHOLD) && blockIdx.x == 0) return;   // test hook: a streamer that never shows up
+  else if constexpr (FX) s2w_streamer_fx(a, A);
   else s2_streamer_i8(a);
 }
 

@@ -380,9 +380,11 @@ def test_affine_winv_long_chain_stays_on_the_oracle(model):
     assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
 
 
-@pytest.mark.parametrize("env", [{"BWGR_WINV": "0"}, {"BWGR_WLAG": "2"}, {"BWGR_WLAG": "3"}, {"BWGR_WPF": "0"}, {"BWGR_WPF": "1", "BWGR_WAHEAD": "2"}])
+@pytest.mark.parametrize("env", [{"BWGR_WINV": "0"}, {"BWGR_WLAG": "2"}, {"BWGR_WLAG": "3"}, {"BWGR_WPF": "0"}, {"BWGR_WPF": "1", "BWGR_WAHEAD": "2"},
+                                 {"BWGR_WFX": "0"}, {"BWGR_WFX": "0", "BWGR_WLAG": "2"}, {"BWGR_WNQ": "2"}, {"BWGR_WNQ": "4"}])
 def test_affine_winv_variants_agree(env, monkeypatch):
-    """The serial sequencer (BWGR_WINV=0), shallower pipelines (cross terms of one or two blocks back instead of three) and the
+    """The serial sequencer (BWGR_WINV=0), k_sweep2's streamers under the product sequencer (BWGR_WFX=0: fp64 residual and one
+    word per streamer instead of the fixed-point residual and atomic sums), shallower pipelines (cross terms of one or two blocks back instead of three) and the
     L2 prefetch workgroups switched off or down: the oracle's chain every time, and the default's to 2e-7 (bit for bit where only
     the prefetch changed)."""
     import bwgr_amd
@@ -390,7 +392,7 @@ def test_affine_winv_variants_agree(env, monkeypatch):
     X, y = synth_small(900, 1300, seed=29)
     out = {}
     for name, e in (("default", {}), ("variant", env)):
-        for k in ("BWGR_WINV", "BWGR_WLAG", "BWGR_WPF", "BWGR_WAHEAD"):
+        for k in ("BWGR_WINV", "BWGR_WLAG", "BWGR_WPF", "BWGR_WAHEAD", "BWGR_WFX", "BWGR_WNQ"):
             monkeypatch.delenv(k, raising=False)
         for k, v in e.items():
             monkeypatch.setenv(k, v)
@@ -405,7 +407,8 @@ def test_affine_winv_variants_agree(env, monkeypatch):
     for name in out:
         assert scaled_err(out[name]["b"], o["b"]) < TOL and scaled_err(out[name]["e"], o["e"]) < TOL
     # (another depth means other partial sums of the same numbers, and a float rounding of a draw flips here and there)
-    tol = 0.0 if set(env) <= {"BWGR_WPF", "BWGR_WAHEAD"} else 2e-7
+    # (the streamers' slab-dot sums are exact integers: any number of copies of the sums gives the same bits)
+    tol = 0.0 if set(env) <= {"BWGR_WPF", "BWGR_WAHEAD", "BWGR_WNQ"} else 2e-7
     assert scaled_err(out["default"]["b"], out["variant"]["b"]) <= tol
 
 
