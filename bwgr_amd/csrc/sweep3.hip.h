@@ -43,6 +43,8 @@ static constexpr int S3_MAXD = 16;                    // deepest fold-in lag, bl
 static constexpr int S3_LSTRIDE = 2 * SW_MAXM + 2;    // 8-byte words of one block's list: header, two per entry, one spare
 static constexpr int S3_ND = 7;                       // signed base-256 digits of the fixed-point residual and steps (|q| < 2^55)
 static constexpr int S3_RING = S3_MAXD * SW_MAXM;     // flat ring of included markers in the sequencer's LDS (a power of two)
+static constexpr int S3_GPD_BYTES = 16384;            // LDS copy of a packed diagonal Gram block, 16-bit entries (8128 of them at m = 128)
+static constexpr int S3_NRX = 8;                      // distance-1 / 2 rows of the first S3_NRX included markers of a block land in LDS by DMA
 static constexpr int S3_OS = 12;                      // dwords per row of the int32 recombination scratch (8 used; b128 reads conflict-free)
 
 struct Sweep3Args {
@@ -128,17 +130,32 @@ __device__ __forceinline__ bool s3_epoch_is(unsigned long long w, uint32_t epoch
 
 typedef unsigned int s3_u4 __attribute__((ext_vector_type(4)));
 
+// LDS-DMA as inline asm (16 or 4 bytes per lane to lds_base + 16 / 4 * lane): hipcc tracks the builtin's LDS writes and puts a
+// vmcnt(0) in front of the next LDS access it cannot prove disjoint, which is exactly the wait these copies are meant to avoid
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void s3_dma16(const void *gsrc, const void *lds_base) {
+  const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)lds_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(la) : "memory", "m0");
+}
+__device__ __forceinline__ void s3_dma4(const void *gsrc, const void *lds_base) {
+  const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)lds_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(gsrc), "s"(la) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 __host__ __device__ inline size_t s3_streamer_lds(int R3) {
   const size_t Rp = (size_t)R3 + 16;
   return 2 * (size_t)SW_MAXM * Rp + 2 * 16 * Rp + 2 * 16 * (size_t)S2_DP + (size_t)64 * S3_OS * 4 * 4 + (size_t)8 * 32 * S3_OS * 4 + 64;
 }
-__host__ __device__ inline size_t s3_seq_lds(int D) {
+__host__ __device__ inline size_t s3_seq_lds(int D, bool g16) {
   size_t s = 2 * sizeof(StageBuf) + 2 * 2 * SW_MAXM * sizeof(double);            // constants, spec + gjj
   s += 2 * SW_MAXM * sizeof(double) + 2 * 3 * SW_MAXM * sizeof(double);          // q sums, far-field partial sums (three waves)
   s += 2 * 3 * SW_MAXM * sizeof(float);                                          // state of a block
   (void)D;
   s += (size_t)S3_RING * (sizeof(double) + sizeof(long long) + sizeof(int));       // the included markers of the last D blocks
-  s += (size_t)2 * 3 * 16 * SW_MAXM * 4;                                           // far-field rows in flight (sized for 32-bit entries)
+  s += (size_t)2 * 3 * 16 * SW_MAXM * (g16 ? 2 : 4);                               // far-field rows in flight
+  if (g16) s += (size_t)3 * S3_GPD_BYTES + (size_t)S3_NRX * 2 * SW_MAXM * 2;       // the packed diagonal block of three blocks, distance-1 / 2 rows of this block's included markers
   return s + 256;
 }
 
@@ -779,6 +796,12 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   float2 *accS = reinterpret_cast<float2 *>(smem + off); off += (size_t)S3_RING * sizeof(float2);          // ... as the two float steps {included, rejected}
   int *accK = reinterpret_cast<int *>(smem + off); off += (size_t)S3_RING * sizeof(int);                    // k | source block << 8
   unsigned char *rowf_s = smem + off; off += (size_t)2 * 3 * 16 * SW_MAXM * sizeof(GT);                     // far-field rows landing by LDS-DMA [parity][wave][row]
+  constexpr bool G16 = (sizeof(GT) == 2);
+  // 16-bit panels: the packed diagonal block of the block in flight and of the next one (LDS-DMA by the staging waves, a phase
+  // ahead), so that an included marker's row is an LDS read inside the chain instead of an HBM miss; and the distance-1 / 2 rows
+  // of the block's included markers, requested by DMA when the marker is included and consumed after the block's last round
+  unsigned char *gpd_s = smem + off; if (G16) off += (size_t)3 * S3_GPD_BYTES;
+  unsigned char *rowx_s = smem + off; if (G16) off += (size_t)S3_NRX * 2 * SW_MAXM * 2;
   int *ctrl_s = reinterpret_cast<int *>(smem + off);   // [0] ok flag
   int *pos_s = ctrl_s + 8;                             // [b & 31]: ring position where block b's entries begin
   const unsigned char **gx_s = reinterpret_cast<const unsigned char **>(ctrl_s + 40);   // the cross Gram arrays' base addresses (a table in LDS: indexed per entry)
@@ -812,6 +835,17 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   auto stage_commit = [&](int c) {
     const int t = tid - 128;
     *stage_dst(c, t) = sg0; *stage_dst(c, t + 128) = sg1; *stage_dst(c, t + 256) = sg2; *stage_dst(c, t + 384) = sg3;
+  };
+  auto gpd_issue = [&](int c) {   // waves 2-3, 16-bit panels: block c's packed diagonal block, 1 KiB pieces alternating between the two waves
+    if constexpr (G16) {
+      const int gpbytes = pstride * 2;
+      const unsigned char *src = reinterpret_cast<const unsigned char *>(gp_all + (size_t)(a.blk_begin + c) * pstride);
+      unsigned char *dst = gpd_s + (size_t)(c % 3) * S3_GPD_BYTES;
+      for (int pc = wave - 2; pc * 1024 < gpbytes; pc += 2) {
+        const int o = pc * 1024 + lane * 16;
+        if (o + 16 <= gpbytes) s3_dma16(src + o, dst + pc * 1024);   // (pstride is a multiple of 8 entries: whole 16-byte chunks)
+      }
+    }
   };
   // wave 1: the K3 slab dots of block c, summed by the streamers' atomics; two markers per lane.  The four words a lane needs are
   // requested one phase ahead (pq_*): the streamers run blocks ahead of the sequencer, so in steady state the words are complete
@@ -991,7 +1025,13 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   };
   auto helper_phase = [&](int c) {   // block c >= 1, while wave 0 runs block c-1
     if (wave == 1) { if (!(A.dbg & 32768)) { if (!poll_q(c)) ctrl_s[0] = 0; } }
-    else if (wave <= 3) { if (!(A.dbg & 8192)) { stage_commit(c); if (c + 1 < nb) stage_request(c + 1); } }
+    else if (wave <= 3) { if (!(A.dbg & 8192)) {
+      // the constants of block c, requested a phase ago -- waiting for them also waits for block c's packed diagonal block, whose
+      // DMA was issued before them; then the requests for block c+1 (the DMA first), which have this whole phase to land
+      stage_commit(c);
+      if (c + 1 < nb) { gpd_issue(c + 1); stage_request(c + 1); }
+      else if constexpr (G16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } }
     else if (wave == 4) { }   // idle: the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots
     else if (wave <= 6) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1009,7 +1049,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   if (tid >= 64 && tid < 64 + S3_MAXD) gx_s[tid - 64] = reinterpret_cast<const unsigned char *>(A.gx[tid - 64]);
   __syncthreads();
   if (wave == 1) { poll_request(0); if (!poll_q(0)) ctrl_s[0] = 0; }
-  else if (wave == 2 || wave == 3) { stage_request(0); stage_commit(0); if (nb > 1) stage_request(1); }
+  else if (wave == 2 || wave == 3) { gpd_issue(0); stage_request(0); stage_commit(0); if constexpr (G16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (nb > 1) { gpd_issue(1); stage_request(1); } }
   else if (wave >= 5 && wave <= 6) { far_consume(0, wave - 5); far_issue(1, wave - 5); }
   else if (wave == 7) { for (int c = 0; c < PF; ++c) touch(c); chi_request(0); }
   __syncthreads();
@@ -1073,21 +1113,35 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
 #define S3_INCLUDE(KOFF_, D1F_, DR_) { \
         const int k_ = (KOFF_) + js; \
         const int pr_ = prow(k_); \
-        GT ga_ = (GT)1, gb_ = (GT)1, xa_ = (GT)1, xb_ = (GT)1, ya_ = (GT)1, yb_ = (GT)1; \
+        GT ga_ = (GT)1, gb_ = (GT)1, xa_ = (GT)0, xb_ = (GT)0, ya_ = (GT)0, yb_ = (GT)0; \
+        bool direct_ = true; \
         if (!(A.dbg & 64)) { \
-        ga_ = gp[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gp[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)];   /* (the last row is empty) */ \
+        if constexpr (G16) { \
+          const GT *gpl_ = reinterpret_cast<const GT *>(gpd_s + (size_t)(b % 3) * S3_GPD_BYTES); \
+          ga_ = gpl_[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gpl_[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)]; \
+          if (nacc < S3_NRX) {   /* the rows for the next two blocks: by DMA, consumed after the last round */ \
+            direct_ = false; \
+            const int ro_ = min(lane * 4, rowbytes - 4); \
+            if (use1) s3_dma4(reinterpret_cast<const unsigned char *>(g1 + (size_t)k_ * m) + ro_, rowx_s + (size_t)(nacc * 2) * (SW_MAXM * 2)); \
+            if (use2) s3_dma4(reinterpret_cast<const unsigned char *>(g2 + (size_t)k_ * m) + ro_, rowx_s + (size_t)(nacc * 2 + 1) * (SW_MAXM * 2)); \
+          } \
+        } else { \
+          ga_ = gp[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gp[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)];   /* (the last row is empty) */ \
+        } \
+        if (direct_) { \
         const GT *row_ = g1 + (use1 ? (size_t)k_ * m : (size_t)0);   /* (without a next block: a harmless in-bounds read) */ \
         xa_ = row_[use1 ? min(l0, m - 1) : 0]; xb_ = row_[use1 ? l1c : 0]; \
         const GT *row2_ = g2 + (use2 ? (size_t)k_ * m : (size_t)0); \
-        ya_ = row2_[use2 ? min(l0, m - 1) : 0]; yb_ = row2_[use2 ? l1c : 0]; } \
+        ya_ = row2_[use2 ? min(l0, m - 1) : 0]; yb_ = row2_[use2 ? l1c : 0]; } } \
         const float dacc_ = readlane_f32(D1F_, js), drj_ = readlane_f32(DR_, js); \
         const double corr_ = (double)dacc_ - (double)drj_; \
         if (lane == 0) { const int sl_ = (pos0 + nacc) & (ring - 1); accK[sl_] = k_ | (b << 8); accC[sl_] = corr_; accS[sl_] = make_float2(dacc_, drj_); } \
         ++nacc; \
         r0 = fma(-(double)((l0 > k_) ? ga_ : (GT)0), corr_, r0); \
         r1 = fma(-(double)((l1 > k_ && l1 < m) ? gb_ : (GT)0), corr_, r1); \
+        if (direct_) { \
         if (use1) { rnext0 = fma(-(double)xa_, corr_, rnext0); rnext1 = fma(-(double)xb_, corr_, rnext1); } \
-        if (use2) { rnxt20 = fma(-(double)ya_, corr_, rnxt20); rnxt21 = fma(-(double)yb_, corr_, rnxt21); } }
+        if (use2) { rnxt20 = fma(-(double)ya_, corr_, rnxt20); rnxt21 = fma(-(double)yb_, corr_, rnxt21); } } }
       // exact speculative rounds, first over markers 0..63, then 64..127: every lane assumes "nobody before me is included"
       if (!(A.dbg & 128)) {
         const int cnt0 = min(64, mB);
@@ -1119,6 +1173,19 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       }
 #undef S3_EVAL
 #undef S3_INCLUDE
+      if constexpr (G16) {
+        if (nacc > 0 && !(A.dbg & 64)) {   // the distance-1 / 2 rows requested as the markers appeared
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          const int nx = min(nacc, S3_NRX);
+          for (int i = 0; i < nx; ++i) {
+            const double cf = accC[(pos0 + i) & (ring - 1)];
+            const uint16_t *rw1 = reinterpret_cast<const uint16_t *>(rowx_s + (size_t)(i * 2) * (SW_MAXM * 2));
+            const uint16_t *rw2 = reinterpret_cast<const uint16_t *>(rowx_s + (size_t)(i * 2 + 1) * (SW_MAXM * 2));
+            if (use1) { rnext0 = fma(-(double)rw1[min(l0, m - 1)], cf, rnext0); rnext1 = fma(-(double)rw1[l1c], cf, rnext1); }
+            if (use2) { rnxt20 = fma(-(double)rw2[min(l0, m - 1)], cf, rnxt20); rnxt21 = fma(-(double)rw2[l1c], cf, rnxt21); }
+          }
+        }
+      }
       S3ST(2, sq0);
       // the block's new effects (every lane's r is final for its own marker); the rest of the outputs is wave 7's
       {
