@@ -1068,8 +1068,8 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     else if (wave <= 3) { if (!(A.dbg & 8192)) {
       // the constants of block c, requested a phase ago -- waiting for them also waits for block c's packed diagonal block, whose
       // DMA was issued before them; then the requests for block c+1 (the DMA first), which have this whole phase to land
-      stage_commit(c);
-      if (c + 1 < nb) { gpd_issue(c + 1); stage_request(c + 1); }
+      if (!(A.dbg & 262144)) stage_commit(c);
+      if (c + 1 < nb) { if (!(A.dbg & 131072)) gpd_issue(c + 1); if (!(A.dbg & 262144)) stage_request(c + 1); }
       else if constexpr (G16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } }
     else if (wave == 4) { }   // idle: the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots
@@ -1309,14 +1309,18 @@ __device__ __forceinline__ void s3_prefetcher(const Sweep3Args &A) {
         __builtin_amdgcn_s_sleep(4);
       }
     }
+    // what the staging waves will ask for: the block's constants, speculative terms and packed diagonal Gram block, one dword per
+    // 128-byte line (their loads are HBM misses ~2 us away on the sequencer's CU, and they must be back within one block period)
     const int blk = a.blk_begin + c;
     const unsigned char *gpb = reinterpret_cast<const unsigned char *>(A.gp) + (size_t)blk * gpbytes;
-    for (size_t o = (size_t)tid * 128; o < gpbytes; o += (size_t)SW_THREADS * 128) sink += *reinterpret_cast<const uint32_t *>(gpb + o);
-    for (int d = 1; d <= 2; ++d) {
-      if (d >= A.D || c + d >= nb) continue;
-      const unsigned char *gxb = reinterpret_cast<const unsigned char *>(A.gx[d - 1]) + (size_t)(blk + d) * gxbytes;
-      for (size_t o = (size_t)tid * 128; o < gxbytes; o += (size_t)SW_THREADS * 128) sink += *reinterpret_cast<const uint32_t *>(gxb + o);
-    }
+    const unsigned char *stb = reinterpret_cast<const unsigned char *>(a.ps.blocks + blk);
+    const unsigned char *spb = reinterpret_cast<const unsigned char *>(a.ps.spec + blk);
+    const size_t o = (size_t)tid * 128;
+    if (o < sizeof(StageBuf)) sink += *reinterpret_cast<const uint32_t *>(stb + o);
+    if (o < sizeof(SpecBuf)) sink += *reinterpret_cast<const uint32_t *>(spb + o);
+    if (o < gpbytes) sink += *reinterpret_cast<const uint32_t *>(gpb + o);
+    if (a.ps.ev3 && o < sizeof(Eval3Buf)) sink += *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(a.ps.ev3 + blk) + o);
+    (void)gxbytes;
   }
   if (sink == 0x9E3779B9u && a.stamps) a.stamps[255] = sink;   // (keeps the loads alive)
 }
