@@ -222,7 +222,7 @@ def main():
     for name in ("r02_pmc_c4.json", "r01_pmc_c4.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if pm["workload"] == args.workload and pm["n"] == n and pm["p"] == p and pm.get("kernel", "k_sweep2<int8>").split("<")[0] == kernel.split("<")[0]:
+            if pm["workload"] == args.workload and pm["n"] == n and pm["p"] == p and kernel.split("<")[0] in pm.get("kernel", "k_sweep2<int8>").split("<")[0].split("::")[-1].split():
                 traffic, traffic_source = pm["traffic_bytes_per_launch"], "profiles/%s (an earlier rocprofv3 --pmc pass of this kernel, not measured in this run)" % name
                 break
         except Exception:
