@@ -131,8 +131,10 @@ def main():
     K, W = args.steps, args.warmup
     if bwgr_amd.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: bwgr_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = local_rank
+    ndev = torch.cuda.device_count()
+    shared = local_rank >= ndev     # rehearsal on a box with fewer GPUs than ranks: ranks share devices, gloo instead of RCCL
+    dev = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev)
 
     if (world > 1 and args.sharded) or os.environ.get("BWGR_FORCE_DIST"):   # BWGR_FORCE_DIST=1: rehearse the sharded leg with one rank
         from bwgr_amd import dist as bdist
@@ -146,8 +148,10 @@ def main():
         # partitioned sampler the north-star sketches overshoots on uncentred genotypes at every exchange window that would scale).
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        shared_any = world > ndev
         if not dist.is_initialized():
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            if shared_any: dist.init_process_group("gloo")
+            else: dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         X = synth.genotypes(n, p, device=dev)
         y = synth.scale_phenotype(synth.phenotype(X, n))
         P = bwgr_amd.Panel(X, n=n, device=dev, block=args.block, nwg=args.nwg)
@@ -159,7 +163,7 @@ def main():
         t0 = time.perf_counter()
         ch.run(K); ch.sync()
         dist.barrier(); torch.cuda.synchronize()
-        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda:%d" % dev)
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if shared_any else "cuda:%d" % dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
         sweep_ms, launches = ch.sweep_ms()
