@@ -926,6 +926,7 @@ struct bwgr_panel {
   double *winv = nullptr;         // per handle: [nblocks][S2W_WDOUBLES], written by k_affine_inv before every affine sweep
   unsigned char *gxt[S2W_MAXDIST] = {};   // the cross Gram blocks as the sequencer's MFMA operand (k_gx_planes); shared with clones
   unsigned long long *qsumw = nullptr;    // per handle: the fixed-point streamers' slab-dot sums [nblocks][SW_MAXM][2]
+  int wpf = 4, wahead = 5, wnq = 0, wlag_cap = 4;   // BWGR_WPF / BWGR_WAHEAD / BWGR_WNQ (0: by the streamer count) / BWGR_WLAG, read when the panel is made
   bool wfx_on = true;             // BWGR_WFX=0: k_sweep2's streamers under the product sequencer instead of the fixed-point ones
   int winv_nd = 0;                // distances built = the deepest lag the affine sweeps can run, minus one
   size_t ldsw_bytes = 0;
@@ -1180,15 +1181,13 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
   }
   if (use_winv(P, a.flags) && P->winv) {
     S2WArgs A;
+    memset(&A, 0, sizeof(A));
     A.winv = P->winv; A.nd = a.lag - 1;
     for (int d = 0; d < S2W_MAXDIST; ++d) A.gxt[d] = P->gxt[d < P->winv_nd ? d : 0];
-    A.npf = 4;      // measured at C2: 0 -> 540, 2 -> 636, 4 -> 685 iter/s (6 and 8 no better)
-    A.ahead = 5;
-    if (const char *pv = getenv("BWGR_WPF")) A.npf = std::max(0, std::min(8, atoi(pv)));
-    if (const char *pv = getenv("BWGR_WAHEAD")) A.ahead = std::max(1, atoi(pv));
+    A.npf = P->wpf;      // measured at C2: 0 -> 540, 2 -> 636, 4 -> 685 iter/s (6 and 8 no better)
+    A.ahead = P->wahead;
     A.fx = use_wfx(P) ? 1 : 0; A.qsum = P->qsumw; A.sub = P->R / S2W_FXR; A.K3 = P->K * A.sub;
-    A.nq = A.K3 > 48 ? 2 : 1;
-    if (const char *qv = getenv("BWGR_WNQ")) { const int v = atoi(qv); if (v == 1 || v == 2 || v == 4) A.nq = v; }
+    A.nq = P->wnq ? P->wnq : (A.K3 > 48 ? 2 : 1);   // (C2, 40 streamers: one copy 1.10 ms, two 1.21; C4 shape, 80 streamers: 27.8 / 25.6 / 27.6 ms with 1 / 2 / 4)
     if (A.fx) (void)hipMemsetAsync(P->qsumw + (size_t)a.blk_begin * A.nq * 2 * SW_MAXM, 0, sizeof(unsigned long long) * A.nq * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
     if (A.fx) hipLaunchKernelGGL(k_sweep2w<true>, dim3(A.K3 + 1 + 8 * A.npf), dim3(S2W_THREADS), P->ldsw_bytes, P->stream, a, A);
     else hipLaunchKernelGGL(k_sweep2w<false>, dim3(P->K + 1 + 8 * A.npf), dim3(S2W_THREADS), P->ldsw_bytes, P->stream, a, A);
@@ -1232,8 +1231,7 @@ static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
   }
   a.lag = lag < cap ? lag : cap;
   if (use_winv(P, a.flags)) {   // the affine sweeps' product sequencer: as deep as the panel's cross Gram planes reach (BWGR_WLAG caps it)
-    a.lag = std::min(4, P->winv_nd + 1);
-    if (const char *wl = getenv("BWGR_WLAG")) if (wl[0] >= '2' && wl[0] <= '4') a.lag = std::min(a.lag, wl[0] - '0');
+    a.lag = std::min(std::min(4, P->winv_nd + 1), P->wlag_cap);
   }
 }
 static int launch_sweep(bwgr_panel *P, SweepArgs &a) {
@@ -1547,6 +1545,10 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   if (!P->is_f32) P->ldsw_bytes = s2w_lds_bytes(m, R);
   if (const char *wv = getenv("BWGR_WINV")) P->winv_on = !(wv[0] == '0');
   if (const char *wv = getenv("BWGR_WFX")) P->wfx_on = !(wv[0] == '0');
+  if (const char *pv = getenv("BWGR_WPF")) P->wpf = std::max(0, std::min(8, atoi(pv)));
+  if (const char *pv = getenv("BWGR_WAHEAD")) P->wahead = std::max(1, atoi(pv));
+  if (const char *qv = getenv("BWGR_WNQ")) { const int v = atoi(qv); if (v == 1 || v == 2 || v == 4) P->wnq = v; }
+  if (const char *wl = getenv("BWGR_WLAG")) if (wl[0] >= '2' && wl[0] <= '4') P->wlag_cap = wl[0] - '0';
   if (const char *dv = getenv("BWGR_DENSE_THR")) { const float v = (float)atof(dv); if (v >= 0.0f) P->dense_thr = std::max(v, 1e-9f); }   // (0: always)
 #undef PCHK
   (void)rc;
