@@ -1624,7 +1624,8 @@ extern "C" int bwgr_panel_max_concurrent(const bwgr_panel *P, int selection, int
   if (!P || !count) return fail(BWGR_EINVAL, "null pointer");
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, P->device));
-  const int wgs = (selection && P->sweep_version == 3 && P->e3_ready) ? P->K3 + 1 : P->K + 1 + ((P->sweep_version >= 2 && selection) ? P->nfeed : 0);
+  int wgs = (selection && P->sweep_version == 3 && P->e3_ready) ? P->K3 + 1 : P->K + 1 + ((P->sweep_version >= 2 && selection) ? P->nfeed : 0);
+  if (!selection && use_winv(P, 0)) wgs = (use_wfx(P) ? P->K * (P->R / S2W_FXR) : P->K) + 1 + P->wpf;   // streamers, sequencer, L2 prefetchers (the launch's other workgroups leave at once)
   // one sweep workgroup per CU even where the LDS would admit two (small blocks): measured, sharing a CU costs more than it adds
   *count = std::max(1, prop.multiProcessorCount / wgs);
   if (const char *ov = getenv("BWGR_MAX_CONCURRENT")) { const int v = atoi(ov); if (v > 0) *count = v; }   // experiments
