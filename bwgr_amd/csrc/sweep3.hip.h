@@ -1331,7 +1331,11 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep3(const Sweep3Args A) {
   if ((int)blockIdx.x == A.pf) { s3_prefetcher<GT>(A); return; }
   if (blockIdx.x == 0) { if (!(A.dbg & 1024)) s3_sequencer<GT>(A); }
   else if ((A.a.flags & SWF_DEBUG_WITHHOLD) && blockIdx.x == 1 && A.pf != 1) return;   // test hook: a streamer that never shows up
+#ifdef BWGR_S3V2
   else if (!(A.dbg & 2048)) { if ((A.dbg & 4) && A.R3 >= 128) s3_streamer_v2(A); else s3_streamer(A); }   // (BWGR_DBG3=4: the streamer with hand-counted waits; measured no faster)
+#else
+  else if (!(A.dbg & 2048)) s3_streamer(A);   // (the hand-counted streamer is compiled in with -DBWGR_S3V2 only: measured no faster, and 10 KB of code less in the kernel)
+#endif
 }
 
 }  // namespace bwgr
