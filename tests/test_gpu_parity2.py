@@ -464,3 +464,22 @@ def test_dense_recurrence_is_the_same_chain(model, pi, thr, monkeypatch):
     o = O.bayes(model, y, X, it=10, bi=2, pi=pi, seed=6)["last"]
     assert np.array_equal(st["d"], o["d"])
     assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
+
+
+@pytest.mark.parametrize("model,pi", [("BayesB", 0.97), ("BayesCpi", 0.0)])
+def test_long_chains_on_a_mid_size_panel(model, pi, monkeypatch):
+    """150 iterations at n = 2000 x p = 16 000 (125 blocks, 8 slabs): k_sweep3 with its LDS-staged Gram blocks and deferred row
+    requests (BayesB) and the dense selection sweeps of k_sweep2 (BayesCpi), hundreds of thousands of block hand-offs each, against
+    the oracle: identical decisions, effects and residual to 1e-6."""
+    import bwgr_amd
+    from oracle import oracle as O
+    monkeypatch.setenv("BWGR_ENG3_THR", "0.05")
+    X, y = synth_small(2000, 16000, seed=43, causal=0.01)
+    P = bwgr_amd.Panel(X)
+    ch = bwgr_amd.Chain(P, model, y, it=150, bi=50, pi=pi, seed=21)
+    ch.run(150)
+    st = ch.state()
+    ch.close(); P.close()
+    o = O.bayes(model, y, X, it=150, bi=50, pi=pi, seed=21)["last"]
+    assert np.array_equal(st["d"], o["d"])
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
