@@ -825,6 +825,10 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   int *accK = reinterpret_cast<int *>(smem + off); off += (size_t)S3_RING * sizeof(int);                    // k | source block << 8
   unsigned char *rowf_s = smem + off; off += (size_t)2 * 3 * 16 * SW_MAXM * sizeof(GT);                     // far-field rows landing by LDS-DMA [parity][wave][row]
   constexpr bool G16 = (sizeof(GT) == 2);
+#ifndef BWGR_GPD3
+#define BWGR_GPD3 1
+#endif
+  constexpr bool GPD = G16 && (BWGR_GPD3 != 0);   // the packed diagonal block staged through LDS (else: an included marker's row is read from global memory inside the chain)
   // 16-bit panels: the packed diagonal block of the block in flight and of the next one (LDS-DMA by the staging waves, a phase
   // ahead), so that an included marker's row is an LDS read inside the chain instead of an HBM miss; and the distance-1 / 2 rows
   // of the block's included markers, requested by DMA when the marker is included and consumed after the block's last round
@@ -877,7 +881,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     }
   };
   auto gpd_issue = [&](int c) {   // waves 2-3, 16-bit panels: block c's packed diagonal block, 1 KiB pieces alternating between the two waves
-    if constexpr (G16) {
+    if constexpr (GPD) {
       const int gpbytes = pstride * 2;
       const unsigned char *src = reinterpret_cast<const unsigned char *>(gp_all + (size_t)(a.blk_begin + c) * pstride);
       unsigned char *dst = gpd_s + (size_t)(c % 3) * S3_GPD_BYTES;
@@ -1070,7 +1074,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       // DMA was issued before them; then the requests for block c+1 (the DMA first), which have this whole phase to land
       if (!(A.dbg & 262144)) stage_commit(c);
       if (c + 1 < nb) { if (!(A.dbg & 131072)) gpd_issue(c + 1); if (!(A.dbg & 262144)) stage_request(c + 1); }
-      else if constexpr (G16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if constexpr (GPD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } }
     else if (wave == 4) { }   // idle: the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots
     else if (wave <= 6) {
@@ -1173,8 +1177,12 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
         bool direct_ = true; \
         if (!(A.dbg & 64)) { \
         if constexpr (G16) { \
-          const GT *gpl_ = reinterpret_cast<const GT *>(gpd_s + (size_t)(b % 3) * S3_GPD_BYTES); \
-          ga_ = gpl_[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gpl_[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)]; \
+          if constexpr (GPD) { \
+            const GT *gpl_ = reinterpret_cast<const GT *>(gpd_s + (size_t)(b % 3) * S3_GPD_BYTES); \
+            ga_ = gpl_[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gpl_[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)]; \
+          } else { \
+            ga_ = gp[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gp[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)]; \
+          } \
           if (nacc < S3_NRX) {   /* the rows for the next two blocks: by DMA, consumed after the last round */ \
             direct_ = false; \
             const int ro_ = min(lane * 4, rowbytes - 4); \
