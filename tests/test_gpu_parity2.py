@@ -483,3 +483,23 @@ def test_long_chains_on_a_mid_size_panel(model, pi, monkeypatch):
     o = O.bayes(model, y, X, it=150, bi=50, pi=pi, seed=21)["last"]
     assert np.array_equal(st["d"], o["d"])
     assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
+
+
+@pytest.mark.parametrize("model,pi", [("BayesA", 0.0), ("BayesB", 0.9)])
+@pytest.mark.parametrize("scale", [1e-6, 1e5])
+def test_fixed_point_engines_follow_the_phenotype_scale(model, pi, scale):
+    """k_sweep3 and the affine engine's streamers keep the residual on a per-sweep fixed-point grid chosen from the residual's own
+    largest exponent: phenotypes a million times smaller or a hundred thousand times larger than unit variance give the same chain,
+    scaled (no range flag, same parity)."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y = synth_small(500, 900, seed=47)
+    ys = (y * scale).astype(y.dtype)
+    P = bwgr_amd.Panel(X)
+    ch = bwgr_amd.Chain(P, model, ys, it=12, bi=2, pi=pi, seed=5)
+    ch.run(12)
+    st = ch.state()
+    ch.close(); P.close()
+    o = O.bayes(model, ys, X, it=12, bi=2, pi=pi, seed=5)["last"]
+    assert pi == 0.0 or np.array_equal(st["d"], o["d"])
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
