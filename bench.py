@@ -61,6 +61,42 @@ def cpu_baseline(Xs_host, y_host, model, pi, p_total, budget_s=14.0):
                       "flags), %.3f s per slice sweep; host has %d cores" % (ps, p_total, n, per_sweep, per_sweep_o2, os.cpu_count())}
 
 
+def paired_leg(P, model, y, pi, npairs, K, W, n, p):
+    """2 x npairs independent chains, two to a set of streamer workgroups (bwgr_chain_run_pair, k_sweep3p: one pass over the
+    genotypes serves a pair; every chain is bit-identical to the one it would be alone, tests/test_gpu_parity2.py)."""
+    import torch
+    import bwgr_amd
+    from bwgr_amd import synth
+    handles = [P] + [P.clone() for _ in range(2 * npairs - 1)]
+    chains = [bwgr_amd.Chain(h, model, y, it=W + K, bi=W, pi=pi, df=5, R2=0.5, seed=synth.SEED + i) for i, h in enumerate(handles)]
+    try:
+        for _ in range(W):
+            for i in range(npairs):
+                chains[2 * i].run_pair(chains[2 * i + 1], 1)
+        for c in chains:
+            c.sync(); c.sweep_ms()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            for i in range(npairs):
+                chains[2 * i].run_pair(chains[2 * i + 1], 1)
+        for c in chains:
+            c.sync()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        kms = [chains[2 * i].sweep_ms()[0] for i in range(npairs)]
+        rate = 2 * npairs * K / el
+        return {"chains": 2 * npairs, "pairs": npairs, "value": rate, "unit": "chain-iter/s", "ms_per_step_all_chains": 1e3 * el / K,
+                "sweep_kernel_ms_per_pair": kms, "genotype_GBps": npairs * (K / el) * float(n) * float(p) / 1e9,
+                "frac_of_hbm_peak": npairs * (K / el) * float(n) * float(p) / 1e9 / HBM_PEAK_GBS,
+                "note": "two chains share one read of X: bytes moved = pairs x n x p per step"}
+    finally:
+        for c in chains:
+            c.close()
+        for h in handles[1:]:
+            h.close()
+
+
 def concurrent_leg(P, model, y, pi, nch, K, W, n, p):
     """nch independent chains (seeds SEED, SEED+1, ...) of the same model on the one resident panel, each on its own
     clone (private sweep scratch + stream, shared genotypes): K iterations of every chain, timed like the main leg.
@@ -112,6 +148,7 @@ def main():
                     "resident panel (0 = as many as fit the chip, 1 = skip the leg); reported as concurrent_chains")
     ap.add_argument("--sharded", action="store_true", help="N > 1: the marker-sharded partitioned sampler (one chain over N GPUs, RCCL "
                     "residual all-reduce) instead of N replica chains; statistically unsound on uncentred genotypes, see DESIGN.md section 8")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs of chains in the paired-chains leg (0: as many as fit)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-slice", type=int, default=20000)
     args = ap.parse_args()
@@ -255,6 +292,13 @@ def main():
             out["concurrent_chains"] = concurrent_leg(P, model, y, pi, nch, K, W, n, p)
         except Exception as ex:   # the headline leg above stands on its own
             out["concurrent_chains"] = {"chains": nch, "error": str(ex)}
+    if pi and pl["generation"] == 3 and args.chains != 1:
+        npairs = args.pairs if args.pairs > 0 else max(1, (256 - 40) // (P.nwg * (P.slab_rows // 256 if P.slab_rows >= 256 else 1) + 2))   # (a pair holds K3 + 2 CUs for the sweep; ~40 CUs stay free for the iterations' small kernels: six pairs at C4 measured slower than five)
+        try:
+            os.environ["BWGR_ENG3_THR"] = os.environ.get("BWGR_ENG3_THR", "0.02")
+            out["paired_chains"] = paired_leg(P, model, y, pi, npairs, K, W, n, p)
+        except Exception as ex:
+            out["paired_chains"] = {"pairs": npairs, "error": str(ex)}
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(Xs_host, y.cpu().numpy(), model, pi, p)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -172,6 +172,12 @@ class Chain:
     def run(self, iters):
         check(_lib.lib().bwgr_chain_run(self._h, int(iters)))
 
+    def run_pair(self, other, iters):
+        """Advance this chain and `other` (a chain on a clone of the same resident panel) `iters` iterations in lockstep on one set
+        of streamer workgroups -- one pass over the genotypes for both (bwgr_chain_run_pair).  Each chain's results are the ones it
+        would have alone."""
+        check(_lib.lib().bwgr_chain_run_pair(self._h, other._h, int(iters)))
+
     def sync(self):
         check(_lib.lib().bwgr_chain_sync(self._h))
 

@@ -15,6 +15,7 @@
 #include "sweep.hip.h"
 #include "sweep3.hip.h"
 #include "sweep2w.hip.h"
+#include "sweep3p.hip.h"
 #include <stdlib.h>
 
 using namespace bwgr;
@@ -932,6 +933,7 @@ struct bwgr_panel {
   size_t ldsw_bytes = 0;
   float dense_thr = 1.0f;         // selection sweeps of chains with at least this share of markers in the model run the marker-by-marker recurrence
                                   // (BWGR_DENSE_THR; >= 1, the default: never -- measured no faster than the rounds at any inclusion rate)
+  bool force3 = false;            // a pair run (bwgr_chain_run_pair): every selection sweep is k_sweep3's, whatever the inclusion rate
   float eng3_thr = 0.02f;         // k_sweep3 takes the sweeps whose chains hold fewer than this share of markers in the model (BWGR_ENG3_THR)
   hipStream_t own_stream = nullptr;
 };
@@ -1084,11 +1086,13 @@ static int sweep3_build(bwgr_panel *P) {
   CHK(sweep3_alloc_scratch(P));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<int32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3p<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3p<int32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   P->e3_ready = true;
   return BWGR_OK;
 }
-static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
-  Sweep3Args A;
+// what one launch of k_sweep3 / k_sweep3p needs beside the sweep's own arguments; zeroes the launch's slab-dot sums, takes a new epoch
+static void sweep3_args(bwgr_panel *P, const SweepArgs &a, Sweep3Args &A) {
   memset(&A, 0, sizeof(A));
   A.a = a;
   const bwgr_panel *root = P->parent ? P->parent : P;
@@ -1098,13 +1102,18 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
   A.qsum = P->qsum3; A.lists = P->lists3;
   P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1;
   A.epoch = P->epoch3;
+  A.pf = -1;
   if (const char *dv = getenv("BWGR_DBG3")) A.dbg = atoi(dv);
-  // one more workgroup, on the sequencer's XCD (workgroups with equal index mod 8 share an XCD), warms that XCD's L2 with the Gram
-  // rows the sequencer reads on demand; BWGR_PF3=1 switches it on
-  const char *pv = getenv("BWGR_PF3");
-  const bool pf_on = (pv && pv[0] == '1') && P->K3 + 2 <= 256;   // (measured: helps panels of few blocks' acceptance-heavy early sweeps, not C4; off by default)
-  A.pf = pf_on ? ((P->K3 + 2 > 8) ? 8 : P->K3 + 1) : -1;
   (void)hipMemsetAsync(P->qsum3 + (size_t)a.blk_begin * 2 * SW_MAXM, 0, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
+}
+static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
+  Sweep3Args A;
+  sweep3_args(P, a, A);
+  // one more workgroup, on the sequencer's XCD (workgroups with equal index mod 8 share an XCD), warms that XCD's L2 with what the
+  // staging waves load; BWGR_PF3=1 switches it on
+  const char *pv = getenv("BWGR_PF3");
+  const bool pf_on = (pv && pv[0] == '1') && P->K3 + 2 <= 256;   // (measured: no gain at C4; off by default)
+  A.pf = pf_on ? ((P->K3 + 2 > 8) ? 8 : P->K3 + 1) : -1;
   const dim3 grid(P->K3 + 1 + (pf_on ? 1 : 0)), blk(SW_THREADS);
   if (A.g16) hipLaunchKernelGGL(k_sweep3<uint16_t>, grid, blk, P->lds3_bytes, P->stream, A);
   else hipLaunchKernelGGL(k_sweep3<int32_t>, grid, blk, P->lds3_bytes, P->stream, A);
@@ -1113,7 +1122,7 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
 // The selection models' sweeps on a panel that has k_sweep3: the device picks the engine from the chain's current inclusion
 // rate (ChainScalars::inc_rate against the panel's threshold), so both engines' kernels are enqueued and one side leaves at once
 // (a few microseconds per iteration); a threshold >= 1 means k_sweep3 always and the other side is not enqueued at all.
-static float sweep3_gate(const bwgr_panel *P, int flags) { return use_sweep3(P, flags) ? (P->eng3_thr >= 1.0f ? INFINITY : P->eng3_thr) : 0.0f; }
+static float sweep3_gate(const bwgr_panel *P, int flags) { return use_sweep3(P, flags) ? ((P->eng3_thr >= 1.0f || P->force3) ? INFINITY : P->eng3_thr) : 0.0f; }
 
 // The affine sweeps of an int8 panel with 16-bit Gram staging run k_sweep2w: the block solve as a product with the inverse
 // k_affine_inv forms before the sweep (sweep2w.hip.h).
@@ -1840,14 +1849,10 @@ extern "C" int bwgr_chain_create(bwgr_chain **out, bwgr_panel *P, int model, con
   return bwgr_chain_create_sharded(out, P, model, y, memloc, it, bi, pi, df, R2, seed, rng_mode, 0, P->p, P->MSx, nullptr);
 }
 
-extern "C" int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end) {
-  if (!C) return fail(BWGR_EINVAL, "null chain");
-  bwgr_panel *P = C->P;
-  if (blk_begin < 0 || blk_end > P->nblocks || blk_begin >= blk_end) return fail(BWGR_EINVAL, "sweep_blocks: bad range [%d,%d) of %lld", blk_begin, blk_end, (long long)P->nblocks);
-  if (C->done >= C->iit) return fail(BWGR_EINVAL, "sweep_blocks: all %d iterations already run", C->iit);
-  HIPCHK(hipSetDevice(P->device));
+static void chain_args(const bwgr_chain *C, int blk_begin, int blk_end, SweepArgs &a) {
+  const bwgr_panel *P = C->P;
   const int model = C->model;
-  SweepArgs a; memset(&a, 0, sizeof(a));
+  memset(&a, 0, sizeof(a));
   fill_panel_args(P, a);
   a.blk_begin = blk_begin; a.blk_end = blk_end;
   int fl = 0;
@@ -1857,6 +1862,16 @@ extern "C" int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end
   a.flags = fl | C->flags_extra;
   a.e = C->e; a.b = C->b; a.d = C->d; a.vb = C->vb; a.xx = P->xx; a.lam = C->lam; a.sc = C->sc;
   a.iter = (uint32_t)C->done; a.marker0 = (uint32_t)C->marker0; a.rng = make_rng(C->seed, C->rng_mode);
+}
+
+extern "C" int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end) {
+  if (!C) return fail(BWGR_EINVAL, "null chain");
+  bwgr_panel *P = C->P;
+  if (blk_begin < 0 || blk_end > P->nblocks || blk_begin >= blk_end) return fail(BWGR_EINVAL, "sweep_blocks: bad range [%d,%d) of %lld", blk_begin, blk_end, (long long)P->nblocks);
+  if (C->done >= C->iit) return fail(BWGR_EINVAL, "sweep_blocks: all %d iterations already run", C->iit);
+  HIPCHK(hipSetDevice(P->device));
+  SweepArgs a;
+  chain_args(C, blk_begin, blk_end, a);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   choose_lag(P, a);
@@ -1975,6 +1990,63 @@ extern "C" int bwgr_chain_run(bwgr_chain *C, int iters) {
     CHK(bwgr_chain_end_iteration(C, nullptr));
   }
   return BWGR_OK;
+}
+
+// Two chains of the same resident panel (C1 on a clone of C0's panel, or the other way round), advanced in lockstep by k_sweep3p: one
+// set of streamer workgroups -- one pass over the genotypes -- serves both, each chain keeps its own sequencer.  Selection models on
+// panels that have k_sweep3; every sweep of the pair is k_sweep3's (no device-side choice of engine).  Each chain's results are
+// bit-identical to a run of its own.  (No reference counterpart: the callers that fit many models on one X -- mcmcCV's loop,
+// /root/reference/R/cv.R:113-216 -- are where it plugs in.)
+extern "C" int bwgr_chain_run_pair(bwgr_chain *C0, bwgr_chain *C1, int iters) {
+  if (!C0 || !C1 || C0 == C1) return fail(BWGR_EINVAL, "chain_run_pair: two distinct chains");
+  bwgr_panel *P0 = C0->P, *P1 = C1->P;
+  const bwgr_panel *r0 = P0->parent ? P0->parent : P0, *r1 = P1->parent ? P1->parent : P1;
+  if (r0 != r1 || P0 == P1) return fail(BWGR_EINVAL, "chain_run_pair: the chains must sit on two handles (panel and clone) of one resident panel");
+  if (iters < 0 || C0->done + iters > C0->iit || C1->done + iters > C1->iit) return fail(BWGR_EINVAL, "chain_run_pair: %d more iterations exceed it", iters);
+  SweepArgs t0, t1;
+  chain_args(C0, 0, (int)P0->nblocks, t0); chain_args(C1, 0, (int)P1->nblocks, t1);
+  if (!use_sweep3(P0, t0.flags) || !use_sweep3(P1, t1.flags) || !P0->qsum3 || !P1->qsum3)
+    return fail(BWGR_EINVAL, "chain_run_pair: both chains must be selection models on a panel with k_sweep3");
+  if (s3p_streamer_lds(P0->R3) > (size_t)160 * 1024) return fail(BWGR_EINVAL, "chain_run_pair: the paired streamers' LDS does not fit");
+  HIPCHK(hipSetDevice(P0->device));
+  // everything of the pair runs on C0's stream, and C1's handle moves onto it for good (one cross-stream wait, the first time: a
+  // wait per call would sit in a hardware queue that other pairs' streams share, and stall them)
+  hipStream_t s0 = P0->stream;
+  if (P1->stream != s0) {
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev, P1->stream)); HIPCHK(hipStreamWaitEvent(s0, ev, 0));
+    HIPCHK(hipEventDestroy(ev));
+    P1->stream = s0;
+  }
+  P0->force3 = P1->force3 = true;
+  int rc = BWGR_OK;
+  const size_t lds = std::max(s3p_streamer_lds(P0->R3), s3_seq_lds(P0->e3_D, r0->gram16));
+  for (int k = 0; k < iters && rc == BWGR_OK; ++k) {
+    SweepArgs a0, a1;
+    chain_args(C0, 0, (int)P0->nblocks, a0); chain_args(C1, 0, (int)P1->nblocks, a1);
+    choose_lag(P0, a0); choose_lag(P1, a1);
+    if ((rc = reset_exchange(P0)) != BWGR_OK || (rc = reset_exchange(P1)) != BWGR_OK) break;
+    launch_prestage(P0, a0); launch_prestage(P1, a1);
+    P0->ps_owner = C0; P0->ps_iter = C0->done; P1->ps_owner = C1; P1->ps_iter = C1->done;
+    a0.gate3 = a1.gate3 = INFINITY;
+    Sweep3Args A0, A1;
+    sweep3_args(P0, a0, A0); sweep3_args(P1, a1, A1);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = fail(BWGR_EHIP, "chain_run_pair: event"); break; }
+    (void)hipEventRecord(e0, s0);
+    const dim3 grid(P0->K3 + 2), blk(SW_THREADS);
+    if (A0.g16) hipLaunchKernelGGL(k_sweep3p<uint16_t>, grid, blk, lds, s0, A0, A1);
+    else hipLaunchKernelGGL(k_sweep3p<int32_t>, grid, blk, lds, s0, A0, A1);
+    (void)hipEventRecord(e1, s0);
+    C0->ev.push_back(e0); C0->ev.push_back(e1);
+    if (hipGetLastError() != hipSuccess) { rc = fail(BWGR_EHIP, "chain_run_pair: launch failed"); break; }
+    if ((rc = bwgr_chain_end_iteration(C0, nullptr)) != BWGR_OK) break;
+    rc = bwgr_chain_end_iteration(C1, nullptr);
+    if (C0->ev.size() >= 4096) (void)bwgr_chain_sweep_ms(C0, nullptr, nullptr);
+  }
+  P0->force3 = P1->force3 = false;
+  return rc;
 }
 
 extern "C" int bwgr_chain_sync(bwgr_chain *C) {

@@ -116,6 +116,12 @@ int bwgr_chain_destroy(bwgr_chain *C);
 /* run the next `iters` MCMC iterations (sweep + intercept + variance draws + posterior sums);
  * asynchronous on the panel's stream */
 int bwgr_chain_run(bwgr_chain *C, int iters);
+/* Two chains of one resident panel (one on the panel, one on a clone of it -- or on two clones) advanced in lockstep, `iters`
+ * iterations each: one set of streamer workgroups, one pass over the genotypes, serves both (k_sweep3p); each chain's results are
+ * bit-identical to a run of its own.  Selection models (BayesB/C/Cpi/Dpi) on int8 panels that have k_sweep3; BWGR_EINVAL otherwise.
+ * No reference counterpart: this is how the callers that fit many models on one X (mcmcCV, /root/reference/R/cv.R:113-216; replicate
+ * chains) use fewer compute units per chain. */
+int bwgr_chain_run_pair(bwgr_chain *C0, bwgr_chain *C1, int iters);
 /* wait for the stream and report in-kernel exchange failures */
 int bwgr_chain_sync(bwgr_chain *C);
 /* iterations completed so far */

@@ -503,3 +503,30 @@ def test_fixed_point_engines_follow_the_phenotype_scale(model, pi, scale):
     o = O.bayes(model, ys, X, it=12, bi=2, pi=pi, seed=5)["last"]
     assert pi == 0.0 or np.array_equal(st["d"], o["d"])
     assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
+
+
+@pytest.mark.parametrize("models", [("BayesB", "BayesB"), ("BayesB", "BayesC"), ("BayesDpi", "BayesB")])
+def test_chain_pairs_share_the_streamers_and_nothing_else(models, monkeypatch):
+    """bwgr_chain_run_pair (k_sweep3p): two chains of one resident panel on one set of streamer workgroups -- chain 1's digits ride in
+    the idle columns of chain 0's MFMA products.  Each chain is bit for bit the chain it is alone (same fixed-point arithmetic, exact
+    integer slab-dot sums), whatever the partner's model or seed; mixing paired and single iterations changes nothing either."""
+    import bwgr_amd
+    monkeypatch.setenv("BWGR_ENG3_THR", "1")
+    X, y = synth_small(700, 2600, seed=53, causal=0.02)
+    P = bwgr_amd.Panel(X)
+    Q = P.clone()
+    solo = []
+    for h, mdl, seed in ((P, models[0], 3), (Q, models[1], 4)):
+        ch = bwgr_amd.Chain(h, mdl, y, it=9, bi=2, pi=0.95, seed=seed)
+        ch.run(9)
+        solo.append(ch.state()); ch.close()
+    c0 = bwgr_amd.Chain(P, models[0], y, it=9, bi=2, pi=0.95, seed=3)
+    c1 = bwgr_amd.Chain(Q, models[1], y, it=9, bi=2, pi=0.95, seed=4)
+    c0.run_pair(c1, 4)
+    c0.run(1); c1.run(1)
+    c0.run_pair(c1, 4)
+    s0, s1 = c0.state(), c1.state()
+    c0.close(); c1.close(); Q.close(); P.close()
+    for got, want in ((s0, solo[0]), (s1, solo[1])):
+        assert np.array_equal(got["d"], want["d"]) and np.array_equal(got["b"], want["b"]) and np.array_equal(got["e"], want["e"])
+        assert got["ve"] == want["ve"]
