@@ -365,16 +365,23 @@ _SELECTION = ("BayesB", "BayesC", "BayesCpi", "BayesDpi")
 _DEFAULT_PI = {"BayesB": 0.95, "BayesC": 0.95}
 
 
-def fit_many(X, jobs, concurrent=None, chunk=4, **panel_kw):
+def fit_many(X, jobs, concurrent=None, chunk=4, pair=None, **panel_kw):
     """Several fused-sampler fits on ONE resident X, run side by side: jobs = [dict(model=, y=, it=, bi=, pi=, df=,
     R2=, seed=, rng_mode=), ...] (same defaults as the BayesX functions); returns the BayesX return lists in job order.
     Every job's chain is the one BayesX(y, X, ...) alone would run -- bit for bit -- because a chain's arithmetic does
     not depend on what else is on the chip: the panel is cloned (bwgr_panel_clone: shared genotypes and Gram, private
     sweep scratch and stream) once per slot, a sweep occupies nwg + 1 + feeders compute units, and up to
     Panel.max_concurrent() of them fit.  This is the shape of the reference's multi-fit callers (mcmcCV runs seven
-    samplers per fold on the same training matrix, R/cv.R:124-130), which it runs one after the other."""
+    samplers per fold on the same training matrix, R/cv.R:124-130), which it runs one after the other.
+
+    pair: sparse selection jobs (BayesB / BayesC with pi >= 0.9 on a panel that has k_sweep3) run TWO to a set of streamer
+    workgroups (Chain.run_pair: one pass over the genotypes serves both).  A paired chain is bit for bit the chain it is alone on
+    k_sweep3; a single chain whose inclusion rate passes 2 % takes some sweeps on k_sweep2 instead (the device chooses), which
+    agrees to ~1e-9, not bit for bit.  None = whenever at least two jobs qualify, False = never, True = every selection job
+    (dense chains are slow on k_sweep3)."""
     P, own = _as_panel(X, **panel_kw)
-    handles, active, results = [], {}, [None] * len(jobs)   # active: slot -> [job index, chain, iterations left]
+    handles, results = [], [None] * len(jobs)
+    live = []   # every chain still open (closed on the way out, whatever happens)
     try:
         norm = []
         for j in jobs:
@@ -384,34 +391,87 @@ def fit_many(X, jobs, concurrent=None, chunk=4, **panel_kw):
                          float(j.pop("df", 5)), float(j.pop("R2", 0.5)), j.pop("seed", None), int(j.pop("rng_mode", 0))))
             if j:
                 raise TypeError("fit_many: unknown job keys %s" % sorted(j))
-        cap = P.max_concurrent(any(m in _SELECTION for m, *_ in norm))
-        nslot = max(1, min(len(norm), cap if concurrent is None else min(int(concurrent), cap)))
-        handles = [P] + [P.clone() for _ in range(nslot - 1)]
-        queue = list(range(len(norm)))
-        while queue or active:
-            for slot in range(nslot):
-                if slot not in active and queue:
-                    i = queue.pop(0)
-                    model, y, it, bi, pi, df, R2, seed, rng_mode = norm[i]
-                    active[slot] = [i, Chain(handles[slot], model, y, it, bi, pi, df, R2, seed, rng_mode), it]
-            # a few iterations per chain per turn keeps every stream's launch queue fed without one chain hogging the host
-            for slot in list(active):
-                i, ch, left = active[slot]
-                step = min(int(chunk), left)
-                ch.run(step)
-                active[slot][2] = left - step
-            for slot in list(active):
-                i, ch, left = active[slot]
-                if left == 0:
-                    try:
-                        results[i] = ch.result()
-                    finally:
-                        ch.close()
-                    del active[slot]
+        gen3 = P.pipeline(True)["generation"] == 3   # (int8 panels with k_sweep3)
+        if pair is True:
+            paired = [i for i, r in enumerate(norm) if r[0] in _SELECTION] if gen3 else []
+        elif pair is None:
+            paired = [i for i, r in enumerate(norm) if r[0] in ("BayesB", "BayesC") and r[4] >= 0.9] if gen3 else []
+        else:
+            paired = []
+        if len(paired) < 2:
+            paired = []
+        single = [i for i in range(len(norm)) if i not in set(paired)]
+
+        def make(i, handle):
+            model, y, it, bi, pi, df, R2, seed, rng_mode = norm[i]
+            ch = Chain(handle, model, y, it, bi, pi, df, R2, seed, rng_mode)
+            live.append(ch)
+            return [i, ch, it]
+
+        def finish(rec):
+            i, ch, _ = rec
+            try:
+                results[i] = ch.result()
+            finally:
+                ch.close(); live.remove(ch)
+
+        def need(n):   # handles 0 .. n-1 exist
+            while len(handles) < n:
+                handles.append(P if not handles else P.clone())
+
+        # ---- pairs: slot s owns handles 2s and 2s+1; a pair holds (streamers + 2) compute units ----
+        if paired:
+            k3 = P.nwg * max(1, P.slab_rows // 256)
+            cap = max(1, (256 - 40) // (k3 + 2))
+            nslot = max(1, min((len(paired) + 1) // 2, cap if concurrent is None else min(int(concurrent), cap)))
+            need(2 * nslot)
+            queue, active = list(paired), {}
+            while queue or active:
+                for s_ in range(nslot):
+                    rec = active.setdefault(s_, [None, None])
+                    for h in (0, 1):
+                        if rec[h] is None and queue:
+                            rec[h] = make(queue.pop(0), handles[2 * s_ + h])
+                for s_, rec in list(active.items()):
+                    a_, b_ = rec
+                    if a_ is not None and b_ is not None:
+                        step = min(int(chunk), a_[2], b_[2])
+                        a_[1].run_pair(b_[1], step)
+                        a_[2] -= step; b_[2] -= step
+                    else:
+                        for r in (a_, b_):
+                            if r is not None:
+                                step = min(int(chunk), r[2]); r[1].run(step); r[2] -= step
+                for s_, rec in list(active.items()):
+                    for h in (0, 1):
+                        if rec[h] is not None and rec[h][2] == 0:
+                            finish(rec[h]); rec[h] = None
+                    if rec[0] is None and rec[1] is None and not queue:
+                        del active[s_]
+        # ---- the rest, one chain per handle ----
+        if single:
+            cap = P.max_concurrent(any(norm[i][0] in _SELECTION for i in single))
+            nslot = max(1, min(len(single), cap if concurrent is None else min(int(concurrent), cap)))
+            need(nslot)
+            queue, active = list(single), {}
+            while queue or active:
+                for slot in range(nslot):
+                    if slot not in active and queue:
+                        active[slot] = make(queue.pop(0), handles[slot])
+                # a few iterations per chain per turn keeps every stream's launch queue fed without one chain hogging the host
+                for slot in list(active):
+                    rec = active[slot]
+                    step = min(int(chunk), rec[2])
+                    rec[1].run(step)
+                    rec[2] -= step
+                for slot in list(active):
+                    if active[slot][2] == 0:
+                        finish(active[slot])
+                        del active[slot]
         return results
     finally:
-        for rec in active.values():
-            rec[1].close()
+        for ch in list(live):
+            ch.close()
         for h in handles[1:]:
             h.close()
         if own:

@@ -465,9 +465,15 @@ def test_fit_many_runs_the_same_chains_side_by_side():
         jobs = [dict(model=m, y=y, it=30, bi=10, seed=100 + i) for i, m in enumerate(models)]
         many = bwgr_amd.fit_many(P, jobs)
         few = bwgr_amd.fit_many(P, jobs, concurrent=3, chunk=7)
+        # ... and with the selection jobs two to a set of streamer workgroups (bwgr_chain_run_pair); a longer partner, an odd one out
+        jobs2 = [dict(model=m, y=y, it=30, bi=10, seed=100 + i) for i, m in enumerate(models)] + [dict(model="BayesB", y=y, it=41, bi=10, pi=0.97, seed=77)]
+        pairs = bwgr_amd.fit_many(P, jobs2, pair=True, chunk=5)
+        alone77 = bwgr_amd.BayesB(y, P, it=41, bi=10, pi=0.97, seed=77)
+        for k in alone77:
+            np.testing.assert_array_equal(np.asarray(pairs[-1][k]), np.asarray(alone77[k]), err_msg="paired BayesB %s" % k)
         for i, m in enumerate(models):
             alone = getattr(bwgr_amd, m)(y, P, it=30, bi=10, seed=100 + i)
-            for got in (many[i], few[i]):
+            for got in (many[i], few[i], pairs[i]):
                 assert list(got) == list(alone)
                 for k in alone:
                     np.testing.assert_array_equal(np.asarray(got[k]), np.asarray(alone[k]), err_msg="%s %s" % (m, k))
