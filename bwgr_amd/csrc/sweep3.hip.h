@@ -457,355 +457,6 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// streamer, second version: the same algebra and LDS layout as s3_streamer, but EVERY global read is an inline-asm load
-// whose arrival is awaited by a hand-counted s_waitcnt vmcnt(N).  hipcc keeps count of its own loads only within straight-line
-// code: across the block loop's back edge it falls back to vmcnt(0) at the next use, and since the memory counter completes in
-// order that one wait drains everything in flight (the second tile, the list request, the atomics' acknowledgements): the
-// block period could not drop below one loaded-HBM round trip.  With asm loads the compiler has nothing to wait for; the counts
-// below are exact because every wave issues a FIXED number of memory operations per block, in a fixed order:
-//   update waves (0 .. NU-1):  8 column bytes (fold of the NEXT block), 1 list request (the block after), 1 step request, 4 tile loads
-//   dots waves  (NU .. 7):     4 tile loads, 2 atomics
-// Unused slots issue harmless dummy loads.  The list of block b-D goes through three stages: its words are requested at block b-2,
-// decoded at b-1 (when the column bytes of its markers are requested), applied at b.  A list that is late, long (> 8 entries)
-// or torn takes the slow path at b: the compiler's own loads, which drain the counter (correct, just slower).
-// ------------------------------------------------------------------------------------------------------------------
-#define S3_ASM_LD128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(ptr) : "memory")
-#define S3_ASM_LD64_SC1(dst, ptr) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
-#define S3_ASM_LD32(dst, ptr) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
-#define S3_ASM_LDU8(dst, ptr) asm volatile("global_load_ubyte %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
-#define S3_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-// a 64-bit add without return, device scope (counts in vmcnt like the loads: gfx950 has one counter, completing in issue order)
-#define S3_ASM_ATOM64(ptr, val, offs) do { const void *ap_ = (ptr); const unsigned long long av_ = (val); \
-    asm volatile("global_atomic_add_x2 %0, %1, off offset:" #offs : : "v"(ap_), "v"(av_) : "memory"); } while (0)
-struct s3_true { static constexpr bool value = true; };
-struct s3_false { static constexpr bool value = false; };
-
-__device__ __forceinline__ void s3_streamer_v2(const Sweep3Args &A) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const SweepArgs &a = A.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m16 = lane & 15, grp = lane >> 4;
-  const int w = (int)blockIdx.x - 1 - ((A.pf >= 0 && (int)blockIdx.x > A.pf) ? 1 : 0);
-  const int m = a.m, R = a.R, R3 = A.R3, Rp = R3 + 16, D = A.D;
-  const int slab = w / A.sub, hsub = w - slab * A.sub;
-  const int nb = a.blk_end - a.blk_begin;
-  const int NU = R3 >> 6, ND = 8 - NU;
-  const int cprs = (R3 == 256) ? 4 : (R3 == 128 ? 3 : 2);
-  const int8_t *Xs = reinterpret_cast<const int8_t *>(a.X) + (size_t)slab * a.p * R + (size_t)hsub * R3;
-  const int64_t row0 = (int64_t)slab * R + (int64_t)hsub * R3;
-  uint32_t *abortw = a.xflags + (size_t)a.K * SW_FLAG_STRIDE;
-  const size_t tile_b = (size_t)SW_MAXM * Rp;
-  int8_t *tile0 = reinterpret_cast<int8_t *>(smem);
-  size_t off = 2 * tile_b;
-  int8_t *edig0 = reinterpret_cast<int8_t *>(smem + off); off += (size_t)2 * 16 * Rp;
-  int8_t *ddig0 = reinterpret_cast<int8_t *>(smem + off); off += (size_t)2 * 16 * S2_DP;
-  int *outu = reinterpret_cast<int *>(smem + off); off += (size_t)64 * S3_OS * 4 * 4;
-  int *outd = reinterpret_cast<int *>(smem + off); off += (size_t)8 * 32 * S3_OS * 4;
-  uint32_t *ctl_s = reinterpret_cast<uint32_t *>(smem + off);
-  const int sh = a.sc->e3_sh;
-  const double S = s3_pow2(sh), invS = s3_pow2(-sh);
-  auto blk_j0 = [&](int b) { return (a.blk_begin + b) * m; };
-  auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
-  const bool st_u = false, st_d = false; (void)st_u; (void)st_d;
-
-  for (int i = tid; i < (int)((2 * 16 * Rp + 2 * 16 * S2_DP) / 4); i += SW_THREADS) reinterpret_cast<uint32_t *>(edig0)[i] = 0u;
-  if (tid < 16) ctl_s[tid] = 0u;
-  long long e_own = 0;
-  const bool upd = wave < NU;
-  if (upd) e_own = __double2ll_rn(a.e[row0 + 64 * wave + lane] * S);
-
-  // ---- the memory pipeline's registers ----
-  s3_u4 ta0 = {0, 0, 0, 0}, ta1 = ta0, ta2 = ta0, ta3 = ta0, tb0 = ta0, tb1 = ta0, tb2 = ta0, tb3 = ta0;   // tile t in set t & 1
-  uint32_t cx0 = 0, cx1 = 0, cx2 = 0, cx3 = 0, cx4 = 0, cx5 = 0, cx6 = 0, cx7 = 0;   // column bytes of the list being folded next
-  long long cq0 = 0, cq1 = 0, cq2 = 0, cq3 = 0, cq4 = 0, cq5 = 0, cq6 = 0, cq7 = 0;  // their corrections (already decoded)
-  unsigned long long lw = 0ull;      // list words of the block after (lane i: word i)
-  uint32_t drw = 0u;                 // the rejected step of marker tid & 127 of the next block (float bits)
-  int fold_state = 0;                // of the block about to be processed: 0 nothing to fold, 1 fast (cx / cq hold it), 2 slow path
-  const int8_t *dummy8 = Xs;         // a valid address for unused slots
-
-  auto tile_ptr = [&](int b_, int u) -> const void * {
-    const int bb = min(b_, nb - 1);
-    const int j0t = blk_j0(bb), mBt = blk_m(bb), tot = m << cprs;
-    const int cc = min(tid + u * SW_THREADS, tot - 1);
-    const int jj = min(cc >> cprs, mBt - 1), ii = cc & ((1 << cprs) - 1);
-    return Xs + (size_t)(j0t + jj) * R + ii * 16;
-  };
-#define S3V_TILE_ISSUE(b_, T0, T1, T2, T3) do { const void *p0_ = tile_ptr(b_, 0), *p1_ = tile_ptr(b_, 1), *p2_ = tile_ptr(b_, 2), *p3_ = tile_ptr(b_, 3); \
-    S3_ASM_LD128(T0, p0_); S3_ASM_LD128(T1, p1_); S3_ASM_LD128(T2, p2_); S3_ASM_LD128(T3, p3_); } while (0)
-#define S3V_COMMIT1(u, name) { const int c_ = tid + (u) * SW_THREADS; if (c_ < tot_) { const int jj_ = c_ >> cprs, ii_ = c_ & ((1 << cprs) - 1); \
-    *reinterpret_cast<s3_u4 *>(dst_ + (size_t)jj_ * Rp + ii_ * 16) = name; } }
-#define S3V_TILE_COMMIT(b_, T0, T1, T2, T3) do { int8_t *dst_ = tile0 + (size_t)((b_) & 1) * tile_b; const int tot_ = m << cprs; \
-    S3V_COMMIT1(0, T0) S3V_COMMIT1(1, T1) S3V_COMMIT1(2, T2) S3V_COMMIT1(3, T3) } while (0)
-  auto list_ptr = [&](int bdst) -> const unsigned long long * {   // the words of the list that is folded before block bdst
-    return A.lists + (size_t)(a.blk_begin + max(min(bdst, nb - 1) - D, 0)) * S3_LSTRIDE + lane;
-  };
-  auto drej_ptr = [&](int b_) -> const float * { return a.ps.blocks[a.blk_begin + min(b_, nb - 1)].drej + (tid & (SW_MAXM - 1)); };
-  // decode the list words in lw (requested two blocks ahead of block bdst) and request the column bytes of its markers;
-  // always exactly eight byte loads
-  auto decode_and_request = [&](int bdst) {
-    fold_state = 0;
-    const uint32_t wlo = (uint32_t)lw, whi = (uint32_t)(lw >> 32);
-    const unsigned long long hv = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wlo) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)whi) << 32);
-    int cnt = 0;
-    if (bdst >= D && bdst < nb) {
-      fold_state = 2;
-      if (s3_epoch_is(hv, A.epoch)) {
-        cnt = (int)(uint32_t)hv;
-        const bool mine = lane >= 1 && lane <= 2 * cnt;
-        if (cnt <= 8 && __ballot(mine && !s3_epoch_is(lw, A.epoch)) == 0ull) fold_state = 1; else cnt = 0;
-      }
-    }
-    const int8_t *col = Xs + (size_t)((a.blk_begin + max(bdst - D, 0)) * m) * R + 64 * wave + lane;
-#define S3V_COL(u, CX, CQ) { const bool on_ = (fold_state == 1) && (u) < cnt; \
-      const uint32_t a0_ = __builtin_amdgcn_readlane((int)wlo, 1 + 2 * (u)), a1_ = __builtin_amdgcn_readlane((int)whi, 1 + 2 * (u)), b0_ = __builtin_amdgcn_readlane((int)wlo, 2 + 2 * (u)); \
-      CQ = on_ ? (long long)(((unsigned long long)b0_ << 32) | (unsigned long long)a0_) : 0ll; \
-      const void *p_ = on_ ? (const void *)(col + (size_t)(a1_ & 0xFFu) * R) : (const void *)dummy8; \
-      S3_ASM_LDU8(CX, p_); }
-    S3V_COL(0, cx0, cq0) S3V_COL(1, cx1, cq1) S3V_COL(2, cx2, cq2) S3V_COL(3, cx3, cq3)
-    S3V_COL(4, cx4, cq4) S3V_COL(5, cx5, cq5) S3V_COL(6, cx6, cq6) S3V_COL(7, cx7, cq7)
-#undef S3V_COL
-  };
-  // the slow path of a fold: synchronous asm loads, each followed by a full drain of the memory counter (every later counted
-  // wait of the block is then trivially true).  No load of this function -- of the whole block loop -- is the compiler's: one
-  // tracked load anywhere in the loop makes hipcc guard every register it cannot prove idle with a vmcnt(0).
-  auto ld64_sync = [&](const unsigned long long *q) -> unsigned long long {
-    unsigned long long v; const void *qp = q;
-    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(qp) : "memory");
-    return v;
-  };
-  auto ld32_sync = [&](const uint32_t *q) -> uint32_t {
-    uint32_t v; const void *qp = q;
-    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(qp) : "memory");
-    return v;
-  };
-  auto fold_slow = [&](int bs) -> int {
-    const int Bs = a.blk_begin + bs;
-    const unsigned long long *L = A.lists + (size_t)Bs * S3_LSTRIDE;
-    const int8_t *col = Xs + (size_t)(Bs * m) * R + 64 * wave + lane;
-    const uint64_t t0 = wall_clock64();
-    unsigned spins = 0;
-    unsigned long long hv;
-    for (;;) {
-      hv = ld64_sync(L);
-      hv = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hv) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hv >> 32)) << 32);
-      if (s3_epoch_is(hv, A.epoch)) break;
-      if ((++spins & 63u) == 0u) {
-        if (ld32_sync(abortw) != 0u) return 0;
-        if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    const int cnt = (int)(uint32_t)hv;
-    for (int c0 = 0; c0 < cnt; c0 += 31) {
-      const int nw = min(62, 2 * (cnt - c0));
-      unsigned long long wv = 0ull;
-      for (;;) {
-        const bool mine = lane >= 1 && lane <= nw;
-        wv = ld64_sync(L + 2 * c0 + min(lane, S3_LSTRIDE - 1 - 2 * c0));   // (every lane loads: no load under a branch)
-        if (__ballot(mine && !s3_epoch_is(wv, A.epoch)) == 0ull) break;
-        if ((++spins & 63u) == 0u) {
-          if (ld32_sync(abortw) != 0u) return 0;
-          if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      const uint32_t wlo = (uint32_t)wv, whi = (uint32_t)(wv >> 32);
-      for (int e0 = 0; e0 < nw / 2; e0 += 8) {
-        uint32_t xb0, xb1, xb2, xb3, xb4, xb5, xb6, xb7; long long cq[8];
-        const void *cp[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int ee = min(e0 + u, nw / 2 - 1);
-          const uint32_t a0 = __builtin_amdgcn_readlane((int)wlo, 1 + 2 * ee), a1 = __builtin_amdgcn_readlane((int)whi, 1 + 2 * ee);
-          const uint32_t b0 = __builtin_amdgcn_readlane((int)wlo, 2 + 2 * ee);
-          cq[u] = (e0 + u < nw / 2) ? (long long)(((unsigned long long)b0 << 32) | (unsigned long long)a0) : 0ll;
-          cp[u] = col + (size_t)(a1 & 0xFFu) * R;
-        }
-        S3_ASM_LDU8(xb0, cp[0]); S3_ASM_LDU8(xb1, cp[1]); S3_ASM_LDU8(xb2, cp[2]); S3_ASM_LDU8(xb3, cp[3]);
-        S3_ASM_LDU8(xb4, cp[4]); S3_ASM_LDU8(xb5, cp[5]); S3_ASM_LDU8(xb6, cp[6]); S3_ASM_LDU8(xb7, cp[7]);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xb0), "+v"(xb1), "+v"(xb2), "+v"(xb3), "+v"(xb4), "+v"(xb5), "+v"(xb6), "+v"(xb7) :: "memory");
-        e_own -= (long long)(int)(int8_t)xb0 * cq[0] + (long long)(int)(int8_t)xb1 * cq[1] + (long long)(int)(int8_t)xb2 * cq[2] + (long long)(int)(int8_t)xb3 * cq[3];
-        e_own -= (long long)(int)(int8_t)xb4 * cq[4] + (long long)(int)(int8_t)xb5 * cq[5] + (long long)(int)(int8_t)xb6 * cq[6] + (long long)(int)(int8_t)xb7 * cq[7];
-      }
-    }
-    return 1;
-  };
-
-  // ---- prologue: tile 0 into LDS; then the operations "blocks -2 and -1" would have issued, so that the counts hold from block 0 ----
-  S3V_TILE_ISSUE(0, ta0, ta1, ta2, ta3);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(ta0), "+v"(ta1), "+v"(ta2), "+v"(ta3) :: "memory");
-  S3V_TILE_COMMIT(0, ta0, ta1, ta2, ta3);
-  unsigned long long *qdummy = A.qsum + ((size_t)a.blk_begin * SW_MAXM + 0) * 2;   // (dummy atomics add 0 there)
-  if (upd) {
-    S3V_TILE_ISSUE(1, tb0, tb1, tb2, tb3);                       // "block -2": tile 1
-    lw = 0ull; decode_and_request(0);                            // "block -1": eight dummy column bytes (nothing to fold before block 0)
-    { const void *lp = list_ptr(1); S3_ASM_LD64_SC1(lw, lp); }   //             the list words of the fold before block 1
-    { const void *dp = drej_ptr(0); S3_ASM_LD32(drw, dp); }      //             the steps of block 0
-    S3V_TILE_ISSUE(2, ta0, ta1, ta2, ta3);                       //             tile 2
-  } else {
-    S3V_TILE_ISSUE(1, tb0, tb1, tb2, tb3);
-    if (lane < 2) { S3_ASM_ATOM64(qdummy + lane, 0ull, 0); S3_ASM_ATOM64(qdummy + lane, 0ull, 0); }
-    S3V_TILE_ISSUE(2, ta0, ta1, ta2, ta3);
-    if (lane < 2) { S3_ASM_ATOM64(qdummy + lane, 0ull, 0); S3_ASM_ATOM64(qdummy + lane, 0ull, 0); }
-  }
-  __syncthreads();
-
-  // one block; T0..T3: the register set of tile b+1 (committed here) and then of tile b+3 (requested here)
-  auto step = [&](auto role, int b, s3_u4 &T0, s3_u4 &T1, s3_u4 &T2, s3_u4 &T3) -> bool {
-    constexpr bool UPD = decltype(role)::value;   // (the two roles run separate loops: their memory pipelines differ, and hipcc's
-                                                  // wait-count pass would otherwise merge the two and fall back to vmcnt(0))
-    const int mB = blk_m(b), par = b & 1;
-    int8_t *tile = tile0 + (size_t)par * tile_b;
-    int8_t *edig = edig0 + (size_t)par * 16 * Rp;
-    int8_t *ddig = ddig0 + (size_t)par * 16 * S2_DP;
-    if constexpr (UPD) {
-      // A: the column bytes of the fold before this block have landed (younger: list request, step request, four tile loads) and
-      // with them, being older, tile b+1.  (The registers are operands of the wait so that no use of them can be scheduled above it.)
-      asm volatile("s_waitcnt vmcnt(6)" : "+v"(cx0), "+v"(cx1), "+v"(cx2), "+v"(cx3), "+v"(cx4), "+v"(cx5), "+v"(cx6), "+v"(cx7),
-                                          "+v"(T0), "+v"(T1), "+v"(T2), "+v"(T3) :: "memory");
-      if (fold_state == 1) {
-        e_own -= (long long)(int)(int8_t)cx0 * cq0 + (long long)(int)(int8_t)cx1 * cq1 + (long long)(int)(int8_t)cx2 * cq2 + (long long)(int)(int8_t)cx3 * cq3;
-        e_own -= (long long)(int)(int8_t)cx4 * cq4 + (long long)(int)(int8_t)cx5 * cq5 + (long long)(int)(int8_t)cx6 * cq6 + (long long)(int)(int8_t)cx7 * cq7;
-      } else if (fold_state == 2) {
-        if (!fold_slow(b - D)) ctl_s[0] = 1u;     // (drains the counter: every later wait of this block is then trivially true)
-      }
-      // B: the steps of this block and the list words of the next fold have landed (younger: four tile loads)
-      asm volatile("s_waitcnt vmcnt(4)" : "+v"(drw), "+v"(lw) :: "memory");
-      if ((unsigned long long)(e_own + (1ll << 54)) >> 55) ctl_s[1] = 1u;       // left the 55-bit range
-      s3_put_digits7(e_own, edig + 64 * wave + lane, Rp);
-      if (tid < SW_MAXM) {
-        const double qd = (tid < mB) ? rint((double)__uint_as_float(drw) * S) : 0.0;
-        if (!(fabs(qd) < 18014398509481984.0)) ctl_s[1] = 1u;                    // 2^54
-        s3_put_digits7((long long)qd, ddig + tid, S2_DP);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (ctl_s[0]) { if (tid == 0) a.sc->error = 1u; return false; }
-    if constexpr (UPD) {
-      // C: tile b+1 landed long ago (older than the column bytes waited for above); requests for the blocks ahead, fixed count
-      if (b + 1 < nb) S3V_TILE_COMMIT(b + 1, T0, T1, T2, T3);
-      decode_and_request(b + 1);                                   // lw: the words of the fold before block b+1 (landed: older than the steps)
-      { const void *lp = list_ptr(b + 2); S3_ASM_LD64_SC1(lw, lp); }
-      { const void *dp = drej_ptr(b + 1); S3_ASM_LD32(drw, dp); }
-      S3V_TILE_ISSUE(b + 3, T0, T1, T2, T3);
-      // ---- slab update with the rejected steps: out[row][n] = sum_markers x[row][marker] * digit_n(drej[marker]) ----
-      // lane (m16, grp): row quad 16 wave + m16 (rows 4 * that + k for accumulator k); k slots (dword u, byte q) of step s0 are the
-      // markers s0 + 16 u + 4 grp + q (the interleave keeps the four lane groups on different LDS banks)
-      const int rowoff = 4 * (16 * wave + m16);
-      s2_v4i acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-      for (int s0 = 0; s0 < ((A.dbg & 256) ? 0 : mB); s0 += 64) {
-        const int8_t *tp = tile + __mul24(s0 + 4 * grp, Rp) + rowoff;
-        uint32_t c[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            c[u][q] = *reinterpret_cast<const uint32_t *>(tp + (16 * u + q) * Rp);
-        const int8_t *bp = ddig + (size_t)m16 * S2_DP + s0 + 4 * grp;
-        const s2_v4i bv = {*reinterpret_cast<const int *>(bp), *reinterpret_cast<const int *>(bp + 16),
-                           *reinterpret_cast<const int *>(bp + 32), *reinterpret_cast<const int *>(bp + 48)};
-        uint32_t rw[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t t0 = __builtin_amdgcn_perm(c[u][1], c[u][0], 0x05010400u), t1 = __builtin_amdgcn_perm(c[u][1], c[u][0], 0x07030602u);
-          const uint32_t t2 = __builtin_amdgcn_perm(c[u][3], c[u][2], 0x05010400u), t3 = __builtin_amdgcn_perm(c[u][3], c[u][2], 0x07030602u);
-          rw[0][u] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); rw[1][u] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
-          rw[2][u] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); rw[3][u] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
-        }
-        acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[0][0], (int)rw[0][1], (int)rw[0][2], (int)rw[0][3]}, bv, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[1][0], (int)rw[1][1], (int)rw[1][2], (int)rw[1][3]}, bv, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[2][0], (int)rw[2][1], (int)rw[2][2], (int)rw[2][3]}, bv, acc2, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[3][0], (int)rw[3][1], (int)rw[3][2], (int)rw[3][3]}, bv, acc3, 0, 0, 0);
-      }
-      int *ou = outu + (size_t)wave * 64 * S3_OS;
-      if (m16 < 8) {      // lane: digit n = m16; acc_k[reg] belongs to local row 4 (4 grp + reg) + k
-        int *op = ou + (size_t)(4 * (4 * grp)) * S3_OS + m16;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          op[(4 * reg + 0) * S3_OS] = acc0[reg]; op[(4 * reg + 1) * S3_OS] = acc1[reg];
-          op[(4 * reg + 2) * S3_OS] = acc2[reg]; op[(4 * reg + 3) * S3_OS] = acc3[reg];
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes (in order; no other wave reads this scratch)
-      {
-        const int4 o0 = *reinterpret_cast<const int4 *>(ou + (size_t)lane * S3_OS);
-        const int4 o1 = *reinterpret_cast<const int4 *>(ou + (size_t)lane * S3_OS + 4);
-        long long v = (long long)o0.x + ((long long)o0.y << 8) + ((long long)o0.z << 16) + ((long long)o0.w << 24);
-        v += ((long long)o1.x << 32) + ((long long)o1.y << 40) + ((long long)o1.z << 48);
-        e_own -= v;
-      }
-    } else {
-      // C': tile b+1 landed (younger: two atomics, four tile loads, two atomics)
-      asm volatile("s_waitcnt vmcnt(8)" : "+v"(T0), "+v"(T1), "+v"(T2), "+v"(T3) :: "memory");
-      if (b + 1 < nb) S3V_TILE_COMMIT(b + 1, T0, T1, T2, T3);
-      S3V_TILE_ISSUE(b + 3, T0, T1, T2, T3);
-      int natom = 0;
-      // ---- slab dots of block b against the digits of e: markers in groups of 16, groups gm and gm + ND together on wave
-      // NU + gm (the two groups' MFMAs, LDS round trips and atomics overlap) ----
-      for (int gm = wave - NU; 16 * gm < m; gm += 2 * ND) {
-        const int gm2 = gm + ND;
-        const bool two = 16 * gm2 < m;
-        const int8_t *bp = edig + (size_t)m16 * Rp + 16 * grp;
-        const int8_t *ap = tile + (size_t)(16 * gm + m16) * Rp + 16 * grp;
-        const int8_t *ap2 = tile + (size_t)(16 * (two ? gm2 : gm) + m16) * Rp + 16 * grp;
-        s2_v4i acc = {0, 0, 0, 0}, acc2 = acc;
-        for (int r = 0; r < ((A.dbg & 256) ? 0 : R3); r += 64) {
-          const s2_v4i bv = *reinterpret_cast<const s2_v4i *>(bp + r);
-          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap + r), bv, acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap2 + r), bv, acc2, 0, 0, 0);
-        }
-        int *od = outd + (size_t)wave * 32 * S3_OS;
-        if (m16 < 8) {      // lane: digit n = m16 of markers 16 gm + 4 grp + reg (rows 0..15 of the scratch) and of group gm2 (rows 16..31)
-          int *op = od + (size_t)(4 * grp) * S3_OS + m16;
-          op[0] = acc[0]; op[S3_OS] = acc[1]; op[2 * S3_OS] = acc[2]; op[3 * S3_OS] = acc[3];
-          op[16 * S3_OS] = acc2[0]; op[17 * S3_OS] = acc2[1]; op[18 * S3_OS] = acc2[2]; op[19 * S3_OS] = acc2[3];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane < (two ? 32 : 16)) {
-          const int4 o0 = *reinterpret_cast<const int4 *>(od + (size_t)lane * S3_OS);
-          const int4 o1 = *reinterpret_cast<const int4 *>(od + (size_t)lane * S3_OS + 4);
-          const long long lo = (long long)o0.x + ((long long)o0.y << 8) + ((long long)o0.z << 16);
-          const long long hi = (long long)o0.w + ((long long)o1.x << 8) + ((long long)o1.y << 16) + ((long long)o1.z << 24);
-          const int mk = 16 * ((lane < 16) ? gm : gm2) + (lane & 15);
-          unsigned long long *qs = A.qsum + ((size_t)(a.blk_begin + b) * SW_MAXM + mk) * 2;
-          S3_ASM_ATOM64(qs, (unsigned long long)((lo << 8) + 1), 0);
-          S3_ASM_ATOM64(qs, (unsigned long long)((hi << 8) + 1), 8);
-        }
-        natom += 2;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch is read before the next pass overwrites it
-      }
-      // exactly two atomic instructions per block and wave, whatever the block's width (the wait counts depend on it)
-      for (; natom < 2; ++natom) if (lane < 2) S3_ASM_ATOM64(qdummy + lane, 0ull, 0);
-    }
-    return true;
-  };
-  if (upd) {
-    for (int b = 0; b < nb; b += 2) {
-      if (!step(s3_true{}, b, tb0, tb1, tb2, tb3)) return;                     // b even: tile b+1 travels in set 1
-      if (b + 1 < nb && !step(s3_true{}, b + 1, ta0, ta1, ta2, ta3)) return;
-    }
-  } else {
-    for (int b = 0; b < nb; b += 2) {
-      if (!step(s3_false{}, b, tb0, tb1, tb2, tb3)) return;
-      if (b + 1 < nb && !step(s3_false{}, b + 1, ta0, ta1, ta2, ta3)) return;
-    }
-  }
-  S3_VMCNT(0);
-  // the lists of the last D blocks
-  if (upd) for (int bs = max(0, nb - D); bs < nb; ++bs) {
-    if (!fold_slow(bs)) { ctl_s[0] = 1u; break; }
-  }
-  if (upd && ((unsigned long long)(e_own + (1ll << 54)) >> 55)) ctl_s[1] = 1u;
-  __syncthreads();
-  if (ctl_s[0]) { if (tid == 0) a.sc->error = 1u; return; }
-  if (ctl_s[1] && tid == 0) a.sc->error = 2u;
-  if (upd) a.e[row0 + 64 * wave + lane] = (double)e_own * invS;
-#undef S3V_TILE_ISSUE
-#undef S3V_COMMIT1
-#undef S3V_TILE_COMMIT
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // sequencer
 // ------------------------------------------------------------------------------------------------------------------
 template <typename GT>
@@ -1339,11 +990,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep3(const Sweep3Args A) {
   if ((int)blockIdx.x == A.pf) { s3_prefetcher<GT>(A); return; }
   if (blockIdx.x == 0) { if (!(A.dbg & 1024)) s3_sequencer<GT>(A); }
   else if ((A.a.flags & SWF_DEBUG_WITHHOLD) && blockIdx.x == 1 && A.pf != 1) return;   // test hook: a streamer that never shows up
-#ifdef BWGR_S3V2
-  else if (!(A.dbg & 2048)) { if ((A.dbg & 4) && A.R3 >= 128) s3_streamer_v2(A); else s3_streamer(A); }   // (BWGR_DBG3=4: the streamer with hand-counted waits; measured no faster)
-#else
-  else if (!(A.dbg & 2048)) s3_streamer(A);   // (the hand-counted streamer is compiled in with -DBWGR_S3V2 only: measured no faster, and 10 KB of code less in the kernel)
-#endif
+  else if (!(A.dbg & 2048)) s3_streamer(A);   // (a second streamer whose every load was inline asm with hand-counted waits measured no faster and was removed: DESIGN 9.0)
 }
 
 }  // namespace bwgr
