@@ -2030,6 +2030,7 @@ extern "C" int bwgr_chain_run_pair(bwgr_chain *C0, bwgr_chain *C1, int iters) {
     launch_prestage(P0, a0); launch_prestage(P1, a1);
     P0->ps_owner = C0; P0->ps_iter = C0->done; P1->ps_owner = C1; P1->ps_iter = C1->done;
     a0.gate3 = a1.gate3 = INFINITY;
+    if (P0->debug_withhold || P1->debug_withhold) { a0.flags |= SWF_DEBUG_WITHHOLD; a1.flags |= SWF_DEBUG_WITHHOLD; }
     Sweep3Args A0, A1;
     sweep3_args(P0, a0, A0); sweep3_args(P1, a1, A1);
     hipEvent_t e0, e1;

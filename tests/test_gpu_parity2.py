@@ -530,3 +530,38 @@ def test_chain_pairs_share_the_streamers_and_nothing_else(models, monkeypatch):
     for got, want in ((s0, solo[0]), (s1, solo[1])):
         assert np.array_equal(got["d"], want["d"]) and np.array_equal(got["b"], want["b"]) and np.array_equal(got["e"], want["e"])
         assert got["ve"] == want["ve"]
+
+
+def test_chain_pairs_abort_path(monkeypatch):
+    """A streamer workgroup of a pair's launch withheld: both chains' sequencers and the remaining streamers must reach their
+    wall-clock bound, both chains report BWGR_ETIMEOUT, and the next paired launch on the same handles succeeds and gives the
+    chains they are alone."""
+    import time
+    import bwgr_amd
+    from bwgr_amd import _lib
+    monkeypatch.setenv("BWGR_ENG3_THR", "1")
+    X, y = synth_small(700, 1500, seed=59, causal=0.02)
+    P = bwgr_amd.Panel(X)
+    Q = P.clone()
+    _lib.check(_lib.lib().bwgr_debug_withhold(P._h, 1))
+    c0 = bwgr_amd.Chain(P, "BayesB", y, it=2, bi=0, pi=0.95, seed=2)
+    c1 = bwgr_amd.Chain(Q, "BayesB", y, it=2, bi=0, pi=0.95, seed=3)
+    t0 = time.time()
+    c0.run_pair(c1, 1)
+    for c in (c0, c1):
+        with pytest.raises(bwgr_amd.BwgrError) as ei:
+            c.sync()
+        assert ei.value.code == 4                                   # BWGR_ETIMEOUT
+    assert time.time() - t0 < 30.0
+    c0.close(); c1.close()
+    _lib.check(_lib.lib().bwgr_debug_withhold(P._h, 0))
+    solo = []
+    for h, seed in ((P, 2), (Q, 3)):
+        ch = bwgr_amd.Chain(h, "BayesB", y, it=5, bi=0, pi=0.95, seed=seed); ch.run(5); solo.append(ch.state()); ch.close()
+    c0 = bwgr_amd.Chain(P, "BayesB", y, it=5, bi=0, pi=0.95, seed=2)
+    c1 = bwgr_amd.Chain(Q, "BayesB", y, it=5, bi=0, pi=0.95, seed=3)
+    c0.run_pair(c1, 5)
+    s0, s1 = c0.state(), c1.state()
+    c0.close(); c1.close(); Q.close(); P.close()
+    for got, want in ((s0, solo[0]), (s1, solo[1])):
+        assert np.array_equal(got["d"], want["d"]) and np.array_equal(got["b"], want["b"])
