@@ -933,6 +933,7 @@ struct bwgr_panel {
   size_t ldsw_bytes = 0;
   float dense_thr = 1.0f;         // selection sweeps of chains with at least this share of markers in the model run the marker-by-marker recurrence
                                   // (BWGR_DENSE_THR; >= 1, the default: never -- measured no faster than the rounds at any inclusion rate)
+  std::vector<hipStream_t> pair_streams;   // root panel: the streams pairs of chains run on (bwgr_chain_run_pair); owned here, so that they outlive every clone
   bool force3 = false;            // a pair run (bwgr_chain_run_pair): every selection sweep is k_sweep3's, whatever the inclusion rate
   float eng3_thr = 0.02f;         // k_sweep3 takes the sweeps whose chains hold fewer than this share of markers in the model (BWGR_ENG3_THR)
   hipStream_t own_stream = nullptr;
@@ -1311,6 +1312,7 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   hipFree(P->qsum3); hipFree(P->lists3); hipFree(P->winv); hipFree(P->qsumw);
   hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->ps.ev3); hipFree(P->xpart); hipFree(P->xchg); hipFree(P->stamps);
   if (P->own_stream) hipStreamDestroy(P->own_stream);
+  for (hipStream_t q : P->pair_streams) hipStreamDestroy(q);
   delete P;
   return BWGR_OK;
 }
@@ -1604,6 +1606,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   HIPCHK(hipStreamSynchronize(root->stream));   // the shared arrays are complete
   bwgr_panel *P = new bwgr_panel(*root);
   P->parent = root; P->nclones = 0; P->nchains = 0; P->own_stream = nullptr; P->stream = nullptr; P->ps_owner = nullptr; P->ps_iter = -1;
+  P->pair_streams.clear();   // (the root's: a clone owns none)
   P->qsum3 = P->lists3 = nullptr; P->epoch3 = 0; P->xmax_dev = nullptr; P->winv = nullptr; P->qsumw = nullptr;
   P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->xchg = nullptr; P->stamps = nullptr;
   root->nclones++;
@@ -2009,15 +2012,22 @@ extern "C" int bwgr_chain_run_pair(bwgr_chain *C0, bwgr_chain *C1, int iters) {
     return fail(BWGR_EINVAL, "chain_run_pair: both chains must be selection models on a panel with k_sweep3");
   if (s3p_streamer_lds(P0->R3) > (size_t)160 * 1024) return fail(BWGR_EINVAL, "chain_run_pair: the paired streamers' LDS does not fit");
   HIPCHK(hipSetDevice(P0->device));
-  // everything of the pair runs on C0's stream, and C1's handle moves onto it for good (one cross-stream wait, the first time: a
-  // wait per call would sit in a hardware queue that other pairs' streams share, and stall them)
-  hipStream_t s0 = P0->stream;
-  if (P1->stream != s0) {
+  // everything of the pair runs on ONE stream, owned by the root panel (it outlives both handles), and both handles move onto it
+  // for good -- one cross-stream wait each, the first time: a wait per call would sit in a hardware queue that other pairs'
+  // streams share, and stall them
+  bwgr_panel *root = P0->parent ? P0->parent : P0;
+  auto is_pair_stream = [&](hipStream_t st) { for (hipStream_t q : root->pair_streams) if (q == st) return true; return false; };
+  hipStream_t s0 = nullptr;
+  if (is_pair_stream(P0->stream)) s0 = P0->stream;
+  else if (is_pair_stream(P1->stream)) s0 = P1->stream;
+  else { HIPCHK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking)); root->pair_streams.push_back(s0); }
+  for (bwgr_panel *PX : {P0, P1}) {
+    if (PX->stream == s0) continue;
     hipEvent_t ev;
     HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ev, P1->stream)); HIPCHK(hipStreamWaitEvent(s0, ev, 0));
+    HIPCHK(hipEventRecord(ev, PX->stream)); HIPCHK(hipStreamWaitEvent(s0, ev, 0));
     HIPCHK(hipEventDestroy(ev));
-    P1->stream = s0;
+    PX->stream = s0;
   }
   P0->force3 = P1->force3 = true;
   int rc = BWGR_OK;
