@@ -931,8 +931,6 @@ struct bwgr_panel {
   bool wfx_on = true;             // BWGR_WFX=0: k_sweep2's streamers under the product sequencer instead of the fixed-point ones
   int winv_nd = 0;                // distances built = the deepest lag the affine sweeps can run, minus one
   size_t ldsw_bytes = 0;
-  float dense_thr = 1.0f;         // selection sweeps of chains with at least this share of markers in the model run the marker-by-marker recurrence
-                                  // (BWGR_DENSE_THR; >= 1, the default: never -- measured no faster than the rounds at any inclusion rate)
   std::vector<hipStream_t> pair_streams;   // root panel: the streams pairs of chains run on (bwgr_chain_run_pair); owned here, so that they outlive every clone
   bool force3 = false;            // a pair run (bwgr_chain_run_pair): every selection sweep is k_sweep3's, whatever the inclusion rate
   float eng3_thr = 0.02f;         // k_sweep3 takes the sweeps whose chains hold fewer than this share of markers in the model (BWGR_ENG3_THR)
@@ -1180,15 +1178,6 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
   // streamers, sequencer, and for the selection models the q feeders (the affine recurrence is compute-bound: its
   // sequencer gathers q itself under the recurrence, and a feeder hop in its lag-2 chain measured 15 % slower)
   a.nfeed = (P->sweep_version >= 2 && sel) ? P->nfeed : 0;
-  // the selection sweeps' twin for dense inclusion (int8 panels): the generic sequencer's marker-by-marker recurrence, two blocks
-  // deep; both launches are enqueued, the device runs the one whose regime the chain's last inclusion rate says it is
-  const bool twin = sel && P->sweep_version >= 2 && !P->is_f32 && P->dense_thr < 1.0f;
-  a.gate_dense = twin ? P->dense_thr : 0.0f;
-  if (twin) {
-    SweepArgs ad = a;
-    ad.flags |= SWF_DENSE; ad.lag = 2;
-    hipLaunchKernelGGL((k_sweep2<int8_t, true>), dim3(P->K + 1 + ad.nfeed), dim3(SW_THREADS), P->lds2_bytes, P->stream, ad);
-  }
   if (use_winv(P, a.flags) && P->winv) {
     S2WArgs A;
     memset(&A, 0, sizeof(A));
@@ -1228,12 +1217,15 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
   }
 }
 
-// selection models run the deeper pipelines (their cross terms are sparse); BWGR_LAG=2|3 caps the depth (A/B tests)
+// selection models run the deeper pipelines (their cross terms are sparse)
 static bool use_winv(const bwgr_panel *P, int flags);
 static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
   const char *lv = getenv("BWGR_LAG");
-  // depth 4 where the panel has the third cross Gram array (int8, 16-bit staging), else 3; BWGR_LAG=2|3 caps it (A/B tests)
-  const int cap = (lv && lv[0] >= '2' && lv[0] <= '4') ? lv[0] - '0' : 4;
+  // Selection sweeps of k_sweep2: three blocks deep.  (The single-barrier sequencer also knows a fourth level, BWGR_LAG=4: it was
+  // the default while k_sweep2 also ran the sparse chains; those are k_sweep3's now, and from 5 % of the markers in the model upwards
+  // the third cross term's row fetches cost more than the depth gives -- C4-size BayesC at 5 / 19 / 36 % inclusion: 31.4 / 21.3 /
+  // 14.5 iter/s at depth 3 against 30.9 / 19.4 / 9.4 at depth 4; BayesCpi at 51 %: 11.1 against 6.7.)  BWGR_LAG=2|3|4 sets it (A/B tests).
+  const int cap = (lv && lv[0] >= '2' && lv[0] <= '4') ? lv[0] - '0' : 3;
   int lag = 2;
   if (P->sweep_version >= 2 && (a.flags & SWF_SELECT)) {
     if (P->gramx2) lag = 3;   // fp32 panels too (generic streamer and sequencer)
@@ -1560,7 +1552,6 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   if (const char *pv = getenv("BWGR_WAHEAD")) P->wahead = std::max(1, atoi(pv));
   if (const char *qv = getenv("BWGR_WNQ")) { const int v = atoi(qv); if (v == 1 || v == 2 || v == 4) P->wnq = v; }
   if (const char *wl = getenv("BWGR_WLAG")) if (wl[0] >= '2' && wl[0] <= '4') P->wlag_cap = wl[0] - '0';
-  if (const char *dv = getenv("BWGR_DENSE_THR")) { const float v = (float)atof(dv); if (v >= 0.0f) P->dense_thr = std::max(v, 1e-9f); }   // (0: always)
 #undef PCHK
   (void)rc;
   *out = P;

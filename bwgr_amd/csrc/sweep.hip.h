@@ -47,7 +47,6 @@ enum : int {
   SWF_EM_BL = 512,    // emBL: G + Half_L2 (:379-387); Lmb1 in sc->lam, 1/(xx + cxx) in the sdz1 slot (cxx in sc->Sb)
   SWF_EM_LASSO = 1024, // lasso: yx = (e + x b0).x, soft threshold (yx -/+ Lmb)/xx clamped at 0 (:1477-1485); Lmb in sc->lam; yx_j leaves in d[j]
   SWF_EM_ANY = SWF_EM_SEL | SWF_EM_EN | SWF_EM_BL | SWF_EM_LASSO,
-  SWF_DENSE = 1 << 18,           // k_sweep2's generic sequencer: the selection models' in-block recurrence marker by marker (dense inclusion)
   SWF_SERIAL = 1 << 19,          // affine sweep that must keep the lane-ordered recurrence (wgr's de: Vb_j = |b_j| sqrt(Ve/MSx) feeds rounding-level
                                  // differences of b back into the next sweep's shrinkage, amplified; R/wgr.R:118)
   SWF_DEBUG_WITHHOLD = 1 << 20   // test hook (bwgr_debug_withhold): slab workgroup 0 leaves at once, so every wait on it must time out
@@ -115,8 +114,6 @@ struct SweepArgs {
   unsigned long long *dgran;    // k_sweep2: [S2_NSLOT][SW_MAXM] {epoch, float delta} granules
   uint32_t *xflags;             // [K*SW_FLAG_STRIDE] epochs, then the abort word
   unsigned long long *stamps;   // diagnostic build only (-DBWGR_STAMPS): per-phase cycle sums of workgroup 0
-  float gate_dense;             // > 0: the selection sweeps of k_sweep2 are enqueued twice -- speculative rounds (sparse inclusion) and the marker-by-marker
-                                // recurrence (SWF_DENSE, lag 2) -- and the device runs the one whose regime sc->inc_rate says it is; 0: no gating
   float gate3;                  // > 0: both engines of the selection models are launched and the device picks one -- k_sweep3 (and its
                                 // k_escale / k_spec3) runs when sc->inc_rate < gate3, k_sweep2 (and k_spec) otherwise; 0: no gating
 };
@@ -423,6 +420,112 @@ __device__ __forceinline__ bool lane_accept(double r, float b1, const LaneConst 
   if (__builtin_expect(__ballot(!(sure_acc || sure_rej)) == 0ull, 1)) return sure_acc;   // every lane decided by its thresholds
   const bool exact = lane_accept_exact(diffd, c.mk, flags, Cc, odds, one_minus_pi, rng, iter);
   return sure_acc ? true : (sure_rej ? false : exact);
+}
+
+// The inclusion test as two compares on the marker's residual dot.  With D1 = rden*r + k1 the un-rounded step, lane_accept's
+// x = C*(|e2|^2 - |e1|^2) is C*Q(r) with Q a parabola in r: Q = A*(r - zc)^2 + Qmin, A = rden*(2 - gjj*rden) > 0, and C < 0.  So
+//   x < tacc   <=>  |r - zc| > sqrt((tacc/C - Qmin)/A),     x > trej   <=>  |r - zc| < sqrt((trej/C - Qmin)/A).
+// lane_accept evaluates x through four float roundings (the draw, the step, the float of Q, the product with C); their sum is bounded
+// (err below, in units of Q, with a fourfold margin on the dominant term) and the two radii are moved apart by it: |z| > ha is a
+// certain accept of lane_accept, |z| < hr a certain reject, and the sliver between (about one decision in 10^6; tools/quick_accept_check.py
+// straddles the radii at relative distances 1e-15 .. 1e-6 with lane_accept's float arithmetic restated) is left to lane_accept
+// itself.  The decisions are therefore lane_accept's, bit for bit; what leaves the rounds' dependent chain is its eleven operations.
+__device__ __forceinline__ void lane_quick(const LaneConst &c, int flags, float Cc, double &zc, double &ha, double &hr) {
+  const double b0 = (double)c.b0, D2 = (double)((flags & SWF_ALT_B2) ? (c.b2 - c.b0) : (0.0f - c.b0));
+  const double k1 = fma((double)c.xxb0, c.rden, c.sdz1) - b0;
+  const double gr = c.gjj * c.rden;
+  const double A = c.rden * (2.0 - gr), Bh = (k1 - D2) - gr * k1, C0 = c.gjj * (D2 * D2 - k1 * k1);
+  zc = -Bh / A;
+  const double Qmin = fma(Bh, zc, C0);
+  const double qa = (double)c.tacc / (double)Cc, qr = (double)c.trej / (double)Cc;   // C < 0: qr <= qa; -inf / +inf thresholds map to +inf / -inf
+  auto err = [&](double h, double q) {
+    const double ra = fabs(zc) + h;                                   // the larger |r| of the two crossings
+    const double d1 = fma(c.rden, ra, fabs(k1)), t = d1 + fabs(b0);   // bounds of |step| and |draw| there
+    const double eD = 6.1e-8 * (t + d1);                              // the draw's and the step's roundings to float
+    return 4.0 * (2.0 * (ra + c.gjj * d1) * eD + c.gjj * eD * eD) + 2.5e-7 * fabs(q)
+           + 1e-13 * (2.0 * ra * (d1 + fabs(D2)) + c.gjj * (D2 * D2 + d1 * d1));
+  };
+  ha = INFINITY; hr = -1.0;   // neither test ever certain: every decision is lane_accept's
+  if (A > 0.0 && fabs(zc) < 1e300 && Cc < 0.0f) {
+    if (fabs(qa) < INFINITY) {
+      const double num = (qa - Qmin) + err(sqrt(fmax(0.0, (qa - Qmin) / A)), qa);
+      ha = (num > 0.0) ? sqrt(num / A) * (1.0 + 1e-12) : -1.0;
+    }
+    if (qr == INFINITY) hr = INFINITY;   // (dead lanes: trej = -inf)
+    else if (fabs(qr) < INFINITY) {
+      const double num = (qr - Qmin) - err(sqrt(fmax(0.0, (qr - Qmin) / A)), qr);
+      hr = (num > 0.0) ? sqrt(num / A) * (1.0 - 1e-12) : -1.0;
+    }
+  }
+}
+// The speculative rounds of one 128-marker block on lane_quick's compares (wave-wide; lane = marker, two lane groups).  Every lane
+// holds its marker's residual dot as if no undecided marker before it were included (their rejected steps are inside r); a round
+// finds the first lane that is not a certain reject -- certain accepts are taken, the sliver asks lane_accept -- applies what that
+// marker changes beyond its speculated step to the later lanes through its packed Gram row, and the next round re-tests.  The row
+// of the likely next marker (the following candidate under the state before the step) is requested while the step is applied.
+// Same decisions and the same arithmetic on r as rounds made of lane_accept.  gp: packed Gram block in LDS (row k's entry for
+// marker j > k at prow(k) + j - k - 1; unconditional loads: the buffers carry slack).
+// (One wave issues at most one instruction every four to five cycles, scalar ones included, so the rounds cost their instruction
+// count, not their dependent chain: the loop below is written for few instructions -- the packed row's offset from a lane-indexed
+// table by one v_readlane instead of the triangular-number arithmetic, one exit test, the correction formed per lane before the
+// lane is known, the sliver's code out of line.)
+template <typename GT>
+__device__ __forceinline__ void quick_rounds(double (&r)[2], const LaneConst (&lc)[2], unsigned long long (&accmask)[2], const GT *gp, int m, int mB,
+                                             int lane, int flags, float Cc, float odds, float one_minus_pi, const Rng &rng, uint32_t iter) {
+  const int ngrp = (mB + 63) >> 6;
+  double zc[2], ha[2], hr[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) lane_quick(lc[q], flags, Cc, zc[q], ha[q], hr[q]);
+  const GT *gl = gp + lane;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (q < ngrp) {
+      const int base = 64 * q, cnt = min(64, mB - base);
+      const int kk = base + lane;
+      const int tab = (kk * (m - 1) - kk * (kk - 1) / 2 - lane - 1) * (int)sizeof(GT);   // byte offset (from gl) of this lane's packed row, entry "lane 0"
+      unsigned long long livem = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);        // lanes not yet passed
+      unsigned long long am = 0ull;
+      double rq = r[q], ro = r[1], z = rq - zc[q];
+      const double haq = ha[q], hrq = hr[q], drejd = (double)lc[q].drej;
+      const float b0q = lc[q].b0;
+      // (uniform gotos: one exit test at the top, the sliver's code out of line, one back edge)
+      {
+        unsigned long long cand, accm;
+        int js;
+        float b1;
+        double cd, corr, gm0;
+        GT g0, g1;
+      qr_top:
+        cand = livem & ~__ballot(fabs(z) < hrq);
+        if (cand == 0ull) goto qr_done;
+        js = (int)__builtin_ctzll(cand);
+        {   // its packed row, requested at once (a reject in the sliver wastes the request, nothing else)
+          const GT *row = reinterpret_cast<const GT *>(reinterpret_cast<const char *>(gl) + __builtin_amdgcn_readlane(tab, js));
+          g0 = row[0]; g1 = row[64];
+        }
+        accm = __ballot(fabs(z) > haq);
+        b1 = lane_b1(rq, lc[q]);
+        cd = (double)(b1 - b0q) - drejd;                          // per lane: what its accepted step changes beyond the speculated one
+        livem &= (~1ull << js);
+        if (__builtin_expect(!((accm >> js) & 1ull), 0)) goto qr_sliver;
+      qr_apply:
+        corr = readlane_f64(cd, js);
+        am |= (1ull << js);
+        gm0 = (double)((lane > js) ? g0 : (GT)0);
+        rq = fma(-gm0, corr, rq);
+        z = fma(-gm0, corr, z);
+        if (q == 0) ro = fma(-(double)g1, corr, ro);   // (with one lane group r[1] is never read; the loads stay inside the buffer's slack)
+        goto qr_top;
+      qr_sliver:   // between the radii: the full test decides; a reject leaves its speculated step standing, nothing moves
+        if ((__ballot(lane_accept(rq, b1, lc[q], flags, Cc, odds, one_minus_pi, rng, iter)) >> js) & 1ull) goto qr_apply;
+        goto qr_top;
+      qr_done:;
+      }
+      r[q] = rq;
+      if (q == 0) r[1] = ro;
+      accmask[q] |= am;
+    }
+  }
 }
 
 template <typename XT, bool SELECT>

@@ -787,8 +787,6 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
       S2STAMP(5);
       // affine models: the recurrence's variable, the un-rounded draw t = (r + xx*b0)*rden + sd*z
       double u[2] = {fma(r[0] + (double)lc[0].xxb0, lc[0].rden, lc[0].sdz1), fma(r[1] + (double)lc[1].xxb0, lc[1].rden, lc[1].sdz1)};
-      // packed row k: entry for marker j (> k) sits at prow(k) + j - k - 1
-      auto gat = [&](int k, int j) -> GT { return (j > k && j < m) ? gp[prow(k) + j - k - 1] : (GT)0; };
       unsigned long long accmask[2] = {0ull, 0ull};
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -876,69 +874,9 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
 #undef S2_AFFINE_STEP
               u[q] = ua; if (two) u[1] = ub;   // (group 1 continues from here)
             }
-          } else if (a.flags & SWF_DENSE) {
-            // Dense inclusion (BayesCpi / Dpi, small pi): the speculative rounds need one pass per included marker, so past ~20 % of
-            // the markers in the model the recurrence runs marker by marker instead -- the affine loop's shape (packed Gram rows
-            // requested four markers ahead, one readlane per step) with the threshold test inlined.  Every lane evaluates its own
-            // marker from its current r at every step; step l keeps lane l's answer.  r moves only by what an INCLUDED marker
-            // changed beyond its speculated rejected step, in marker order: the same numbers in the same order as the rounds.
-            const bool two = (q == 0 && ngrp > 1);
-            const int oA = prow(base) - 1;
-            double ra = r[q], rb = two ? r[1] : 0.0;
-            const LaneConst &c = lc[q];
-            const float d2f = (a.flags & SWF_ALT_B2) ? (c.b2 - c.b0) : (0.0f - c.b0);
-            const double D2 = (double)d2f, D2sq = D2 * D2, drejd = (double)c.drej;
-            unsigned long long am = 0ull;
-            int oL = oA;
-            GT ga0, ga1, ga2, ga3, gb0 = (GT)0, gb1 = (GT)0, gb2 = (GT)0, gb3 = (GT)0;
-#define S2_DENSE_STEP(TWO_, l_, GA, GB) { \
-              const GT g0 = (lane > (l_)) ? GA : (GT)0, g1 = GB; \
-              GA = gp[oL + lane]; if (TWO_) GB = gp[oL + 64 + lane]; oL += m - 2 - (base + (l_) + 4); \
-              const float b1 = lane_b1(ra, c); \
-              const float d1f = b1 - c.b0; const double D1 = (double)d1f; \
-              const double diffd = 2.0 * ra * (D1 - D2) + c.gjj * (D2sq - D1 * D1); \
-              const float x = Cc * (float)diffd; \
-              bool acc = x < c.tacc; \
-              const bool und = !(acc || x > c.trej); \
-              if (__builtin_expect((__ballot(und) >> (l_)) & 1ull, 0)) { if (und) acc = lane_accept_exact(diffd, c.mk, a.flags, Cc, odds, one_minus_pi, a.rng, a.iter); } \
-              const unsigned long long bal = __ballot(acc); \
-              const double cd = acc ? (D1 - drejd) : 0.0; \
-              const double dd = readlane_f64(cd, (l_)); \
-              am |= bal & (1ull << (l_)); \
-              ra = fma(-(double)g0, dd, ra); \
-              if (TWO_) rb = fma(-(double)g1, dd, rb); }
-#define S2_DENSE_LOOP(TWO_) { \
-              ga0 = gp[oL + lane]; if (TWO_) gb0 = gp[oL + 64 + lane]; oL += m - 2 - (base + 0); \
-              ga1 = gp[oL + lane]; if (TWO_) gb1 = gp[oL + 64 + lane]; oL += m - 2 - (base + 1); \
-              ga2 = gp[oL + lane]; if (TWO_) gb2 = gp[oL + 64 + lane]; oL += m - 2 - (base + 2); \
-              ga3 = gp[oL + lane]; if (TWO_) gb3 = gp[oL + 64 + lane]; oL += m - 2 - (base + 3); \
-              int l = 0; \
-              for (; l + 4 <= cnt; l += 4) { S2_DENSE_STEP(TWO_, l, ga0, gb0) S2_DENSE_STEP(TWO_, l + 1, ga1, gb1) S2_DENSE_STEP(TWO_, l + 2, ga2, gb2) S2_DENSE_STEP(TWO_, l + 3, ga3, gb3) } \
-              for (; l < cnt; ++l) { \
-                S2_DENSE_STEP(TWO_, l, ga0, gb0) \
-                const GT ta = ga0, tb = gb0; \
-                ga0 = ga1; ga1 = ga2; ga2 = ga3; ga3 = ta; gb0 = gb1; gb1 = gb2; gb2 = gb3; gb3 = tb; \
-              } }
-            if (two) S2_DENSE_LOOP(1) else S2_DENSE_LOOP(0)
-#undef S2_DENSE_LOOP
-#undef S2_DENSE_STEP
-            r[q] = ra; if (two) r[1] = rb;
-            accmask[q] = am;
-          } else {
-            int front = 0;
-            while (front < cnt) {
-              const float b1 = lane_b1(r[q], lc[q]);
-              const bool acc = lane_accept(r[q], b1, lc[q], a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
-              const unsigned long long bal = __ballot(acc && lane >= front && lane < cnt);
-              if (bal == 0ull) break;
-              const int js = __ffsll((long long)bal) - 1;
-              const float corr_f1 = b1 - lc[q].b0;
-              const double corr = (double)readlane_f32(corr_f1, js) - (double)readlane_f32(lc[q].drej, js);
-              r[q] = fma(-(double)gat(base + js, base + lane), corr, r[q]);
-              if (q == 0 && ngrp > 1) r[1] = fma(-(double)gat(base + js, 64 + lane), corr, r[1]);
-              accmask[q] |= (1ull << js);
-              front = js + 1;
-            }
+          } else if (q == 0) {
+            // exact speculative rounds, both lane groups, decided by lane_quick's two compares (sweep.hip.h)
+            quick_rounds(r, lc, accmask, gp, m, mB, lane, a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
           }
         }
       }
@@ -1202,7 +1140,6 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
   const int pchunks = pstride / GPT, xchunks = m * m / GPT;
   const int L = a.lag;
   auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
-  auto prow = [&](int k) { return k * (m - 1) - k * (k - 1) / 2; };   // offset of packed row k
   constexpr int NCH = (int)(sizeof(StageBuf) / 16), NSP = (int)(sizeof(SpecBuf) / 16);
   static_assert(NCH <= 2 * 320 && NSP <= 320, "at most two StageBuf chunks and one SpecBuf chunk per thread of waves 1-5");
 
@@ -1389,7 +1326,6 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       const GT *gp = Q16_GP(b);
       int *acc_k = acc_k2 + (size_t)(b & 3) * SW_MAXM;
       double *acc_corr = acc_corr2 + (size_t)(b & 3) * SW_MAXM;
-      const int ngrp = (mB + 63) >> 6;
       double r[2];
       LaneConst lc[2];
       {   // all loads unconditional (the buffers hold SW_MAXM entries) and issued before the first use; dead lanes masked after
@@ -1416,30 +1352,8 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       }
       S2STAMP(5);
       unsigned long long accmask[2] = {0ull, 0ull};
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (q < ngrp) {
-          const int base = 64 * q, cnt = min(64, mB - base);
-          int front = 0;
-          while (front < cnt) {   // exact speculative rounds: all lanes assume "nobody before me is accepted"
-            const float b1 = lane_b1(r[q], lc[q]);
-            const bool acc = lane_accept(r[q], b1, lc[q], a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
-            const unsigned long long bal = __ballot(acc && lane >= front && lane < cnt);
-            if (bal == 0ull) break;
-            const int js = __ffsll((long long)bal) - 1;
-            const float corr_f1 = b1 - lc[q].b0;
-            const double corr = (double)readlane_f32(corr_f1, js) - (double)readlane_f32(lc[q].drej, js);
-            // packed row k = base+js: own-group entry of this lane at prow(k) + lane - js - 1 (used for lane > js), the other
-            // group's (q == 0: marker 64+lane) 64 entries further; both loads unconditional (the buffers carry slack)
-            const int o0 = prow(base + js) + lane - js - 1;
-            const GT g0 = gp[o0], g1 = gp[o0 + 64];
-            r[q] = fma(-(double)((lane > js) ? g0 : (GT)0), corr, r[q]);
-            if (q == 0 && ngrp > 1) r[1] = fma(-(double)((64 + lane < m) ? g1 : (GT)0), corr, r[1]);
-            accmask[q] |= (1ull << js);
-            front = js + 1;
-          }
-        }
-      }
+      // exact speculative rounds (all lanes assume "nobody before me is accepted"), decided by lane_quick's two compares
+      quick_rounds(r, lc, accmask, gp, m, mB, lane, a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
       S2STAMP(6);
       // outputs; delta_b goes out at once as {epoch, float} granules (one 8-byte write-through store per marker)
       unsigned long long *gslot = a.dgran + (size_t)(b % S2_NSLOT) * SW_MAXM;
@@ -1558,10 +1472,6 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
 template <typename XT, bool SELECT, typename GT = typename XTraits<XT>::GT>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep2(const SweepArgs a) {
   if (a.gate3 > 0.0f && a.sc->inc_rate < a.gate3) return;   // this sweep is k_sweep3's (every workgroup sees the same scalar)
-  if (SELECT && a.gate_dense > 0.0f) {   // sparse / dense twins of one sweep: the launch whose regime it is not leaves at once
-    const bool dense_now = a.sc->inc_rate >= a.gate_dense;
-    if (((a.flags & SWF_DENSE) != 0) != dense_now) return;
-  }
   if ((int)blockIdx.x > a.K) {
     if constexpr (SELECT) s2_feeder(a, (int)blockIdx.x - a.K - 1);   // (the affine variants are launched without feeders)
   } else if ((int)blockIdx.x == a.K) {

@@ -445,15 +445,15 @@ def test_affine_winv_forty_slabs():
     assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
 
 
-@pytest.mark.parametrize("model,pi,thr", [("BayesCpi", 0.0, "0"), ("BayesDpi", 0.0, "0"), ("BayesB", 0.6, "0.3"), ("BayesC", 0.7, "0.25")])
-def test_dense_recurrence_is_the_same_chain(model, pi, thr, monkeypatch):
-    """BWGR_DENSE_THR (opt-in): selection sweeps of chains with that share of markers in the model run the generic sequencer's
-    marker-by-marker recurrence, two blocks deep, instead of the speculative rounds; the device switches sweep by sweep
-    (thresholds 0.3 / 0.25 sit where these chains' inclusion rates wander).  Same numbers in the same order: the oracle's chain,
-    identical decisions (/root/reference/src/Rcpp20260726ai.cpp:884-909 BayesCpi, :950-975 BayesDpi)."""
+@pytest.mark.parametrize("lag", ["2", "3", "4"])
+@pytest.mark.parametrize("model,pi", [("BayesCpi", 0.0), ("BayesDpi", 0.0), ("BayesB", 0.6), ("BayesC", 0.7)])
+def test_dense_inclusion_rounds_are_the_same_chain(model, pi, lag, monkeypatch):
+    """Selection sweeps with 30-50 % of the markers in the model (k_sweep2; a round per included marker, decided by lane_quick's two
+    compares on the residual dot with lane_accept behind them for the sliver between the radii), at every pipeline depth: the
+    oracle's chain, identical decisions (/root/reference/src/Rcpp20260726ai.cpp:884-909 BayesCpi, :950-975 BayesDpi)."""
     import bwgr_amd
     from oracle import oracle as O
-    monkeypatch.setenv("BWGR_DENSE_THR", thr)
+    monkeypatch.setenv("BWGR_LAG", lag)
     monkeypatch.setenv("BWGR_ENG3_THR", "0.02")
     X, y = synth_small(600, 1500, seed=41)
     P = bwgr_amd.Panel(X)
