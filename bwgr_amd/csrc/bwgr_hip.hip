@@ -1302,7 +1302,7 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   }
   // the scratch a sweep writes: speculative cross terms, pre-staged constants, exchange words
   hipFree(P->qsum3); hipFree(P->lists3); hipFree(P->winv); hipFree(P->qsumw);
-  hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->ps.ev3); hipFree(P->xpart); hipFree(P->xchg); hipFree(P->stamps);
+  hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->ps.quick); hipFree(P->ps.ev3); hipFree(P->xpart); hipFree(P->xchg); hipFree(P->stamps);
   if (P->own_stream) hipStreamDestroy(P->own_stream);
   for (hipStream_t q : P->pair_streams) hipStreamDestroy(q);
   delete P;
@@ -1523,6 +1523,7 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
     PCHK(hipMalloc(&P->gram16_bad, sizeof(int)));
   }
   PCHK(hipMalloc(&P->ps.spec, sizeof(SpecBuf) * (size_t)P->nblocks));
+  if (P->sweep_version >= 2) PCHK(hipMalloc(&P->ps.quick, sizeof(QuickBuf) * (size_t)P->nblocks));
   PCHK(hipMalloc(&P->xx, sizeof(float) * p));
   PCHK(hipMalloc(&P->vx, sizeof(float) * p));
   PCHK(hipMalloc(&P->msx_dev, sizeof(float)));
@@ -1607,6 +1608,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   if (root->xspec2) PCHK(hipMalloc(&P->xspec2, sizeof(double) * (size_t)P->nblocks * SW_MAXM));
   if (root->xspec3) PCHK(hipMalloc(&P->xspec3, sizeof(double) * (size_t)P->nblocks * SW_MAXM));
   PCHK(hipMalloc(&P->ps.spec, sizeof(SpecBuf) * (size_t)P->nblocks));
+  if (P->sweep_version >= 2) PCHK(hipMalloc(&P->ps.quick, sizeof(QuickBuf) * (size_t)P->nblocks));
   PCHK(hipMalloc(&P->ps.blocks, sizeof(StageBuf) * (size_t)P->nblocks));
   PCHK(hipMalloc(&P->xpart, sizeof(double) * 2 * (size_t)K * SW_MAXM));
   PCHK(alloc_exchange(P));

@@ -75,6 +75,9 @@ struct SpecBuf {                // r-independent per-marker terms of one block (
   double xspec[128];            // sum_k Gx_b[k][j] * drej_{b-1}[k]      (selection models; unused for the first block of a launch)
   double gjj[128];              // G_bb[j][j]
 };
+struct QuickBuf {               // lane_quick's centre and radii of one block (k_sweep2's selection rounds), filled by k_spec
+  double zc[128], ha[128], hr[128];
+};
 struct Eval3Buf {               // k_sweep3's quick inclusion test (k_spec3): with r the marker's residual dot,
   double qa[128], qb[128];      //   Q(r) = (qa r + qb) r + qc* is C-signed (|e2|^2 - |e1|^2 - threshold), without the float roundings of the exact chain;
   double qca[128], qcr[128];    //   included for certain if Q_a(r) > g(|r|), rejected for certain if Q_r(r) < -g(|r|),
@@ -83,6 +86,7 @@ struct Eval3Buf {               // k_sweep3's quick inclusion test (k_spec3): wi
 struct PreStage {
   StageBuf *blocks;   // one StageBuf per marker block, filled by k_prestage
   SpecBuf *spec;      // one SpecBuf per marker block, filled by k_spec
+  QuickBuf *quick;    // one per marker block, filled by k_spec (selection sweeps of k_sweep2)
   Eval3Buf *ev3;      // one per marker block, filled by k_spec3 (null: k_sweep3 evaluates the exact chain in every round)
 };
 
@@ -278,45 +282,6 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
   __syncthreads();
   if (threadIdx.x == 0 && dex_s != 0u) atomicMax(&a.sc->e3_dex, dex_s);
 }
-// k_spec: the r-independent speculative terms of every block of a sweep (one workgroup of 128 threads per block,
-// thread = marker j; Gram rows are read coalesced across j; fixed summation order k ascending)
-template <typename GT>
-__global__ __launch_bounds__(128) void k_spec(const SweepArgs a, int blk_begin, int select) {
-  if (a.gate3 > 0.0f && a.sc->inc_rate < a.gate3) return;   // this sweep is k_sweep3's
-  const int blk = blk_begin + blockIdx.x, j = threadIdx.x, m = a.m;
-  const int mB = min(m, a.p - blk * m);
-  const GT *G = reinterpret_cast<const GT *>(a.gram) + (size_t)blk * m * m;
-  SpecBuf &sp = a.ps.spec[blk];
-  __shared__ float dr[128], drp[128];
-  const StageBuf &st = a.ps.blocks[blk];
-  dr[j] = (j < mB) ? st.drej[j] : 0.0f;
-  drp[j] = (blk > blk_begin) ? a.ps.blocks[blk - 1].drej[j] : 0.0f;   // previous block is always a full block
-  __syncthreads();
-  double s = 0.0, xs = 0.0, gjj = 0.0;
-  if (j < mB) {
-    gjj = (double)G[(size_t)j * m + j];
-    if (select) {
-      for (int k = 0; k < j; ++k) s = fma((double)G[(size_t)k * m + j], (double)dr[k], s);
-      if (blk > blk_begin) {
-        const GT *Gx = reinterpret_cast<const GT *>(a.gramx) + (size_t)blk * m * m;
-        for (int k = 0; k < m; ++k) xs = fma((double)Gx[(size_t)k * m + j], (double)drp[k], xs);
-      }
-    }
-  }
-  sp.spec[j] = s; sp.xspec[j] = xs; sp.gjj[j] = gjj;
-  for (int dist = 2; dist < a.lag; ++dist) {   // further cross terms of the deeper pipelines
-    double xs2 = 0.0;
-    __syncthreads();
-    drp[j] = (blk - dist >= blk_begin) ? a.ps.blocks[blk - dist].drej[j] : 0.0f;
-    __syncthreads();
-    if (j < mB && select && blk - dist >= blk_begin) {
-      const GT *Gxd = reinterpret_cast<const GT *>(dist == 2 ? a.gramx2 : a.gramx3) + (size_t)blk * m * m;
-      for (int k = 0; k < m; ++k) xs2 = fma((double)Gxd[(size_t)k * m + j], (double)drp[k], xs2);
-    }
-    (dist == 2 ? a.xspec2 : a.xspec3)[(size_t)blk * SW_MAXM + j] = xs2;
-  }
-}
-
 // block constants global -> LDS: one StageBuf is sizeof(StageBuf)/16 chunks, at most one per thread
 __device__ inline void stage_block(StageBuf &st, int blk, const SweepArgs &a, int tid0, int nthreads) {
   constexpr int NCH = (int)(sizeof(StageBuf) / 16);
@@ -470,12 +435,10 @@ __device__ __forceinline__ void lane_quick(const LaneConst &c, int flags, float 
 // table by one v_readlane instead of the triangular-number arithmetic, one exit test, the correction formed per lane before the
 // lane is known, the sliver's code out of line.)
 template <typename GT>
-__device__ __forceinline__ void quick_rounds(double (&r)[2], const LaneConst (&lc)[2], unsigned long long (&accmask)[2], const GT *gp, int m, int mB,
+__device__ __forceinline__ void quick_rounds(double (&r)[2], const LaneConst (&lc)[2], const double (&zc)[2], const double (&ha)[2], const double (&hr)[2],
+                                             unsigned long long (&accmask)[2], const GT *gp, int m, int mB,
                                              int lane, int flags, float Cc, float odds, float one_minus_pi, const Rng &rng, uint32_t iter) {
   const int ngrp = (mB + 63) >> 6;
-  double zc[2], ha[2], hr[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) lane_quick(lc[q], flags, Cc, zc[q], ha[q], hr[q]);
   const GT *gl = gp + lane;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -525,6 +488,56 @@ __device__ __forceinline__ void quick_rounds(double (&r)[2], const LaneConst (&l
       if (q == 0) r[1] = ro;
       accmask[q] |= am;
     }
+  }
+}
+
+// k_spec: the r-independent speculative terms of every block of a sweep (one workgroup of 128 threads per block,
+// thread = marker j; Gram rows are read coalesced across j; fixed summation order k ascending)
+template <typename GT>
+__global__ __launch_bounds__(128) void k_spec(const SweepArgs a, int blk_begin, int select) {
+  if (a.gate3 > 0.0f && a.sc->inc_rate < a.gate3) return;   // this sweep is k_sweep3's
+  const int blk = blk_begin + blockIdx.x, j = threadIdx.x, m = a.m;
+  const int mB = min(m, a.p - blk * m);
+  const GT *G = reinterpret_cast<const GT *>(a.gram) + (size_t)blk * m * m;
+  SpecBuf &sp = a.ps.spec[blk];
+  __shared__ float dr[128], drp[128];
+  const StageBuf &st = a.ps.blocks[blk];
+  dr[j] = (j < mB) ? st.drej[j] : 0.0f;
+  drp[j] = (blk > blk_begin) ? a.ps.blocks[blk - 1].drej[j] : 0.0f;   // previous block is always a full block
+  __syncthreads();
+  double s = 0.0, xs = 0.0, gjj = 0.0;
+  if (j < mB) {
+    gjj = (double)G[(size_t)j * m + j];
+    if (select) {
+      for (int k = 0; k < j; ++k) s = fma((double)G[(size_t)k * m + j], (double)dr[k], s);
+      if (blk > blk_begin) {
+        const GT *Gx = reinterpret_cast<const GT *>(a.gramx) + (size_t)blk * m * m;
+        for (int k = 0; k < m; ++k) xs = fma((double)Gx[(size_t)k * m + j], (double)drp[k], xs);
+      }
+    }
+  }
+  sp.spec[j] = s; sp.xspec[j] = xs; sp.gjj[j] = gjj;
+  if (select && a.ps.quick) {   // the rounds' two compares (lane_quick): off the sequencer's one serial wave, some 300 instructions per lane group
+    double zc = 0.0, ha = INFINITY, hr = INFINITY;   // unused lanes: a certain reject
+    if (j < mB) {
+      LaneConst c;
+      c.b0 = st.b0[j]; c.xxb0 = st.xxb0[j]; c.b2 = st.b2[j]; c.drej = st.drej[j];
+      c.rden = st.rden[j]; c.sdz1 = st.sdz1[j]; c.gjj = gjj; c.tacc = st.tacc[j]; c.trej = st.trej[j]; c.mk = 0u;
+      lane_quick(c, a.flags, a.sc->C, zc, ha, hr);
+    }
+    QuickBuf &qb = a.ps.quick[blk];
+    qb.zc[j] = zc; qb.ha[j] = ha; qb.hr[j] = hr;
+  }
+  for (int dist = 2; dist < a.lag; ++dist) {   // further cross terms of the deeper pipelines
+    double xs2 = 0.0;
+    __syncthreads();
+    drp[j] = (blk - dist >= blk_begin) ? a.ps.blocks[blk - dist].drej[j] : 0.0f;
+    __syncthreads();
+    if (j < mB && select && blk - dist >= blk_begin) {
+      const GT *Gxd = reinterpret_cast<const GT *>(dist == 2 ? a.gramx2 : a.gramx3) + (size_t)blk * m * m;
+      for (int k = 0; k < m; ++k) xs2 = fma((double)Gxd[(size_t)k * m + j], (double)drp[k], xs2);
+    }
+    (dist == 2 ? a.xspec2 : a.xspec3)[(size_t)blk * SW_MAXM + j] = xs2;
   }
 }
 

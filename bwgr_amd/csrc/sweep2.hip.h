@@ -723,6 +723,13 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
     if (tid < mB) r0_s[tid] = (part_s[tid] + part_s[SW_MAXM + tid]) + part_s[2 * SW_MAXM + tid];
   }
   double sum_d = 0.0, sum_b2 = 0.0;
+  // the selection rounds' centres and radii (k_spec's QuickBuf) of the next block: wave 0 reads them itself, a block ahead
+  double nzc[2] = {0.0, 0.0}, nha[2] = {INFINITY, INFINITY}, nhr[2] = {-1.0, -1.0};
+  const QuickBuf *quick = (SELECT && a.ps.quick) ? a.ps.quick + a.blk_begin : nullptr;
+  if (SELECT && wave == 0 && quick) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) { nzc[g] = quick[0].zc[64 * g + lane]; nha[g] = quick[0].ha[64 * g + lane]; nhr[g] = quick[0].hr[64 * g + lane]; }
+  }
   // helper threads' prefetch registers (plain named locals: an aggregate would end up in scratch memory)
   static_assert(PCH <= 5 && XCH <= 10, "named prefetch registers cover 5 + 10 chunks per helper thread");
   constexpr int NCH = (int)(sizeof(StageBuf) / 16), NSP = (int)(sizeof(SpecBuf) / 16);
@@ -876,7 +883,17 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
             }
           } else if (q == 0) {
             // exact speculative rounds, both lane groups, decided by lane_quick's two compares (sweep.hip.h)
-            quick_rounds(r, lc, accmask, gp, m, mB, lane, a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
+            double zc[2] = {nzc[0], nzc[1]}, ha[2] = {nha[0], nha[1]}, hr[2] = {nhr[0], nhr[1]};
+            if (quick) {
+              if (have_next) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) { nzc[g] = quick[b + 1].zc[64 * g + lane]; nha[g] = quick[b + 1].ha[64 * g + lane]; nhr[g] = quick[b + 1].hr[64 * g + lane]; }
+              }
+            } else {
+#pragma unroll
+              for (int g = 0; g < 2; ++g) lane_quick(lc[g], a.flags, Cc, zc[g], ha[g], hr[g]);
+            }
+            quick_rounds(r, lc, zc, ha, hr, accmask, gp, m, mB, lane, a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
           }
         }
       }
@@ -1305,10 +1322,17 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
   }
   double sum_d = 0.0, sum_b2 = 0.0;
   double rnext[2] = {0.0, 0.0};
+  // the rounds' centres and radii (k_spec's QuickBuf) of the next block: wave 0 reads them itself, a block ahead, into registers
+  double nzc[2] = {0.0, 0.0}, nha[2] = {INFINITY, INFINITY}, nhr[2] = {-1.0, -1.0};
+  const QuickBuf *quick = a.ps.quick ? a.ps.quick + a.blk_begin : nullptr;
   if (wave == 0) {
     const double *ps = Q16_QS(0);
 #pragma unroll
     for (int q = 0; q < 2; ++q) rnext[q] = ps[64 * q + lane];
+    if (quick) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { nzc[q] = quick[0].zc[64 * q + lane]; nha[q] = quick[0].ha[64 * q + lane]; nhr[q] = quick[0].hr[64 * q + lane]; }
+    }
   }
   S2STAMP_DECL;
 
@@ -1353,7 +1377,17 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
       S2STAMP(5);
       unsigned long long accmask[2] = {0ull, 0ull};
       // exact speculative rounds (all lanes assume "nobody before me is accepted"), decided by lane_quick's two compares
-      quick_rounds(r, lc, accmask, gp, m, mB, lane, a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
+      double zc[2] = {nzc[0], nzc[1]}, ha[2] = {nha[0], nha[1]}, hr[2] = {nhr[0], nhr[1]};
+      if (quick) {
+        if (have_next) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) { nzc[q] = quick[b + 1].zc[64 * q + lane]; nha[q] = quick[b + 1].ha[64 * q + lane]; nhr[q] = quick[b + 1].hr[64 * q + lane]; }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) lane_quick(lc[q], a.flags, Cc, zc[q], ha[q], hr[q]);
+      }
+      quick_rounds(r, lc, zc, ha, hr, accmask, gp, m, mB, lane, a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
       S2STAMP(6);
       // outputs; delta_b goes out at once as {epoch, float} granules (one 8-byte write-through store per marker)
       unsigned long long *gslot = a.dgran + (size_t)(b % S2_NSLOT) * SW_MAXM;
