@@ -26,6 +26,8 @@ WORKLOADS = {
     "c3": (10000, 500000, "BayesB", 0.99),
     "c4": (10000, 1000000, "BayesB", 0.99),
     "c4a": (10000, 1000000, "BayesA", 0.0),    # (not a BASELINE config: C4's shape with an affine model, as wgr() runs by default)
+    "c5": (50000, 1000000, "BayesCpi", 0.5),   # BASELINE config 5's panel and model on ONE GPU (50 GB of int8 genotypes; Gram entries need 32 bits)
+    "c5b": (50000, 1000000, "BayesB", 0.99),   # (not a BASELINE config: config 5's panel under the headline model)
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -220,7 +222,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "traffic_source": None, "kernel": kernel + " (rank 0)", "kernel_ms": sweep_ms,
                          "launches": launches, "algorithmic_bytes_per_launch": alg_bytes},
-            "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d": float(st["d"].mean())},
+            "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d": mean_d},
         }
         ch.close(); P.close()
         dist.destroy_process_group()
@@ -257,8 +259,12 @@ def main():
     alg_bytes = float(n) * float(p) * 1.0      # every genotype byte read once per sweep
     # HBM traffic per launch comes from separate rocprofv3 --pmc passes (it cannot be read inside this process); the
     # corrected figure is committed under profiles/ and quoted only for the workload it was measured on
-    pl = P.pipeline(bool(pi))
-    kernel = {4: "k_sweep2w", 3: "k_sweep3<uint16>", 2: "k_sweep2<int8>", 1: "k_sweep<int8>"}[pl["generation"]]
+    pl = P.pipeline(bool(pi) or model in ("BayesCpi", "BayesDpi"))
+    mean_d = float(st["d"].mean())
+    if pl["generation"] == 3 and mean_d >= float(os.environ.get("BWGR_ENG3_THR", "0.02")):
+        # the device picks the selection sweeps' engine from the chain's inclusion rate: above the threshold k_sweep2 ran them
+        pl = {"generation": 2, "lag": int(os.environ.get("BWGR_LAG", "3")), "feeders": 0}
+    kernel = {4: "k_sweep2w", 3: "k_sweep3<uint%d>" % pl.get("gram_bits", 16), 2: "k_sweep2<int8>", 1: "k_sweep<int8>"}[pl["generation"]]
     traffic, traffic_source = None, None
     for name in ("r02_pmc_c4.json", "r01_pmc_c4.json"):
         try:
@@ -275,14 +281,14 @@ def main():
         "vs_baseline": None, "dtype": "f32 scalars, fixed-point / f64 residual, int8 genotypes", "data": "synthetic",
         "config": {"workload": "%s: synthetic n=%d x p=%d int8, %s%s, exact chain (blocked sweep, block=%d, %d slabs "
                                "x %d rows + 1 sequencer%s)" % (args.workload, n, p, model,
-                                                          " pi=%.2f (1%% in model)" % pi if pi else "", P.block, P.nwg, P.slab_rows,
+                                                          " pi=%.2f (%.1f%% of the markers in the model at the last sweep)" % (pi, 100.0 * mean_d) if pi else "", P.block, P.nwg, P.slab_rows,
                                                           (" + %d q feeders" % pl["feeders"] if pl["feeders"] else "") + ", engine generation %d, lag %d blocks" % (pl["generation"], pl["lag"])),
                    "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel,
                      "kernel_ms": sweep_ms, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes},
         "setup_s": setup_s,
-        "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d": float(st["d"].mean())},
+        "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d": mean_d},
     }
     ch.close()
     nch = args.chains if args.chains > 0 else P.max_concurrent(bool(pi))
@@ -292,7 +298,7 @@ def main():
             out["concurrent_chains"] = concurrent_leg(P, model, y, pi, nch, K, W, n, p)
         except Exception as ex:   # the headline leg above stands on its own
             out["concurrent_chains"] = {"chains": nch, "error": str(ex)}
-    if pi and pl["generation"] == 3 and args.chains != 1:
+    if model in ("BayesB", "BayesC") and pi >= 0.9 and pl["generation"] == 3 and args.chains != 1:   # (fit_many's rule for pairing)
         npairs = args.pairs if args.pairs > 0 else max(1, (256 - 40) // (P.nwg * (P.slab_rows // 256 if P.slab_rows >= 256 else 1) + 2))   # (a pair holds K3 + 2 CUs for the sweep; ~40 CUs stay free for the iterations' small kernels: six pairs at C4 measured slower than five)
         try:
             os.environ["BWGR_ENG3_THR"] = os.environ.get("BWGR_ENG3_THR", "0.02")
