@@ -261,7 +261,7 @@ def main():
     # corrected figure is committed under profiles/ and quoted only for the workload it was measured on
     pl = P.pipeline(bool(pi) or model in ("BayesCpi", "BayesDpi"))
     mean_d = float(st["d"].mean())
-    if pl["generation"] == 3 and mean_d >= float(os.environ.get("BWGR_ENG3_THR", "0.02")):
+    if pl["generation"] == 3 and mean_d >= float(os.environ.get("BWGR_ENG3_THR", "0.03")):
         # the device picks the selection sweeps' engine from the chain's inclusion rate: above the threshold k_sweep2 ran them
         pl = {"generation": 2, "lag": int(os.environ.get("BWGR_LAG", "3")), "feeders": 0}
     kernel = {4: "k_sweep2w", 3: "k_sweep3<uint%d>" % pl.get("gram_bits", 16), 2: "k_sweep2<int8>", 1: "k_sweep<int8>"}[pl["generation"]]
@@ -298,10 +298,10 @@ def main():
             out["concurrent_chains"] = concurrent_leg(P, model, y, pi, nch, K, W, n, p)
         except Exception as ex:   # the headline leg above stands on its own
             out["concurrent_chains"] = {"chains": nch, "error": str(ex)}
-    if model in ("BayesB", "BayesC") and pi >= 0.9 and pl["generation"] == 3 and args.chains != 1:   # (fit_many's rule for pairing)
+    if model in ("BayesB", "BayesC") and pi >= 0.95 and pl["generation"] == 3 and args.chains != 1:   # (fit_many's rule for pairing)
         npairs = args.pairs if args.pairs > 0 else max(1, (256 - 40) // (P.nwg * (P.slab_rows // 256 if P.slab_rows >= 256 else 1) + 2))   # (a pair holds K3 + 2 CUs for the sweep; ~40 CUs stay free for the iterations' small kernels: six pairs at C4 measured slower than five)
         try:
-            os.environ["BWGR_ENG3_THR"] = os.environ.get("BWGR_ENG3_THR", "0.02")
+            os.environ["BWGR_ENG3_THR"] = os.environ.get("BWGR_ENG3_THR", "0.03")
             out["paired_chains"] = paired_leg(P, model, y, pi, npairs, K, W, n, p)
         except Exception as ex:
             out["paired_chains"] = {"pairs": npairs, "error": str(ex)}

@@ -374,7 +374,7 @@ def fit_many(X, jobs, concurrent=None, chunk=4, pair=None, **panel_kw):
     Panel.max_concurrent() of them fit.  This is the shape of the reference's multi-fit callers (mcmcCV runs seven
     samplers per fold on the same training matrix, R/cv.R:124-130), which it runs one after the other.
 
-    pair: sparse selection jobs (BayesB / BayesC with pi >= 0.9 on a panel that has k_sweep3) run TWO to a set of streamer
+    pair: sparse selection jobs (BayesB / BayesC with pi >= 0.95 on a panel that has k_sweep3: up to about 6 % of the markers in the model a pair does more per compute unit than two chains apart) run TWO to a set of streamer
     workgroups (Chain.run_pair: one pass over the genotypes serves both).  A paired chain is bit for bit the chain it is alone on
     k_sweep3; a single chain whose inclusion rate passes 2 % takes some sweeps on k_sweep2 instead (the device chooses), which
     agrees to ~1e-9, not bit for bit.  None = whenever at least two jobs qualify, False = never, True = every selection job
@@ -395,7 +395,7 @@ def fit_many(X, jobs, concurrent=None, chunk=4, pair=None, **panel_kw):
         if pair is True:
             paired = [i for i, r in enumerate(norm) if r[0] in _SELECTION] if gen3 else []
         elif pair is None:
-            paired = [i for i, r in enumerate(norm) if r[0] in ("BayesB", "BayesC") and r[4] >= 0.9] if gen3 else []
+            paired = [i for i, r in enumerate(norm) if r[0] in ("BayesB", "BayesC") and r[4] >= 0.95] if gen3 else []
         else:
             paired = []
         if len(paired) < 2:

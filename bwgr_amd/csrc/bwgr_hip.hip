@@ -933,7 +933,8 @@ struct bwgr_panel {
   size_t ldsw_bytes = 0;
   std::vector<hipStream_t> pair_streams;   // root panel: the streams pairs of chains run on (bwgr_chain_run_pair); owned here, so that they outlive every clone
   bool force3 = false;            // a pair run (bwgr_chain_run_pair): every selection sweep is k_sweep3's, whatever the inclusion rate
-  float eng3_thr = 0.02f;         // k_sweep3 takes the sweeps whose chains hold fewer than this share of markers in the model (BWGR_ENG3_THR)
+  float eng3_thr = 0.03f;         // k_sweep3 takes the sweeps whose chains hold fewer than this share of markers in the model (BWGR_ENG3_THR);
+                                  // measured crossover at n = 10 000: us per block at 1.4 / 3.7 / 5.8 / 10.9 % inclusion: k_sweep3 2.26 / 3.73 / 5.56 / 12.1, k_sweep2 3.07 / 3.29 / 3.60 / 4.69
   hipStream_t own_stream = nullptr;
 };
 
