@@ -750,7 +750,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   __syncthreads();
   if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
 
-  const bool sq0 = (tid == 0), sq1 = (tid == 64), sq2 = (tid == 128), sq4 = (tid == 320);
+  const bool sq0 = (tid == 0), sq1 = (tid == 64), sq2 = (tid == 128), sq4 = (tid == 320), sq3 = (tid == 192), sq6 = (tid == 384), sq7 = (tid == 448);
   const bool altb2 = (a.flags & SWF_ALT_B2) != 0;
   if (wave == 0 && !(A.dbg & 1)) __builtin_amdgcn_s_setprio(3);   // the chain's wave goes first wherever it shares an issue port
   // wave 0: what the included markers of block b change in blocks b+1 and b+2 (distances 1 and 2), accumulated as they appear
@@ -758,7 +758,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   for (int b = 0; b < nb; ++b) {
     const int mB = blk_m(b), blk = a.blk_begin + b;
     const bool have_next = (b + 1 < nb);
-    S3ST(0, sq0 || sq1 || sq2 || sq4);
+    S3ST(0, sq0 || sq1 || sq2 || sq4 || sq3 || sq6 || sq7);
     if (wave == 0 && !(A.dbg & 16384)) {
       // Wave 0 is one long dependent chain, so everything here is counted in instructions.  Dead lanes of a ragged last block need
       // no masks: k_prestage fills their constants so that they reject for certain, and their q, spec and far terms are zero.
@@ -925,15 +925,15 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       S3ST(3, sq0);
     } else if (have_next && wave != 0) {
       helper_phase(b + 1);
-      S3ST(1, sq1 || sq2 || sq4);
+      S3ST(1, sq1 || sq2 || sq4 || sq3 || sq6 || sq7);
     }
     // block b's rounds are done, its list is in LDS; everything block b+1 needs from the helpers is in LDS.  (A bare barrier:
     // __syncthreads() would drain the far-field rows that are meant to stay in flight across it.)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    S3ST(4, sq0 || sq1 || sq2 || sq4);
+    S3ST(4, sq0 || sq1 || sq2 || sq4 || sq3 || sq6 || sq7);
     if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
   }
-  S3ST_FLUSH(16, sq0); S3ST_FLUSH(24, sq1); S3ST_FLUSH(32, sq2); S3ST_FLUSH(40, sq4);
+  S3ST_FLUSH(16, sq0); S3ST_FLUSH(24, sq1); S3ST_FLUSH(32, sq2); S3ST_FLUSH(40, sq4); S3ST_FLUSH(48, sq3); S3ST_FLUSH(56, sq6); S3ST_FLUSH(64, sq7);
   if (wave == 7) {   // the last two blocks
     if (nb >= 2) finish_block(nb - 2);
     finish_block(nb - 1);
