@@ -26,7 +26,7 @@ WORKLOADS = {
     "c3": (10000, 500000, "BayesB", 0.99),
     "c4": (10000, 1000000, "BayesB", 0.99),
     "c4a": (10000, 1000000, "BayesA", 0.0),    # (not a BASELINE config: C4's shape with an affine model, as wgr() runs by default)
-    "c5": (50000, 1000000, "BayesCpi", 0.5),   # BASELINE config 5's panel and model on ONE GPU (50 GB of int8 genotypes; Gram entries need 32 bits)
+    "c5": (50000, 1000000, "BayesCpi", 0.5),   # BASELINE config 5's panel and model on ONE GPU (50 GB of int8 genotypes)
     "c5b": (50000, 1000000, "BayesB", 0.99),   # (not a BASELINE config: config 5's panel under the headline model)
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
