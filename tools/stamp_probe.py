@@ -11,15 +11,17 @@ B.LIB = so
 import numpy as np, torch
 import bwgr_amd
 from bwgr_amd import synth, _lib
-wl = {"c2": (5000, 50000, "BayesA", 0.0), "c4s": (10000, 100000, "BayesB", 0.99), "c4d": (10000, 100000, "BayesCpi", 0.5)}
+wl = {"c2": (5000, 50000, "BayesA", 0.0), "c4s": (10000, 100000, "BayesB", 0.99), "c4d": (10000, 100000, "BayesCpi", 0.5), "c4m": (10000, 100000, "BayesB", 0.95)}
 names2 = {0: "streamer: loop top + tile issue", 9: "streamer: tile commit (vmcnt(0) + LDS stores)", 10: "streamer: delta poll (early request or loop)", 11: "streamer: wave max + LDS atomic", 1: "streamer: barrier after the poll", 2: "streamer: delta digits", 3: "streamer: update MFMA (wave 0)", 4: "streamer: update barrier", 5: "streamer: e update + max", 6: "streamer: e digits", 7: "streamer: dots (barrier, MFMA, barrier)", 8: "streamer: q recombine + store",
           16: "sequencer: top barrier", 21: "sequencer: lane constants", 22: "sequencer: recurrence rounds", 17: "sequencer: outputs + delta store", 18: "sequencer: wait at barrier A (helpers, q_{b+1})", 19: "sequencer: post (state, r0 of next block)", 20: "sequencer: post tail"}
 names = ["top-barrier", "dot", "combine+exchange", "wait for prefetch waves", "outputs+update", "spec matvec", "recurrence (wave 0)", "-", "wave1: prefetch until tile+stage stored", "wave1: residual vmcnt(0)", "wave1: t(gram loads landed)", "wave1: t(+stage landed)"]
+names2w = dict(names2)
 if os.environ.get("BWGR_WINV", "1") != "0":   # affine sweeps run k_sweep2w: its sequencer stamps wave 4 (sweep2w.hip.h)
-    names2.update({16: "sequencer w4: wait at B0", 17: "-", 18: "sequencer w4: wait at B2 (waves 0-3: cross terms + rhs)", 19: "sequencer w4: collect q_{c+1}, request q_{c+2}", 20: "sequencer w4: wait at B3 (waves 0-3: product)", 21: "sequencer w4: outputs, granules, digits", 22: "-",
+    names2w.update({16: "sequencer w4: wait at B0", 17: "-", 18: "sequencer w4: wait at B2 (waves 0-3: cross terms + rhs)", 19: "sequencer w4: collect q_{c+1}, request q_{c+2}", 20: "sequencer w4: wait at B3 (waves 0-3: product)", 21: "sequencer w4: outputs, granules, digits", 22: "-",
                    24: "sequencer w0: wait for the constants (vmcnt)", 25: "sequencer w0: wait at B0", 26: "sequencer w0: cross terms + rhs", 27: "sequencer w0: plane requests", 28: "sequencer w0: wait at B2", 29: "sequencer w0: product (incl. wait for W)", 30: "sequencer w0: W + constants requests, reduce, d", 31: "sequencer w0: wait at B3 + loop"})
 for key in sys.argv[1:] or ["c2", "c4s"]:
     n, p, model, pi = wl[key]
+    names2 = names2 if pi else names2w
     X = synth.genotypes(n, p); y = synth.scale_phenotype(synth.phenotype(X, n))
     P = bwgr_amd.Panel(X, n=n); del X
     ch = bwgr_amd.Chain(P, model, y, it=4, bi=0, pi=pi, seed=1)
