@@ -1340,9 +1340,8 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
     const int mB = blk_m(b);
     const bool have_next = (b + 1 < nb);
     const int mBn = have_next ? blk_m(b + 1) : 0;
-    float bn[2] = {0.0f, 0.0f}, dn[2] = {0.0f, 0.0f}, corr_own[2] = {0.0f, 0.0f}, drej_own[2] = {0.0f, 0.0f};
+    float bn[2] = {0.0f, 0.0f}, dn[2] = {0.0f, 0.0f};
     double chi[2] = {1.0, 1.0};
-    unsigned long long am0 = 0ull, am1 = 0ull;
     int nacc = 0;
     if (wave == 0) {
       const StageBuf &st = stage[b & 1];
@@ -1410,8 +1409,6 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
           float *sp = Q16_STATE(b);
           sp[t] = bn[q]; sp[SW_MAXM + t] = dn[q];
           if (a.flags & SWF_VB_VEC) sp[2 * SW_MAXM + t] = (float)((double)(Sb + bn[q] * bn[q]) / chi[q]);
-          corr_own[q] = (b1 - lc[q].b0);
-          drej_own[q] = lc[q].drej;
           sum_d += (double)dn[q];
           sum_b2 = fma((double)bn[q], (double)bn[q], sum_b2);
         }
@@ -1421,7 +1418,6 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
         if (lane < mB) st_agent_raw64(gslot + lane, s2_dgranule(b, exmax, dl_own[0]));
         if (64 + lane < mB) st_agent_raw64(gslot + 64 + lane, s2_dgranule(b, exmax, dl_own[1]));
       }
-      am0 = accmask[0]; am1 = accmask[1];
       if (lane == 0) ctrl_s[4 + (b & 3)] = nacc;
       S2WALL(0, lane == 0 && b + L < nb);
       S2WALL(7, lane == 0 && b == 100); S2WALL(9, lane == 0 && b == 101); S2WALL(11, lane == 0 && b == 102); S2WALL(12, lane == 0 && b == 103);
@@ -1471,19 +1467,22 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
 #pragma unroll
         for (int w = 0; w < 8; ++w) { s0 += dpost[(size_t)w * SW_MAXM + lane]; s1 += dpost[(size_t)w * SW_MAXM + 64 + lane]; }
         r0 -= s0; r1 -= s1;
-      } else {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          unsigned long long mk = q ? am1 : am0;
-          while (mk) {
-            const int js = __ffsll((long long)mk) - 1;
-            mk &= mk - 1ull;
-            const double corr = (double)readlane_f32(corr_own[q], js) - (double)readlane_f32(drej_own[q], js);
-            const GT *row = gxn + (size_t)(64 * q + js) * m;
-            const GT ga = row[lane], gb = row[min(64 + lane, m - 1)];
-            r0 = fma(-(double)ga, corr, r0);
-            r1 = fma(-(double)gb, corr, r1);
-          }
+      } else if (naccb > 0) {
+        // sparse blocks: this block's list (acc_k / acc_corr, written with the outputs) read once, lane i = entry i, and handed to
+        // the wave by readlane -- a dozen instructions per accepted marker instead of the two dozen of a loop over the masks
+        const int *lk = acc_k2 + (size_t)(b & 3) * SW_MAXM;
+        const double *lcf = acc_corr2 + (size_t)(b & 3) * SW_MAXM;
+        const int ei = min(lane, naccb - 1);                       // (naccb <= 12 here)
+        const int rowoff = lk[ei] * m * (int)sizeof(GT);
+        const double cfl = lcf[ei];
+        const unsigned char *gl0 = reinterpret_cast<const unsigned char *>(gxn + lane);
+        const unsigned char *gl1 = reinterpret_cast<const unsigned char *>(gxn + min(64 + lane, m - 1));
+        for (int i = 0; i < naccb; ++i) {
+          const int ro = __builtin_amdgcn_readlane(rowoff, i);
+          const double corr = readlane_f64(cfl, i);
+          const GT ga = *reinterpret_cast<const GT *>(gl0 + ro), gb = *reinterpret_cast<const GT *>(gl1 + ro);
+          r0 = fma(-(double)ga, corr, r0);
+          r1 = fma(-(double)gb, corr, r1);
         }
       }
       rnext[0] = l0 ? r0 : 0.0; rnext[1] = l1 ? r1 : 0.0;
