@@ -486,7 +486,14 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   unsigned char *gpd_s = smem + off; if (G16) off += (size_t)3 * S3_GPD_BYTES;
   unsigned char *rowx_s = smem + off; if (G16) off += (size_t)S3_NRX * 2 * SW_MAXM * 2;
   Eval3Buf *ev_s = reinterpret_cast<Eval3Buf *>(smem + off); off += 2 * sizeof(Eval3Buf);
+#ifndef BWGR_W0LEAN
+#define BWGR_W0LEAN 0
+#endif
+#if BWGR_W0LEAN & 1
+  constexpr bool fastev = false;
+#else
   const bool fastev = a.ps.ev3 != nullptr && !(A.dbg & 65536);
+#endif
   constexpr int NEV = (int)(sizeof(Eval3Buf) / 16);   // 448 chunks
   int *ctrl_s = reinterpret_cast<int *>(smem + off);   // [0] ok flag
   int *pos_s = ctrl_s + 8;                             // [b & 31]: ring position where block b's entries begin
@@ -505,15 +512,19 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   // ---- the helpers' work for block c (relative): everything that does not depend on block c-1's rounds ----
   uint4 sg0 = make_uint4(0, 0, 0, 0), sg1 = sg0, sg2 = sg0, sg3 = sg0;   // staging waves: block c's chunks, requested one phase earlier
   uint4 sg4 = sg0, sg5 = sg0, sg6 = sg0, sg7 = sg0;                       // ... and the quick test's constants (448 chunks, the last loads repeat)
+  // (selects, not branches: where exec-masked branches join, the compiler puts an s_waitcnt vmcnt(0) in front of its register copies,
+  // and a staging wave would wait out the loads it has just issued)
   auto stage_src = [&](int c, int ch) -> const uint4 * {
     const int blk = a.blk_begin + c;
-    if (ch < NCH) return reinterpret_cast<const uint4 *>(a.ps.blocks + blk) + ch;
-    if (ch < NCH + 64) return reinterpret_cast<const uint4 *>(a.ps.spec[blk].spec) + (ch - NCH);
-    return reinterpret_cast<const uint4 *>(a.ps.spec[blk].gjj) + (ch - NCH - 64);
+    const uintptr_t p0 = (uintptr_t)(reinterpret_cast<const uint4 *>(a.ps.blocks + blk) + ch);
+    const uintptr_t p1 = (uintptr_t)(reinterpret_cast<const uint4 *>(a.ps.spec[blk].spec) + (ch - NCH));
+    const uintptr_t p2 = (uintptr_t)(reinterpret_cast<const uint4 *>(a.ps.spec[blk].gjj) + (ch - NCH - 64));
+    return reinterpret_cast<const uint4 *>(ch < NCH ? p0 : (ch < NCH + 64 ? p1 : p2));
   };
   auto stage_dst = [&](int c, int ch) -> uint4 * {
-    if (ch < NCH) return reinterpret_cast<uint4 *>(&stage[c & 1]) + ch;
-    return reinterpret_cast<uint4 *>(spec_s + (size_t)(c & 1) * 2 * SW_MAXM) + (ch - NCH);   // spec (64 chunks) then gjj (64 chunks), contiguous
+    const uintptr_t d0 = (uintptr_t)(reinterpret_cast<uint4 *>(&stage[c & 1]) + ch);
+    const uintptr_t d1 = (uintptr_t)(reinterpret_cast<uint4 *>(spec_s + (size_t)(c & 1) * 2 * SW_MAXM) + (ch - NCH));   // spec (64 chunks) then gjj (64 chunks), contiguous
+    return reinterpret_cast<uint4 *>(ch < NCH ? d0 : d1);
   };
   auto stage_request = [&](int c) {   // waves 2-3
     const int t = tid - 128;
@@ -718,16 +729,25 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       }
     }
   };
+#ifndef BWGR_ROLEBAR
+#define BWGR_ROLEBAR 1
+#endif
+  // BWGR_ROLEBAR: every role reaches the block barrier inside its own branch.  The roles are exec-masked branches of one function, and
+  // where they join the compiler copies role-specific registers and puts an s_waitcnt vmcnt(0) in front of the copies -- which every
+  // wave executes: with the barrier behind the join, a staging wave waited out the round trip of the requests it had just issued,
+  // every block, before it reached the barrier.  With the barrier in front of the join that wait falls into the next phase, where the
+  // wave waits for those requests anyway.
+#define S3_ROLE_BARRIER() do { if (BWGR_ROLEBAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
   auto helper_phase = [&](int c) {   // block c >= 1, while wave 0 runs block c-1
-    if (wave == 1) { if (!(A.dbg & 32768)) { if (!poll_q(c)) ctrl_s[0] = 0; } }
+    if (wave == 1) { if (!(A.dbg & 32768)) { if (!poll_q(c)) ctrl_s[0] = 0; } S3_ROLE_BARRIER(); }
     else if (wave <= 3) { if (!(A.dbg & 8192)) {
       // the constants of block c, requested a phase ago -- waiting for them also waits for block c's packed diagonal block, whose
       // DMA was issued before them; then the requests for block c+1 (the DMA first), which have this whole phase to land
       if (!(A.dbg & 262144)) stage_commit(c);
       if (c + 1 < nb) { if (!(A.dbg & 131072)) gpd_issue(c + 1); if (!(A.dbg & 262144)) stage_request(c + 1); }
       else if constexpr (GPD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } }
-    else if (wave == 4) { }   // idle: the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots
+    } S3_ROLE_BARRIER(); }
+    else if (wave == 4) { S3_ROLE_BARRIER(); }   // idle: the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots
     else if (wave <= 6) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       S3ST(5, tid == 320);
@@ -735,8 +755,9 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       S3ST(6, tid == 320);
       far_issue(c + 1, wave - 5);
       S3ST(7, tid == 320);
+      S3_ROLE_BARRIER();
     }
-    else { if (c >= 2 && !(A.dbg & 4096)) finish_block(c - 2); touch(c + PF); }
+    else { if (c >= 2 && !(A.dbg & 4096)) finish_block(c - 2); touch(c + PF); S3_ROLE_BARRIER(); }
   };
 
   // ---- prologue: block 0 ----
@@ -759,7 +780,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     const int mB = blk_m(b), blk = a.blk_begin + b;
     const bool have_next = (b + 1 < nb);
     S3ST(0, sq0 || sq1 || sq2 || sq4 || sq3 || sq6 || sq7);
-    if (wave == 0 && !(A.dbg & 16384)) {
+    if (wave == 0 && ((BWGR_W0LEAN & 2) || !(A.dbg & 16384))) {
       // Wave 0 is one long dependent chain, so everything here is counted in instructions.  Dead lanes of a ragged last block need
       // no masks: k_prestage fills their constants so that they reject for certain, and their q, spec and far terms are zero.
       const StageBuf &st = stage[b & 1];
@@ -826,7 +847,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
         const int pr_ = prow(k_); \
         GT ga_ = (GT)1, gb_ = (GT)1, xa_ = (GT)0, xb_ = (GT)0, ya_ = (GT)0, yb_ = (GT)0; \
         bool direct_ = true; \
-        if (!(A.dbg & 64)) { \
+        if ((BWGR_W0LEAN & 4) || !(A.dbg & 64)) { \
         if constexpr (G16) { \
           if constexpr (GPD) { \
             const GT *gpl_ = reinterpret_cast<const GT *>(gpd_s + (size_t)(b % 3) * S3_GPD_BYTES); \
@@ -858,7 +879,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
         if (use1) { rnext0 = fma(-(double)xa_, corr_, rnext0); rnext1 = fma(-(double)xb_, corr_, rnext1); } \
         if (use2) { rnxt20 = fma(-(double)ya_, corr_, rnxt20); rnxt21 = fma(-(double)yb_, corr_, rnxt21); } } }
       // exact speculative rounds, first over markers 0..63, then 64..127: every lane assumes "nobody before me is included"
-      if (!(A.dbg & 128)) {
+      if ((BWGR_W0LEAN & 8) || !(A.dbg & 128)) {
         const int cnt0 = min(64, mB);
         int front = 0;
         for (;;) {
@@ -877,7 +898,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
           S3_INCLUDE(0, d1f, dra)
         }
       }
-      if (mB > 64 && !(A.dbg & 128)) {
+      if (mB > 64 && ((BWGR_W0LEAN & 8) || !(A.dbg & 128))) {
         const int cnt1 = mB - 64;
         int front = 0;
         for (;;) {
@@ -900,7 +921,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
 #undef S3_INCLUDE
 #undef S3_FEVAL
       if constexpr (G16) {
-        if (nacc > 0 && !(A.dbg & 64)) {   // the distance-1 / 2 rows requested as the markers appeared
+        if (nacc > 0 && ((BWGR_W0LEAN & 4) || !(A.dbg & 64))) {   // the distance-1 / 2 rows requested as the markers appeared
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
           const int nx = min(nacc, S3_NRX);
           for (int i = 0; i < nx; ++i) {
@@ -923,13 +944,14 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       }
       if (lane == 0) pos_s[(b + 1) & 31] = (pos0 + nacc) & (ring - 1);
       S3ST(3, sq0);
+      S3_ROLE_BARRIER();
     } else if (have_next && wave != 0) {
       helper_phase(b + 1);
       S3ST(1, sq1 || sq2 || sq4 || sq3 || sq6 || sq7);
-    }
+    } else S3_ROLE_BARRIER();
     // block b's rounds are done, its list is in LDS; everything block b+1 needs from the helpers is in LDS.  (A bare barrier:
     // __syncthreads() would drain the far-field rows that are meant to stay in flight across it.)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!BWGR_ROLEBAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     S3ST(4, sq0 || sq1 || sq2 || sq4 || sq3 || sq6 || sq7);
     if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
   }
