@@ -265,6 +265,8 @@ def main():
         # the device picks the selection sweeps' engine from the chain's inclusion rate: above the threshold k_sweep2 ran them
         pl = {"generation": 2, "lag": int(os.environ.get("BWGR_LAG", "3")), "feeders": 0}
     kernel = {4: "k_sweep2w", 3: "k_sweep3<uint%d>" % pl.get("gram_bits", 16), 2: "k_sweep2<int8>", 1: "k_sweep<int8>"}[pl["generation"]]
+    # (a chain that has the GPU to itself runs k_sweep3 with 128-row streamers, two to a slab: bwgr_hip.hip, launch_sweep3)
+    solo3 = pl["generation"] == 3 and os.environ.get("BWGR_SOLO3", "1") != "0" and P.slab_rows == 256 and 2 * P.nwg + 1 <= 256 and not os.environ.get("BWGR_R3")
     traffic, traffic_source = None, None
     for name in ("r02_pmc_c4.json", "r01_pmc_c4.json"):
         try:
@@ -282,7 +284,9 @@ def main():
         "config": {"workload": "%s: synthetic n=%d x p=%d int8, %s%s, exact chain (blocked sweep, block=%d, %d slabs "
                                "x %d rows + 1 sequencer%s)" % (args.workload, n, p, model,
                                                           " pi=%.2f (%.1f%% of the markers in the model at the last sweep)" % (pi, 100.0 * mean_d) if pi else "", P.block, P.nwg, P.slab_rows,
-                                                          (" + %d q feeders" % pl["feeders"] if pl["feeders"] else "") + ", engine generation %d, lag %d blocks" % (pl["generation"], pl["lag"])),
+                                                          (" + %d q feeders" % pl["feeders"] if pl["feeders"] else "")
+                                                          + (", the chain alone on the GPU: %d streamers x 128 rows" % (2 * P.nwg) if solo3 else "")
+                                                          + ", engine generation %d, lag %d blocks" % (pl["generation"], pl["lag"])),
                    "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel,

@@ -915,6 +915,7 @@ struct bwgr_panel {
   bool e3_ready = false;
   int e3_D = 0;                   // fold-in lag in blocks; cross Gram arrays reach D-1 blocks back
   int K3 = 0, R3 = 0, sub3 = 0;   // streamer workgroups, rows of each, streamers per slab
+  bool solo3 = true;              // a chain alone on the GPU runs 128-row streamers (BWGR_SOLO3=0: never)
   void *g3x[S3_MAXD] = {};        // g3x[d-1]: cross Gram blocks of distance d in the element type k_sweep3 reads (aliases the older arrays where they fit)
   bool g3own[S3_MAXD] = {};       // allocated here (not an alias)
   int xmax = 0;                   // largest |x| of an int8 panel
@@ -1049,6 +1050,7 @@ static int sweep3_build(bwgr_panel *P) {
     return BWGR_OK;
   }
   P->R3 = R3; P->sub3 = sub; P->K3 = K3; P->e3_D = D; P->lds3_bytes = lds;
+  if (const char *sv3 = getenv("BWGR_SOLO3")) P->solo3 = sv3[0] != '0';
   if (const char *tv = getenv("BWGR_ENG3_THR")) { const float v = (float)atof(tv); if (v > 0.0f) P->eng3_thr = v; }
   const size_t blk_elems = (size_t)P->nblocks * m * m;
   const bool g16 = P->gram16;
@@ -1111,10 +1113,14 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
   sweep3_args(P, a, A);
   // one more workgroup, on the sequencer's XCD (workgroups with equal index mod 8 share an XCD), warms that XCD's L2 with what the
   // staging waves load; BWGR_PF3=1 switches it on
+  // A chain that has the GPU to itself (a root panel without clones) runs 128-row streamers, two to a slab: 80 compute units instead
+  // of 41, 15.98-16.18 against 16.49 ms per sweep at C4 (the same chain bit for bit: the slab dots are integer sums).  With clones
+  // alive -- chains side by side, pairs -- every chain keeps the 256-row streamers the concurrency counts assume.  BWGR_SOLO3=0: never.
+  if (P->solo3 && !P->parent && P->nclones == 0 && P->R3 == 256 && 2 * P->K3 + 1 <= 256) { A.R3 = 128; A.sub = P->R / 128; A.K3 = P->K * A.sub; }
   const char *pv = getenv("BWGR_PF3");
-  const bool pf_on = (pv && pv[0] == '1') && P->K3 + 2 <= 256;   // (measured: no gain at C4; off by default)
-  A.pf = pf_on ? ((P->K3 + 2 > 8) ? 8 : P->K3 + 1) : -1;
-  const dim3 grid(P->K3 + 1 + (pf_on ? 1 : 0)), blk(SW_THREADS);
+  const bool pf_on = (pv && pv[0] == '1') && A.K3 + 2 <= 256;   // (measured: no gain at C4; off by default)
+  A.pf = pf_on ? ((A.K3 + 2 > 8) ? 8 : A.K3 + 1) : -1;
+  const dim3 grid(A.K3 + 1 + (pf_on ? 1 : 0)), blk(SW_THREADS);
   if (A.g16) hipLaunchKernelGGL(k_sweep3<uint16_t>, grid, blk, P->lds3_bytes, P->stream, A);
   else hipLaunchKernelGGL(k_sweep3<int32_t>, grid, blk, P->lds3_bytes, P->stream, A);
 }
