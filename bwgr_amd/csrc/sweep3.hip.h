@@ -169,6 +169,10 @@ __device__ __forceinline__ void s3_dma4(const void *gsrc, const void *lds_base) 
   const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)lds_base);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(gsrc), "s"(la) : "memory", "m0");
 }
+// ... and from a wave-uniform base (SGPR pair) plus a per-lane byte offset, to a uniform LDS address: no 64-bit vector arithmetic
+__device__ __forceinline__ void s3_dma4s(const unsigned char *gbase, uint32_t voff, uint32_t la) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(gbase), "s"(la) : "memory", "m0");
+}
 #pragma clang diagnostic pop
 
 __host__ __device__ inline size_t s3_streamer_lds(int R3) {
@@ -772,6 +776,13 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
 
   const bool sq0 = (tid == 0), sq1 = (tid == 64), sq2 = (tid == 128), sq4 = (tid == 320), sq3 = (tid == 192), sq6 = (tid == 384), sq7 = (tid == 448);
+  // wave 0's included-marker path, counted in instructions: the packed row's byte offset from a lane-indexed table by one v_readlane
+  // (lane = the marker within its group; entry j of packed row k sits at prow(k) + j - k - 1), the lane's dword of a cross row, and the
+  // LDS addresses of the packed blocks and of the row slots as scalars
+  const int tabp0 = 2 * (lane * (m - 1) - lane * (lane - 1) / 2 - lane - 1);
+  const int tabp1 = 2 * ((64 + lane) * (m - 1) - (64 + lane) * (63 + lane) / 2 - (64 + lane) - 1);
+  const uint32_t rolane = (uint32_t)min(lane * 4, rowbytes - 4);
+  const uint32_t rowx_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)rowx_s);
   const bool altb2 = (a.flags & SWF_ALT_B2) != 0;
   if (wave == 0 && !(A.dbg & 1)) __builtin_amdgcn_s_setprio(3);   // the chain's wave goes first wherever it shares an issue port
   // wave 0: what the included markers of block b change in blocks b+1 and b+2 (distances 1 and 2), accumulated as they appear
@@ -850,16 +861,15 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
         if ((BWGR_W0LEAN & 4) || !(A.dbg & 64)) { \
         if constexpr (G16) { \
           if constexpr (GPD) { \
-            const GT *gpl_ = reinterpret_cast<const GT *>(gpd_s + (size_t)(b % 3) * S3_GPD_BYTES); \
-            ga_ = gpl_[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gpl_[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)]; \
+            const unsigned char *gpl_ = gpd_s + (size_t)(b % 3) * S3_GPD_BYTES + 2 * lane + __builtin_amdgcn_readlane((KOFF_) ? tabp1 : tabp0, js); \
+            ga_ = *reinterpret_cast<const GT *>(gpl_); gb_ = *reinterpret_cast<const GT *>(gpl_ + 128);   /* (lanes at or before k_: masked below) */ \
           } else { \
             ga_ = gp[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gp[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)]; \
           } \
           if (nacc < S3_NRX) {   /* the rows for the next two blocks: by DMA, consumed after the last round */ \
             direct_ = false; \
-            const int ro_ = min(lane * 4, rowbytes - 4); \
-            if (use1) s3_dma4(reinterpret_cast<const unsigned char *>(g1 + (size_t)k_ * m) + ro_, rowx_s + (size_t)(nacc * 2) * (SW_MAXM * 2)); \
-            if (use2) s3_dma4(reinterpret_cast<const unsigned char *>(g2 + (size_t)k_ * m) + ro_, rowx_s + (size_t)(nacc * 2 + 1) * (SW_MAXM * 2)); \
+            if (use1) s3_dma4s(reinterpret_cast<const unsigned char *>(g1) + (size_t)(k_ * rowbytes), rolane, rowx_la + (uint32_t)(nacc * 2) * (SW_MAXM * 2)); \
+            if (use2) s3_dma4s(reinterpret_cast<const unsigned char *>(g2) + (size_t)(k_ * rowbytes), rolane, rowx_la + (uint32_t)(nacc * 2 + 1) * (SW_MAXM * 2)); \
           } \
         } else { \
           ga_ = gp[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gp[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)];   /* (the last row is empty) */ \
