@@ -1116,9 +1116,12 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
   // A chain that has the GPU to itself (a root panel without clones) runs 128-row streamers, two to a slab: 80 compute units instead
   // of 41, 15.98-16.18 against 16.49 ms per sweep at C4 (the same chain bit for bit: the slab dots are integer sums).  With clones
   // alive -- chains side by side, pairs -- every chain keeps the 256-row streamers the concurrency counts assume.  BWGR_SOLO3=0: never.
-  if (P->solo3 && !P->parent && P->nclones == 0 && P->R3 == 256 && 2 * P->K3 + 1 <= 256) { A.R3 = 128; A.sub = P->R / 128; A.K3 = P->K * A.sub; }
+  const bool solo = P->solo3 && !P->parent && P->nclones == 0;
+  if (solo && P->R3 == 256 && 2 * P->K3 + 1 <= 256) { A.R3 = 128; A.sub = P->R / 128; A.K3 = P->K * A.sub; }
   const char *pv = getenv("BWGR_PF3");
-  const bool pf_on = (pv && pv[0] == '1') && A.K3 + 2 <= 256;   // (measured: no gain at C4; off by default)
+  // (on for a chain alone on the GPU: 15.61 -> 15.37 ms per sweep at C4 on the steadied kernel; beside other chains the workgroup is
+  // not counted by bwgr_panel_max_concurrent, so it stays off there; BWGR_PF3=0|1 decides otherwise)
+  const bool pf_on = (pv ? pv[0] == '1' : solo) && A.K3 + 2 <= 256;
   A.pf = pf_on ? ((A.K3 + 2 > 8) ? 8 : A.K3 + 1) : -1;
   const dim3 grid(A.K3 + 1 + (pf_on ? 1 : 0)), blk(SW_THREADS);
   if (A.g16) hipLaunchKernelGGL(k_sweep3<uint16_t>, grid, blk, P->lds3_bytes, P->stream, A);
