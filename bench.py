@@ -207,6 +207,7 @@ def main():
         elapsed = float(el.item())
         sweep_ms, launches = ch.sweep_ms()
         st = ch.state()
+        mean_d = float(st["d"].mean())
         pl = P.pipeline(bool(pi))
         kernel = {4: "k_sweep2w", 3: "k_sweep3<uint16>", 2: "k_sweep2<int8>", 1: "k_sweep<int8>"}[pl["generation"]]
         alg_bytes = float(n) * float(p)
