@@ -565,3 +565,36 @@ def test_chain_pairs_abort_path(monkeypatch):
     c0.close(); c1.close(); Q.close(); P.close()
     for got, want in ((s0, solo[0]), (s1, solo[1])):
         assert np.array_equal(got["d"], want["d"]) and np.array_equal(got["b"], want["b"])
+
+
+def test_a_chain_changes_streamer_height_with_its_company(monkeypatch):
+    """k_sweep3 gives a chain that has the GPU to itself 128-row streamers (two to a slab) and the L2 prefetcher workgroup, and 256-row
+    streamers as soon as the root panel has a live clone (launch_sweep3).  The slab dots are integer sums, so the chain is the same bit
+    for bit whichever geometry a sweep ran on -- alone throughout, beside a clone throughout, or changing in mid-chain with a clone's
+    chain running at the same time -- and equal to the oracle's."""
+    import bwgr_amd
+    from oracle import oracle as O
+    monkeypatch.setenv("BWGR_ENG3_THR", "1")
+    X, y = synth_small(1100, 2600, seed=61, causal=0.02)
+    P = bwgr_amd.Panel(X)
+    assert P.pipeline(True)["generation"] == 3
+    ch = bwgr_amd.Chain(P, "BayesB", y, it=8, bi=2, pi=0.95, seed=9)
+    ch.run(8)
+    alone = ch.state(); ch.close()
+    ch = bwgr_amd.Chain(P, "BayesB", y, it=8, bi=2, pi=0.95, seed=9)
+    ch.run(3)                                   # alone: 128-row streamers (not waited for)
+    Q = P.clone()
+    other = bwgr_amd.Chain(Q, "BayesC", y, it=8, bi=2, pi=0.95, seed=10)
+    other.run(5); ch.run(3)                     # side by side: 256-row streamers
+    other.sync(); other.close(); Q.close()
+    ch.run(2)                                   # alone again
+    mixed = ch.state(); ch.close()
+    monkeypatch.setenv("BWGR_SOLO3", "0")
+    P2 = bwgr_amd.Panel(X)
+    ch = bwgr_amd.Chain(P2, "BayesB", y, it=8, bi=2, pi=0.95, seed=9)
+    ch.run(8)
+    tall = ch.state(); ch.close(); P2.close(); P.close()
+    for got in (mixed, tall):
+        assert np.array_equal(got["d"], alone["d"]) and np.array_equal(got["b"], alone["b"]) and np.array_equal(got["e"], alone["e"]) and got["ve"] == alone["ve"]
+    o = O.bayes("BayesB", y, X, it=8, bi=2, pi=0.95, seed=9)["last"]
+    assert np.array_equal(alone["d"], o["d"]) and scaled_err(alone["b"], o["b"]) < TOL and scaled_err(alone["e"], o["e"]) < TOL
