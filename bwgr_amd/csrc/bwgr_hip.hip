@@ -1037,7 +1037,7 @@ static int sweep3_build(bwgr_panel *P) {
   if (P->is_f32 || !P->want3 || P->sweep_version != 3) return BWGR_OK;
   const int m = P->m;
   int R3 = (P->R % 256 == 0) ? 256 : 128;
-  if (const char *rv = getenv("BWGR_R3")) { const int v = atoi(rv); if ((v == 64 || v == 128 || v == 256) && P->R % v == 0) R3 = v; }
+  if (const char *rv = getenv("BWGR_R3")) { const int v = atoi(rv); if ((v == 64 || v == 128 || v == 256) && P->R % v == 0) { R3 = v; P->solo3 = false; } }   // (an explicit height holds for every launch)
   const int sub = P->R / R3, K3 = P->K * sub;
   int D = 8;
   // (at least 2: a block's list leaves the sequencer while the next block is in its rounds)
