@@ -787,6 +787,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   if (wave == 0 && !(A.dbg & 1)) __builtin_amdgcn_s_setprio(3);   // the chain's wave goes first wherever it shares an issue port
   // wave 0: what the included markers of block b change in blocks b+1 and b+2 (distances 1 and 2), accumulated as they appear
   double rnext0 = 0.0, rnext1 = 0.0, rnxt20 = 0.0, rnxt21 = 0.0;
+  const GT *gx0_w0 = reinterpret_cast<const GT *>(A.gx[0]) + (size_t)a.blk_begin * m * m, *gx1_w0 = reinterpret_cast<const GT *>(A.gx[1]) + (size_t)a.blk_begin * m * m;
   for (int b = 0; b < nb; ++b) {
     const int mB = blk_m(b), blk = a.blk_begin + b;
     const bool have_next = (b + 1 < nb);
@@ -801,9 +802,9 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       const int pos0 = pos_s[b & 31];
       const GT *gp = gp_all + (size_t)blk * pstride;
       const bool use1 = have_next && D >= 2;   // (D = 1: the streamers fold block b's list in before the dots of block b+1)
-      const GT *g1 = use1 ? reinterpret_cast<const GT *>(A.gx[0]) + (size_t)(blk + 1) * m * m : gp;
+      const GT *g1 = use1 ? gx0_w0 + (size_t)(b + 1) * (uint32_t)(m * m) : gp;   // (bases hoisted out of the block loop: no kernel-argument reload, a 32 x 32 bit product)
       const bool use2 = (b + 2 < nb) && D >= 3;
-      const GT *g2 = use2 ? reinterpret_cast<const GT *>(A.gx[1]) + (size_t)(blk + 2) * m * m : gp;
+      const GT *g2 = use2 ? gx1_w0 + (size_t)(b + 2) * (uint32_t)(m * m) : gp;
       const int l0 = lane, l1 = 64 + lane;
       const int l1c = min(l1, m - 1);
       // constants of this lane's two markers
