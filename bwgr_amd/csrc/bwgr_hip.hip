@@ -1026,9 +1026,6 @@ static int sweep3_alloc_scratch(bwgr_panel *P) {
   HIPCHK(hipMalloc(&P->qsum3, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)P->nblocks));
   HIPCHK(hipMalloc(&P->lists3, sizeof(unsigned long long) * S3_LSTRIDE * (size_t)P->nblocks));
   HIPCHK(hipMemsetAsync(P->lists3, 0, sizeof(unsigned long long) * S3_LSTRIDE * (size_t)P->nblocks, P->stream));
-  // BWGR_FEVAL3=1: the rounds' quick inclusion test (Eval3Buf).  Exact, but measured no faster at C4 (17.0 against 16.6 ms per sweep:
-  // its constants cost more on the staging path than the shorter test saves), so off by default
-  { const char *fv = getenv("BWGR_FEVAL3"); if (fv && fv[0] == '1') HIPCHK(hipMalloc(&P->ps.ev3, sizeof(Eval3Buf) * (size_t)P->nblocks)); }
   return BWGR_OK;
 }
 // the cross Gram arrays of distance 2 .. D-1 in the element type of the 16-bit (or, failing that, 32-bit) staging
@@ -1312,7 +1309,7 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   }
   // the scratch a sweep writes: speculative cross terms, pre-staged constants, exchange words
   hipFree(P->qsum3); hipFree(P->lists3); hipFree(P->winv); hipFree(P->qsumw);
-  hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->ps.quick); hipFree(P->ps.ev3); hipFree(P->xpart); hipFree(P->xchg); hipFree(P->stamps);
+  hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->ps.quick); hipFree(P->xpart); hipFree(P->xchg); hipFree(P->stamps);
   if (P->own_stream) hipStreamDestroy(P->own_stream);
   for (hipStream_t q : P->pair_streams) hipStreamDestroy(q);
   delete P;

@@ -78,16 +78,10 @@ struct SpecBuf {                // r-independent per-marker terms of one block (
 struct QuickBuf {               // lane_quick's centre and radii of one block (k_sweep2's selection rounds), filled by k_spec
   double zc[128], ha[128], hr[128];
 };
-struct Eval3Buf {               // k_sweep3's quick inclusion test (k_spec3): with r the marker's residual dot,
-  double qa[128], qb[128];      //   Q(r) = (qa r + qb) r + qc* is C-signed (|e2|^2 - |e1|^2 - threshold), without the float roundings of the exact chain;
-  double qca[128], qcr[128];    //   included for certain if Q_a(r) > g(|r|), rejected for certain if Q_r(r) < -g(|r|),
-  double g2[128], g1[128], g0[128];   // g(|r|) = (g2 |r| + g1) |r| + g0 bounds those roundings with a wide margin; otherwise the exact chain decides
-};
 struct PreStage {
   StageBuf *blocks;   // one StageBuf per marker block, filled by k_prestage
   SpecBuf *spec;      // one SpecBuf per marker block, filled by k_spec
   QuickBuf *quick;    // one per marker block, filled by k_spec (selection sweeps of k_sweep2)
-  Eval3Buf *ev3;      // one per marker block, filled by k_spec3 (null: k_sweep3 evaluates the exact chain in every round)
 };
 
 struct SweepArgs {

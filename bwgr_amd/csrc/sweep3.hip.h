@@ -113,33 +113,6 @@ __global__ __launch_bounds__(128) void k_spec3(const SweepArgs a, int blk_begin)
     for (; k < j; ++k) s0 = fma((double)G[(size_t)k * m + j], dr[k], s0);
   }
   sp.spec[j] = (s0 + s1) + (s2 + s3); sp.xspec[j] = 0.0; sp.gjj[j] = gjj;
-  if (a.ps.ev3) {
-    // The quick test of the sequencer's rounds.  Without its float roundings the exact chain's norm difference is a quadratic in r:
-    // D1 = rd r + c1 (c1 = xxb0 rd + sd z - b0), diff = gjj (D2^2 - D1^2) + 2 r (D1 - D2) = A r^2 + B r + C; "x = C_c diff < tacc" is
-    // diff > tacc / C_c for the negative C_c of every sampler (signs flipped otherwise).  The exact chain rounds the draw and the
-    // step to float (2^-24 of |b1| and |D1| each: at most (2 gjj |D1| + 2 |r|)(|b1| + |D1|) 2^-23 in diff) and diff itself
-    // (2^-24 |diff|, twice); g is 2^-20 times a termwise bound of all that, eight times what can occur.
-    Eval3Buf &ev = a.ps.ev3[blk];
-    double qa = 0.0, qb = 0.0, qca = -INFINITY, qcr = -INFINITY, g2 = 0.0, g1 = 0.0, g0 = 0.0;   // (unused markers: rejected for certain)
-    if (j < mB) {
-      const StageBuf &st = a.ps.blocks[blk];
-      const double Cc = (double)a.sc->C;
-      const double sgn = (Cc < 0.0) ? 1.0 : -1.0;
-      const double rd = st.rden[j], xb = (double)st.xxb0[j], sz = st.sdz1[j], b0 = (double)st.b0[j];
-      const double D2 = (double)(((a.flags & SWF_ALT_B2) ? st.b2[j] : 0.0f) - st.b0[j]);
-      const double c1 = fma(xb, rd, sz) - b0;
-      const double grd = gjj * rd;
-      const double A_ = rd * (2.0 - grd), B_ = 2.0 * (c1 * (1.0 - grd) - D2), C_ = gjj * (D2 * D2 - c1 * c1);
-      const double ta = (double)st.tacc[j] / Cc, tr = (double)st.trej[j] / Cc;
-      const double eps = 9.5367431640625e-07;   // 2^-20
-      qa = sgn * A_; qb = sgn * B_; qca = sgn * (C_ - ta); qcr = sgn * (C_ - tr);
-      const double K1 = 12.0 * fabs(c1) + 4.0 * fabs(b0), K0 = 2.0 * gjj * fabs(c1) * (2.0 * fabs(c1) + fabs(b0));
-      g2 = eps * (fabs(A_) + 8.0 * rd * (1.0 + grd)); g1 = eps * (fabs(B_) + K1 * (1.0 + grd) + 2.0 * fabs(D2));
-      g0 = eps * (fabs(C_) + (isfinite(ta) ? fabs(ta) : 0.0) + (isfinite(tr) ? fabs(tr) : 0.0) + K0 + gjj * D2 * D2);
-      if (!(isfinite(g2) && isfinite(g1) && isfinite(g0) && isfinite(qa) && isfinite(qb)) || Cc == 0.0) { qa = qb = 0.0; qca = 0.0; qcr = 0.0; g2 = g1 = 0.0; g0 = 1.0; }   // (always the exact chain)
-    }
-    ev.qa[j] = qa; ev.qb[j] = qb; ev.qca[j] = qca; ev.qcr[j] = qcr; ev.g2[j] = g2; ev.g1[j] = g1; ev.g0[j] = g0;
-  }
 }
 
 // The seven signed base-256 digits of q (|q| < 2^55) as bytes: adding 0x80 to each of the seven low bytes turns the signed digits
@@ -187,7 +160,6 @@ __host__ __device__ inline size_t s3_seq_lds(int D, bool g16) {
   s += (size_t)S3_RING * (sizeof(double) + sizeof(long long) + sizeof(int));       // the included markers of the last D blocks
   s += (size_t)2 * 3 * 16 * SW_MAXM * (g16 ? 2 : 4);                               // far-field rows in flight
   if (g16) s += (size_t)3 * S3_GPD_BYTES + (size_t)S3_NRX * 2 * SW_MAXM * 2;       // the packed diagonal block of three blocks, distance-1 / 2 rows of this block's included markers
-  s += 2 * sizeof(Eval3Buf);                                                       // the quick test's constants
   return s + 256;
 }
 
@@ -489,16 +461,6 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   // of the block's included markers, requested by DMA when the marker is included and consumed after the block's last round
   unsigned char *gpd_s = smem + off; if (G16) off += (size_t)3 * S3_GPD_BYTES;
   unsigned char *rowx_s = smem + off; if (G16) off += (size_t)S3_NRX * 2 * SW_MAXM * 2;
-  Eval3Buf *ev_s = reinterpret_cast<Eval3Buf *>(smem + off); off += 2 * sizeof(Eval3Buf);
-#ifndef BWGR_W0LEAN
-#define BWGR_W0LEAN 0
-#endif
-#if BWGR_W0LEAN & 1
-  constexpr bool fastev = false;
-#else
-  const bool fastev = a.ps.ev3 != nullptr && !(A.dbg & 65536);
-#endif
-  constexpr int NEV = (int)(sizeof(Eval3Buf) / 16);   // 448 chunks
   int *ctrl_s = reinterpret_cast<int *>(smem + off);   // [0] ok flag
   int *pos_s = ctrl_s + 8;                             // [b & 31]: ring position where block b's entries begin
   const unsigned char **gx_s = reinterpret_cast<const unsigned char **>(ctrl_s + 40);   // the cross Gram arrays' base addresses (a table in LDS: indexed per entry)
@@ -515,7 +477,6 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
 
   // ---- the helpers' work for block c (relative): everything that does not depend on block c-1's rounds ----
   uint4 sg0 = make_uint4(0, 0, 0, 0), sg1 = sg0, sg2 = sg0, sg3 = sg0;   // staging waves: block c's chunks, requested one phase earlier
-  uint4 sg4 = sg0, sg5 = sg0, sg6 = sg0, sg7 = sg0;                       // ... and the quick test's constants (448 chunks, the last loads repeat)
   // (selects, not branches: where exec-masked branches join, the compiler puts an s_waitcnt vmcnt(0) in front of its register copies,
   // and a staging wave would wait out the loads it has just issued)
   auto stage_src = [&](int c, int ch) -> const uint4 * {
@@ -533,18 +494,10 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   auto stage_request = [&](int c) {   // waves 2-3
     const int t = tid - 128;
     sg0 = *stage_src(c, t); sg1 = *stage_src(c, t + 128); sg2 = *stage_src(c, t + 256); sg3 = *stage_src(c, t + 384);
-    if (fastev) {
-      const uint4 *es = reinterpret_cast<const uint4 *>(a.ps.ev3 + (a.blk_begin + c));
-      sg4 = es[t]; sg5 = es[t + 128]; sg6 = es[t + 256]; sg7 = es[min(t + 384, NEV - 1)];
-    }
   };
   auto stage_commit = [&](int c) {
     const int t = tid - 128;
     *stage_dst(c, t) = sg0; *stage_dst(c, t + 128) = sg1; *stage_dst(c, t + 256) = sg2; *stage_dst(c, t + 384) = sg3;
-    if (fastev) {
-      uint4 *ed = reinterpret_cast<uint4 *>(&ev_s[c & 1]);
-      ed[t] = sg4; ed[t + 128] = sg5; ed[t + 256] = sg6; if (t + 384 < NEV) ed[t + 384] = sg7;
-    }
   };
   auto gpd_issue = [&](int c) {   // waves 2-3, 16-bit panels: block c's packed diagonal block, 1 KiB pieces alternating between the two waves
     if constexpr (GPD) {
@@ -792,7 +745,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     const int mB = blk_m(b), blk = a.blk_begin + b;
     const bool have_next = (b + 1 < nb);
     S3ST(0, sq0 || sq1 || sq2 || sq4 || sq3 || sq6 || sq7);
-    if (wave == 0 && ((BWGR_W0LEAN & 2) || !(A.dbg & 16384))) {
+    if (wave == 0 && !(A.dbg & 16384)) {
       // Wave 0 is one long dependent chain, so everything here is counted in instructions.  Dead lanes of a ragged last block need
       // no masks: k_prestage fills their constants so that they reject for certain, and their q, spec and far terms are zero.
       const StageBuf &st = stage[b & 1];
@@ -821,22 +774,6 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       S3ST(1, sq0);
       unsigned long long am0 = 0ull, am1 = 0ull;
       int nacc = 0;
-      // the quick test's constants of this lane's two markers
-      const Eval3Buf &ev = ev_s[b & 1];
-      double eqa0 = 0.0, eqb0 = 0.0, eca0 = 0.0, ecr0 = 0.0, eg20 = 0.0, eg10 = 0.0, eg00 = 1.0;
-      double eqa1 = 0.0, eqb1 = 0.0, eca1 = 0.0, ecr1 = 0.0, eg21 = 0.0, eg11 = 0.0, eg01 = 1.0;
-      if (fastev) {
-        eqa0 = ev.qa[l0]; eqb0 = ev.qb[l0]; eca0 = ev.qca[l0]; ecr0 = ev.qcr[l0]; eg20 = ev.g2[l0]; eg10 = ev.g1[l0]; eg00 = ev.g0[l0];
-        eqa1 = ev.qa[l1]; eqb1 = ev.qb[l1]; eca1 = ev.qca[l1]; ecr1 = ev.qcr[l1]; eg21 = ev.g2[l1]; eg11 = ev.g1[l1]; eg01 = ev.g0[l1];
-      }
-      // three dependent operations to "included / rejected for certain" (S3_EVAL: eleven); UND_: the exact chain has to decide
-#define S3_FEVAL(R_, QA_, QB_, QCA_, QCR_, G2_, G1_, G0_, ACC_, UND_) { \
-        const double t1_ = fma((QA_), (R_), (QB_)); \
-        const double ar_ = fabs(R_); \
-        const double g_ = fma(fma((G2_), ar_, (G1_)), ar_, (G0_)); \
-        const double Qa_ = fma(t1_, (R_), (QCA_)), Qr_ = fma(t1_, (R_), (QCR_)); \
-        ACC_ = Qa_ > g_; \
-        UND_ = !(ACC_ || Qr_ < -g_); }
       // One evaluation: the in-model draw b1 given r and whether the Bernoulli step includes the marker (the algebra of lane_b1 /
       // lane_accept with the r-independent factors hoisted: 11 dependent operations).
 #define S3_EVAL(R_, XB_, RD_, SZ_, B0_, D2_, D2S_, GJ_, TA_, TR_, MKOFF_, D1F_, ACC_) { \
@@ -859,7 +796,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
         const int pr_ = prow(k_); \
         GT ga_ = (GT)1, gb_ = (GT)1, xa_ = (GT)0, xb_ = (GT)0, ya_ = (GT)0, yb_ = (GT)0; \
         bool direct_ = true; \
-        if ((BWGR_W0LEAN & 4) || !(A.dbg & 64)) { \
+        if (!(A.dbg & 64)) { \
         if constexpr (G16) { \
           if constexpr (GPD) { \
             const unsigned char *gpl_ = gpd_s + (size_t)(b % 3) * S3_GPD_BYTES + 2 * lane + __builtin_amdgcn_readlane((KOFF_) ? tabp1 : tabp0, js); \
@@ -890,17 +827,12 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
         if (use1) { rnext0 = fma(-(double)xa_, corr_, rnext0); rnext1 = fma(-(double)xb_, corr_, rnext1); } \
         if (use2) { rnxt20 = fma(-(double)ya_, corr_, rnxt20); rnxt21 = fma(-(double)yb_, corr_, rnxt21); } } }
       // exact speculative rounds, first over markers 0..63, then 64..127: every lane assumes "nobody before me is included"
-      if ((BWGR_W0LEAN & 8) || !(A.dbg & 128)) {
+      if (!(A.dbg & 128)) {
         const int cnt0 = min(64, mB);
         int front = 0;
         for (;;) {
           float d1f; bool acc;
-          if (fastev) {
-            bool und;
-            S3_FEVAL(r0, eqa0, eqb0, eca0, ecr0, eg20, eg10, eg00, acc, und)
-            if (__builtin_expect(__ballot(und && lane >= front && lane < cnt0) != 0ull, 0)) { S3_EVAL(r0, xba, rda, sza, b0a, D2a, D2sa, gja, taa, tra, 0, d1f, acc) }
-            else d1f = (float)fma(r0 + xba, rda, sza) - b0a;   // (an included marker's step; off the chain when nobody is included)
-          } else { S3_EVAL(r0, xba, rda, sza, b0a, D2a, D2sa, gja, taa, tra, 0, d1f, acc) }
+          S3_EVAL(r0, xba, rda, sza, b0a, D2a, D2sa, gja, taa, tra, 0, d1f, acc)
           const unsigned long long bal = __ballot(acc && lane >= front && lane < cnt0);
           if (bal == 0ull) break;
           const int js = __ffsll((long long)bal) - 1;
@@ -909,17 +841,12 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
           S3_INCLUDE(0, d1f, dra)
         }
       }
-      if (mB > 64 && ((BWGR_W0LEAN & 8) || !(A.dbg & 128))) {
+      if (mB > 64 && (!(A.dbg & 128))) {
         const int cnt1 = mB - 64;
         int front = 0;
         for (;;) {
           float d1f; bool acc;
-          if (fastev) {
-            bool und;
-            S3_FEVAL(r1, eqa1, eqb1, eca1, ecr1, eg21, eg11, eg01, acc, und)
-            if (__builtin_expect(__ballot(und && lane >= front && lane < cnt1) != 0ull, 0)) { S3_EVAL(r1, xbb, rdb, szb, b0b, D2b, D2sb, gjb, tab, trb, 64, d1f, acc) }
-            else d1f = (float)fma(r1 + xbb, rdb, szb) - b0b;
-          } else { S3_EVAL(r1, xbb, rdb, szb, b0b, D2b, D2sb, gjb, tab, trb, 64, d1f, acc) }
+          S3_EVAL(r1, xbb, rdb, szb, b0b, D2b, D2sb, gjb, tab, trb, 64, d1f, acc)
           const unsigned long long bal = __ballot(acc && lane >= front && lane < cnt1);
           if (bal == 0ull) break;
           const int js = __ffsll((long long)bal) - 1;
@@ -930,9 +857,8 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       }
 #undef S3_EVAL
 #undef S3_INCLUDE
-#undef S3_FEVAL
       if constexpr (G16) {
-        if (nacc > 0 && ((BWGR_W0LEAN & 4) || !(A.dbg & 64))) {   // the distance-1 / 2 rows requested as the markers appeared
+        if (nacc > 0 && (!(A.dbg & 64))) {   // the distance-1 / 2 rows requested as the markers appeared
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
           const int nx = min(nacc, S3_NRX);
           for (int i = 0; i < nx; ++i) {
@@ -1011,7 +937,6 @@ __device__ __forceinline__ void s3_prefetcher(const Sweep3Args &A) {
     if (o < sizeof(StageBuf)) sink += *reinterpret_cast<const uint32_t *>(stb + o);
     if (o < sizeof(SpecBuf)) sink += *reinterpret_cast<const uint32_t *>(spb + o);
     if (o < gpbytes) sink += *reinterpret_cast<const uint32_t *>(gpb + o);
-    if (a.ps.ev3 && o < sizeof(Eval3Buf)) sink += *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(a.ps.ev3 + blk) + o);
     (void)gxbytes;
   }
   if (sink == 0x9E3779B9u && a.stamps) a.stamps[255] = sink;   // (keeps the loads alive)

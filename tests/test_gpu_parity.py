@@ -273,7 +273,7 @@ def test_both_sweep_engines_give_the_same_chain(model, monkeypatch):
 @pytest.mark.parametrize("env", [{"BWGR_SWEEP": "2"}, {"BWGR_SWEEP": "2", "BWGR_LAG": "4"}, {"BWGR_SWEEP": "2", "BWGR_LAG": "2"},
                                  {"BWGR_SWEEP": "2", "BWGR_GRAM16": "0"}, {"BWGR_SWEEP": "2", "BWGR_GRAM16": "0", "BWGR_LAG": "2"},
                                  {}, {"BWGR_D3": "2"}, {"BWGR_D3": "3"}, {"BWGR_D3": "5"}, {"BWGR_R3": "64"}, {"BWGR_R3": "128", "BWGR_D3": "3"},
-                                 {"BWGR_GRAM16": "0"}, {"BWGR_GRAM16": "0", "BWGR_D3": "4"}, {"BWGR_FEVAL3": "1"}, {"BWGR_FEVAL3": "1", "BWGR_GRAM16": "0"}])
+                                 {"BWGR_GRAM16": "0"}, {"BWGR_GRAM16": "0", "BWGR_D3": "4"}])
 def test_selection_pipeline_variants_give_the_same_chain(model, env, monkeypatch):
     """Selection models on int8 panels run the trajectory engine k_sweep3 by default (sweep3.hip.h: streamers on the all-rejected
     trajectory in fixed point, included markers folded in D blocks later, Gram rows on demand; D = 2 .. 12, 64 / 128 / 256 rows per
