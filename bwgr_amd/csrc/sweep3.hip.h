@@ -773,7 +773,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       rnext0 = rnxt20; rnext1 = rnxt21; rnxt20 = 0.0; rnxt21 = 0.0;
       S3ST(1, sq0);
       unsigned long long am0 = 0ull, am1 = 0ull;
-      int nacc = 0;
+      int nacc = 0, nslot = 0, napp = 0;   // included markers of this block; row slots in use; entries whose rows are applied already
       // One evaluation: the in-model draw b1 given r and whether the Bernoulli step includes the marker (the algebra of lane_b1 /
       // lane_accept with the r-independent factors hoisted: 11 dependent operations).
 #define S3_EVAL(R_, XB_, RD_, SZ_, B0_, D2_, D2S_, GJ_, TA_, TR_, MKOFF_, D1F_, ACC_) { \
@@ -791,41 +791,51 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       // An included marker k = KOFF_ + js: its step beyond the speculated one, corr = (b1 - b0) - drej (both floats, exact in
       // fp64; the streamers fold in the same difference on the fixed-point grid, 2^-44 of the scale away), and its Gram rows, read
       // on demand: the packed diagonal block for the later markers of this block, the distance-1 cross block for the next one.
+      // the distance-1 / 2 rows requested so far (16-bit panels: S3_NRX pairs of LDS slots): waited for and applied to the next two
+      // blocks' dots -- after the block's last round, and when a block includes more markers than there are slots
+#define S3_APPLY_ROWS() { \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+        for (int i_ = 0; i_ < nslot; ++i_) { \
+          const double cf_ = accC[(pos0 + napp + i_) & (ring - 1)]; \
+          const uint16_t *rw1_ = reinterpret_cast<const uint16_t *>(rowx_s + (size_t)(i_ * 2) * (SW_MAXM * 2)); \
+          const uint16_t *rw2_ = reinterpret_cast<const uint16_t *>(rowx_s + (size_t)(i_ * 2 + 1) * (SW_MAXM * 2)); \
+          if (use1) { rnext0 = fma(-(double)rw1_[min(l0, m - 1)], cf_, rnext0); rnext1 = fma(-(double)rw1_[l1c], cf_, rnext1); } \
+          if (use2) { rnxt20 = fma(-(double)rw2_[min(l0, m - 1)], cf_, rnxt20); rnxt21 = fma(-(double)rw2_[l1c], cf_, rnxt21); } \
+        } \
+        napp += nslot; nslot = 0; }
 #define S3_INCLUDE(KOFF_, D1F_, DR_) { \
         const int k_ = (KOFF_) + js; \
-        const int pr_ = prow(k_); \
-        GT ga_ = (GT)1, gb_ = (GT)1, xa_ = (GT)0, xb_ = (GT)0, ya_ = (GT)0, yb_ = (GT)0; \
-        bool direct_ = true; \
-        if (!(A.dbg & 64)) { \
+        GT ga_ = (GT)1, gb_ = (GT)1; \
         if constexpr (G16) { \
+          if (!(A.dbg & 64)) { \
           if constexpr (GPD) { \
             const unsigned char *gpl_ = gpd_s + (size_t)(b % 3) * S3_GPD_BYTES + 2 * lane + __builtin_amdgcn_readlane((KOFF_) ? tabp1 : tabp0, js); \
             ga_ = *reinterpret_cast<const GT *>(gpl_); gb_ = *reinterpret_cast<const GT *>(gpl_ + 128);   /* (lanes at or before k_: masked below) */ \
           } else { \
+            const int pr_ = prow(k_); \
             ga_ = gp[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gp[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)]; \
           } \
-          if (nacc < S3_NRX) {   /* the rows for the next two blocks: by DMA, consumed after the last round */ \
-            direct_ = false; \
-            if (use1) s3_dma4s(reinterpret_cast<const unsigned char *>(g1) + (size_t)(k_ * rowbytes), rolane, rowx_la + (uint32_t)(nacc * 2) * (SW_MAXM * 2)); \
-            if (use2) s3_dma4s(reinterpret_cast<const unsigned char *>(g2) + (size_t)(k_ * rowbytes), rolane, rowx_la + (uint32_t)(nacc * 2 + 1) * (SW_MAXM * 2)); \
-          } \
-        } else { \
+          if (__builtin_expect(nslot == S3_NRX, 0)) S3_APPLY_ROWS()   /* every slot taken: the rows so far first */ \
+          if (use1) s3_dma4s(reinterpret_cast<const unsigned char *>(g1) + (size_t)(k_ * rowbytes), rolane, rowx_la + (uint32_t)(nslot * 2) * (SW_MAXM * 2)); \
+          if (use2) s3_dma4s(reinterpret_cast<const unsigned char *>(g2) + (size_t)(k_ * rowbytes), rolane, rowx_la + (uint32_t)(nslot * 2 + 1) * (SW_MAXM * 2)); \
+          ++nslot; } \
+        } else if (!(A.dbg & 64)) {   /* 32-bit Gram entries: the rows straight from global memory */ \
+          const int pr_ = prow(k_); \
           ga_ = gp[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gp[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)];   /* (the last row is empty) */ \
         } \
-        if (direct_) { \
-        const GT *row_ = g1 + (use1 ? (size_t)k_ * m : (size_t)0);   /* (without a next block: a harmless in-bounds read) */ \
-        xa_ = row_[use1 ? min(l0, m - 1) : 0]; xb_ = row_[use1 ? l1c : 0]; \
-        const GT *row2_ = g2 + (use2 ? (size_t)k_ * m : (size_t)0); \
-        ya_ = row2_[use2 ? min(l0, m - 1) : 0]; yb_ = row2_[use2 ? l1c : 0]; } } \
         const float dacc_ = readlane_f32(D1F_, js), drj_ = readlane_f32(DR_, js); \
         const double corr_ = (double)dacc_ - (double)drj_; \
         if (lane == 0) { const int sl_ = (pos0 + nacc) & (ring - 1); accK[sl_] = k_ | (b << 8); accC[sl_] = corr_; accS[sl_] = make_float2(dacc_, drj_); } \
         ++nacc; \
         r0 = fma(-(double)((l0 > k_) ? ga_ : (GT)0), corr_, r0); \
         r1 = fma(-(double)((l1 > k_ && l1 < m) ? gb_ : (GT)0), corr_, r1); \
-        if (direct_) { \
-        if (use1) { rnext0 = fma(-(double)xa_, corr_, rnext0); rnext1 = fma(-(double)xb_, corr_, rnext1); } \
-        if (use2) { rnxt20 = fma(-(double)ya_, corr_, rnxt20); rnxt21 = fma(-(double)yb_, corr_, rnxt21); } } }
+        if constexpr (!G16) { if (!(A.dbg & 64)) { \
+          const GT *row_ = g1 + (use1 ? (size_t)k_ * m : (size_t)0);   /* (without a next block: a harmless in-bounds read) */ \
+          const GT xa_ = row_[use1 ? min(l0, m - 1) : 0], xb_ = row_[use1 ? l1c : 0]; \
+          const GT *row2_ = g2 + (use2 ? (size_t)k_ * m : (size_t)0); \
+          const GT ya_ = row2_[use2 ? min(l0, m - 1) : 0], yb_ = row2_[use2 ? l1c : 0]; \
+          if (use1) { rnext0 = fma(-(double)xa_, corr_, rnext0); rnext1 = fma(-(double)xb_, corr_, rnext1); } \
+          if (use2) { rnxt20 = fma(-(double)ya_, corr_, rnxt20); rnxt21 = fma(-(double)yb_, corr_, rnxt21); } } } }
       // exact speculative rounds, first over markers 0..63, then 64..127: every lane assumes "nobody before me is included"
       if (!(A.dbg & 128)) {
         const int cnt0 = min(64, mB);
@@ -857,19 +867,8 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       }
 #undef S3_EVAL
 #undef S3_INCLUDE
-      if constexpr (G16) {
-        if (nacc > 0 && (!(A.dbg & 64))) {   // the distance-1 / 2 rows requested as the markers appeared
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-          const int nx = min(nacc, S3_NRX);
-          for (int i = 0; i < nx; ++i) {
-            const double cf = accC[(pos0 + i) & (ring - 1)];
-            const uint16_t *rw1 = reinterpret_cast<const uint16_t *>(rowx_s + (size_t)(i * 2) * (SW_MAXM * 2));
-            const uint16_t *rw2 = reinterpret_cast<const uint16_t *>(rowx_s + (size_t)(i * 2 + 1) * (SW_MAXM * 2));
-            if (use1) { rnext0 = fma(-(double)rw1[min(l0, m - 1)], cf, rnext0); rnext1 = fma(-(double)rw1[l1c], cf, rnext1); }
-            if (use2) { rnxt20 = fma(-(double)rw2[min(l0, m - 1)], cf, rnxt20); rnxt21 = fma(-(double)rw2[l1c], cf, rnxt21); }
-          }
-        }
-      }
+      if constexpr (G16) { if (nslot > 0) S3_APPLY_ROWS() }   // the distance-1 / 2 rows requested as the markers appeared
+#undef S3_APPLY_ROWS
       S3ST(2, sq0);
       // the block's new effects (every lane's r is final for its own marker); the rest of the outputs is wave 7's
       {
