@@ -735,6 +735,8 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   const int tabp0 = 2 * (lane * (m - 1) - lane * (lane - 1) / 2 - lane - 1);
   const int tabp1 = 2 * ((64 + lane) * (m - 1) - (64 + lane) * (63 + lane) / 2 - (64 + lane) - 1);
   const uint32_t rolane = (uint32_t)min(lane * 4, rowbytes - 4);
+  const unsigned char *gpd_lane = gpd_s + 2 * lane;   // this lane's entry of a packed row, before the row's and the buffer's offsets
+  int gpd_off = 0;                                     // (b % 3) * S3_GPD_BYTES, stepped once per block
   const uint32_t rowx_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)rowx_s);
   const bool altb2 = (a.flags & SWF_ALT_B2) != 0;
   if (wave == 0 && !(A.dbg & 1)) __builtin_amdgcn_s_setprio(3);   // the chain's wave goes first wherever it shares an issue port
@@ -755,9 +757,11 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       const int pos0 = pos_s[b & 31];
       const GT *gp = gp_all + (size_t)blk * pstride;
       const bool use1 = have_next && D >= 2;   // (D = 1: the streamers fold block b's list in before the dots of block b+1)
-      const GT *g1 = use1 ? gx0_w0 + (size_t)(b + 1) * (uint32_t)(m * m) : gp;   // (bases hoisted out of the block loop: no kernel-argument reload, a 32 x 32 bit product)
+      // (bases hoisted out of the block loop: no kernel-argument reload, a 32 x 32 bit product; 16-bit panels touch g1 / g2 only under
+      // use1 / use2, the 32-bit path reads "a harmless in-bounds" entry otherwise and wants the fallback)
+      const GT *g1 = (G16 || use1) ? gx0_w0 + (size_t)(b + 1) * (uint32_t)(m * m) : gp;
       const bool use2 = (b + 2 < nb) && D >= 3;
-      const GT *g2 = use2 ? gx1_w0 + (size_t)(b + 2) * (uint32_t)(m * m) : gp;
+      const GT *g2 = (G16 || use2) ? gx1_w0 + (size_t)(b + 2) * (uint32_t)(m * m) : gp;
       const int l0 = lane, l1 = 64 + lane;
       const int l1c = min(l1, m - 1);
       // constants of this lane's two markers
@@ -809,7 +813,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
         if constexpr (G16) { \
           if (!(A.dbg & 64)) { \
           if constexpr (GPD) { \
-            const unsigned char *gpl_ = gpd_s + (size_t)(b % 3) * S3_GPD_BYTES + 2 * lane + __builtin_amdgcn_readlane((KOFF_) ? tabp1 : tabp0, js); \
+            const unsigned char *gpl_ = gpd_lane + gpd_off + __builtin_amdgcn_readlane((KOFF_) ? tabp1 : tabp0, js); \
             ga_ = *reinterpret_cast<const GT *>(gpl_); gb_ = *reinterpret_cast<const GT *>(gpl_ + 128);   /* (lanes at or before k_: masked below) */ \
           } else { \
             const int pr_ = prow(k_); \
@@ -880,6 +884,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       }
       if (lane == 0) pos_s[(b + 1) & 31] = (pos0 + nacc) & (ring - 1);
       S3ST(3, sq0);
+      gpd_off = (gpd_off == 2 * S3_GPD_BYTES) ? 0 : gpd_off + S3_GPD_BYTES;
       S3_ROLE_BARRIER();
     } else if (have_next && wave != 0) {
       helper_phase(b + 1);
