@@ -1,5 +1,7 @@
 """Diagnostic only: builds libbwgr_hip_stamps.so (-DBWGR_STAMPS) and prints where k_sweep3's roles spend their cycles per
-block (s_memtime ticks).  Never quote this build's run time."""
+block (s_memtime ticks).  Never quote this build's run time.  (Since the sequencer's roles reach the block barrier inside their
+own branches, the helper waves' second slot -- "poll + convert", "commit + request", ... -- includes their wait at that barrier;
+wave 0's slots are unchanged: constants + r0, rounds incl. the wait for the distance-1 / 2 rows, outputs, barrier.)"""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
