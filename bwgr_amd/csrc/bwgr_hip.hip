@@ -1235,8 +1235,12 @@ static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
   const int cap = (lv && lv[0] >= '2' && lv[0] <= '4') ? lv[0] - '0' : 3;
   int lag = 2;
   if (P->sweep_version >= 2 && (a.flags & SWF_SELECT)) {
-    if (P->gramx2) lag = 3;   // fp32 panels too (generic streamer and sequencer)
-    if (!P->is_f32 && P->gramx3 && P->gram16 && P->lag4_ok) lag = 4;   // only the 16-bit / single-barrier sequencer knows the third cross term
+    // the generic sequencer (32-bit Gram entries, fp32 panels) reads a distance-2 row per accepted marker straight from global memory on
+    // one wave: two blocks deep unless asked (us per block at n = 10 000, depth 2 / 3: 1.4 % inclusion 4.53 / 4.67, 10.9 % 5.29 / 14.5,
+    // BayesCpi at 52 % 12.7 / 58.0); the 16-bit / single-barrier sequencer stages those rows and knows a third cross term as well
+    if (P->gramx2 && lv) lag = 3;
+    if (!P->is_f32 && P->gramx2 && P->gram16) lag = 3;
+    if (!P->is_f32 && P->gramx3 && P->gram16 && P->lag4_ok) lag = 4;
   }
   a.lag = lag < cap ? lag : cap;
   if (use_winv(P, a.flags)) {   // the affine sweeps' product sequencer: as deep as the panel's cross Gram planes reach (BWGR_WLAG caps it)
