@@ -695,17 +695,18 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   // every block, before it reached the barrier.  With the barrier in front of the join that wait falls into the next phase, where the
   // wave waits for those requests anyway.
 #define S3_ROLE_BARRIER() do { if (BWGR_ROLEBAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
+  const int wvu = __builtin_amdgcn_readfirstlane(wave);   // the role as a scalar: real branches, every wave runs its own role's code (and barrier) only
   auto helper_phase = [&](int c) {   // block c >= 1, while wave 0 runs block c-1
-    if (wave == 1) { if (!(A.dbg & 32768)) { if (!poll_q(c)) ctrl_s[0] = 0; } S3_ROLE_BARRIER(); }
-    else if (wave <= 3) { if (!(A.dbg & 8192)) {
+    if (wvu == 1) { if (!(A.dbg & 32768)) { if (!poll_q(c)) ctrl_s[0] = 0; } S3_ROLE_BARRIER(); }
+    else if (wvu <= 3) { if (!(A.dbg & 8192)) {
       // the constants of block c, requested a phase ago -- waiting for them also waits for block c's packed diagonal block, whose
       // DMA was issued before them; then the requests for block c+1 (the DMA first), which have this whole phase to land
       if (!(A.dbg & 262144)) stage_commit(c);
       if (c + 1 < nb) { if (!(A.dbg & 131072)) gpd_issue(c + 1); if (!(A.dbg & 262144)) stage_request(c + 1); }
       else if constexpr (GPD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } S3_ROLE_BARRIER(); }
-    else if (wave == 4) { S3_ROLE_BARRIER(); }   // idle: the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots
-    else if (wave <= 6) {
+    else if (wvu == 4) { S3_ROLE_BARRIER(); }   // idle: the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots
+    else if (wvu <= 6) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       S3ST(5, tid == 320);
       far_consume(c, wave - 5);
@@ -747,7 +748,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     const int mB = blk_m(b), blk = a.blk_begin + b;
     const bool have_next = (b + 1 < nb);
     S3ST(0, sq0 || sq1 || sq2 || sq4 || sq3 || sq6 || sq7);
-    if (wave == 0 && !(A.dbg & 16384)) {
+    if (wvu == 0 && !(A.dbg & 16384)) {
       // Wave 0 is one long dependent chain, so everything here is counted in instructions.  Dead lanes of a ragged last block need
       // no masks: k_prestage fills their constants so that they reject for certain, and their q, spec and far terms are zero.
       const StageBuf &st = stage[b & 1];
@@ -886,7 +887,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       S3ST(3, sq0);
       gpd_off = (gpd_off == 2 * S3_GPD_BYTES) ? 0 : gpd_off + S3_GPD_BYTES;
       S3_ROLE_BARRIER();
-    } else if (have_next && wave != 0) {
+    } else if (have_next && wvu != 0) {
       helper_phase(b + 1);
       S3ST(1, sq1 || sq2 || sq4 || sq3 || sq6 || sq7);
     } else S3_ROLE_BARRIER();
