@@ -16,6 +16,7 @@
 #include "sweep3.hip.h"
 #include "sweep2w.hip.h"
 #include "sweep3p.hip.h"
+#include "sweep4.hip.h"
 #include <stdlib.h>
 
 using namespace bwgr;
@@ -923,6 +924,14 @@ struct bwgr_panel {
   unsigned long long *qsum3 = nullptr, *lists3 = nullptr;   // per handle (clones have their own)
   uint32_t epoch3 = 0;
   size_t lds3_bytes = 0;
+  // k_sweep4 (sweep4.hip.h): the trajectory engine with super-block streamers and the eight-wave token sequencer -- a chain alone on
+  // the GPU, int8 panel, 128-marker blocks, 16-bit Gram entries; every other sparse selection sweep stays with k_sweep3
+  bool e4_ready = false;
+  bool sweep4_on = false;         // BWGR_SWEEP4=1 enables it (off while it is slower than k_sweep3)
+  int e4_DQ = S4_MAXDQ, e4_SS = 4;
+  unsigned long long *lists4 = nullptr;   // root panels only
+  uint16_t *gd16 = nullptr;               // [nblocks][128][128] the diagonal Gram blocks in full, 16-bit (rows land in the sequencer's LDS by DMA: whole aligned rows)
+  size_t lds4_bytes = 0;
   // the affine models' block solve as a triangular product (sweep2w.hip.h)
   bool winv_on = true;            // BWGR_WINV=0: the serial recurrence of k_sweep2's sequencer instead
   double *winv = nullptr;         // per handle: [nblocks][S2W_WDOUBLES], written by k_affine_inv before every affine sweep
@@ -1051,8 +1060,15 @@ static int sweep3_build(bwgr_panel *P) {
   if (const char *tv = getenv("BWGR_ENG3_THR")) { const float v = (float)atof(tv); if (v > 0.0f) P->eng3_thr = v; }
   const size_t blk_elems = (size_t)P->nblocks * m * m;
   const bool g16 = P->gram16;
+  // k_sweep4: 128-row streamers on 128-marker blocks with 16-bit Gram entries; its cross Gram arrays reach 4 DQ - 1 blocks back
+  P->e4_ready = false;
+  if (const char *s4 = getenv("BWGR_SWEEP4")) P->sweep4_on = s4[0] == '1';
+  if (const char *dq = getenv("BWGR_DQ4")) { const int v = atoi(dq); if (v >= 2 && v <= S4_MAXDQ) P->e4_DQ = v; }
+  const bool want4 = P->sweep4_on && g16 && m == SW_MAXM && (P->R % 128) == 0 && P->K * (P->R / 128) <= 255 && P->K * (P->R / 128) + 2 <= 256 &&
+                     (uint64_t)P->p * (uint64_t)P->R < (1ull << 32) && s4_streamer_lds(128, P->e4_SS) <= (size_t)160 * 1024 && !P->parent;
+  const int Dbuild = want4 ? std::max(D, S4_QB * P->e4_DQ) : D;
   int32_t *tmp = nullptr;
-  for (int d = 1; d < D; ++d) {
+  for (int d = 1; d < Dbuild; ++d) {
     if (P->nblocks <= d) { P->g3x[d - 1] = nullptr; continue; }
     if (d == 1) { P->g3x[0] = g16 ? (void *)P->gramx16 : P->gramx; continue; }
     if (!g16 && d == 2 && P->gramx2) { P->g3x[1] = P->gramx2; continue; }
@@ -1083,6 +1099,17 @@ static int sweep3_build(bwgr_panel *P) {
     return BWGR_OK;
   }
   CHK(sweep3_alloc_scratch(P));
+  if (want4) {
+    const size_t nq = (size_t)(P->nblocks + S4_QB - 1) / S4_QB;
+    HIPCHK(hipMalloc(&P->gd16, (size_t)P->nblocks * m * m * 2));
+    hipLaunchKernelGGL(k_gram_narrow, dim3(2048), dim3(256), 0, P->stream, (const int32_t *)P->gram, P->gd16, (int64_t)P->nblocks * m * m, P->gram16_bad);   // (the diagonal entries are among the packed ones already checked)
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMalloc(&P->lists4, sizeof(unsigned long long) * S4_LSTRIDE * nq));
+    HIPCHK(hipMemsetAsync(P->lists4, 0, sizeof(unsigned long long) * S4_LSTRIDE * nq, P->stream));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    P->lds4_bytes = std::max(s4_streamer_lds(128, P->e4_SS), s4_seq_lds());
+    P->e4_ready = true;
+  }
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<int32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3p<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1105,7 +1132,33 @@ static void sweep3_args(bwgr_panel *P, const SweepArgs &a, Sweep3Args &A) {
   if (const char *dv = getenv("BWGR_DBG3")) A.dbg = atoi(dv);
   (void)hipMemsetAsync(P->qsum3 + (size_t)a.blk_begin * 2 * SW_MAXM, 0, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
 }
+// k_sweep4 takes a sparse selection sweep when the chain has the GPU to itself and the range starts on a quad boundary (k_spec4's
+// in-super-block terms are laid out from block 0 of the panel); what it needs beside the sweep's own arguments
+static bool use_sweep4(const bwgr_panel *P, const SweepArgs &a) {
+  return P->e4_ready && !P->parent && P->nclones == 0 && P->lists4 && (a.blk_begin % S4_QB) == 0 && !P->force3;
+}
+static void launch_sweep4(bwgr_panel *P, const SweepArgs &a) {
+  Sweep4Args A;
+  memset(&A, 0, sizeof(A));
+  A.a = a;
+  for (int d = 0; d < S3_MAXD; ++d) A.gx[d] = P->g3x[d];
+  A.gp = P->gramp16; A.gd = P->gd16;
+  A.DQ = P->e4_DQ; A.SS = P->e4_SS; A.R3 = 128; A.sub = P->R / 128; A.K3 = P->K * A.sub;
+  A.qsum = P->qsum3; A.lists = P->lists4;
+  P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1;
+  A.epoch = P->epoch3;
+  if (const char *dv = getenv("BWGR_DBG4")) A.dbg = atoi(dv);
+  (void)hipMemsetAsync(P->qsum3 + (size_t)a.blk_begin * 2 * SW_MAXM, 0, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
+  // L2 prefetcher workgroups on the sequencer's XCD (workgroup indices that are multiples of 8): BWGR_PF4 = how many (default 4)
+  int npf = 4;
+  if (const char *pv = getenv("BWGR_PF4")) npf = std::max(0, std::min(8, atoi(pv)));
+  while (npf > 0 && (8 * npf >= 1 + A.K3 + npf || 1 + A.K3 + npf > 256)) --npf;
+  A.npf = npf;
+  const dim3 grid(1 + A.K3 + npf), blk(SW_THREADS);
+  hipLaunchKernelGGL(k_sweep4<4>, grid, blk, P->lds4_bytes, P->stream, A);
+}
 static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
+  if (use_sweep4(P, a)) { launch_sweep4(P, a); return; }
   Sweep3Args A;
   sweep3_args(P, a, A);
   // one more workgroup, on the sequencer's XCD (workgroups with equal index mod 8 share an XCD), warms that XCD's L2 with what the
@@ -1157,6 +1210,14 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
   if (s3) {   // the sweep's fixed-point scale, then the in-block speculative terms on that grid
     int xbits = 0; while ((1 << xbits) < std::max(1, (P->parent ? P->parent : P)->xmax)) ++xbits;
     hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, xbits, a.gate3);
+    if (P->e4_ready && (a.blk_begin % S4_QB) == 0) {   // k_spec3's terms plus k_sweep4's in-super-block ones and the rounds' radii: either engine may follow
+      Sweep4Args A4;
+      memset(&A4, 0, sizeof(A4));
+      A4.a = a; A4.SS = P->e4_SS;
+      const bwgr_panel *root = P->parent ? P->parent : P;
+      for (int d = 0; d < S3_MAXD; ++d) A4.gx[d] = root->g3x[d];
+      hipLaunchKernelGGL(k_spec4, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, A4, a.blk_begin);
+    } else
     hipLaunchKernelGGL(k_spec3, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin);
     if (std::isinf(a.gate3)) return;
   }
@@ -1305,6 +1366,7 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   (void)hipSetDevice(P->device);
   if (!P->parent) {
     for (int d = 0; d < S3_MAXD; ++d) if (P->g3own[d]) hipFree(P->g3x[d]);
+    hipFree(P->lists4); hipFree(P->gd16);
     hipFree(P->xmax_dev);
     for (int d = 0; d < S2W_MAXDIST; ++d) hipFree(P->gxt[d]);
     hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->gramx3); hipFree(P->gramp16); hipFree(P->gramx16); hipFree(P->gram16_bad); hipFree(P->gramp); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev);
@@ -1610,7 +1672,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   bwgr_panel *P = new bwgr_panel(*root);
   P->parent = root; P->nclones = 0; P->nchains = 0; P->own_stream = nullptr; P->stream = nullptr; P->ps_owner = nullptr; P->ps_iter = -1;
   P->pair_streams.clear();   // (the root's: a clone owns none)
-  P->qsum3 = P->lists3 = nullptr; P->epoch3 = 0; P->xmax_dev = nullptr; P->winv = nullptr; P->qsumw = nullptr;
+  P->qsum3 = P->lists3 = nullptr; P->lists4 = nullptr; P->gd16 = nullptr; P->epoch3 = 0; P->xmax_dev = nullptr; P->winv = nullptr; P->qsumw = nullptr;
   P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->xchg = nullptr; P->stamps = nullptr;
   root->nclones++;
   auto bail = [&](int code) { bwgr_panel_destroy(P); return code; };
