@@ -930,6 +930,7 @@ struct bwgr_panel {
   bool sweep4_on = false;         // BWGR_SWEEP4=1 enables it (off while it is slower than k_sweep3)
   int e4_DQ = S4_MAXDQ, e4_SS = 4;
   unsigned long long *lists4 = nullptr;   // root panels only
+  double *fin4 = nullptr;                 // k_sweep4_finish's partial sums
   uint16_t *gd16 = nullptr;               // [nblocks][128][128] the diagonal Gram blocks in full, 16-bit (rows land in the sequencer's LDS by DMA: whole aligned rows)
   size_t lds4_bytes = 0;
   // the affine models' block solve as a triangular product (sweep2w.hip.h)
@@ -1107,7 +1108,7 @@ static int sweep3_build(bwgr_panel *P) {
     HIPCHK(hipMalloc(&P->lists4, sizeof(unsigned long long) * S4_LSTRIDE * nq));
     HIPCHK(hipMemsetAsync(P->lists4, 0, sizeof(unsigned long long) * S4_LSTRIDE * nq, P->stream));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    P->lds4_bytes = std::max(s4_streamer_lds(128, P->e4_SS), s4_seq_lds());
+    P->lds4_bytes = std::max(std::max(s4_streamer_lds(128, P->e4_SS), s4_seq_lds()), s4c_seq_lds());
     P->e4_ready = true;
   }
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1148,6 +1149,8 @@ static void launch_sweep4(bwgr_panel *P, const SweepArgs &a) {
   P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1;
   A.epoch = P->epoch3;
   if (const char *dv = getenv("BWGR_DBG4")) A.dbg = atoi(dv);
+  A.seq = 1;   // (1: the token walk over eight waves -- the faster of the two so far; 2: the chain wave with helpers)
+  if (const char *sv = getenv("BWGR_SEQ4")) A.seq = (sv[0] == '2') ? 2 : 1;
   (void)hipMemsetAsync(P->qsum3 + (size_t)a.blk_begin * 2 * SW_MAXM, 0, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
   // L2 prefetcher workgroups on the sequencer's XCD (workgroup indices that are multiples of 8): BWGR_PF4 = how many (default 4)
   int npf = 4;
@@ -1155,7 +1158,16 @@ static void launch_sweep4(bwgr_panel *P, const SweepArgs &a) {
   while (npf > 0 && (8 * npf >= 1 + A.K3 + npf || 1 + A.K3 + npf > 256)) --npf;
   A.npf = npf;
   const dim3 grid(1 + A.K3 + npf), blk(SW_THREADS);
+  if (A.seq == 2) {   // the chain wave writes the included markers' b and d = 1 only
+    const int j0 = a.blk_begin * a.m, j1 = (int)std::min<int64_t>(P->p, (int64_t)a.blk_end * a.m);
+    (void)hipMemsetAsync(a.d + j0, 0, sizeof(float) * (size_t)(j1 - j0), P->stream);
+  }
   hipLaunchKernelGGL(k_sweep4<4>, grid, blk, P->lds4_bytes, P->stream, A);
+  if (A.seq == 2) {
+    if (!P->fin4) (void)hipMalloc(&P->fin4, sizeof(double) * 2 * 256);
+    hipLaunchKernelGGL(k_sweep4_finish, dim3(256), dim3(256), 0, P->stream, a, P->fin4);
+    hipLaunchKernelGGL(k_sweep4_finish2, dim3(1), dim3(64), 0, P->stream, a, (const double *)P->fin4, 256);
+  }
 }
 static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
   if (use_sweep4(P, a)) { launch_sweep4(P, a); return; }
@@ -1366,7 +1378,7 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   (void)hipSetDevice(P->device);
   if (!P->parent) {
     for (int d = 0; d < S3_MAXD; ++d) if (P->g3own[d]) hipFree(P->g3x[d]);
-    hipFree(P->lists4); hipFree(P->gd16);
+    hipFree(P->lists4); hipFree(P->gd16); hipFree(P->fin4);
     hipFree(P->xmax_dev);
     for (int d = 0; d < S2W_MAXDIST; ++d) hipFree(P->gxt[d]);
     hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->gramx3); hipFree(P->gramp16); hipFree(P->gramx16); hipFree(P->gram16_bad); hipFree(P->gramp); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev);
@@ -1672,7 +1684,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   bwgr_panel *P = new bwgr_panel(*root);
   P->parent = root; P->nclones = 0; P->nchains = 0; P->own_stream = nullptr; P->stream = nullptr; P->ps_owner = nullptr; P->ps_iter = -1;
   P->pair_streams.clear();   // (the root's: a clone owns none)
-  P->qsum3 = P->lists3 = nullptr; P->lists4 = nullptr; P->gd16 = nullptr; P->epoch3 = 0; P->xmax_dev = nullptr; P->winv = nullptr; P->qsumw = nullptr;
+  P->qsum3 = P->lists3 = nullptr; P->lists4 = nullptr; P->gd16 = nullptr; P->fin4 = nullptr; P->epoch3 = 0; P->xmax_dev = nullptr; P->winv = nullptr; P->qsumw = nullptr;
   P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->xchg = nullptr; P->stamps = nullptr;
   root->nclones++;
   auto bail = [&](int code) { bwgr_panel_destroy(P); return code; };

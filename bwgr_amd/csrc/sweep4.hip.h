@@ -60,6 +60,7 @@ struct Sweep4Args {
   unsigned long long *lists;     // [nquads][S4_LSTRIDE] epoch-tagged words
   uint32_t epoch;
   int dbg;                       // experiment switches (BWGR_DBG4)
+  int seq;                       // which sequencer: 1 the token walk over eight waves, 2 the chain wave with helpers
   int npf;                       // L2 prefetcher workgroups: blockIdx 8, 16, .. 8 npf (the sequencer's XCD under round-robin placement)
 };
 // which role a workgroup of k_sweep4's grid plays: 0 the sequencer; 8 i (i = 1..npf) prefetcher i - 1; every other one a streamer
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(128) void k_spec4(const Sweep4Args A, int blk_begin
     }
   }
   // spec: what k_spec3 writes (k_sweep3 may run the launch instead); xspec: the super-block terms, k_sweep4's alone
-  sp.spec[j] = (s0 + s1) + (s2 + s3); sp.xspec[j] = (x0 + x1) + (x2 + x3); sp.gjj[j] = gjj;
+  // (xspec: everything k_sweep4 subtracts from q -- the in-block terms plus the super-block ones)
+  sp.spec[j] = (s0 + s1) + (s2 + s3); sp.xspec[j] = ((s0 + s1) + (s2 + s3)) + ((x0 + x1) + (x2 + x3)); sp.gjj[j] = gjj;
   double zc = 0.0, ha = INFINITY, hr = INFINITY;   // unused lanes: a certain reject
   if (j < mB) {
     LaneConst c;
@@ -140,6 +142,11 @@ __device__ __forceinline__ void lds_st32(uint32_t *p, uint32_t v) {
 // LDS-DMA of 16 bytes per lane from a wave-uniform base (SGPR pair) plus a per-lane byte offset to lds_addr + 16 * lane
 __device__ __forceinline__ void s4_dma16s(const void *gbase, uint32_t voff, uint32_t la) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(gbase), "s"(la) : "memory", "m0");
+}
+// ... 4 bytes per lane; the LDS address is made scalar here (callers pass values that are wave-uniform but not provably so)
+__device__ __forceinline__ void s4_dma4u(const unsigned char *gbase, uint32_t voff, uint32_t la) {
+  const uint32_t las = (uint32_t)__builtin_amdgcn_readfirstlane((int)la);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(gbase), "s"(las) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 
@@ -300,7 +307,8 @@ __device__ __forceinline__ void s4_streamer(const Sweep4Args &A) {
           const uint32_t a0 = __builtin_amdgcn_readlane(wlo, 1 + 2 * ee), a1 = __builtin_amdgcn_readlane(whi, 1 + 2 * ee);
           const uint32_t b0 = __builtin_amdgcn_readlane(wlo, 2 + 2 * ee), b1 = __builtin_amdgcn_readlane(whi, 2 + 2 * ee);
           const int k = (int)(a1 & 0xFFu) | (int)((b1 & 0x1u) << 8);
-          cq[u] = (e0 + u < nw / 2) ? (long long)(((unsigned long long)b0 << 32) | (unsigned long long)a0) : 0ll;
+          // (the entry carries the marker's two float steps {included, rejected}: what it changed beyond its rejected step, on the grid)
+          cq[u] = (e0 + u < nw / 2) ? ((long long)rint((double)__uint_as_float(a0) * S) - (long long)rint((double)__uint_as_float(b0) * S)) : 0ll;
           xb[u] = (int)col[(size_t)k * R];
         }
 #pragma unroll
@@ -328,7 +336,7 @@ __device__ __forceinline__ void s4_streamer(const Sweep4Args &A) {
       const uint32_t a0 = __builtin_amdgcn_readlane(wlo, 1 + 2 * ee), a1 = __builtin_amdgcn_readlane(whi, 1 + 2 * ee);
       const uint32_t b0 = __builtin_amdgcn_readlane(wlo, 2 + 2 * ee), b1 = __builtin_amdgcn_readlane(whi, 2 + 2 * ee);
       const int k = (cnt > 0) ? ((int)(a1 & 0xFFu) | (int)((b1 & 0x1u) << 8)) : 0;
-      pcq[u] = (u < cnt) ? (long long)(((unsigned long long)b0 << 32) | (unsigned long long)a0) : 0ll;
+      pcq[u] = (u < cnt) ? ((long long)rint((double)__uint_as_float(a0) * S) - (long long)rint((double)__uint_as_float(b0) * S)) : 0ll;
       pxb[u] = (int)col[(size_t)k * R];
     }
     pre_n = cnt;
@@ -685,7 +693,7 @@ __device__ __forceinline__ void s4_sequencer(const Sweep4Args &A) {
     }
     if (failed) { lds_st64(ctl + 1, 1ull); break; }
     S4ST(2, stq);
-    double r = valid ? fma((double)((long long)c_qhi >> 8), 16777216.0, (double)((long long)c_qlo >> 8)) * invS - (c_spec + c_xspec) : 0.0;
+    double r = valid ? fma((double)((long long)c_qhi >> 8), 16777216.0, (double)((long long)c_qlo >> 8)) * invS - c_xspec : 0.0;
     const double hr_l = valid ? c_hr : INFINITY, ha_l = valid ? c_ha : INFINITY;   // dead lanes: a certain reject
     // ---- (3) far rows, in ring order; then the near entries published so far ----
     if (live_w) {
@@ -895,12 +903,11 @@ __device__ __forceinline__ void s4_sequencer(const Sweep4Args &A) {
       const int cnt = (int)(ninc - n0);
       if (lane < cnt) {
         const int sl = (int)((n0 + (uint32_t)lane) & (ring - 1));
-        const float2 st2 = accS[sl];
-        const long long cq = (long long)rint((double)st2.x * S) - (long long)rint((double)st2.y * S);   // what the streamers fold in
+        const float2 st2 = accS[sl];   // the two float steps {included, rejected}: the streamers fold in their difference on the fixed-point grid
         const uint32_t k9 = (uint32_t)(accK[sl] - S4_QM * Q);
         const uint32_t idx = n0 + (uint32_t)lane - p0;
-        st_agent_raw64(L + 1 + 2 * idx, ((unsigned long long)A.epoch << 40) | ((unsigned long long)(k9 & 0xFFu) << 32) | ((unsigned long long)cq & 0xFFFFFFFFull));
-        st_agent_raw64(L + 2 + 2 * idx, ((unsigned long long)A.epoch << 40) | ((unsigned long long)(0xE0u | (k9 >> 8)) << 32) | ((unsigned long long)cq >> 32));
+        st_agent_raw64(L + 1 + 2 * idx, ((unsigned long long)A.epoch << 40) | ((unsigned long long)(k9 & 0xFFu) << 32) | (unsigned long long)__float_as_uint(st2.x));
+        st_agent_raw64(L + 2 + 2 * idx, ((unsigned long long)A.epoch << 40) | ((unsigned long long)(0xE0u | (k9 >> 8)) << 32) | (unsigned long long)__float_as_uint(st2.y));
       }
       if (wvu == 7 && lane == 0) st_agent_raw64(L, s3_hdr(A.epoch, (int)(ninc - p0)));
     }
@@ -929,6 +936,598 @@ __device__ __forceinline__ void s4_sequencer(const Sweep4Args &A) {
     for (int w8 = 0; w8 < 8; ++w8) { sd += red[2 * w8]; sb2 += red[2 * w8 + 1]; }
     a.sc->sum_d += sd; a.sc->sum_b2 += sb2;
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// sequencer, second form (A.seq == 2): ONE wave runs the whole chain.
+//
+// The token sequencer above pays an LDS hand-off per 64 markers and per included marker (publish -> the next wave's poll -> its
+// row read -> its token poll: ~1.5k cycles each).  Here wave 0 (the CHAIN wave) keeps the residual dots of the four lane groups
+// (64 markers each) it will decide next in its own registers: an included marker is applied to all of them by four LDS row reads
+// and four FMAs, no other wave is waited for, and the rounds of group T + 1 start the instruction after those of group T end.
+// Everything else belongs to the other waves and reaches the chain wave through LDS long before it is needed:
+//   helpers (waves 1..6)  take the lane groups ("tasks", eight per quad) in turn: constants, q, the window's Gram rows from global
+//       memory -> r; they publish {r, radii} as a task record and then FOLLOW the chain (every newly included marker is applied
+//       and the record rewritten under a sequence lock) until the chain wave adopts the group, three groups before it decides it;
+//       they announce the group's candidates (row sets of four rows, distances 0..3, landed in LDS by DMA, plus the candidate's
+//       constants as a record); after the chain wave is through with the group they write its outputs.
+//   servicer (wave 7)     lands the row sets of candidates the chain wave itself discovers in its adopted groups.
+// A candidate nobody announced in time costs the chain wave a wait for its row set (L2 or HBM latency); a marker with no free
+// row-set slot (dense chains) goes through scratch rows fetched on the spot.
+// ------------------------------------------------------------------------------------------------------------------
+static constexpr int S4C_NS = 48;       // row-set slots: 0 .. NSH - 1 the helpers' (a shared counter), the rest the chain wave's own
+static constexpr int S4C_NSH = 32;
+static constexpr int S4C_NROW = 4;      // rows of a set: towards the marker's own block and the three behind it
+static constexpr int S4C_NTR = 16;      // task records (two quads)
+static constexpr int S4C_LEAD = 8;      // a helper publishes task T when the chain has finished task T - LEAD - 1
+static constexpr int S4C_LOOK = 3;      // groups the chain wave holds beyond the one it decides
+static constexpr int S4C_NH = 6;        // helper waves
+static constexpr int S4C_QN = 32;       // announce requests in flight from the chain wave to the servicer
+struct S4CRec {                          // a candidate's constants (what an inclusion needs of its marker), 64 bytes
+  int kk, state;                         // marker index within the launch; kk + 1 once the row set has landed
+  float b0, xxb0, drej, b2, tacc, trej;
+  double rden, sdz1, gjj, ha;
+};
+struct S4CTask {                         // one lane group as the chain wave adopts it
+  double r[64], zc[64], ha[64], hr[64];
+  int gs[64];                            // the lane's row-set slot, or -1
+  uint32_t seq, W, ready, pad;           // sequence lock of {r, W, an}; ring entries below W are inside r; task + 1 when published
+  unsigned long long an;                 // lanes that have a row set
+  unsigned long long pad2;
+};
+struct S4CGroup { unsigned long long am; uint32_t n0, n1; };   // what the chain wave decided: included lanes, their ring entries [n0, n1)
+__host__ __device__ inline size_t s4c_seq_lds() {
+  return (size_t)S4_RING * (8 + 4 + 4 + 4) + 64 + 64 + 128 + 128 + (size_t)S4C_NTR * sizeof(S4CTask) + (size_t)S4C_NTR * sizeof(S4CGroup) + (size_t)(S4C_NS + 1) * sizeof(S4CRec)
+       + (size_t)S4C_QN * 8 + (size_t)(S4C_NS + 1) * S4C_NROW * SW_MAXM * 2 + (size_t)8 * S4C_NROW * SW_MAXM * 2 + 64;
+}
+__device__ __forceinline__ void s4_sequencer_cw(const Sweep4Args &A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const SweepArgs &a = A.a;
+  typedef uint16_t GT;
+  typedef const __attribute__((address_space(1))) GT gGT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wvu = __builtin_amdgcn_readfirstlane(wave);
+  const int m = SW_MAXM, nb = a.blk_end - a.blk_begin, DQ = A.DQ;
+  const int nq = (nb + S4_QB - 1) / S4_QB, ntask = 8 * nq;
+  constexpr int ring = S4_RING;
+  size_t off = 0;
+  double *accC = reinterpret_cast<double *>(smem + off); off += (size_t)S4_RING * 8;      // what marker k changed beyond drej
+  int *accK = reinterpret_cast<int *>(smem + off); off += (size_t)S4_RING * 4;            // marker index within the launch
+  int *accT = reinterpret_cast<int *>(smem + off); off += (size_t)S4_RING * 4;            // its row-set slot, or -1
+  float *accB = reinterpret_cast<float *>(smem + off); off += (size_t)S4_RING * 4;        // its new effect
+  unsigned long long *ctl = reinterpret_cast<unsigned long long *>(smem + off); off += 64;   // [0] {tasks decided, inclusions so far}, [1] failure, [2] {slot counter, -}, [3] {queue tail, queue head}
+  uint32_t *posq = reinterpret_cast<uint32_t *>(smem + off); off += 64;                    // [Q & 15]: inclusions before quad Q
+  const unsigned char **tab = reinterpret_cast<const unsigned char **>(smem + off); off += 128;   // [0] diagonal blocks in full, [d] distance-d cross blocks
+  double *red = reinterpret_cast<double *>(smem + off); off += 128;                        // [wave][2] posterior sums
+  S4CTask *TR = reinterpret_cast<S4CTask *>(smem + off); off += (size_t)S4C_NTR * sizeof(S4CTask);
+  S4CGroup *GR = reinterpret_cast<S4CGroup *>(smem + off); off += (size_t)S4C_NTR * sizeof(S4CGroup);
+  S4CRec *crec = reinterpret_cast<S4CRec *>(smem + off); off += (size_t)(S4C_NS + 1) * sizeof(S4CRec);   // (the last one: the chain wave's slot for a marker nobody announced)
+  unsigned long long *queue = reinterpret_cast<unsigned long long *>(smem + off); off += (size_t)S4C_QN * 8;   // {slot << 32 | kk}
+  GT *nrow = reinterpret_cast<GT *>(smem + off); off += (size_t)(S4C_NS + 1) * S4C_NROW * SW_MAXM * 2;        // [slot][distance 0..3][128]
+  GT *srow = reinterpret_cast<GT *>(smem + off) + (size_t)wave * S4C_NROW * SW_MAXM;                            // this wave's scratch rows
+  const uint32_t nrow_la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)reinterpret_cast<unsigned char *>(nrow);
+  const uint32_t srow_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)reinterpret_cast<unsigned char *>(srow));
+  uint32_t *ctl32 = reinterpret_cast<uint32_t *>(ctl);
+  const float Cc = a.sc->C, odds = a.sc->odds, one_minus_pi = 1.0f - a.sc->pi, Sb = a.sc->Sb;
+  const int sh = a.sc->e3_sh;
+  const double S = s3_pow2(sh), invS = s3_pow2(-sh);
+  uint32_t *abortw = a.xflags + (size_t)a.K * SW_FLAG_STRIDE;
+  const bool vbv = (a.flags & SWF_VB_VEC) != 0;
+
+  for (int i = tid; i < (int)((S4C_NTR * sizeof(S4CTask) + S4C_NTR * sizeof(S4CGroup) + (S4C_NS + 1) * sizeof(S4CRec)) / 4); i += SW_THREADS) reinterpret_cast<uint32_t *>(TR)[i] = 0u;   // adjacent
+  if (tid < 16) { ctl32[tid] = 0u; posq[tid] = 0u; }
+  if (tid >= 64 && tid < 64 + 16) tab[tid - 64] = (tid == 64) ? reinterpret_cast<const unsigned char *>(A.gd) : reinterpret_cast<const unsigned char *>(A.gx[tid - 65]);
+  __syncthreads();
+  if (tid < S4C_NS) crec[tid].kk = -(1 << 20);   // (no slot holds a marker)
+  __syncthreads();
+
+  auto tab_base = [&](int d) -> const unsigned char * {
+    const unsigned long long bu = (unsigned long long)(uintptr_t)tab[d];
+    return reinterpret_cast<const unsigned char *>((uintptr_t)(
+        (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bu) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bu >> 32)) << 32)));
+  };
+  // a row-set slot for marker kk, or -1: slots go round; one is free once the chain is through with the last block its rows lead to
+  auto slot_alloc = [&](int kk) -> int {
+    uint32_t sN = 0u;
+    if (lane == 0) sN = __hip_atomic_fetch_add((lu32_t *)(ctl32 + 4), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int sl = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)sN) % (uint32_t)S4C_NSH);
+    const int prev = __builtin_amdgcn_readfirstlane(crec[sl].kk);
+    const uint32_t done = (uint32_t)lds_ld64(ctl);                      // tasks the chain has decided
+    if ((int)done < 2 * ((prev >> 7) + S4C_NROW)) return -1;            // (two tasks per block)
+    if (lane == 0) { crec[sl].kk = kk; crec[sl].state = 0; }
+    return sl;
+  };
+  // the row set of marker kk into slot sl: rows towards blocks ck .. ck + 3 (those that exist), by DMA
+  auto rows_request = [&](int kk, int sl) {
+    const int ck = kk >> 7, kl = kk & 127;
+    for (int d = 0; d < S4C_NROW; ++d) if (ck + d < nb) {
+      const unsigned char *rb = tab_base(d) + (((size_t)(a.blk_begin + ck + d) * m + (size_t)kl) * m) * sizeof(GT);
+      s4_dma4u(rb, (uint32_t)lane * 4u, nrow_la + (uint32_t)(((sl * S4C_NROW + d) * SW_MAXM) * (int)sizeof(GT)));
+    }
+  };
+  bool failed = false;
+
+  if (wvu == 0) {
+    // ==============================================================================================================
+    // the chain wave: everything here is counted in instructions (one wave issues one every ~7 cycles).  Per lane group it keeps
+    // r, the rounds' centre and the certain-reject radius in registers; what only an INCLUDED marker needs (the accept radius, its
+    // row-set slot, its constants) is read from LDS when a marker is included
+    // ==============================================================================================================
+    double R[4] = {0, 0, 0, 0}, ZC[4] = {0, 0, 0, 0}, HR[4];
+    unsigned long long AN[4] = {0, 0, 0, 0};                             // lanes of the set that have a row set (wave-uniform)
+    bool LV[4] = {false, false, false, false};                           // the set holds a group that exists
+#pragma unroll
+    for (int i = 0; i < 4; ++i) HR[i] = INFINITY;
+    uint32_t ninc = 0u, qtail = 0u;
+    int own_kk = -(1 << 20);   // lane i: the marker that holds the chain wave's own slot NSH + i (i < NS - NSH)
+    int own_next = 0;
+    uint32_t qhead_seen = 0u, qpos = 0u;   // (qpos: inclusions before the quad in hand)
+#ifdef BWGR_STAMPS
+    unsigned long long xt4[4] = {0, 0, 0, 0};
+#endif
+    S4ST_DECL;
+    const bool stq = (lane == 0);
+    __builtin_amdgcn_s_setprio(3);
+    // this lane's element of row d of slot sl, half hwj
+    auto lds_row = [&](int sl, int d, int hwj) -> double { return (double)nrow[(size_t)((sl * S4C_NROW + d) * SW_MAXM) + 64 * hwj + lane]; };
+    auto push_request = [&](int kk, int sl) {
+      if (lane == 0) { crec[sl].kk = kk; crec[sl].state = 0; queue[qtail & (S4C_QN - 1)] = ((unsigned long long)(uint32_t)sl << 32) | (unsigned long long)(uint32_t)kk; }
+      ++qtail;
+      asm volatile("" ::: "memory");
+      lds_st32(ctl32 + 6, qtail);
+    };
+    // adopt task Tn into register set si: its record (under the sequence lock), then the ring entries its helper had not seen
+    auto adopt = [&](int Tn, auto si_c) {
+      constexpr int si = decltype(si_c)::value;
+      LV[si] = false; R[si] = 0.0; ZC[si] = 0.0; HR[si] = INFINITY; AN[si] = 0ull;
+      if (Tn >= ntask) return;
+      const S4CTask &tr = TR[Tn & (S4C_NTR - 1)];
+      uint64_t t0 = 0;
+      unsigned spins = 0;
+      uint32_t W;
+#ifdef BWGR_STAMPS
+      const unsigned long long tw_ = __builtin_amdgcn_s_memtime();
+#endif
+      double zc_n = 0.0, hr_n = INFINITY;
+      for (;;) {
+        // every read of the record in one batch (LDS returns them in order): ready, sequence, {r, W, an}, sequence again, centre, radius
+        const uint32_t rdy = lds_ld32(&tr.ready);
+        const uint32_t s1 = lds_ld32(&tr.seq);
+        const double rr = tr.r[lane];
+        W = lds_ld32(&tr.W);
+        const unsigned long long an = lds_ld64(&tr.an);
+        const uint32_t s2 = lds_ld32(&tr.seq);
+        zc_n = tr.zc[lane]; hr_n = tr.hr[lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (rdy == (uint32_t)(Tn + 1) && s1 == s2 && !(s1 & 1u)) { R[si] = rr; AN[si] = an; break; }
+        if ((++spins & 255u) == 0u) {
+          if ((uint32_t)lds_ld64(ctl + 1) != 0u) { failed = true; return; }   // (the helpers watch the launch's abort word)
+          if (t0 == 0) t0 = wall_clock64();                             // (the clock is read only once a wait has become long)
+          if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); failed = true; return; }
+        }
+      }
+#ifdef BWGR_STAMPS
+      if (stq) { ph4[3] += __builtin_amdgcn_s_memtime() - tw_; }
+#endif
+      ZC[si] = zc_n; HR[si] = hr_n;
+      LV[si] = ((Tn >> 1) < nb);
+      // catch up: entries [W, ninc) (the last few the chain published)
+      const int cj = Tn >> 1, hwj = Tn & 1;
+      for (uint32_t e = W; LV[si] && e != ninc; ++e) {
+        const int sl = (int)(e & (ring - 1));
+        const int kk = __builtin_amdgcn_readfirstlane(accK[sl]), slot = __builtin_amdgcn_readfirstlane(accT[sl]);
+        const double cf = accC[sl];
+        const int ck = kk >> 7, kl = kk & 127, d = cj - ck;
+        double g;
+        if (slot >= 0 && d < S4C_NROW) g = lds_row(slot, d, hwj);
+        else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const unsigned char *rb = tab_base(d) + (((size_t)(a.blk_begin + cj) * m + (size_t)kl) * m) * sizeof(GT);
+          s4_dma4u(rb, (uint32_t)lane * 4u, srow_la);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          g = (double)srow[64 * hwj + lane];
+        }
+        R[si] = fma(-g, (ck != cj || 64 * hwj + lane > kl) ? cf : 0.0, R[si]);
+      }
+    };
+    // new candidates of an adopted set that nobody announced yet: one request per call goes to the servicer, into one of the chain
+    // wave's own slots (taken in turn; free once the chain is through with the last block its rows lead to: no LDS traffic to find one)
+    auto look = [&](int Tj, auto sj_c) {
+      constexpr int sj = decltype(sj_c)::value;
+      const unsigned long long cand = __ballot(!(fabs(R[sj] - ZC[sj]) < HR[sj])) & ~AN[sj];
+      if (cand == 0ull || !LV[sj]) return;
+      const int js = (int)__builtin_ctzll(cand);
+      const int kk = 64 * Tj + js;
+      const int prev = __builtin_amdgcn_readlane(own_kk, own_next);
+      if (Tj - S4C_LOOK < 2 * ((prev >> 7) + S4C_NROW) || qtail - qhead_seen >= (uint32_t)S4C_QN) {
+        qhead_seen = lds_ld32(ctl32 + 7);
+        return;                                                         // (the marker stays unannounced for now)
+      }
+      const int sl = S4C_NSH + own_next;
+      if (lane == own_next) own_kk = kk;
+      own_next = (own_next + 1 == S4C_NS - S4C_NSH) ? 0 : own_next + 1;
+      S4ST_ADD(5, 1, stq);
+      AN[sj] |= (1ull << js);
+      if (lane == 0) TR[Tj & (S4C_NTR - 1)].gs[js] = sl;
+      push_request(kk, sl);
+    };
+    // the rounds of task T held in set si; sets si + 1 .. si + 3 hold tasks T + 1 .. T + 3
+    auto decide = [&](int T, auto si_c) {
+      constexpr int si = decltype(si_c)::value;
+      constexpr int s1 = (si + 1) & 3, s2 = (si + 2) & 3, s3 = (si + 3) & 3;
+      const int Q = T >> 3, c = T >> 1, hw = T & 1;
+      const uint32_t n0 = ninc;
+      unsigned long long am = 0ull;
+      if (LV[si] && !(A.dbg & 128)) {
+        const int mBc = min(m, a.p - (a.blk_begin + c) * m);
+        unsigned long long livem = (mBc - 64 * hw >= 64) ? ~0ull : ((mBc - 64 * hw > 0) ? ((1ull << (mBc - 64 * hw)) - 1ull) : 0ull);
+        const S4CTask &tr = TR[T & (S4C_NTR - 1)];
+        const int d1 = ((T + 1) >> 1) - c, d2 = ((T + 2) >> 1) - c, d3 = ((T + 3) >> 1) - c;
+        for (;;) {
+          const unsigned long long cand = livem & ~__ballot(fabs(R[si] - ZC[si]) < HR[si]);
+          if (cand == 0ull) break;
+          const int js = (int)__builtin_ctzll(cand);
+          const int kk = 64 * T + js, kl = 64 * hw + js;
+          livem &= (~1ull << js);
+          // what only an included marker needs: its accept radius, its centre, its row-set slot
+          const double zc_j = tr.zc[js];
+          int slot = __builtin_amdgcn_readfirstlane(tr.gs[js]);
+          bool own_set = true;
+          if (__builtin_expect(slot < 0, 0)) {
+            // nobody announced this marker (it became a candidate this very moment, or no slot was free -- dense chains): its row set and
+            // constants come through the servicer now, into the spare slot, and the chain waits for them.  (No load the compiler knows of
+            // in this wave: a vector-memory load here would put s_waitcnt vmcnt(0) on the common path, behind the list words' stores.)
+            slot = S4C_NS; own_set = false;
+            uint64_t t0 = 0;
+            unsigned spins = 0;
+            while (qtail - lds_ld32(ctl32 + 7) >= (uint32_t)S4C_QN) {
+              if ((++spins & 255u) == 0u) { if (t0 == 0) t0 = wall_clock64(); if ((uint32_t)lds_ld64(ctl + 1) != 0u || wall_clock64() - t0 > SW_TIMEOUT_TICKS) { failed = true; break; } }
+            }
+            if (failed) break;
+            push_request(kk, slot);
+            S4ST_ADD(4, 1, stq);
+          }
+          const S4CRec &cr = crec[slot];
+          {
+            uint64_t t0 = 0;
+            unsigned spins = 0;
+#ifdef BWGR_STAMPS
+            const unsigned long long tc_ = __builtin_amdgcn_s_memtime();
+#endif
+            while (lds_ld32(reinterpret_cast<const uint32_t *>(&cr.state)) != (uint32_t)(kk + 1)) {   // its row set is still on the way
+              if ((++spins & 255u) == 0u) {
+                if (t0 == 0) t0 = wall_clock64();
+                if ((uint32_t)lds_ld64(ctl + 1) != 0u || wall_clock64() - t0 > SW_TIMEOUT_TICKS) { failed = true; break; }
+              }
+            }
+            if (failed) break;
+#ifdef BWGR_STAMPS
+            if (stq) { ph4[6] += __builtin_amdgcn_s_memtime() - tc_; }
+#endif
+            asm volatile("" ::: "memory");
+          }
+          const float k_b0 = cr.b0, k_xxb0 = cr.xxb0, k_drej = cr.drej;
+          const double k_rden = cr.rden, k_sdz1 = cr.sdz1, ha_j = cr.ha;
+          const double g0 = lds_row(slot, 0, hw), g1 = lds_row(slot, d1, (T + 1) & 1), g2 = lds_row(slot, d2, (T + 2) & 1), g3 = lds_row(slot, d3, (T + 3) & 1);
+#ifdef BWGR_STAMPS
+          unsigned long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
+          const double rj = readlane_f64(R[si], js);
+          const float b1 = (float)fma(rj + (double)k_xxb0, k_rden, k_sdz1);
+          const float d1f = b1 - k_b0;
+          if (__builtin_expect(!(fabs(rj - zc_j) > ha_j), 0)) {     // between the radii: the full test decides; a reject leaves its speculated step standing
+            LaneConst lc;
+            lc.b0 = k_b0; lc.xxb0 = k_xxb0; lc.b2 = cr.b2; lc.drej = k_drej; lc.rden = k_rden; lc.sdz1 = k_sdz1; lc.gjj = cr.gjj; lc.tacc = cr.tacc; lc.trej = cr.trej;
+            lc.mk = a.marker0 + (uint32_t)((a.blk_begin + c) * m + kl);
+            if (!__builtin_amdgcn_readfirstlane((int)lane_accept(rj, b1, lc, a.flags, Cc, odds, one_minus_pi, a.rng, a.iter))) continue;
+          }
+          const double corr = (double)d1f - (double)k_drej;
+          am |= (1ull << js);
+          {   // publish: the helpers that follow the chain apply it to the groups not yet adopted; the list words go straight out
+            const int sl = (int)(ninc & (ring - 1));
+            const uint32_t k9 = (uint32_t)(kk - S4_QM * Q), idx = ninc - qpos;
+            unsigned long long *L = A.lists + (size_t)Q * S4_LSTRIDE;
+            if (lane == 0) {
+              accK[sl] = kk; accT[sl] = own_set ? slot : -1; accC[sl] = corr; accB[sl] = b1;
+              const int jg = (a.blk_begin + c) * m + kl;           // the included marker's outputs (every other marker's are k_sweep4_finish's)
+              a.b[jg] = b1; a.d[jg] = 1.0f;
+              st_agent_raw64(L + 1 + 2 * idx, ((unsigned long long)A.epoch << 40) | ((unsigned long long)(k9 & 0xFFu) << 32) | (unsigned long long)__float_as_uint(d1f));
+              st_agent_raw64(L + 2 + 2 * idx, ((unsigned long long)A.epoch << 40) | ((unsigned long long)(0xE0u | (k9 >> 8)) << 32) | (unsigned long long)__float_as_uint(k_drej));
+            }
+            ++ninc;
+            asm volatile("" ::: "memory");
+            lds_st64(ctl, ((unsigned long long)ninc << 32) | (unsigned long long)(uint32_t)T);
+          }
+#ifdef BWGR_STAMPS
+          { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); if (stq) xt4[0] += tn_ - tq_; tq_ = tn_; }
+#endif
+          R[si] = fma(-((lane > js) ? g0 : 0.0), corr, R[si]);
+          R[s1] = fma(-g1, corr, R[s1]); R[s2] = fma(-g2, corr, R[s2]); R[s3] = fma(-g3, corr, R[s3]);
+          // candidates this step created in the sets ahead get their row sets requested now
+          if (!(A.dbg & 64)) { look(T + 1, std::integral_constant<int, s1>{}); look(T + 2, std::integral_constant<int, s2>{}); if (!(A.dbg & 32)) look(T + 3, std::integral_constant<int, s3>{}); }
+#ifdef BWGR_STAMPS
+          { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); if (stq) xt4[1] += tn_ - tq_; }
+#endif
+        }
+      }
+      // the group is decided
+      if (lane == 0) { S4CGroup &gr = GR[T & (S4C_NTR - 1)]; gr.am = am; gr.n0 = n0; gr.n1 = ninc; }
+      if ((T & 7) == 7) {
+        if (lane == 0) { posq[(Q + 1) & 15] = ninc; st_agent_raw64(A.lists + (size_t)Q * S4_LSTRIDE, s3_hdr(A.epoch, (int)(ninc - qpos))); }
+        qpos = ninc;
+      }
+      asm volatile("" ::: "memory");
+      lds_st64(ctl, ((unsigned long long)ninc << 32) | (unsigned long long)(uint32_t)(T + 1));
+      S4ST_ADD(7, ninc - n0, stq);
+    };
+    adopt(0, std::integral_constant<int, 0>{}); adopt(1, std::integral_constant<int, 1>{}); adopt(2, std::integral_constant<int, 2>{});
+    for (int T0 = 0; T0 < ntask && !failed; T0 += 4) {
+      S4ST(0, stq);
+      adopt(T0 + 3, std::integral_constant<int, 3>{}); if (failed) break;
+      S4ST(1, stq);
+      decide(T0, std::integral_constant<int, 0>{}); if (failed) break;
+      S4ST(2, stq);
+      adopt(T0 + 4, std::integral_constant<int, 0>{}); if (failed) break;
+      decide(T0 + 1, std::integral_constant<int, 1>{}); if (failed) break;
+      adopt(T0 + 5, std::integral_constant<int, 1>{}); if (failed) break;
+      decide(T0 + 2, std::integral_constant<int, 2>{}); if (failed) break;
+      adopt(T0 + 6, std::integral_constant<int, 2>{}); if (failed) break;
+      decide(T0 + 3, std::integral_constant<int, 3>{}); if (failed) break;
+    }
+    if (failed) lds_st64(ctl + 1, 1ull);
+    S4ST_FLUSH(64, stq);
+#ifdef BWGR_STAMPS
+    if (stq && a.stamps) for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&a.stamps[72 + k_], xt4[k_]);
+#endif
+  } else if (wvu == 7) {
+    // ==============================================================================================================
+    // the servicer: row sets and constants of the candidates the chain wave found in its adopted groups
+    // ==============================================================================================================
+    uint32_t head = 0u;
+    const uint64_t t0 = wall_clock64();
+    unsigned spins = 0;
+    for (;;) {
+      const uint32_t done = (uint32_t)lds_ld64(ctl);
+      const uint32_t tail = lds_ld32(ctl32 + 6);
+      if (head == tail) {
+        if ((int)done >= ntask || (uint32_t)lds_ld64(ctl + 1) != 0u) break;
+        if ((++spins & 1023u) == 0u && wall_clock64() - t0 > 64 * SW_TIMEOUT_TICKS) break;
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      asm volatile("" ::: "memory");
+      const unsigned long long rq = queue[head & (S4C_QN - 1)];
+      const int kk = __builtin_amdgcn_readfirstlane((int)(uint32_t)rq), sl = __builtin_amdgcn_readfirstlane((int)(uint32_t)(rq >> 32));
+      rows_request(kk, sl);
+      const int blk = a.blk_begin + (kk >> 7), kl = kk & 127;
+      const StageBuf &st = a.ps.blocks[blk];
+      const float v_b0 = st.b0[kl], v_xxb0 = st.xxb0[kl], v_drej = st.drej[kl], v_b2 = st.b2[kl], v_tacc = st.tacc[kl], v_trej = st.trej[kl];
+      const double v_rden = st.rden[kl], v_sdz1 = st.sdz1[kl], v_gjj = a.ps.spec[blk].gjj[kl], v_ha = a.ps.quick[blk].ha[kl];
+      S4CRec &cr = crec[sl];
+      if (lane == 0) { cr.b0 = v_b0; cr.xxb0 = v_xxb0; cr.drej = v_drej; cr.b2 = v_b2; cr.tacc = v_tacc; cr.trej = v_trej; cr.rden = v_rden; cr.sdz1 = v_sdz1; cr.gjj = v_gjj; cr.ha = v_ha; }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the rows have landed, the record is written
+      lds_st32(reinterpret_cast<uint32_t *>(&cr.state), (uint32_t)(kk + 1));
+      ++head;
+      lds_st32(ctl32 + 7, head);
+    }
+  } else {
+    // ==============================================================================================================
+    // helpers: a lane group's r as the chain wave adopts it.  Per lane only what r and the rounds' first test need (q, the speculative
+    // terms, centre, certain-reject radius); a candidate's other constants are read when it is announced; the outputs of the markers
+    // that are NOT included are written by k_sweep4_finish after the sweep
+    // ==============================================================================================================
+    const int hi = wvu - 1;
+    double c_sx = 0.0, c_zc = 0.0, c_hr = INFINITY; unsigned long long c_qlo = 0ull, c_qhi = 0ull;
+    double n_sx = 0.0, n_zc = 0.0, n_hr = INFINITY; unsigned long long n_qlo = 0ull, n_qhi = 0ull;
+#define S4C_LOAD_CONSTS(T_, P_) do {                                           /* unconditional loads (clamped block) */ \
+    const int cl_ = min((T_) >> 1, nb - 1), bk_ = a.blk_begin + cl_, t_ = 64 * ((T_) & 1) + lane; \
+    P_##sx = a.ps.spec[bk_].xspec[t_]; P_##zc = a.ps.quick[bk_].zc[t_]; P_##hr = a.ps.quick[bk_].hr[t_]; \
+    const unsigned long long *g_ = A.qsum + ((size_t)bk_ * SW_MAXM + t_) * 2; \
+    P_##qlo = ld_agent_raw64(g_); P_##qhi = ld_agent_raw64(g_ + 1); } while (0)
+    // ring entries in batches: lane u forms the descriptor of entry e0 + u for a task in block cq (absolute block bq); the wave takes them
+    // one by one through v_readlane.  Rows from the LDS row sets where one reaches the block, else from global memory
+    unsigned long long d_gb = 0ull; double d_cf = 0.0; int d_loff = -1, d_klm = -1;
+    auto describe_for = [&](uint32_t e0, int n, int cq, int bq) {
+      const int sl = (int)((e0 + (uint32_t)min(lane, n - 1)) & (ring - 1));
+      const int kk = accK[sl], slot = accT[sl];
+      d_cf = (lane < n) ? accC[sl] : 0.0;
+      const int ck = kk >> 7, kl = kk & 127, d = cq - ck;
+      d_gb = (unsigned long long)(uintptr_t)tab[min(max(d, 0), 15)] + (((unsigned long long)bq * m + (unsigned long long)kl) * m) * sizeof(GT);
+      d_loff = (slot >= 0 && d < S4C_NROW) ? ((slot * S4C_NROW + d) * SW_MAXM) * (int)sizeof(GT) : -1;
+      d_klm = (ck == cq) ? kl : -1;
+    };
+    auto row_of_for = [&](int u, int tq) -> uint32_t {     // entry u of the described batch: this lane's element of its row
+      const int lo = __builtin_amdgcn_readlane(d_loff, u);
+      if (lo >= 0) return (uint32_t)*reinterpret_cast<const GT *>(reinterpret_cast<const unsigned char *>(nrow) + lo + 2 * tq);
+      const unsigned long long gbu = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d_gb, u) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(d_gb >> 32), u) << 32);
+      return (uint32_t)((gGT *)(uintptr_t)gbu)[tq];
+    };
+    // the first 32 entries of a task's window, requested while the helper still works on its previous task
+    uint32_t fg[32]; double fcf = 0.0; int fklm = -1, f_nf = 0; uint32_t f_napp = 0u;
+#define S4C_BULK_REQUEST(T_) do { \
+    const int Qn_ = (T_) >> 3, cn_ = (T_) >> 1, tn_ = 64 * ((T_) & 1) + lane; \
+    f_napp = (Qn_ - DQ + 1 > 0) ? lds_ld32(posq + ((Qn_ - DQ + 1) & 15)) : 0u; \
+    f_nf = (cn_ < nb) ? (int)min(32u, (uint32_t)(lds_ld64(ctl) >> 32) - f_napp) : 0; \
+    fcf = 0.0; fklm = -1; \
+    if (f_nf > 0) { \
+      describe_for(f_napp, f_nf, cn_, a.blk_begin + cn_); \
+      fcf = d_cf; fklm = d_klm; \
+      _Pragma("unroll") for (int u_ = 0; u_ < 32; ++u_) fg[u_] = row_of_for(min(u_, f_nf - 1), tn_); \
+    } else { _Pragma("unroll") for (int u_ = 0; u_ < 32; ++u_) fg[u_] = 0u; } } while (0)
+#ifdef BWGR_STAMPS
+    unsigned long long hst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, htl = __builtin_amdgcn_s_memtime();
+#define S4H(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); hst[k] += t_ - htl; htl = t_; } while (0)
+#else
+#define S4H(k) do { } while (0)
+#endif
+    // stage 1 of task T_ from the constants in n_* and the rows in fg: q complete -> r, the first rows applied.  Returns false (nothing
+    // done) while the streamers' sums are still incomplete and `block` is false
+    double r_nx = 0.0; uint32_t napp_nx = 0u; bool have_nx = false;
+    auto stage1 = [&](int Tn, bool block) -> bool {
+      const int cn = Tn >> 1, tn = 64 * (Tn & 1) + lane;
+      const bool lw = cn < nb;
+      const int bk = a.blk_begin + min(cn, nb - 1);
+      const bool vl = lw && tn < min(m, a.p - bk * m);
+      if (lw) {
+        const unsigned long long need = (unsigned long long)A.K3;
+        const unsigned long long *gq = A.qsum + ((size_t)bk * SW_MAXM + tn) * 2;
+        const uint64_t t0 = block ? wall_clock64() : 0;
+        unsigned spins = 0;
+        for (;;) {
+          if (__ballot(vl && ((n_qlo & 0xFFull) != need || (n_qhi & 0xFFull) != need)) == 0ull) break;
+          if (A.dbg & 8) break;
+          n_qlo = ld_agent_raw64(gq); n_qhi = ld_agent_raw64(gq + 1);
+          if (!block) { if (__ballot(vl && ((n_qlo & 0xFFull) != need || (n_qhi & 0xFFull) != need)) == 0ull) break; return false; }
+          if ((++spins & 63u) == 0u) {
+            if (ld_agent_u32(abortw) != 0u || (uint32_t)lds_ld64(ctl + 1) != 0u) { failed = true; return false; }
+            if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); failed = true; return false; }
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      double r = vl ? fma((double)((long long)n_qhi >> 8), 16777216.0, (double)((long long)n_qlo >> 8)) * invS - n_sx : 0.0;
+      uint32_t na = f_napp;
+      if (f_nf > 0) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+          const double cf = readlane_f64(fcf, u);
+          const int km = __builtin_amdgcn_readlane(fklm, min(u, f_nf - 1));
+          r = fma(-(double)fg[u], (tn > km) ? cf : 0.0, r);
+        }
+        na += (uint32_t)f_nf;
+      }
+      r_nx = r; napp_nx = na; have_nx = true;
+      return true;
+    };
+    if (hi < ntask) { S4C_LOAD_CONSTS(hi, n_); S4C_BULK_REQUEST(hi); }
+    for (int T = hi; T < ntask && !failed; T += S4C_NH) {
+      S4H(0);
+      const int Q = T >> 3, c = T >> 1, hw = T & 1, t = 64 * hw + lane;
+      const bool live_w = c < nb;
+      const int blk = a.blk_begin + min(c, nb - 1);
+      const int mBc = live_w ? min(m, a.p - blk * m) : 0;
+      const bool valid = live_w && t < mBc;
+      if (!have_nx) { stage1(T, true); if (failed) break; }
+      S4H(3);
+      double r = r_nx; uint32_t napp = napp_nx; have_nx = false;
+      c_sx = n_sx; c_zc = n_zc; c_hr = n_hr; c_qlo = n_qlo; c_qhi = n_qhi;
+      (void)c_sx; (void)c_qlo; (void)c_qhi; (void)Q;
+      const double hr_l = valid ? c_hr : INFINITY;
+      bool next_loaded = false;      // the next task's constants requested (after this task's record is out)
+      // ring entries [napp, to) into r, in ring order
+      auto apply = [&](uint32_t to) {
+        while (live_w && napp != to) {
+          const int n = (int)min(8u, to - napp);
+          describe_for(napp, n, c, blk);
+          uint32_t g[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) g[u] = row_of_for(min(u, n - 1), t);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const double cf = readlane_f64(d_cf, u);
+            const int km = __builtin_amdgcn_readlane(d_klm, min(u, n - 1));
+            r = fma(-(double)g[u], (t > km) ? cf : 0.0, r);
+          }
+          napp += (uint32_t)n;
+        }
+        if (!live_w) napp = to;
+      };
+      S4H(4);
+      // ---- follow the chain until it is LEAD tasks away, then publish and keep following until the group is adopted ----
+      S4CTask &tr = TR[T & (S4C_NTR - 1)];
+      int myslot = -1;                      // this lane's row-set slot
+      int nann = 0;
+      bool published = false, next_requested = false;
+      uint32_t seq = 0u;
+#ifdef BWGR_STAMPS
+      bool first_pub = true;
+#endif
+      {
+        const uint64_t t0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+          const unsigned long long cw = lds_ld64(ctl);
+          asm volatile("" ::: "memory");
+          const int done = (int)(uint32_t)cw;
+          const uint32_t nn = (uint32_t)(cw >> 32);
+          const bool fresh = (napp != nn);
+          apply(nn);
+          const bool due = done >= T - S4C_LEAD;
+          if (due && (fresh || !published)) {
+            // candidates without a row set: announce (up to four per task from here; the chain wave finds later ones itself).  The rows
+            // are requested and the lanes' slots recorded before the record goes out; their landing is waited for after it
+            int newk[4] = {-1, -1, -1, -1}, news[4] = {-1, -1, -1, -1};
+            float v_b0[4], v_xxb0[4], v_drej[4], v_b2[4], v_tacc[4], v_trej[4]; double v_rden[4], v_sdz1[4], v_gjj[4], v_ha[4];
+            int nnew = 0;
+            if (live_w) {
+              unsigned long long cand = __ballot(valid && !(fabs(r - c_zc) < hr_l) && myslot < 0);
+              while (cand != 0ull && nann < 4) {
+                const int js = (int)__builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                const int kk = 64 * T + js, kl = 64 * hw + js;
+                const int sl = slot_alloc(kk);
+                if (sl < 0) break;
+                if (lane == js) myslot = sl;
+                rows_request(kk, sl);
+                const StageBuf &st = a.ps.blocks[blk];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (q == nnew) {
+                  newk[q] = kk; news[q] = sl;
+                  v_b0[q] = st.b0[kl]; v_xxb0[q] = st.xxb0[kl]; v_drej[q] = st.drej[kl]; v_b2[q] = st.b2[kl]; v_tacc[q] = st.tacc[kl]; v_trej[q] = st.trej[kl];
+                  v_rden[q] = st.rden[kl]; v_sdz1[q] = st.sdz1[kl]; v_gjj[q] = a.ps.spec[blk].gjj[kl]; v_ha[q] = a.ps.quick[blk].ha[kl];
+                }
+                ++nnew; ++nann;
+              }
+            }
+            // the record, under its sequence lock
+            seq += 1u; lds_st32(&tr.seq, seq);
+            asm volatile("" ::: "memory");
+            tr.r[lane] = r; tr.gs[lane] = myslot;
+            if (!published) { tr.zc[lane] = c_zc; tr.hr[lane] = hr_l; }
+            lds_st32(&tr.W, napp);
+            lds_st64(&tr.an, __ballot(myslot >= 0));
+            asm volatile("" ::: "memory");
+            seq += 1u; lds_st32(&tr.seq, seq);
+            if (!published) { asm volatile("" ::: "memory"); lds_st32(&tr.ready, (uint32_t)(T + 1)); published = true; }
+#ifdef BWGR_STAMPS
+            if (first_pub) { first_pub = false; S4H(5); hst[7] += (unsigned long long)(T - done); }
+#endif
+            if (nnew > 0) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) if (q < nnew) {
+                S4CRec &cr = crec[news[q]];
+                if (lane == 0) { cr.b0 = v_b0[q]; cr.xxb0 = v_xxb0[q]; cr.drej = v_drej[q]; cr.b2 = v_b2[q]; cr.tacc = v_tacc[q]; cr.trej = v_trej[q]; cr.rden = v_rden[q]; cr.sdz1 = v_sdz1[q]; cr.gjj = v_gjj[q]; cr.ha = v_ha[q]; }
+              }
+              asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the rows have landed, the records are written
+#pragma unroll
+              for (int q = 0; q < 4; ++q) if (q < nnew) lds_st32(reinterpret_cast<uint32_t *>(&crec[news[q]].state), (uint32_t)(newk[q] + 1));
+            }
+          }
+          // this helper's next task while this one is followed: its constants and first rows are requested once the record is out, and its
+          // stage 1 is done as soon as they and the streamers' sums are there -- the switch to it then costs nothing
+          if (published && !next_requested && T + S4C_NH < ntask) { next_requested = true; next_loaded = true; S4C_LOAD_CONSTS(T + S4C_NH, n_); S4C_BULK_REQUEST(T + S4C_NH); }
+          else if (next_loaded && !have_nx && !fresh) { stage1(T + S4C_NH, false); if (failed) break; }
+          if (done >= T - S4C_LOOK + 1 && published) break;   // adopted (the chain wave adopts task T before it decides task T - 3)
+          if ((++spins & 255u) == 0u) {
+            if ((uint32_t)lds_ld64(ctl + 1) != 0u) { failed = true; break; }
+            if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); failed = true; break; }
+          }
+          if (!due) __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (failed) break;
+      S4H(6);
+    }
+#undef S4C_LOAD_CONSTS
+#undef S4C_BULK_REQUEST
+#ifdef BWGR_STAMPS
+    if (lane == 0 && a.stamps) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&a.stamps[80 + 8 * wave + k_], hst[k_]);
+#endif
+    if (failed) lds_st64(ctl + 1, 1ull);
+  }
+  __syncthreads();
+  if ((uint32_t)lds_ld64(ctl + 1) != 0u) { if (tid == 0) a.sc->error = 1u; return; }
+  // (the posterior sums and the outputs of the markers that were not included: k_sweep4_finish)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -980,12 +1579,48 @@ __device__ __forceinline__ void s4_prefetcher(const Sweep4Args &A, int pi) {
   if (sink == 0x9E3779B9u && a.stamps) a.stamps[255] = sink;   // (keeps the loads alive)
 }
 
+// After a sweep whose sequencer was the chain wave: the markers that were NOT included (d = 0: the launch zeroes d, the chain wave
+// writes b and d = 1 of the included ones) take their rejected draw b2, every marker its variance draw, and the two posterior sums of
+// the launch's markers are formed in a fixed order (256 partial sums, then one thread block).
+__global__ __launch_bounds__(256) void k_sweep4_finish(const SweepArgs a, double *part) {
+  if (!(a.sc->inc_rate < a.gate3)) return;
+  const int j0 = a.blk_begin * a.m, j1 = min(a.p, a.blk_end * a.m);
+  const bool vbv = (a.flags & SWF_VB_VEC) != 0;
+  const float Sb = a.sc->Sb;
+  double sd = 0.0, sb2 = 0.0;
+  for (int j = j0 + (int)(blockIdx.x * blockDim.x + threadIdx.x); j < j1; j += (int)(gridDim.x * blockDim.x)) {
+    const StageBuf &st = a.ps.blocks[j / a.m];
+    const int t = j % a.m;
+    const float dn = a.d[j];
+    float bn;
+    if (dn != 0.0f) bn = a.b[j]; else { bn = st.b2[t]; a.b[j] = bn; }
+    if (vbv) a.vb[j] = (float)((double)(Sb + bn * bn) / st.chi[t]);
+    sd += (double)dn;
+    sb2 = fma((double)bn, (double)bn, sb2);
+  }
+  __shared__ double red[2][256];
+  red[0][threadIdx.x] = sd; red[1][threadIdx.x] = sb2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = red[0][0]; part[2 * blockIdx.x + 1] = red[1][0]; }
+}
+__global__ __launch_bounds__(64) void k_sweep4_finish2(const SweepArgs a, const double *part, int nparts) {
+  if (!(a.sc->inc_rate < a.gate3)) return;
+  if (threadIdx.x != 0) return;
+  double sd = 0.0, sb2 = 0.0;
+  for (int i = 0; i < nparts; ++i) { sd += part[2 * i]; sb2 += part[2 * i + 1]; }
+  a.sc->sum_d += sd; a.sc->sum_b2 += sb2;
+}
+
 template <int SS>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep4(const Sweep4Args A) {
   if (!(A.a.sc->inc_rate < A.a.gate3)) return;   // this sweep is k_sweep2's (dense inclusion: every workgroup sees the same scalar)
   const int b = (int)blockIdx.x;
   if (b > 0 && (b & 7) == 0 && (b >> 3) <= A.npf) { s4_prefetcher(A, (b >> 3) - 1); return; }
-  if (blockIdx.x == 0) { if (!(A.dbg & 1024)) s4_sequencer(A); }
+  if (blockIdx.x == 0) { if (!(A.dbg & 1024)) { if (A.seq == 2) s4_sequencer_cw(A); else s4_sequencer(A); } }
   else if ((A.a.flags & SWF_DEBUG_WITHHOLD) && blockIdx.x == 1) return;   // test hook: a streamer that never shows up
   else if (!(A.dbg & 2048)) s4_streamer<SS>(A);
 }
