@@ -216,6 +216,12 @@ class Chain:
         check(_lib.lib().bwgr_chain_sweep_ms(self._h, C.byref(ms), C.byref(nl)))
         return float(ms.value), int(nl.value)
 
+    def redo_count(self):
+        """Sweeps that left the fixed-point range of their engine and were redone on the fp64 residual."""
+        k = C.c_int()
+        check(_lib.lib().bwgr_chain_redo_count(self._h, C.byref(k)))
+        return int(k.value)
+
     def state(self):
         p, n = self.panel.p, self.panel.n
         b = np.empty(p, np.float32); d = np.empty(p, np.float32); e = np.empty(n, np.float32)

@@ -34,7 +34,9 @@ static int fail(int code, const char *fmt, ...) {
 
 // the status a sweep kernel left in ChainScalars::error
 static int sweep_error(uint32_t code, const char *who) {
-  if (code == 2u) return fail(BWGR_ERANGE, "%s: the residual left the fixed-point range of the sweep (it grew more than eightfold within one sweep); the chain state is invalid", who);
+  // (since round 3 a sweep that leaves the range is redone on the fp64 residual, k_range_recover: this status only surfaces where no fallback
+  // is queued -- chains advanced in pairs)
+  if (code == 2u) return fail(BWGR_ERANGE, "%s: the residual left the fixed-point range of the sweep (it grew beyond the grid's headroom, about a thousandfold of its starting scale, within one sweep); the chain state is invalid", who);
   return fail(BWGR_ETIMEOUT, "%s: a workgroup exchange timed out inside the sweep kernel (the chain state is invalid)", who);
 }
 extern "C" const char *bwgr_last_error(void) { return g_err; }
@@ -878,6 +880,29 @@ __global__ void k_debug_variates(Rng g, int kind, double nu, uint32_t marker0, u
 
 // ------------------------------------------------------------------------------------------------
 // host objects
+// ---- a fixed-point sweep (k_sweep3 / k_sweep4 / k_sweep2w's fixed-point streamers) that leaves its range is redone on the fp64 residual:
+// the state it starts from is kept (12 bytes per marker and the residual: 12 MB against a 10 GB read at C4), and when the range flag
+// comes back the state is restored, the flag cleared and sc->redo set, which lets the fp64 launches queued behind (redo_only) run ----
+namespace {
+struct SnapArgs { double *e, *se; float *b, *d, *vb, *sb, *sd, *svb; int64_t ld; int j0, j1; ChainScalars *sc; };
+__global__ void k_range_snapshot(const SnapArgs s) {
+  const int64_t nt = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = t0; i < s.ld; i += nt) s.se[i] = s.e[i];
+  for (int64_t j = s.j0 + t0; j < s.j1; j += nt) { s.sb[j] = s.b[j]; s.sd[j] = s.d[j]; if (s.vb) s.svb[j] = s.vb[j]; }
+  if (t0 == 0) { s.sc->snap_sum_d = s.sc->sum_d; s.sc->snap_sum_b2 = s.sc->sum_b2; }
+}
+__global__ void k_range_recover(const SnapArgs s) {
+  if (s.sc->error != 2u) return;
+  const int64_t nt = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = t0; i < s.ld; i += nt) s.e[i] = s.se[i];
+  for (int64_t j = s.j0 + t0; j < s.j1; j += nt) { s.b[j] = s.sb[j]; s.d[j] = s.sd[j]; if (s.vb) s.vb[j] = s.svb[j]; }
+}
+__global__ void k_range_flag(ChainScalars *sc) {   // (after k_range_recover: every thread of it has read the status)
+  if (sc->error == 2u) { sc->error = 0u; sc->redo = 1u; sc->nredo += 1u; sc->sum_d = sc->snap_sum_d; sc->sum_b2 = sc->snap_sum_b2; }
+}
+__global__ void k_redo_clear(ChainScalars *sc) { sc->redo = 0u; }
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------
 struct bwgr_panel {
   int device = 0;
@@ -931,6 +956,7 @@ struct bwgr_panel {
   int e4_DQ = S4_MAXDQ, e4_SS = 4;
   unsigned long long *lists4 = nullptr;   // root panels only
   double *fin4 = nullptr;                 // k_sweep4_finish's partial sums
+  double *snap_e = nullptr; float *snap_b = nullptr, *snap_d = nullptr, *snap_vb = nullptr;   // state before a fixed-point sweep (range recovery)
   uint16_t *gd16 = nullptr;               // [nblocks][128][128] the diagonal Gram blocks in full, 16-bit (rows land in the sequencer's LDS by DMA: whole aligned rows)
   size_t lds4_bytes = 0;
   // the affine models' block solve as a triangular product (sweep2w.hip.h)
@@ -1217,11 +1243,14 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
   const int j0 = a.blk_begin * a.m, j1 = (int)std::min<int64_t>(P->p, (int64_t)a.blk_end * a.m);
   const int64_t tasks = 4ll * (j1 - j0);
   const bool s3 = a.gate3 > 0.0f;
-  if (s3) hipLaunchKernelGGL(k_escale_reset, dim3(1), dim3(1), 0, P->stream, a.sc);
+  const bool fxa = !s3 && use_winv(P, a.flags) && P->winv && use_wfx(P);   // an affine sweep on the fixed-point streamers
+  int sh_add = 0;
+  if (const char *dv = getenv("BWGR_DEBUG_SH_ADD")) sh_add = atoi(dv);   // test hook: less headroom, to leave the range on purpose
+  if (s3 || fxa) hipLaunchKernelGGL(k_escale_reset, dim3(1), dim3(1), 0, P->stream, a.sc);
   hipLaunchKernelGGL(k_prestage, dim3((unsigned)std::min<int64_t>(4096, (tasks + 255) / 256)), dim3(256), 0, P->stream, a, j0, j1);
   if (s3) {   // the sweep's fixed-point scale, then the in-block speculative terms on that grid
     int xbits = 0; while ((1 << xbits) < std::max(1, (P->parent ? P->parent : P)->xmax)) ++xbits;
-    hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, xbits, a.gate3);
+    hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, xbits, a.gate3, sh_add);
     if (P->e4_ready && (a.blk_begin % S4_QB) == 0) {   // k_spec3's terms plus k_sweep4's in-super-block ones and the rounds' radii: either engine may follow
       Sweep4Args A4;
       memset(&A4, 0, sizeof(A4));
@@ -1234,9 +1263,9 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
     if (std::isinf(a.gate3)) return;
   }
   if (use_winv(P, a.flags) && P->winv) {
-    if (use_wfx(P)) {   // the sweep's fixed-point scale from the residual alone (the steps are not known before the sweep)
-      hipLaunchKernelGGL(k_escale_reset, dim3(1), dim3(1), 0, P->stream, a.sc);
-      hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, 0, INFINITY);
+    if (use_wfx(P)) {   // the sweep's fixed-point scale: the residual, and what k_prestage knows of the steps (|b0|, the noise terms) times the largest |x|
+      int xbits = 0; while ((1 << xbits) < std::max(1, (P->parent ? P->parent : P)->xmax)) ++xbits;
+      hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, xbits, INFINITY, sh_add);
     }
     hipLaunchKernelGGL(k_affine_inv, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(512), S2W_INV_LDS, P->stream, a, P->winv, (a.flags & SWF_DELTA2) ? 2.0 : 1.0);
     return;
@@ -1249,10 +1278,44 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
   }
 }
 
+static void launch_sweep_kernel_inner(bwgr_panel *P, const SweepArgs &a_in, bool redo);
+// The fixed-point engines between a snapshot of the state they start from and the fp64 engine that redoes the sweep if they left
+// their range (the reference's update cannot fail, src/Rcpp20260726ai.cpp:681).  Off for the debug abort hook (its launches must time out).
+static bool range_snapshot(bwgr_panel *P, const SweepArgs &a, SnapArgs &sn) {
+  const size_t p = (size_t)P->p;
+  if (!P->snap_e) {
+    if (hipMalloc(&P->snap_e, sizeof(double) * (size_t)P->ld) != hipSuccess || hipMalloc(&P->snap_b, sizeof(float) * p) != hipSuccess ||
+        hipMalloc(&P->snap_d, sizeof(float) * p) != hipSuccess || hipMalloc(&P->snap_vb, sizeof(float) * p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  }
+  sn.e = a.e; sn.se = P->snap_e; sn.b = a.b; sn.d = a.d; sn.vb = (a.flags & SWF_VB_VEC) ? a.vb : nullptr; sn.sb = P->snap_b; sn.sd = P->snap_d; sn.svb = P->snap_vb;
+  sn.ld = P->ld; sn.j0 = a.blk_begin * a.m; sn.j1 = (int)std::min<int64_t>(P->p, (int64_t)a.blk_end * a.m); sn.sc = a.sc;
+  hipLaunchKernelGGL(k_range_snapshot, dim3(256), dim3(256), 0, P->stream, sn);
+  return true;
+}
 static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
   SweepArgs a = a_in;
-  if (P->debug_withhold) a.flags |= SWF_DEBUG_WITHHOLD;
   a.gate3 = sweep3_gate(P, a.flags);
+  const bool fx = (a.gate3 > 0.0f) || (use_winv(P, a.flags) && P->winv && use_wfx(P));
+  SnapArgs sn;
+  const bool guarded = fx && !P->debug_withhold && range_snapshot(P, a, sn);
+  launch_sweep_kernel_inner(P, a_in, false);
+  if (guarded) {
+    hipLaunchKernelGGL(k_range_recover, dim3(256), dim3(256), 0, P->stream, sn);
+    hipLaunchKernelGGL(k_range_flag, dim3(1), dim3(1), 0, P->stream, a.sc);
+    (void)reset_exchange(P);
+    launch_sweep_kernel_inner(P, a_in, true);
+    hipLaunchKernelGGL(k_redo_clear, dim3(1), dim3(1), 0, P->stream, a.sc);
+  }
+}
+static void launch_sweep_kernel_inner(bwgr_panel *P, const SweepArgs &a_in, bool redo) {
+  SweepArgs a = a_in;
+  if (P->debug_withhold) a.flags |= SWF_DEBUG_WITHHOLD;
+  a.gate3 = redo ? 0.0f : sweep3_gate(P, a.flags);
+  a.redo_only = redo ? 1 : 0;
+  if (redo && P->sweep_version >= 2 && !use_winv(P, a.flags)) {   // the fp64 engine's speculative terms (k_spec) of the state just restored
+    const int sel = (a.flags & SWF_SELECT) ? 1 : 0;
+    hipLaunchKernelGGL(k_spec<int32_t>, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin, sel);
+  }
   if (a.gate3 > 0.0f) { launch_sweep3(P, a); if (std::isinf(a.gate3)) return; }
   const bool sel = (a.flags & SWF_SELECT) != 0;
   // streamers, sequencer, and for the selection models the q feeders (the affine recurrence is compute-bound: its
@@ -1265,7 +1328,7 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
     for (int d = 0; d < S2W_MAXDIST; ++d) A.gxt[d] = P->gxt[d < P->winv_nd ? d : 0];
     A.npf = P->wpf;      // measured at C2: 0 -> 540, 2 -> 636, 4 -> 685 iter/s (6 and 8 no better)
     A.ahead = P->wahead;
-    A.fx = use_wfx(P) ? 1 : 0; A.qsum = P->qsumw; A.sub = P->R / S2W_FXR; A.K3 = P->K * A.sub;
+    A.fx = (use_wfx(P) && !redo) ? 1 : 0; A.qsum = P->qsumw; A.sub = P->R / S2W_FXR; A.K3 = P->K * A.sub;
     A.nq = P->wnq ? P->wnq : (A.K3 > 48 ? 2 : 1);   // (C2, 40 streamers: one copy 1.10 ms, two 1.21; C4 shape, 80 streamers: 27.8 / 25.6 / 27.6 ms with 1 / 2 / 4)
     if (A.fx) (void)hipMemsetAsync(P->qsumw + (size_t)a.blk_begin * A.nq * 2 * SW_MAXM, 0, sizeof(unsigned long long) * A.nq * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
     if (A.fx) hipLaunchKernelGGL(k_sweep2w<true>, dim3(A.K3 + 1 + 8 * A.npf), dim3(S2W_THREADS), P->ldsw_bytes, P->stream, a, A);
@@ -1387,6 +1450,7 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   }
   // the scratch a sweep writes: speculative cross terms, pre-staged constants, exchange words
   hipFree(P->qsum3); hipFree(P->lists3); hipFree(P->winv); hipFree(P->qsumw);
+  hipFree(P->snap_e); hipFree(P->snap_b); hipFree(P->snap_d); hipFree(P->snap_vb);
   hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->ps.quick); hipFree(P->xpart); hipFree(P->xchg); hipFree(P->stamps);
   if (P->own_stream) hipStreamDestroy(P->own_stream);
   for (hipStream_t q : P->pair_streams) hipStreamDestroy(q);
@@ -1684,7 +1748,8 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   bwgr_panel *P = new bwgr_panel(*root);
   P->parent = root; P->nclones = 0; P->nchains = 0; P->own_stream = nullptr; P->stream = nullptr; P->ps_owner = nullptr; P->ps_iter = -1;
   P->pair_streams.clear();   // (the root's: a clone owns none)
-  P->qsum3 = P->lists3 = nullptr; P->lists4 = nullptr; P->gd16 = nullptr; P->fin4 = nullptr; P->epoch3 = 0; P->xmax_dev = nullptr; P->winv = nullptr; P->qsumw = nullptr;
+  P->qsum3 = P->lists3 = nullptr; P->lists4 = nullptr; P->gd16 = nullptr; P->fin4 = nullptr; P->epoch3 = 0;
+  P->snap_e = nullptr; P->snap_b = P->snap_d = P->snap_vb = nullptr; P->xmax_dev = nullptr; P->winv = nullptr; P->qsumw = nullptr;
   P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->xchg = nullptr; P->stamps = nullptr;
   root->nclones++;
   auto bail = [&](int code) { bwgr_panel_destroy(P); return code; };
@@ -2172,6 +2237,15 @@ extern "C" int bwgr_chain_sweep_ms(bwgr_chain *C, float *avg_ms, int *launches) 
     *avg_ms = C->launch_acc ? C->ms_acc / C->launch_acc : 0.0f;
     C->ms_acc = 0; C->launch_acc = 0;
   }
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_chain_redo_count(bwgr_chain *C, int *count) {
+  if (!C || !count) return fail(BWGR_EINVAL, "null pointer");
+  CHK(bwgr_chain_sync(C));
+  ChainScalars h;
+  HIPCHK(d2h(C->P->stream, &h, C->sc, sizeof(h)));
+  *count = (int)h.nredo;
   return BWGR_OK;
 }
 

@@ -65,6 +65,10 @@ struct ChainScalars {
   uint32_t e3_dex;              // k_sweep3: largest float exponent field among this sweep's rejected steps (k_prestage -> k_escale)
   float inc_rate;               // share of markers in the model, as far as the chain knows (start: 1 - pi; then mean(d) of the last sweep):
                                 // picks the sweep engine of a selection model on the device (SweepArgs::gate3)
+  uint32_t redo;                // a fixed-point sweep left its range (error 2): the state it started from is back and the launches queued
+                                // behind it with SweepArgs::redo_only run the same sweep on the fp64 residual (k_range_recover ... k_redo_clear)
+  double snap_sum_d, snap_sum_b2;   // sum_d / sum_b2 before that sweep
+  uint32_t nredo;               // sweeps redone so far (bwgr_chain_redo_count)
 };
 
 // per-marker constants of one sweep, produced chip-wide by k_prestage before the sweep kernel starts (they depend on
@@ -112,6 +116,7 @@ struct SweepArgs {
   unsigned long long *dgran;    // k_sweep2: [S2_NSLOT][SW_MAXM] {epoch, float delta} granules
   uint32_t *xflags;             // [K*SW_FLAG_STRIDE] epochs, then the abort word
   unsigned long long *stamps;   // diagnostic build only (-DBWGR_STAMPS): per-phase cycle sums of workgroup 0
+  int redo_only;                // this launch is the fp64 fallback of a fixed-point sweep: it runs only when sc->redo is set
   float gate3;                  // > 0: both engines of the selection models are launched and the device picks one -- k_sweep3 (and its
                                 // k_escale / k_spec3) runs when sc->inc_rate < gate3, k_sweep2 (and k_spec) otherwise; 0: no gating
 };
@@ -225,8 +230,12 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
       st.b0[t] = b0;
       st.xxb0[t] = k2 ? b0 : xxj * b0;
       st.rden[t] = 1.0 / (double)den;
-      st.sdz1[t] = (a.flags & SWF_EM_BL) ? 1.0 / (double)(xxj + sc.Sb)             // emBL's second denominator xx + cxx, :380
-                                          : (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z1, 0);
+      const double sdz1 = (a.flags & SWF_EM_BL) ? 1.0 / (double)(xxj + sc.Sb)             // emBL's second denominator xx + cxx, :380
+                                                : (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z1, 0);
+      st.sdz1[t] = sdz1;
+      // affine sweeps on the fixed-point residual (k_sweep2w): a marker's step is not known before the sweep, but |b0| and the noise
+      // term bound what it can be when the residual itself is tiny (a KMUP call with e = 0); k_escale sizes the grid by the larger
+      if (!sel && !(a.flags & SWF_EM_ANY)) atomicMax(&dex_s, (__float_as_uint(fmaxf(fabsf(b0), fabsf((float)sdz1))) >> 23) & 0xFFu);
     } else if (piece == 1) {
       const float b2 = sel ? (float)((double)0.0f + (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z2, 0)) : 0.0f;
       st.b2[t] = b2;
@@ -489,7 +498,7 @@ __device__ __forceinline__ void quick_rounds(double (&r)[2], const LaneConst (&l
 // thread = marker j; Gram rows are read coalesced across j; fixed summation order k ascending)
 template <typename GT>
 __global__ __launch_bounds__(128) void k_spec(const SweepArgs a, int blk_begin, int select) {
-  if (a.gate3 > 0.0f && a.sc->inc_rate < a.gate3) return;   // this sweep is k_sweep3's
+  if (a.redo_only ? (a.sc->redo == 0u) : (a.gate3 > 0.0f && a.sc->inc_rate < a.gate3)) return;   // this sweep is k_sweep3's (or: nothing to redo)
   const int blk = blk_begin + blockIdx.x, j = threadIdx.x, m = a.m;
   const int mB = min(m, a.p - blk * m);
   const GT *G = reinterpret_cast<const GT *>(a.gram) + (size_t)blk * m * m;

@@ -1504,7 +1504,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
 
 template <typename XT, bool SELECT, typename GT = typename XTraits<XT>::GT>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep2(const SweepArgs a) {
-  if (a.gate3 > 0.0f && a.sc->inc_rate < a.gate3) return;   // this sweep is k_sweep3's (every workgroup sees the same scalar)
+  if (a.redo_only ? (a.sc->redo == 0u) : (a.gate3 > 0.0f && a.sc->inc_rate < a.gate3)) return;   // this sweep is k_sweep3's, or nothing to redo (every workgroup sees the same scalar)
   if ((int)blockIdx.x > a.K) {
     if constexpr (SELECT) s2_feeder(a, (int)blockIdx.x - a.K - 1);   // (the affine variants are launched without feeders)
   } else if ((int)blockIdx.x == a.K) {

@@ -837,6 +837,7 @@ __device__ __forceinline__ void s2w_prefetcher(const SweepArgs &a, const S2WArgs
 
 template <bool FX>
 __global__ __launch_bounds__(S2W_THREADS) void k_sweep2w(const SweepArgs a, const S2WArgs A) {
+  if (a.redo_only && a.sc->redo == 0u) return;   // (the fp64 fallback of a fixed-point sweep that stayed in range)
   const int KS = FX ? A.K3 : a.K;   // streamer workgroups; then the sequencer; then every eighth workgroup a prefetcher
   if ((int)blockIdx.x > KS) { const int r = (int)blockIdx.x - KS; if ((r & 7) == 0) s2w_prefetcher(a, A, (r >> 3) - 1); return; }
   if ((int)blockIdx.x == KS) s2_sequencer_winv<FX>(a, A);

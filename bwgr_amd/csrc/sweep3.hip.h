@@ -67,7 +67,8 @@ struct Sweep3Args {
 // and where p > n the steps themselves are larger than the residual), and a grid 2^-44 relative to that scale, far below the
 // last bit of a float step.  k_prestage leaves the largest exponent field of drej in sc->e3_dex (reset here after use). ----
 __global__ void k_escale_reset(ChainScalars *sc) { sc->e3_dex = 0u; }
-__global__ __launch_bounds__(1024) void k_escale(const double *e, int64_t ld, ChainScalars *sc, int xbits, float gate3) {
+// (sh_add: test hook, BWGR_DEBUG_SH_ADD -- a finer grid with that many bits less headroom, so that a test can leave the range on purpose)
+__global__ __launch_bounds__(1024) void k_escale(const double *e, int64_t ld, ChainScalars *sc, int xbits, float gate3, int sh_add = 0) {
   if (!(sc->inc_rate < gate3)) { if (threadIdx.x == 0) sc->e3_dex = 0u; return; }   // this sweep is k_sweep2's
   __shared__ uint32_t mx;
   if (threadIdx.x == 0) mx = 0u;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(1024) void k_escale(const double *e, int64_t ld, Ch
     const int kd = (int)sc->e3_dex - 126 + xbits;        // |x * drej| < 2^kd
     int k = max(ke, kd);
     k = max(-200, min(200, k));                          // (all zero / inf: any scale; the sweep raises the range flag if need be)
-    sc->e3_sh = 44 - k;
+    sc->e3_sh = 44 - k + sh_add;
     sc->e3_dex = 0u;
   }
 }

@@ -136,6 +136,9 @@ int bwgr_chain_state(bwgr_chain *C, float *b, float *d, float *e, float *vb, flo
 /* device-time of the sweep kernel alone, averaged over the launches since the last call (ms);
  * measured with hipEvents on the stream the kernel runs on */
 int bwgr_chain_sweep_ms(bwgr_chain *C, float *avg_ms, int *launches);
+/* sweeps of this chain that left the fixed-point range of their engine and were redone on the fp64 residual (the reference's update,
+ * src/Rcpp20260726ai.cpp:681, has no such failure: the redo keeps the chain the same chain; this only reports how often it happened) */
+int bwgr_chain_redo_count(bwgr_chain *C, int *count);
 
 /* ---- marker-sharded chains (one rank per GPU) ----------------------------------------
  * The panel holds this rank's columns [marker0, marker0 + p_local) of a p_total-marker panel; the residual is
