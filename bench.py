@@ -7,7 +7,10 @@ One "step" = one MCMC iteration of the fused sampler: the full marker sweep plus
 draws and posterior sums (everything inside for(i...) of src/Rcpp20260726ai.cpp:666-688), with X, y and all chain
 state resident in HBM before the timed region.  The default workload is the configuration BASELINE.json's target is
 quoted on: synthetic n=10,000 x p=1,000,000 int8 genotypes, BayesB with 1 % of markers in the model (bWGR pi=0.99).
-It fits one GPU (10.2 GB of X), and for N > 1 the same panel is marker-sharded across ranks (strong scaling).
+It fits one GPU (10.2 GB of X).  For N > 1 every rank runs an exact replica chain on its own copy of the panel, no data-path
+collective, `"scaling": "weak"` (the exact sweep is a recurrence and does not shard); `--sharded` selects
+the marker-sharded partitioned sampler instead (one chain over N GPUs, RCCL residual all-reduce; strong scaling), which runs on
+CENTRED columns -- where it is statistically sound -- unless `--uncentred` is given.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and, at N=1, `cpu_baseline`.
 """
@@ -150,6 +153,8 @@ def main():
                     "resident panel (0 = as many as fit the chip, 1 = skip the leg); reported as concurrent_chains")
     ap.add_argument("--sharded", action="store_true", help="N > 1: the marker-sharded partitioned sampler (one chain over N GPUs, RCCL "
                     "residual all-reduce) instead of N replica chains; statistically unsound on uncentred genotypes, see DESIGN.md section 8")
+    ap.add_argument("--uncentred", action="store_true", help="--sharded on the raw int8 genotypes (statistically UNSOUND for N > 1: DESIGN.md section 8; "
+                    "kept for measurements)")
     ap.add_argument("--pairs", type=int, default=0, help="pairs of chains in the paired-chains leg (0: as many as fit)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-slice", type=int, default=20000)

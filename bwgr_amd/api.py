@@ -105,6 +105,12 @@ class Panel:
         check(_lib.lib().bwgr_panel_max_concurrent(self._h, int(bool(selection)), C.byref(c)))
         return int(c.value)
 
+    def centred(self):
+        """True when every column's |mean| <= 1e-3 sd (from the panel's own statistics): what the marker-sharded sampler needs to be sound."""
+        k = C.c_int()
+        check(_lib.lib().bwgr_panel_centred(self._h, C.byref(k)))
+        return bool(k.value)
+
     def pipeline(self, selection):
         """How a sweep over this panel is pipelined: dict(generation, lag, feeders, gram_bits) (bwgr_panel_pipeline)."""
         info = (C.c_int * 4)()
@@ -308,9 +314,17 @@ class Group:
     benchmark's one-process-per-GPU driver is bwgr_amd/dist.py."""
 
     def __init__(self, model, y, X, devices=(0,), it=1500, bi=500, pi=0.95, df=5.0, R2=0.5, seed=None, rng_mode=0, block=0,
-                 markers_per_sync=0):
+                 markers_per_sync=0, centre=False):
+        """centre=True sweeps x_j - mean(x_j) (a float panel): what makes more than one device statistically sound (on uncentred columns
+        the library refuses len(devices) > 1 unless BWGR_GROUP_ALLOW_UNCENTRED=1).  The posterior of b and hat is unchanged under the
+        flat intercept prior; result() gives mu back in the uncentred parametrisation, mu - sum_j mean_j b_j."""
         X = np.asarray(X)
         assert X.ndim == 2
+        self._xbar = None
+        if centre:
+            Xd = X.astype(np.float64)
+            self._xbar = Xd.mean(0)
+            X = (Xd - self._xbar).astype(np.float32)
         if X.dtype != np.int8:
             fits = bool(X.size == 0 or (X.min() >= -128 and X.max() <= 127))
             if fits and (np.issubdtype(X.dtype, np.integer) or np.all(X == np.rint(X))):
@@ -332,7 +346,15 @@ class Group:
     def info(self):
         v = (C.c_int64 * 4)()
         check(_lib.lib().bwgr_group_info(self._h, v))
-        return dict(zip(("devices", "rounds_per_sweep", "markers_per_round", "rccl"), (int(x) for x in v)))
+        out = dict(zip(("devices", "rounds_per_sweep", "markers_per_round", "rccl"), (int(x) for x in v)))
+        out["statistically_sound"] = self.sound()
+        return out
+
+    def sound(self):
+        """True for one device (the exact chain) or centred columns; False for several devices on uncentred columns."""
+        k = C.c_int()
+        check(_lib.lib().bwgr_group_sound(self._h, C.byref(k)))
+        return bool(k.value)
 
     def run(self, iters):
         check(_lib.lib().bwgr_group_run(self._h, int(iters)))
@@ -349,11 +371,17 @@ class Group:
         check(_lib.lib().bwgr_group_result(self._h, C.byref(mu), _fp(B), _fp(D), _fp(hat), _fp(VB), C.byref(ve), C.byref(h2),
                                             C.byref(msx), C.byref(Pi), _fp(PV)))
         vb = VB if per else float(VB[0])
+        muv = mu.value
+        if self._xbar is not None:      # centred columns: the intercept of the uncentred parametrisation (posterior means are linear in it)
+            muv = float(muv - float(np.dot(self._xbar, B.astype(np.float64))))
         if model in ("BayesA", "BayesL", "BayesRR"):
-            return {"mu": mu.value, "b": B, "hat": hat, "vb": vb, "ve": ve.value, "h2": h2.value, "MSx": msx.value}
-        if model in ("BayesB", "BayesC"):
-            return {"mu": mu.value, "b": B, "d": D, "hat": hat, "vb": vb, "ve": ve.value, "h2": h2.value, "MSx": msx.value}
-        return {"mu": mu.value, "b": B, "d": D, "pi": Pi.value, "hat": hat, "h2": h2.value, "vb": vb, "ve": ve.value, "PVAL": PV}
+            out = {"mu": muv, "b": B, "hat": hat, "vb": vb, "ve": ve.value, "h2": h2.value, "MSx": msx.value}
+        elif model in ("BayesB", "BayesC"):
+            out = {"mu": muv, "b": B, "d": D, "hat": hat, "vb": vb, "ve": ve.value, "h2": h2.value, "MSx": msx.value}
+        else:
+            out = {"mu": muv, "b": B, "d": D, "pi": Pi.value, "hat": hat, "h2": h2.value, "vb": vb, "ve": ve.value, "PVAL": PV}
+        out["statistically_sound"] = self.sound()     # (beyond the reference's list: False for several devices on uncentred columns)
+        return out
 
     def close(self):
         if self._h:

@@ -2727,6 +2727,7 @@ struct bwgr_group {
   std::vector<double *> delta, sums;
   std::vector<bwgr_ncclComm_t> comm;
   bool use_comm = false;
+  bool centred = true;        // every shard's columns are centred (bwgr_panel_centred): what makes G > 1 statistically sound
   float MSx_total = 0;
 };
 
@@ -2747,6 +2748,34 @@ extern "C" int bwgr_group_destroy(bwgr_group *Gp) {
 // X: HOST matrix, column-major n x p (ldx >= n), any bwgr_xtype; y: n host floats.  Device g of `devices` stages the
 // block-aligned column shard [lo_g, hi_g) (as bwgr_amd/dist.py::shard_bounds) and runs the chain of that shard.
 // markers_per_sync: markers swept per device between two residual all-reduces (0: 131072 / ndev, the benchmark's default).
+// ---- are a panel's columns centred?  The marker-sharded partitioned sampler is statistically sound only then (DESIGN.md section 8:
+// uncentred genotypes are all collinear through the mean direction, every shard corrects the same stale residual mean and the summed
+// corrections overshoot; on centred columns 2 / 4 / 8 shards follow the exact chain: tools/centred_shard_probe.py).  From the panel's
+// own statistics: mean_j^2 = (xx_j - (n - 1) vx_j) / n; a column counts as centred when |mean_j| <= 1e-3 sd_j. ----
+namespace {
+__global__ void k_uncentred(const float *xx, const float *vx, int64_t p, double n, int *flag) {
+  int any = 0;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < p; j += (int64_t)gridDim.x * blockDim.x) {
+    const double v = (double)vx[j], m2 = fmax(0.0, ((double)xx[j] - (n - 1.0) * v) / n);
+    any |= (m2 > 1e-6 * v + 1e-30);
+  }
+  if (any) *flag = 1;
+}
+}  // namespace
+extern "C" int bwgr_panel_centred(bwgr_panel *P, int *centred) {
+  if (!P || !centred) return fail(BWGR_EINVAL, "null pointer");
+  HIPCHK(hipSetDevice(P->device));
+  int *flag = nullptr, h = 0;
+  HIPCHK(hipMalloc(&flag, sizeof(int)));
+  HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), P->stream));
+  hipLaunchKernelGGL(k_uncentred, dim3(256), dim3(256), 0, P->stream, P->xx, P->vx, P->p, (double)P->n, flag);
+  HIPCHK(d2h(P->stream, &h, flag, sizeof(int)));
+  HIPCHK(hipFree(flag));
+  *centred = h ? 0 : 1;
+  return BWGR_OK;
+}
+extern "C" int bwgr_group_sound(const bwgr_group *Gp, int *sound);
+
 extern "C" int bwgr_group_create(bwgr_group **out, int ndev, const int *devices, const void *X, int xtype, int64_t n, int64_t p,
                                  int64_t ldx, int block, const float *y, int model, float it, float bi, float pi, float df, float R2,
                                  uint64_t seed, int rng_mode, int64_t markers_per_sync) {
@@ -2771,8 +2800,20 @@ extern "C" int bwgr_group_create(bwgr_group **out, int ndev, const int *devices,
     int rc = bwgr_panel_create(&Gp->P[g], reinterpret_cast<const unsigned char *>(X) + (size_t)lo * (size_t)ldx * esz, xtype, BWGR_HOST, n, hi - lo, ldx, devices[g], m, 0);
     if (rc != BWGR_OK) return bail(rc);
     msx += (double)Gp->P[g]->MSx;
+    int cen = 1;
+    rc = bwgr_panel_centred(Gp->P[g], &cen);
+    if (rc != BWGR_OK) return bail(rc);
+    if (!cen) Gp->centred = false;
   }
   Gp->MSx_total = (float)msx;
+  if (ndev > 1 && !Gp->centred) {
+    const char *ok = getenv("BWGR_GROUP_ALLOW_UNCENTRED");
+    if (!(ok && ok[0] == '1'))
+      return bail(fail(BWGR_EINVAL, "group_create: the columns of X are not centred, and on uncentred columns the marker-sharded sampler of %d devices is "
+                                    "statistically unsound (every shard corrects the same stale residual mean: DESIGN.md section 8).  Pass centred columns "
+                                    "(x_j - mean(x_j), float: the posterior of b and hat is the same under the sampler's flat intercept prior), use one "
+                                    "device, or set BWGR_GROUP_ALLOW_UNCENTRED=1 to run it knowingly", ndev));
+  }
   for (int g = 0; g < ndev; ++g) {
     int rc = bwgr_chain_create_sharded(&Gp->C[g], Gp->P[g], model, y, BWGR_HOST, it, bi, pi, df, R2, seed, rng_mode, Gp->lo[g], p, Gp->MSx_total, nullptr);
     if (rc != BWGR_OK) return bail(rc);
@@ -2805,6 +2846,12 @@ static int group_allreduce(bwgr_group *Gp, std::vector<double *> &buf, size_t co
   const int ne = g_rccl.GroupEnd();
   if (nr == 0) nr = ne;
   if (nr != 0) return fail(BWGR_EHIP, "group: ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(nr) : "?");
+  return BWGR_OK;
+}
+
+extern "C" int bwgr_group_sound(const bwgr_group *Gp, int *sound) {
+  if (!Gp || !sound) return fail(BWGR_EINVAL, "null pointer");
+  *sound = (Gp->G == 1 || Gp->centred) ? 1 : 0;   // one device: the exact chain; more: sound on centred columns only
   return BWGR_OK;
 }
 

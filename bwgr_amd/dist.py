@@ -13,6 +13,14 @@ updates until the next boundary, so it is NOT the reference's chain -- parity is
 Monte-Carlo error), and `blocks_per_sync` trades mixing fidelity for speed.  G = 1 takes no exchange path at all and
 is the exact chain.
 
+SOUND ONLY ON CENTRED COLUMNS.  bWGR never centres X, so all columns are collinear through the mean direction: every
+shard corrects the same stale residual mean and the summed corrections overshoot (4 shards: ve 15 against 1.45; DESIGN.md
+section 8).  On x_j - mean(x_j) the same driver follows the exact chain with 2, 4 and 8 shards (ve within 1-3 %, mean(d)
+equal, cor(hat) 0.994: tools/centred_shard_probe.py, tests/test_gpu_parity3.py::test_partitioned_sampler_on_centred_columns);
+centring leaves the posterior of b and hat unchanged under the samplers' flat intercept prior
+(/root/reference/src/Rcpp20260726ai.cpp:683-684).  bench_sharded therefore centres its shard (a float panel) unless told not to,
+and `statistically_sound` is computed from the panel (bwgr_panel_centred), not from the output.
+
 The driver is engine-agnostic: an engine exposes sweep_blocks / residual / set_residual / sums / end_iteration over
 torch tensors.  The product engine is HipShardEngine (bwgr_amd.Chain on the GPU).  tests/test_dist_gloo.py drives the
 same driver on CPU over gloo with a checker engine.
@@ -146,6 +154,16 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     g = synth.phenotype(X, n, col0=lo, p_total=p)
     dist.all_reduce(g)
     y = synth.scale_phenotype(g)
+    # BWGR_FORCE_CENTRE=1: rehearse the centred float panel with one rank (bench.py's BWGR_FORCE_DIST leg)
+    centre = (world > 1 or bool(os.environ.get("BWGR_FORCE_CENTRE"))) and not getattr(args, "uncentred", False)
+    if centre:   # x_j - mean(x_j) as a float panel (column-major n x p_local on the device, in column chunks to bound the temporaries)
+        Xf = torch.empty((hi - lo, n), dtype=torch.float32, device=X.device)     # (p_local, n): row j = column j, no row padding
+        for c0 in range(0, hi - lo, 8192):
+            blk_ = X[c0:c0 + 8192, :n].to(torch.float32)
+            Xf[c0:c0 + 8192] = blk_ - blk_.mean(dim=1, keepdim=True)
+        del X
+        X = Xf
+        block = 64 if args.block <= 0 else min(args.block, 64)      # (float panels: 64-marker blocks)
     P = bwgr_amd.Panel(X, n=n, device=dev, block=block, nwg=args.nwg)
     del X
     torch.cuda.empty_cache()
@@ -171,28 +189,32 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     ms, launches = eng.chain.sweep_ms()
     sweep_ms_per_iter = ms * launches / K
     st = eng.chain.state()
-    alg = float(n) * float(hi - lo)
+    alg = float(n) * float(hi - lo) * (4.0 if centre else 1.0)
     ach = alg / (sweep_ms_per_iter * 1e-3) / 1e9
     out = {
         "metric": "MCMC iter/sec (full marker sweep)", "value": K / elapsed, "unit": "iter/s", "n_gpus": world, "steps": K,
         "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32 scalars, f64 residual/accumulation, int8 genotypes", "data": "synthetic",
-        "config": {"workload": "%s: synthetic n=%d x p=%d int8, %s%s, markers sharded over %d GPUs (%d per rank), residual "
+        "dtype": "f32 scalars, f64 residual/accumulation, %s genotypes" % ("centred f32" if centre else "int8"), "data": "synthetic",
+        "config": {"workload": "%s: synthetic n=%d x p=%d %s, %s%s, markers sharded over %d GPUs (%d per rank), residual "
                                "all-reduce (n fp64) every %d markers per rank = %d per sweep; partitioned Gibbs (statistical "
-                               "parity for N>1)" % (args.workload, n, p, model, " pi=%.2f" % pi if pi else "", world, hi - lo,
-                                                    bps * P.block, rounds),
+                               "parity for N>1)" % (args.workload, n, p, "int8 centred to f32 columns" if centre else "int8", model,
+                                                    " pi=%.2f" % pi if pi else "", world, hi - lo, bps * P.block, rounds),
                    "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": 1, "block": P.block,
                    "slab_workgroups": P.nwg, "sync_rounds_per_sweep": rounds},
         "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                     "kernel": "k_sweep2<int8> (rank 0, all launches of one sweep summed)", "kernel_ms": sweep_ms_per_iter,
+                     "kernel": "%s (rank 0, all launches of one sweep summed)" % ("k_sweep2<float>" if centre else "k_sweep2<int8> / k_sweep3"), "kernel_ms": sweep_ms_per_iter,
                      "launches": launches, "algorithmic_bytes_per_launch": alg},
         "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d_rank0": float(st["d"].mean())},
     }
-    # the partitioned sampler overshoots on uncentred genotypes (every shard corrects the same stale residual mean); a residual
-    # variance far above the phenotype's (var(y) ~ 1 by construction) says the chain has left the posterior: flag it
-    out["statistically_sound"] = bool(world == 1 or (np.isfinite(st["ve"]) and st["ve"] < 2.0))
-    out["note"] = ("marker-sharded partitioned Gibbs sampler: NOT the reference's chain for N > 1; measured unsound on uncentred "
-                   "genotypes (tests/test_gpu_parity2.py::test_partitioned_sampler_statistics_with_many_shards, DESIGN.md section 8); "
-                   "bench.py's default N > 1 leg runs replica chains instead")
+    # sound = one rank (the exact chain) or centred columns: a criterion on the panel (bwgr_panel_centred: every |mean_j| <= 1e-3 sd_j), not on
+    # the output.  Measured: centred, 2 / 4 / 8 shards follow the exact chain; uncentred they overshoot
+    cen = torch.tensor([1 if P.centred() else 0], dtype=torch.int64, device="cuda:%d" % dev)
+    dist.all_reduce(cen, op=dist.ReduceOp.MIN)
+    out["statistically_sound"] = bool(world == 1 or int(cen.item()) == 1)
+    out["centred_columns"] = bool(int(cen.item()) == 1)
+    out["note"] = ("marker-sharded partitioned Gibbs sampler: NOT the reference's chain for N > 1; statistically sound on centred columns "
+                   "(tests/test_gpu_parity3.py::test_partitioned_sampler_on_centred_columns: 2, 4, 8 shards against the exact chain), unsound on "
+                   "uncentred genotypes (tests/test_gpu_parity2.py::test_partitioned_sampler_characterisation, DESIGN.md section 8); centred shards "
+                   "are float panels (4 bytes per genotype), so `roofline` here is priced on 4 n p bytes")
     dist.destroy_process_group()
     return out

@@ -237,8 +237,12 @@ int bwgr_synth_genotypes(void *Xdev, int64_t n, int64_t p, int64_t ldx, int64_t 
 /* ---- multi-GPU inside the library ----------------------------------------------------------------
  * (new; the reference is single-process, single-threaded R: R/wgr.R:2.)  One marker shard per device of THIS process, the
  * residual replicated, RCCL all-reduces of the residual delta (n fp64) at the exchange rounds, one host thread: what an R
- * .Call needs to use several GPUs.  G > 1 is the partitioned sampler of DESIGN.md section 8 (statistical parity, not the
- * reference's chain); G = 1 is the exact chain.  X is a HOST matrix (column-major n x p, ldx >= n), y n host floats; device g
+ * .Call needs to use several GPUs.  G = 1 is the exact chain.  G > 1 is the partitioned sampler of DESIGN.md section 8: NOT the
+ * reference's chain, and statistically SOUND ONLY ON CENTRED COLUMNS (x_j - mean(x_j); measured: 2 / 4 / 8 shards then follow the exact
+ * chain's ve, mean(d) and hat; on uncentred genotypes -- what bWGR sweeps -- every shard corrects the same stale residual mean and the
+ * sampler diverges: ve 15 against 1.45 with four shards).  bwgr_group_create therefore REFUSES G > 1 on uncentred columns (BWGR_EINVAL)
+ * unless BWGR_GROUP_ALLOW_UNCENTRED=1 is set; bwgr_group_sound says which case a group is in.  Centring leaves the posterior of b and
+ * hat unchanged under the samplers' flat intercept prior (src/Rcpp20260726ai.cpp:683-684); the intercept then absorbs sum_j mean_j b_j.  X is a HOST matrix (column-major n x p, ldx >= n), y n host floats; device g
  * of `devices` takes the block-aligned column shard g.  markers_per_sync: markers swept per device between two all-reduces
  * (0: 131072 / ndev).  bwgr_group_result returns the Bayes* return list over the whole panel (b, d, pval: p floats; vb: p
  * floats for BayesA/B/L/Dpi, else 1; hat: n floats).  info: {devices, exchange rounds per sweep, markers per round, RCCL in use}. */
@@ -249,6 +253,8 @@ int bwgr_group_create(bwgr_group **out, int ndev, const int *devices, const void
 int bwgr_group_run(bwgr_group *G, int iters);
 int bwgr_group_sync(bwgr_group *G);
 int bwgr_group_info(const bwgr_group *G, int64_t info[4]);
+int bwgr_group_sound(const bwgr_group *G, int *sound);      /* 1: one device (exact chain) or centred columns; 0: G > 1 on uncentred columns */
+int bwgr_panel_centred(bwgr_panel *P, int *centred);        /* 1 when every column's |mean| <= 1e-3 sd (from the panel's own statistics) */
 int bwgr_group_result(bwgr_group *G, float *mu, float *b, float *d, float *hat, float *vb, float *ve, float *h2, float *MSx,
                       float *pi_out, float *pval);
 int bwgr_group_destroy(bwgr_group *G);

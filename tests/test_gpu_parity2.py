@@ -311,8 +311,10 @@ def test_partitioned_sampler_characterisation():
         markers share the mean direction, every shard corrects the same stale residual mean, and the summed corrections
         overshoot (measured on MI355X, n = 800 x p = 16 384, BayesB pi = 0.95, 150 kept iterations, exact chain ve = 1.45:
         2 shards x 128 markers per round ve = 2.39, cor(hat) = 0.66; 2 x 512: 9.19, 0.50; 4 x 1024: 16.1).  The runs must
-        complete and stay finite; their statistics are printed, not asserted.  bench.py therefore scales over GPUs with replica
-        chains, and bwgr_amd/dist.py flags its own output (`statistically_sound`)."""
+        complete and stay finite; their statistics are printed, not asserted (the asserting test is the one on CENTRED columns, where
+        the sampler is sound: test_gpu_parity3.py::test_partitioned_sampler_on_centred_columns).  bench.py therefore scales over GPUs
+        with replica chains, its --sharded leg centres its shards, and the library refuses several shards on uncentred columns unless
+        BWGR_GROUP_ALLOW_UNCENTRED=1 (bwgr_group_create)."""
     import os
     import torch
     import bwgr_amd
