@@ -309,7 +309,7 @@ def main():
         except Exception as ex:   # the headline leg above stands on its own
             out["concurrent_chains"] = {"chains": nch, "error": str(ex)}
     if model in ("BayesB", "BayesC") and pi >= 0.95 and pl["generation"] == 3 and args.chains != 1:   # (fit_many's rule for pairing)
-        npairs = args.pairs if args.pairs > 0 else max(1, (256 - 40) // (P.nwg * (P.slab_rows // 256 if P.slab_rows >= 256 else 1) + 2))   # (a pair holds K3 + 2 CUs for the sweep; ~40 CUs stay free for the iterations' small kernels: six pairs at C4 measured slower than five)
+        npairs = args.pairs if args.pairs > 0 else max(1, P.max_pairs())   # (bwgr_panel_max_pairs: a pair holds K3 + 2 CUs for the sweep; ~40 CUs stay free for the iterations' small kernels: six pairs at C4 measured slower than five)
         try:
             os.environ["BWGR_ENG3_THR"] = os.environ.get("BWGR_ENG3_THR", "0.03")
             out["paired_chains"] = paired_leg(P, model, y, pi, npairs, K, W, n, p)

@@ -99,6 +99,12 @@ class Panel:
         root._clones.add(q)
         return q
 
+    def max_pairs(self):
+        """How many pairs of chains (Chain.run_pair) fit the chip at once (bwgr_panel_max_pairs); 0 without k_sweep3."""
+        c = C.c_int(0)
+        check(_lib.lib().bwgr_panel_max_pairs(self._h, C.byref(c)))
+        return c.value
+
     def max_concurrent(self, selection):
         """How many sweeps of this geometry fit the chip at once (bwgr_panel_max_concurrent)."""
         c = C.c_int()
@@ -410,7 +416,7 @@ def fit_many(X, jobs, concurrent=None, chunk=4, pair=None, **panel_kw):
 
     pair: sparse selection jobs (BayesB / BayesC with pi >= 0.95 on a panel that has k_sweep3: up to about 6 % of the markers in the model a pair does more per compute unit than two chains apart) run TWO to a set of streamer
     workgroups (Chain.run_pair: one pass over the genotypes serves both).  A paired chain is bit for bit the chain it is alone on
-    k_sweep3; a single chain whose inclusion rate passes 2 % takes some sweeps on k_sweep2 instead (the device chooses), which
+    k_sweep3; a single chain whose inclusion rate passes 3 % takes some sweeps on k_sweep2 instead (the device chooses), which
     agrees to ~1e-9, not bit for bit.  None = whenever at least two jobs qualify, False = never, True = every selection job
     (dense chains are slow on k_sweep3)."""
     P, own = _as_panel(X, **panel_kw)
@@ -455,8 +461,7 @@ def fit_many(X, jobs, concurrent=None, chunk=4, pair=None, **panel_kw):
 
         # ---- pairs: slot s owns handles 2s and 2s+1; a pair holds (streamers + 2) compute units ----
         if paired:
-            k3 = P.nwg * max(1, P.slab_rows // 256)
-            cap = max(1, (256 - 40) // (k3 + 2))
+            cap = max(1, P.max_pairs())
             nslot = max(1, min((len(paired) + 1) // 2, cap if concurrent is None else min(int(concurrent), cap)))
             need(2 * nslot)
             queue, active = list(paired), {}

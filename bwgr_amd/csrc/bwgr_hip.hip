@@ -10,6 +10,8 @@
 #include <random>
 #include <chrono>
 #include <algorithm>
+#include <mutex>
+#include <utility>
 #include "../../include/bwgr.h"
 #include "rng.hip.h"
 #include "sweep.hip.h"
@@ -973,6 +975,9 @@ struct bwgr_panel {
   float eng3_thr = 0.03f;         // k_sweep3 takes the sweeps whose chains hold fewer than this share of markers in the model (BWGR_ENG3_THR);
                                   // measured crossover at n = 10 000: us per block at 1.4 / 3.7 / 5.8 / 10.9 % inclusion: k_sweep3 2.26 / 3.73 / 5.56 / 12.1, k_sweep2 3.07 / 3.29 / 3.60 / 4.69
   hipStream_t own_stream = nullptr;
+  // occupancy guard: the compute units this handle's enqueued sweeps hold while they run, the stream they run on, and an event behind the last of them
+  hipStream_t pre_pair_stream = nullptr; bool pre_pair_set = false;   // the stream this handle ran on before a pair run moved it (restored by its next sweep alone)
+  hipEvent_t guard_ev = nullptr; int guard_cus = 0; hipStream_t guard_stream = nullptr; bool guard_listed = false;
 };
 
 struct bwgr_chain {
@@ -1042,7 +1047,103 @@ static hipError_t alloc_exchange(bwgr_panel *P) {
   return hipSuccess;
 }
 // polled words are zeroed before every launch (epochs count within a launch)
+// ---- occupancy guard -------------------------------------------------------------------------------------------------------------
+// The sweep kernels' workgroups wait for one another (slab-dot exchanges, the sequencer's decisions), so every workgroup of a launch has
+// to be resident at once -- beside the workgroups of whatever other handles' sweeps are in flight on the same device.  A launch that would
+// not fit spins to its wall-clock bound and ends in BWGR_ETIMEOUT; the guard refuses it up front with BWGR_EINVAL instead.  The sweep's
+// launch code runs twice: once "dry" (g_plan set: SPIN_LAUNCH records kernel, grid, threads and LDS instead of launching, and nothing
+// else is enqueued or allocated), then for real.
+struct SpinLaunch { const void *fn; int grid, threads; size_t lds; };
+static thread_local std::vector<SpinLaunch> *g_plan = nullptr;
+#define SWEEP_DRY (g_plan != nullptr)
+// resident: the workgroups of the grid that stay for the sweep (L2 prefetch workgroups beyond the first few leave at once)
+#define SPIN_LAUNCH_N(resident, kern, grid, blk, lds, stream, ...)                                                                   \
+  do {                                                                                                                             \
+    if (g_plan) g_plan->push_back(SpinLaunch{reinterpret_cast<const void *>(kern), (int)(resident), (int)dim3(blk).x, (size_t)(lds)}); \
+    else hipLaunchKernelGGL(kern, grid, blk, lds, stream, __VA_ARGS__);                                                             \
+  } while (0)
+#define SPIN_LAUNCH(kern, grid, blk, lds, stream, ...) SPIN_LAUNCH_N(dim3(grid).x, kern, grid, blk, lds, stream, __VA_ARGS__)
+static std::mutex g_guard_mu;
+static std::vector<bwgr_panel *> g_guard_panels;   // handles with a guard event (any device)
+// the arithmetic (also bwgr_debug_occupancy_fits, which the CPU tests call): a launch of `grid` workgroups, `per_cu` of which fit one
+// compute unit, needs ceil(grid / per_cu) units; it fits when those and the `busy` units of other streams' sweeps are within `cus`
+static int occupancy_fits(int grid, int per_cu, int cus, int busy, int *need) {
+  if (need) *need = 0;
+  if (grid < 1 || cus < 1 || busy < 0) return BWGR_EINVAL;
+  if (per_cu < 1) return BWGR_EINVAL;
+  const int nd = (grid + per_cu - 1) / per_cu;
+  if (need) *need = nd;
+  return (nd + busy <= cus) ? BWGR_OK : BWGR_EINVAL;
+}
+extern "C" int bwgr_debug_occupancy_fits(int grid, int per_cu, int cus, int busy, int *need) { return occupancy_fits(grid, per_cu, cus, busy, need); }
+static bool guard_on() { const char *g = getenv("BWGR_OCC_GUARD"); return !(g && g[0] == '0'); }
+static int guard_per_cu(const SpinLaunch &L) {
+  static std::mutex mu; static std::vector<std::pair<SpinLaunch, int>> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto &c : cache) if (c.first.fn == L.fn && c.first.threads == L.threads && c.first.lds == L.lds) return c.second;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, L.fn, L.threads, L.lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+  cache.push_back({L, nb});
+  return nb;
+}
+static int device_cus(int device) {
+  static std::mutex mu; static std::vector<int> cus;
+  std::lock_guard<std::mutex> lk(mu);
+  if ((int)cus.size() <= device) cus.resize(device + 1, 0);
+  if (!cus[device]) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus[device] = prop.multiProcessorCount; else (void)hipGetLastError(); }
+  return cus[device];
+}
+// compute units the recorded launches hold: launches of one sweep follow one another on one stream, so the largest of them
+static int plan_cus(const std::vector<SpinLaunch> &plan, int cus, int busy, int *need_out) {
+  int need = 0;
+  for (const SpinLaunch &L : plan) {
+    const int per = guard_per_cu(L);
+    int nd = 0;
+    if (per < 1) return fail(BWGR_EINVAL, "occupancy guard: a sweep kernel (%d threads, %zu bytes of LDS) does not fit a compute unit", L.threads, L.lds);
+    if (occupancy_fits(L.grid, per, cus, busy, &nd) != BWGR_OK)
+      return fail(BWGR_EINVAL, "occupancy guard: a sweep launch of %d workgroups (%d per compute unit) needs %d compute units; %d of %d are held by other handles' sweeps "
+                  "in flight (their workgroups wait for one another, so all must be resident at once: run fewer chains side by side -- bwgr_panel_max_concurrent -- or "
+                  "wait for the others)", L.grid, per, nd, busy, cus);
+    need = std::max(need, nd);
+  }
+  *need_out = need;
+  return BWGR_OK;
+}
+// units held by sweeps in flight on other streams of P's device (handles whose event has completed drop out)
+static int guard_busy(const bwgr_panel *P, hipStream_t mine, const bwgr_panel *partner = nullptr) {
+  std::vector<std::pair<hipStream_t, int>> per_stream;
+  for (bwgr_panel *Q : g_guard_panels) {
+    if (Q == P || Q == partner || Q->device != P->device || Q->guard_cus == 0) continue;   // (a pair's stream waits for both handles' earlier sweeps)
+    if (hipEventQuery(Q->guard_ev) == hipSuccess) { Q->guard_cus = 0; continue; }
+    (void)hipGetLastError();   // (hipErrorNotReady)
+    if (Q->guard_stream == mine) continue;   // the same stream: one after the other
+    bool seen = false;
+    for (auto &ps : per_stream) if (ps.first == Q->guard_stream) { ps.second = std::max(ps.second, Q->guard_cus); seen = true; }
+    if (!seen) per_stream.push_back({Q->guard_stream, Q->guard_cus});
+  }
+  int busy = 0;
+  for (auto &ps : per_stream) busy += ps.second;
+  return busy;
+}
+// after the real launches: this handle holds `need` units until the event behind them completes
+static void guard_mark(bwgr_panel *P, hipStream_t st, int need) {
+  if (need <= 0) return;
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  if (!P->guard_ev) { if (hipEventCreateWithFlags(&P->guard_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); P->guard_ev = nullptr; return; } }
+  if (!P->guard_listed) { g_guard_panels.push_back(P); P->guard_listed = true; }
+  if (P->guard_cus > 0 && P->guard_stream == st && hipEventQuery(P->guard_ev) != hipSuccess) { (void)hipGetLastError(); need = std::max(need, P->guard_cus); }
+  P->guard_cus = need; P->guard_stream = st;
+  (void)hipEventRecord(P->guard_ev, st);
+}
+static void guard_forget(bwgr_panel *P) {
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  for (size_t i = 0; i < g_guard_panels.size(); ++i) if (g_guard_panels[i] == P) { g_guard_panels.erase(g_guard_panels.begin() + i); break; }
+  if (P->guard_ev) { (void)hipEventDestroy(P->guard_ev); P->guard_ev = nullptr; }
+  P->guard_listed = false; P->guard_cus = 0;
+}
+
 static int reset_exchange(bwgr_panel *P) {
+  if (SWEEP_DRY) return BWGR_OK;
   if (P->sweep_version >= 2) {
     HIPCHK(hipMemsetAsync(P->xchg, 0, P->xchg_bytes, P->stream));
   } else if (P->K > 1) {
@@ -1153,10 +1254,11 @@ static void sweep3_args(bwgr_panel *P, const SweepArgs &a, Sweep3Args &A) {
   A.gp = root->gram16 ? (const void *)root->gramp16 : root->gramp;
   A.D = P->e3_D; A.K3 = P->K3; A.R3 = P->R3; A.sub = P->sub3; A.g16 = root->gram16 ? 1 : 0;
   A.qsum = P->qsum3; A.lists = P->lists3;
-  P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1;
-  A.epoch = P->epoch3;
   A.pf = -1;
   if (const char *dv = getenv("BWGR_DBG3")) A.dbg = atoi(dv);
+  if (SWEEP_DRY) return;
+  P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1;
+  A.epoch = P->epoch3;
   (void)hipMemsetAsync(P->qsum3 + (size_t)a.blk_begin * 2 * SW_MAXM, 0, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
 }
 // k_sweep4 takes a sparse selection sweep when the chain has the GPU to itself and the range starts on a quad boundary (k_spec4's
@@ -1172,24 +1274,24 @@ static void launch_sweep4(bwgr_panel *P, const SweepArgs &a) {
   A.gp = P->gramp16; A.gd = P->gd16;
   A.DQ = P->e4_DQ; A.SS = P->e4_SS; A.R3 = 128; A.sub = P->R / 128; A.K3 = P->K * A.sub;
   A.qsum = P->qsum3; A.lists = P->lists4;
-  P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1;
+  if (!SWEEP_DRY) { P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1; }
   A.epoch = P->epoch3;
   if (const char *dv = getenv("BWGR_DBG4")) A.dbg = atoi(dv);
   A.seq = 1;   // (1: the token walk over eight waves -- the faster of the two so far; 2: the chain wave with helpers)
   if (const char *sv = getenv("BWGR_SEQ4")) A.seq = (sv[0] == '2') ? 2 : 1;
-  (void)hipMemsetAsync(P->qsum3 + (size_t)a.blk_begin * 2 * SW_MAXM, 0, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
+  if (!SWEEP_DRY) (void)hipMemsetAsync(P->qsum3 + (size_t)a.blk_begin * 2 * SW_MAXM, 0, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
   // L2 prefetcher workgroups on the sequencer's XCD (workgroup indices that are multiples of 8): BWGR_PF4 = how many (default 4)
   int npf = 4;
   if (const char *pv = getenv("BWGR_PF4")) npf = std::max(0, std::min(8, atoi(pv)));
   while (npf > 0 && (8 * npf >= 1 + A.K3 + npf || 1 + A.K3 + npf > 256)) --npf;
   A.npf = npf;
   const dim3 grid(1 + A.K3 + npf), blk(SW_THREADS);
-  if (A.seq == 2) {   // the chain wave writes the included markers' b and d = 1 only
+  if (A.seq == 2 && !SWEEP_DRY) {   // the chain wave writes the included markers' b and d = 1 only
     const int j0 = a.blk_begin * a.m, j1 = (int)std::min<int64_t>(P->p, (int64_t)a.blk_end * a.m);
     (void)hipMemsetAsync(a.d + j0, 0, sizeof(float) * (size_t)(j1 - j0), P->stream);
   }
-  hipLaunchKernelGGL(k_sweep4<4>, grid, blk, P->lds4_bytes, P->stream, A);
-  if (A.seq == 2) {
+  SPIN_LAUNCH(k_sweep4<4>, grid, blk, P->lds4_bytes, P->stream, A);
+  if (A.seq == 2 && !SWEEP_DRY) {
     if (!P->fin4) (void)hipMalloc(&P->fin4, sizeof(double) * 2 * 256);
     hipLaunchKernelGGL(k_sweep4_finish, dim3(256), dim3(256), 0, P->stream, a, P->fin4);
     hipLaunchKernelGGL(k_sweep4_finish2, dim3(1), dim3(64), 0, P->stream, a, (const double *)P->fin4, 256);
@@ -1212,8 +1314,8 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
   const bool pf_on = (pv ? pv[0] == '1' : solo) && A.K3 + 2 <= 256;
   A.pf = pf_on ? ((A.K3 + 2 > 8) ? 8 : A.K3 + 1) : -1;
   const dim3 grid(A.K3 + 1 + (pf_on ? 1 : 0)), blk(SW_THREADS);
-  if (A.g16) hipLaunchKernelGGL(k_sweep3<uint16_t>, grid, blk, P->lds3_bytes, P->stream, A);
-  else hipLaunchKernelGGL(k_sweep3<int32_t>, grid, blk, P->lds3_bytes, P->stream, A);
+  if (A.g16) SPIN_LAUNCH(k_sweep3<uint16_t>, grid, blk, P->lds3_bytes, P->stream, A);
+  else SPIN_LAUNCH(k_sweep3<int32_t>, grid, blk, P->lds3_bytes, P->stream, A);
 }
 
 // The selection models' sweeps on a panel that has k_sweep3: the device picks the engine from the chain's current inclusion
@@ -1282,6 +1384,7 @@ static void launch_sweep_kernel_inner(bwgr_panel *P, const SweepArgs &a_in, bool
 // The fixed-point engines between a snapshot of the state they start from and the fp64 engine that redoes the sweep if they left
 // their range (the reference's update cannot fail, src/Rcpp20260726ai.cpp:681).  Off for the debug abort hook (its launches must time out).
 static bool range_snapshot(bwgr_panel *P, const SweepArgs &a, SnapArgs &sn) {
+  if (SWEEP_DRY) return true;
   const size_t p = (size_t)P->p;
   if (!P->snap_e) {
     if (hipMalloc(&P->snap_e, sizeof(double) * (size_t)P->ld) != hipSuccess || hipMalloc(&P->snap_b, sizeof(float) * p) != hipSuccess ||
@@ -1300,11 +1403,13 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
   const bool guarded = fx && !P->debug_withhold && range_snapshot(P, a, sn);
   launch_sweep_kernel_inner(P, a_in, false);
   if (guarded) {
-    hipLaunchKernelGGL(k_range_recover, dim3(256), dim3(256), 0, P->stream, sn);
-    hipLaunchKernelGGL(k_range_flag, dim3(1), dim3(1), 0, P->stream, a.sc);
+    if (!SWEEP_DRY) {
+      hipLaunchKernelGGL(k_range_recover, dim3(256), dim3(256), 0, P->stream, sn);
+      hipLaunchKernelGGL(k_range_flag, dim3(1), dim3(1), 0, P->stream, a.sc);
+    }
     (void)reset_exchange(P);
     launch_sweep_kernel_inner(P, a_in, true);
-    hipLaunchKernelGGL(k_redo_clear, dim3(1), dim3(1), 0, P->stream, a.sc);
+    if (!SWEEP_DRY) hipLaunchKernelGGL(k_redo_clear, dim3(1), dim3(1), 0, P->stream, a.sc);
   }
 }
 static void launch_sweep_kernel_inner(bwgr_panel *P, const SweepArgs &a_in, bool redo) {
@@ -1314,7 +1419,7 @@ static void launch_sweep_kernel_inner(bwgr_panel *P, const SweepArgs &a_in, bool
   a.redo_only = redo ? 1 : 0;
   if (redo && P->sweep_version >= 2 && !use_winv(P, a.flags)) {   // the fp64 engine's speculative terms (k_spec) of the state just restored
     const int sel = (a.flags & SWF_SELECT) ? 1 : 0;
-    hipLaunchKernelGGL(k_spec<int32_t>, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin, sel);
+    if (!SWEEP_DRY) hipLaunchKernelGGL(k_spec<int32_t>, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin, sel);
   }
   if (a.gate3 > 0.0f) { launch_sweep3(P, a); if (std::isinf(a.gate3)) return; }
   const bool sel = (a.flags & SWF_SELECT) != 0;
@@ -1330,33 +1435,34 @@ static void launch_sweep_kernel_inner(bwgr_panel *P, const SweepArgs &a_in, bool
     A.ahead = P->wahead;
     A.fx = (use_wfx(P) && !redo) ? 1 : 0; A.qsum = P->qsumw; A.sub = P->R / S2W_FXR; A.K3 = P->K * A.sub;
     A.nq = P->wnq ? P->wnq : (A.K3 > 48 ? 2 : 1);   // (C2, 40 streamers: one copy 1.10 ms, two 1.21; C4 shape, 80 streamers: 27.8 / 25.6 / 27.6 ms with 1 / 2 / 4)
-    if (A.fx) (void)hipMemsetAsync(P->qsumw + (size_t)a.blk_begin * A.nq * 2 * SW_MAXM, 0, sizeof(unsigned long long) * A.nq * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
-    if (A.fx) hipLaunchKernelGGL(k_sweep2w<true>, dim3(A.K3 + 1 + 8 * A.npf), dim3(S2W_THREADS), P->ldsw_bytes, P->stream, a, A);
-    else hipLaunchKernelGGL(k_sweep2w<false>, dim3(P->K + 1 + 8 * A.npf), dim3(S2W_THREADS), P->ldsw_bytes, P->stream, a, A);
+    if (A.fx && !SWEEP_DRY) (void)hipMemsetAsync(P->qsumw + (size_t)a.blk_begin * A.nq * 2 * SW_MAXM, 0, sizeof(unsigned long long) * A.nq * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
+    // (of the 8 npf workgroups past the sequencer, the npf on its XCD prefetch; the others leave at once)
+    if (A.fx) SPIN_LAUNCH_N(A.K3 + 1 + A.npf, k_sweep2w<true>, dim3(A.K3 + 1 + 8 * A.npf), dim3(S2W_THREADS), P->ldsw_bytes, P->stream, a, A);
+    else SPIN_LAUNCH_N(P->K + 1 + A.npf, k_sweep2w<false>, dim3(P->K + 1 + 8 * A.npf), dim3(S2W_THREADS), P->ldsw_bytes, P->stream, a, A);
     return;
   }
   if (P->sweep_version >= 2) {
     const dim3 grid(P->K + 1 + a.nfeed), blk(SW_THREADS);
     if (P->is_f32) {
-      if (sel) hipLaunchKernelGGL((k_sweep2<float, true>), grid, blk, P->lds2_bytes, P->stream, a);
-      else hipLaunchKernelGGL((k_sweep2<float, false>), grid, blk, P->lds2_bytes, P->stream, a);
+      if (sel) SPIN_LAUNCH((k_sweep2<float, true>), grid, blk, P->lds2_bytes, P->stream, a);
+      else SPIN_LAUNCH((k_sweep2<float, false>), grid, blk, P->lds2_bytes, P->stream, a);
     } else {
       if (P->gram16 && sel) {   // selection models: 16-bit staging and the single-barrier sequencer (the affine recurrence is
                                 // compute-bound and measured faster on the 32-bit blocks: no conversion in its inner loop)
         SweepArgs a16 = a;
         a16.gramp = P->gramp16; a16.gramx = P->gramx16;
-        hipLaunchKernelGGL((k_sweep2<int8_t, true, uint16_t>), grid, blk, P->lds2_bytes, P->stream, a16);
-      } else if (sel) hipLaunchKernelGGL((k_sweep2<int8_t, true>), grid, blk, P->lds2_bytes, P->stream, a);
-      else hipLaunchKernelGGL((k_sweep2<int8_t, false>), grid, blk, P->lds2_bytes, P->stream, a);
+        SPIN_LAUNCH((k_sweep2<int8_t, true, uint16_t>), grid, blk, P->lds2_bytes, P->stream, a16);
+      } else if (sel) SPIN_LAUNCH((k_sweep2<int8_t, true>), grid, blk, P->lds2_bytes, P->stream, a);
+      else SPIN_LAUNCH((k_sweep2<int8_t, false>), grid, blk, P->lds2_bytes, P->stream, a);
     }
     return;
   }
   if (P->is_f32) {
-    if (sel) hipLaunchKernelGGL((k_sweep<float, true>), dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
-    else hipLaunchKernelGGL((k_sweep<float, false>), dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
+    if (sel) SPIN_LAUNCH((k_sweep<float, true>), dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
+    else SPIN_LAUNCH((k_sweep<float, false>), dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
   } else {
-    if (sel) hipLaunchKernelGGL((k_sweep<int8_t, true>), dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
-    else hipLaunchKernelGGL((k_sweep<int8_t, false>), dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
+    if (sel) SPIN_LAUNCH((k_sweep<int8_t, true>), dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
+    else SPIN_LAUNCH((k_sweep<int8_t, false>), dim3(P->K), dim3(SW_THREADS), P->lds_bytes, P->stream, a);
   }
 }
 
@@ -1383,14 +1489,43 @@ static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
     a.lag = std::min(std::min(4, P->winv_nd + 1), P->wlag_cap);
   }
 }
+// A handle that a pair run moved onto the pair's stream goes back to the stream it had (its own, or the caller's) when it next sweeps alone:
+// one wait, on the handle's stream -- nothing is enqueued on the pair stream, which other pairs' hardware queue shares
+static int leave_pair_stream(bwgr_panel *P) {
+  if (!P->pre_pair_set) return BWGR_OK;
+  hipEvent_t ev;
+  HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t he = hipEventRecord(ev, P->stream);
+  if (he == hipSuccess) he = hipStreamWaitEvent(P->pre_pair_stream, ev, 0);
+  (void)hipEventDestroy(ev);
+  if (he != hipSuccess) return fail(BWGR_EHIP, "leaving the pair stream: %s", hipGetErrorString(he));
+  P->stream = P->pre_pair_stream; P->pre_pair_set = false;
+  return BWGR_OK;
+}
+// A dry run of the sweep's launch code (nothing is enqueued) gives the compute units its kernels hold; refused with BWGR_EINVAL when they
+// cannot be resident beside the sweeps other handles have in flight on this device.  BWGR_OCC_GUARD=0 switches the guard off.
+static int sweep_guard(bwgr_panel *P, const SweepArgs &a, int *need) {
+  *need = 0;
+  if (!guard_on()) return BWGR_OK;
+  std::vector<SpinLaunch> plan;
+  g_plan = &plan; launch_sweep_kernel(P, a); g_plan = nullptr;
+  const int cus = device_cus(P->device);
+  if (cus < 1) return BWGR_OK;
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  return plan_cus(plan, cus, guard_busy(P, P->stream), need);
+}
 static int launch_sweep(bwgr_panel *P, SweepArgs &a) {
+  CHK(leave_pair_stream(P));
   choose_lag(P, a);
   if (use_winv(P, a.flags)) CHK(winv_alloc(P));
+  int need = 0;
+  CHK(sweep_guard(P, a, &need));
   CHK(reset_exchange(P));
   P->ps_owner = nullptr;   // the scratch is about to hold this sweep's constants, nobody's iteration
   launch_prestage(P, a);
   launch_sweep_kernel(P, a);
   HIPCHK(hipGetLastError());
+  guard_mark(P, P->stream, need);
   return BWGR_OK;
 }
 
@@ -1452,6 +1587,7 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   hipFree(P->qsum3); hipFree(P->lists3); hipFree(P->winv); hipFree(P->qsumw);
   hipFree(P->snap_e); hipFree(P->snap_b); hipFree(P->snap_d); hipFree(P->snap_vb);
   hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->ps.quick); hipFree(P->xpart); hipFree(P->xchg); hipFree(P->stamps);
+  guard_forget(P);
   if (P->own_stream) hipStreamDestroy(P->own_stream);
   for (hipStream_t q : P->pair_streams) hipStreamDestroy(q);
   delete P;
@@ -1748,6 +1884,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   bwgr_panel *P = new bwgr_panel(*root);
   P->parent = root; P->nclones = 0; P->nchains = 0; P->own_stream = nullptr; P->stream = nullptr; P->ps_owner = nullptr; P->ps_iter = -1;
   P->pair_streams.clear();   // (the root's: a clone owns none)
+  P->pre_pair_stream = nullptr; P->pre_pair_set = false; P->guard_ev = nullptr; P->guard_cus = 0; P->guard_stream = nullptr; P->guard_listed = false;
   P->qsum3 = P->lists3 = nullptr; P->lists4 = nullptr; P->gd16 = nullptr; P->fin4 = nullptr; P->epoch3 = 0;
   P->snap_e = nullptr; P->snap_b = P->snap_d = P->snap_vb = nullptr; P->xmax_dev = nullptr; P->winv = nullptr; P->qsumw = nullptr;
   P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->xchg = nullptr; P->stamps = nullptr;
@@ -1779,11 +1916,27 @@ extern "C" int bwgr_panel_max_concurrent(const bwgr_panel *P, int selection, int
   if (!P || !count) return fail(BWGR_EINVAL, "null pointer");
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, P->device));
-  int wgs = (selection && P->sweep_version == 3 && P->e3_ready) ? P->K3 + 1 : P->K + 1 + ((P->sweep_version >= 2 && selection) ? P->nfeed : 0);
+  // selection on a panel with k_sweep3: the device sends a chain above the engine threshold to k_sweep2 (K + 1 + feeders), and a sweep that
+  // leaves the fixed-point range is redone there: the larger of the two
+  const int wgs2 = P->K + 1 + ((P->sweep_version >= 2 && selection) ? P->nfeed : 0);
+  int wgs = (selection && P->sweep_version == 3 && P->e3_ready) ? std::max(P->K3 + 1, wgs2) : wgs2;
   if (!selection && use_winv(P, 0)) wgs = (use_wfx(P) ? P->K * (P->R / S2W_FXR) : P->K) + 1 + P->wpf;   // streamers, sequencer, L2 prefetchers (the launch's other workgroups leave at once)
   // one sweep workgroup per CU even where the LDS would admit two (small blocks): measured, sharing a CU costs more than it adds
   *count = std::max(1, prop.multiProcessorCount / wgs);
   if (const char *ov = getenv("BWGR_MAX_CONCURRENT")) { const int v = atoi(ov); if (v > 0) *count = v; }   // experiments
+  return BWGR_OK;
+}
+
+// pairs of chains (bwgr_chain_run_pair) that fit side by side: a pair's launch holds K3 + 2 compute units, and about 40 stay free for the
+// iterations' small kernels (six pairs at C4 measured slower than five); 0 on a panel without k_sweep3.  BWGR_MAX_PAIRS overrides.
+extern "C" int bwgr_panel_max_pairs(const bwgr_panel *P, int *pairs) {
+  if (!P || !pairs) return fail(BWGR_EINVAL, "null pointer");
+  *pairs = 0;
+  if (!(P->sweep_version == 3 && P->e3_ready) || s3p_streamer_lds(P->R3) > (size_t)160 * 1024) return BWGR_OK;
+  const int cus = device_cus(P->device);
+  if (cus < 1) return fail(BWGR_EHIP, "panel_max_pairs: no device properties");
+  *pairs = std::max(1, (cus - 40) / (P->K3 + 2));
+  if (const char *ov = getenv("BWGR_MAX_PAIRS")) { const int v = atoi(ov); if (v > 0) *pairs = v; }
   return BWGR_OK;
 }
 
@@ -1798,6 +1951,7 @@ extern "C" int bwgr_debug_withhold(bwgr_panel *P, int on) {
 extern "C" int bwgr_panel_set_stream(bwgr_panel *P, void *hip_stream) {
   if (!P) return fail(BWGR_EINVAL, "null panel");
   P->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  P->pre_pair_set = false;   // (the caller's choice stands: no return to an earlier stream)
   return BWGR_OK;
 }
 
@@ -2016,13 +2170,17 @@ extern "C" int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end
   if (blk_begin < 0 || blk_end > P->nblocks || blk_begin >= blk_end) return fail(BWGR_EINVAL, "sweep_blocks: bad range [%d,%d) of %lld", blk_begin, blk_end, (long long)P->nblocks);
   if (C->done >= C->iit) return fail(BWGR_EINVAL, "sweep_blocks: all %d iterations already run", C->iit);
   HIPCHK(hipSetDevice(P->device));
+  CHK(leave_pair_stream(P));
   SweepArgs a;
   chain_args(C, blk_begin, blk_end, a);
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   choose_lag(P, a);
   if (use_winv(P, a.flags)) CHK(winv_alloc(P));
+  int need = 0;
+  CHK(sweep_guard(P, a, &need));   // (before anything of this sweep is enqueued: a refused sweep leaves the chain as it was)
   CHK(reset_exchange(P));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(BWGR_EHIP, "sweep_blocks: hipEventCreate failed"); }
   // the per-marker constants and speculative terms of an iteration depend on the state at its start only (a block's b is
   // untouched until the block is swept), so a chain that sweeps its panel in several ranges -- the exchange rounds of the
   // marker-sharded sampler -- pre-stages all of them with the first range
@@ -2031,11 +2189,12 @@ extern "C" int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end
     launch_prestage(P, all);
     P->ps_owner = C; P->ps_iter = C->done;
   }
-  HIPCHK(hipEventRecord(e0, P->stream));
-  launch_sweep_kernel(P, a);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(e1, P->stream));
+  hipError_t he = hipEventRecord(e0, P->stream);
+  if (he == hipSuccess) { launch_sweep_kernel(P, a); he = hipGetLastError(); }
+  if (he == hipSuccess) he = hipEventRecord(e1, P->stream);
+  if (he != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail(BWGR_EHIP, "sweep_blocks: %s", hipGetErrorString(he)); }
   C->ev.push_back(e0); C->ev.push_back(e1);
+  guard_mark(P, P->stream, need);
   if (C->ev.size() >= 4096) CHK(bwgr_chain_sweep_ms(C, nullptr, nullptr));   // bound the number of live events
   return BWGR_OK;
 }
@@ -2170,11 +2329,19 @@ extern "C" int bwgr_chain_run_pair(bwgr_chain *C0, bwgr_chain *C1, int iters) {
     HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIPCHK(hipEventRecord(ev, PX->stream)); HIPCHK(hipStreamWaitEvent(s0, ev, 0));
     HIPCHK(hipEventDestroy(ev));
+    if (!PX->pre_pair_set) { PX->pre_pair_stream = PX->stream; PX->pre_pair_set = true; }   // (leave_pair_stream takes the handle back)
     PX->stream = s0;
   }
-  P0->force3 = P1->force3 = true;
   int rc = BWGR_OK;
   const size_t lds = std::max(s3p_streamer_lds(P0->R3), s3_seq_lds(P0->e3_D, r0->gram16));
+  int need = 0;
+  if (guard_on() && device_cus(P0->device) > 0) {   // the pair's one launch: K3 streamers and two sequencers, resident beside the other streams' sweeps
+    std::vector<SpinLaunch> plan;
+    plan.push_back(SpinLaunch{r0->gram16 ? reinterpret_cast<const void *>(k_sweep3p<uint16_t>) : reinterpret_cast<const void *>(k_sweep3p<int32_t>), P0->K3 + 2, SW_THREADS, lds});
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    CHK(plan_cus(plan, device_cus(P0->device), guard_busy(P0, s0, P1), &need));
+  }
+  P0->force3 = P1->force3 = true;
   for (int k = 0; k < iters && rc == BWGR_OK; ++k) {
     SweepArgs a0, a1;
     chain_args(C0, 0, (int)P0->nblocks, a0); chain_args(C1, 0, (int)P1->nblocks, a1);
@@ -2186,18 +2353,22 @@ extern "C" int bwgr_chain_run_pair(bwgr_chain *C0, bwgr_chain *C1, int iters) {
     if (P0->debug_withhold || P1->debug_withhold) { a0.flags |= SWF_DEBUG_WITHHOLD; a1.flags |= SWF_DEBUG_WITHHOLD; }
     Sweep3Args A0, A1;
     sweep3_args(P0, a0, A0); sweep3_args(P1, a1, A1);
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = fail(BWGR_EHIP, "chain_run_pair: event"); break; }
-    (void)hipEventRecord(e0, s0);
     const dim3 grid(P0->K3 + 2), blk(SW_THREADS);
+    hipEvent_t evs[4] = {nullptr, nullptr, nullptr, nullptr};   // both chains time the launch they share
+    bool ev_ok = true;
+    for (int q = 0; q < 4 && ev_ok; ++q) ev_ok = hipEventCreate(&evs[q]) == hipSuccess;
+    if (!ev_ok) { for (hipEvent_t q : evs) if (q) (void)hipEventDestroy(q); rc = fail(BWGR_EHIP, "chain_run_pair: hipEventCreate failed"); break; }
+    (void)hipEventRecord(evs[0], s0); (void)hipEventRecord(evs[2], s0);
     if (A0.g16) hipLaunchKernelGGL(k_sweep3p<uint16_t>, grid, blk, lds, s0, A0, A1);
     else hipLaunchKernelGGL(k_sweep3p<int32_t>, grid, blk, lds, s0, A0, A1);
-    (void)hipEventRecord(e1, s0);
-    C0->ev.push_back(e0); C0->ev.push_back(e1);
+    (void)hipEventRecord(evs[1], s0); (void)hipEventRecord(evs[3], s0);
+    C0->ev.push_back(evs[0]); C0->ev.push_back(evs[1]); C1->ev.push_back(evs[2]); C1->ev.push_back(evs[3]);
+    guard_mark(P0, s0, need);
     if (hipGetLastError() != hipSuccess) { rc = fail(BWGR_EHIP, "chain_run_pair: launch failed"); break; }
     if ((rc = bwgr_chain_end_iteration(C0, nullptr)) != BWGR_OK) break;
     rc = bwgr_chain_end_iteration(C1, nullptr);
     if (C0->ev.size() >= 4096) (void)bwgr_chain_sweep_ms(C0, nullptr, nullptr);
+    if (C1->ev.size() >= 4096) (void)bwgr_chain_sweep_ms(C1, nullptr, nullptr);
   }
   P0->force3 = P1->force3 = false;
   return rc;

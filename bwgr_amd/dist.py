@@ -30,6 +30,7 @@ import os
 import time
 
 import numpy as np
+import torch  # noqa: F401  (before the library is loaded: torch bundles its own HIP runtime, see _lib.lib)
 
 
 class HipShardEngine:

@@ -4,6 +4,7 @@ f_j ~ U(0.05,0.5); X_ij ~ Binomial(2,f_j) int8, column-major with ld = n rounded
 markers with beta ~ N(0,1); y scaled so var(y) ~ 1 with h2 = 0.5."""
 import ctypes as C
 import numpy as np
+import torch  # noqa: F401  (before the library is loaded: torch bundles its own HIP runtime, see _lib.lib)
 
 from . import _lib
 

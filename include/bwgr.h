@@ -72,9 +72,21 @@ int bwgr_panel_set_stream(bwgr_panel *P, void *hip_stream); /* NULL = the defaul
  * sweeps) and owns its own sweep scratch and its own non-blocking stream, so chains on `src` and on its clones run
  * side by side on disjoint compute units (a sweep occupies nwg + 1 + feeders of the 256).  This is how the callers
  * that fit many models on one X -- mcmcCV's folds x models loop, R/cv.R:113-216 -- fill the chip.  Destroy the clones
- * before `src`.  bwgr_panel_max_concurrent: how many sweeps of this geometry fit at once (more would time out). */
+ * before `src`.  bwgr_panel_max_concurrent: how many sweeps of this geometry fit at once; for selection models on a panel
+ * with k_sweep3 it counts the larger of the two engines a chain may run (K3 + 1, or nwg + 1 + feeders above the engine
+ * threshold).  bwgr_panel_max_pairs: how many pairs (bwgr_chain_run_pair, K3 + 2 units each) fit, 0 without k_sweep3.
+ *
+ * Occupancy guard: a sweep's workgroups wait for one another, so all of them have to be resident at once, beside the
+ * sweeps other handles (panels, clones, pairs) have in flight on other streams of the same device.  Every sweep entry
+ * point checks that before it enqueues anything -- grid against hipOccupancyMaxActiveBlocksPerMultiprocessor x compute
+ * units, less the units of the sweeps in flight -- and returns BWGR_EINVAL if the launch would not fit (the chain is left
+ * as it was; wait for the others and call again).  Without the guard such a launch spins to BWGR_ETIMEOUT.
+ * BWGR_OCC_GUARD=0 switches it off.  bwgr_debug_occupancy_fits is the guard's arithmetic (a host function: `grid`
+ * workgroups at `per_cu` per unit need ceil(grid / per_cu) units, which must fit `cus` less `busy`). */
 int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src);
 int bwgr_panel_max_concurrent(const bwgr_panel *P, int selection, int *count);
+int bwgr_panel_max_pairs(const bwgr_panel *P, int *pairs);
+int bwgr_debug_occupancy_fits(int grid, int per_cu, int cus, int busy, int *need);
 /* geometry actually chosen: info[0]=n, [1]=p, [2]=ld (padded rows), [3]=block, [4]=nwg, [5]=slab rows,
  * [6]=bytes of X resident, [7]=bytes of Gram resident */
 int bwgr_panel_info(const bwgr_panel *P, int64_t info[8]);

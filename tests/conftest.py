@@ -8,10 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# The selection models' sweeps pick their engine on the device from the chain's inclusion rate (k_sweep3 below 2 % of markers in
+# The selection models' sweeps pick their engine on the device from the chain's inclusion rate (k_sweep3 below 3 % of markers in
 # the model, k_sweep2 above).  The parity tests run small dense chains, so they force k_sweep3 everywhere (threshold 1) unless a
 # test sets the variable itself; test_engine_choice_follows_the_inclusion_rate covers the default switch.
 os.environ.setdefault("BWGR_ENG3_THR", "1")
+# some GPU tests import torch after the library is loaded (device tensors as inputs): have the loader import it first
+os.environ.setdefault("BWGR_PRELOAD_TORCH", "1")
 
 
 def pytest_configure(config):

@@ -292,6 +292,7 @@ def test_group_on_one_device_is_the_plain_chain(tpod, model, pi, monkeypatch):
         assert info["devices"] == 1 and info["rccl"] == int(force) and (force == "0" or info["rounds_per_sweep"] == 4)
         g.run(8); g.sync()
         out = g.result(); g.close()
+        assert out.pop("statistically_sound") is True          # one shard: the exact chain
         assert list(out) == list(ref)
         for k in ref:
             if k == "d":
