@@ -20,6 +20,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_finish(session):
+    """Which tests this session selected: per-file counts on the terminal, every id in gpurun_out/selected_tests.txt (merged back from the GPU box)."""
+    ids = [it.nodeid for it in session.items]
+    per = {}
+    for i in ids:
+        per[i.split("::")[0]] = per.get(i.split("::")[0], 0) + 1
+    print("\nselected %d tests: %s" % (len(ids), ", ".join("%s %d" % (k, v) for k, v in sorted(per.items()))))
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "selected_tests.txt"), "w") as f:
+            f.write("\n".join(ids) + "\n")
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def tpod():
     d = np.load(os.path.join(ROOT, "tests", "golden", "tpod.npz"))

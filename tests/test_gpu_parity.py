@@ -179,6 +179,36 @@ def test_sharded_entry_points_world1_equals_run(tpod):
     a.close(); b.close(); P.close()
 
 
+@pytest.mark.parametrize("model,pi", [("BayesB", 0.8), ("BayesCpi", 0.0), ("BayesRR", 0.0)])
+def test_ranged_sweeps_are_bit_for_bit_on_the_fp64_engine(tpod, monkeypatch, model, pi):
+    """The same comparison on k_sweep2 alone (BWGR_SWEEP=2: no k_sweep3; BWGR_WINV=0: the affine models on k_sweep2's sequencer too):
+    its fp64 arithmetic does not depend on where a launch starts, so ranged sweeps and exchange rounds are the one-launch chain BIT FOR BIT."""
+    import bwgr_amd
+    from bwgr_amd.dist import HipShardEngine
+    monkeypatch.setenv("BWGR_SWEEP", "2"); monkeypatch.setenv("BWGR_WINV", "0")
+    X, y = tpod["gen"], tpod["y"].astype(np.float32)
+    P = bwgr_amd.Panel(X, block=32)
+    a = bwgr_amd.Chain(P, model, y, it=6, bi=1, pi=pi, seed=3); a.run(6); sa = a.state(); a.close()
+    b = bwgr_amd.Chain(P, model, y, it=6, bi=1, pi=pi, seed=3)
+    for _ in range(6):
+        for lo in range(0, b.nblocks, 5):
+            b.sweep_blocks(lo, min(b.nblocks, lo + 5))
+        b.end_iteration(None)
+    sb = b.state(); b.close()
+    eng = HipShardEngine(P, model, y, 6, 1, pi, 5.0, 0.5, 3, 0, P.p, P.stats()[2])
+    for _ in range(6):
+        for lo in range(0, eng.nblocks, 7):
+            eng.round_apply(eng.round_sweep(lo, min(eng.nblocks, lo + 7)))
+        eng.end_iteration(eng.sums())
+    sc = eng.chain.state(); eng.chain.close(); P.close()
+    for other, what in ((sb, "sweep_blocks"), (sc, "exchange rounds")):
+        for k in ("d", "b", "vb"):
+            assert np.array_equal(sa[k], other[k]), (what, k)
+        assert sa["ve"] == other["ve"] and sa["mu"] == other["mu"], what
+    assert np.array_equal(sa["e"], sb["e"])
+    assert scaled_err(sc["e"], sa["e"]) < 1e-12   # (round_apply forms e = e0 + (e - e0) in fp64: the last bit may move)
+
+
 def test_two_shards_on_one_gpu_match_cpu_checker():
     """Two marker shards ('ranks') in one process with a hand-rolled residual exchange, against the CPU checker engine
     (tests/shard_checker.py) doing the same partitioned sampler: global marker ids, MSx_total, p_total, external e."""

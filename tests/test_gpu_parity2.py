@@ -183,6 +183,7 @@ def test_c3_size_properties():
 # measured on MI355X (round 2, ten iterations, tpod and a 600 x 500 synthetic panel, all seven samplers and KMUP):
 # b <= 8.0e-7, e <= 1.9e-6, ve <= 5.6e-7, inclusion decisions equal everywhere
 FAITHFUL_BOUND = {"b": 2e-6, "e": 4e-6, "scalar": 2e-6}
+_FLIPS = {}   # (model, data) -> (flipped inclusion decisions against the float flavour, markers)
 
 
 @pytest.mark.parametrize("model", ALL_MODELS)
@@ -201,13 +202,30 @@ def test_distance_to_the_float_faithful_flavour(tpod, model, data):
     ch.close(); P.close()
     f = O.bayes(model, y, X, it=10, bi=2, pi=0.9, seed=21, flavour="f")["last"]
     w = O.bayes(model, y, X, it=10, bi=2, pi=0.9, seed=21, flavour="w")["last"]
-    same_decisions = np.array_equal(f["d"], w["d"])
+    # inclusion decisions of the GPU chain's last sweep against the float flavour's: a flip (the float flavour's norm cancellation lands on
+    # the other side of a uniform) forks the chains, after which the values have nothing to bound -- so flips are COUNTED, and
+    # test_flip_rate_against_the_float_faithful_flavour fails when they are more than rare
+    selection = model in ("BayesB", "BayesC", "BayesCpi", "BayesDpi")   # (the affine samplers have no decisions: the oracle leaves d = 0)
+    flips = int(np.sum(st["d"] != f["d"])) if selection else 0
+    _FLIPS[(model, data)] = (flips, int(st["d"].size))
     eb, ee, ev = scaled_err(st["b"], f["b"]), scaled_err(st["e"], f["e"]), _rel(st["ve"], f["ve"])
-    print("faithful-distance %s/%s: b %.2e e %.2e ve %.2e (wide: b %.2e e %.2e) decisions_equal=%s" % (
-        model, data, eb, ee, ev, scaled_err(st["b"], w["b"]), scaled_err(st["e"], w["e"]), same_decisions))
+    print("faithful-distance %s/%s: b %.2e e %.2e ve %.2e (wide: b %.2e e %.2e) flipped decisions %d of %d" % (
+        model, data, eb, ee, ev, scaled_err(st["b"], w["b"]), scaled_err(st["e"], w["e"]), flips, st["d"].size))
     assert scaled_err(st["b"], w["b"]) < TOL and scaled_err(st["e"], w["e"]) < TOL
-    if same_decisions:   # a flipped inclusion decision (the float flavour's norm cancellation) forks the chains: nothing to bound
+    assert not selection or np.array_equal(st["d"], w["d"])
+    if flips == 0:
         assert eb < FAITHFUL_BOUND["b"] and ee < FAITHFUL_BOUND["e"] and ev < FAITHFUL_BOUND["scalar"]
+
+
+def test_flip_rate_against_the_float_faithful_flavour():
+    """Stated rate: at most 2 of the 14 (model, data) cases above may contain a flipped inclusion decision at all, and none may
+    have flipped more than 1 % of its markers (measured in rounds 2 and 3: no flip in any case)."""
+    if not _FLIPS:
+        pytest.skip("the per-case tests did not run in this session")
+    bad = {k: v for k, v in _FLIPS.items() if v[0] > 0}
+    print("cases with flipped decisions: %d of %d %s" % (len(bad), len(_FLIPS), bad))
+    assert len(bad) <= 2, bad
+    assert all(v[0] <= 0.01 * v[1] for v in bad.values()), bad
 
 
 @pytest.mark.parametrize("pi", [0.0, 0.3])
@@ -224,8 +242,10 @@ def test_kmup_distance_to_the_float_faithful_flavour(tpod, pi):
     g = bwgr_amd.KMUP(X, b, np.ones(p), xx, e, L, 0.03, pi, seed=77, it=3)
     f = O.kmup(X, b, np.ones(p), xx, e, L, 0.03, pi, seed=77, it=3, flavour="f")
     eb, ee = scaled_err(g["b"], f["b"]), scaled_err(g["e"], f["e"])
-    print("faithful-distance KMUP pi=%.1f: b %.2e e %.2e decisions_equal=%s" % (pi, eb, ee, np.array_equal(g["d"], f["d"])))
-    if np.array_equal(g["d"], f["d"]):
+    flips = int(np.sum(np.asarray(g["d"]) != np.asarray(f["d"])))
+    print("faithful-distance KMUP pi=%.1f: b %.2e e %.2e flipped decisions %d of %d" % (pi, eb, ee, flips, p))
+    assert flips <= 0.01 * p          # (stated rate: a flip is a uniform landing inside the float flavour's cancellation error)
+    if flips == 0:
         assert eb < FAITHFUL_BOUND["b"] and ee < FAITHFUL_BOUND["e"]
 
 
