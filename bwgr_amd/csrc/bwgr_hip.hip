@@ -1429,7 +1429,8 @@ static void launch_sweep_kernel_inner(bwgr_panel *P, const SweepArgs &a_in, bool
   if (use_winv(P, a.flags) && P->winv) {
     S2WArgs A;
     memset(&A, 0, sizeof(A));
-    A.winv = P->winv; A.nd = a.lag - 1;
+    A.winv = P->winv; A.nd = std::min(a.lag - 1, (int)S2W_MAXDIST);
+    if (const char *dv = getenv("BWGR_DBGW")) A.dbg = atoi(dv);
     for (int d = 0; d < S2W_MAXDIST; ++d) A.gxt[d] = P->gxt[d < P->winv_nd ? d : 0];
     A.npf = P->wpf;      // measured at C2: 0 -> 540, 2 -> 636, 4 -> 685 iter/s (6 and 8 no better)
     A.ahead = P->wahead;
@@ -1487,6 +1488,7 @@ static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
   a.lag = lag < cap ? lag : cap;
   if (use_winv(P, a.flags)) {   // the affine sweeps' product sequencer: as deep as the panel's cross Gram planes reach (BWGR_WLAG caps it)
     a.lag = std::min(std::min(4, P->winv_nd + 1), P->wlag_cap);
+    if (const char *tl = getenv("BWGR_WLAG_TIMING")) a.lag = atoi(tl);   // TIMING ONLY: deeper than the cross terms reach (wrong chain)
   }
 }
 // A handle that a pair run moved onto the pair's stream goes back to the stream it had (its own, or the caller's) when it next sweeps alone:
@@ -1831,7 +1833,7 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2w<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2w<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_affine_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  if (!P->is_f32) P->ldsw_bytes = s2w_lds_bytes(m, R);
+  if (!P->is_f32) P->ldsw_bytes = s2w_lds_bytes(m, R, getenv("BWGR_WLAG_TIMING") ? atoi(getenv("BWGR_WLAG_TIMING")) : 4);
   if (const char *wv = getenv("BWGR_WINV")) P->winv_on = !(wv[0] == '0');
   if (const char *wv = getenv("BWGR_WFX")) P->wfx_on = !(wv[0] == '0');
   if (const char *pv = getenv("BWGR_WPF")) P->wpf = std::max(0, std::min(8, atoi(pv)));

@@ -43,7 +43,7 @@ namespace bwgr {
 #define S2WALL_FLUSH_AT(base) do { } while (0)
 #endif
 
-static constexpr int S2_NSLOT = 4;   // ring depth of the q / delta buffers (2 would do; 4 keeps lines apart)
+static constexpr int S2_NSLOT = 8;   // ring depth of the q / delta buffers (the affine sweeps' pipeline runs up to seven blocks deep)
 
 template <typename XT> __host__ __device__ inline size_t s2_seq_lds_bytes(int m);
 __host__ __device__ inline size_t s2i_lds_bytes(int m, int R, int lag = 3);

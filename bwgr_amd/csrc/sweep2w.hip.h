@@ -164,16 +164,19 @@ struct S2WArgs {
   int nq;                                    // copies of the sums (1, 2 or 4; streamer w adds into copy w mod nq: fewer atomics queue on one word)
   int ahead;                                 // blocks a prefetcher may run ahead of the sequencer
   int npf;                                   // L2 prefetch workgroups (blockIdx K + 8, K + 16, ...: the sequencer's XCD)
+  int dbg;                                   // experiments (BWGR_DBGW), timing only: 1 = every step published as zero (the chain stands still), 2 = the sequencer does
+                                             // not wait for the slab dots, 4 = the streamers do not wait for the steps, 8 = no sequencer, 16 = no streamers,
+                                             // 32 = W loaded for the first block only, 64 = the Gram planes loaded for the first block only
 };
 
 __host__ __device__ inline size_t s2w_fx_lds(int L);
-__host__ __device__ inline size_t s2w_lds_bytes(int m, int R) {
+__host__ __device__ inline size_t s2w_lds_bytes(int m, int R, int maxlag = 4) {
   size_t s = 3 * sizeof(StageBuf);
   s += (size_t)(2 * 4 + 1 + 1 + 1 + 1) * SW_MAXM * sizeof(double);   // q parts [parity][4], cross, rhs, d, delta
   s += (size_t)(4 * 4 + 1) * S2W_DROW;                                // delta digits of the last four blocks, a row of zeros
   s += 256;
   size_t streamer = s2i_lds_bytes(m, R, 4);
-  if (s2w_fx_lds(4) > streamer) streamer = s2w_fx_lds(4);
+  if (s2w_fx_lds(maxlag) > streamer) streamer = s2w_fx_lds(maxlag);
   return s > streamer ? s : streamer;
 }
 
@@ -310,7 +313,7 @@ __device__ __forceinline__ int s2w_qf_collect(const SweepArgs &a, const S2WArgs 
   const uint64_t t0 = wall_clock64();
   unsigned spins = 0;
   for (;;) {
-    const bool ok = (t >= mB) || ((v & 0xFFull) == need);
+    const bool ok = (t >= mB) || ((v & 0xFFull) == need) || (A.dbg & 2);
     if (__ballot(!ok) == 0ull) break;
     if ((++spins & 63u) == 0u) {
       if (ld_agent_u32(abortw) != 0u) return 0;
@@ -481,7 +484,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         S2WSTAMP0(2);
         S2W_BAR();                                         // B2: rhs
       }
-      issue_a(c + 1);       // (these waves sit in the memory pipeline's queue now, while waves 4-7 form the product)
+      if (!(A.dbg & 64) || c < 0) issue_a(c + 1);       // (these waves sit in the memory pipeline's queue now, while waves 4-7 form the product)
       issue_stage(c + 2);
       if (c >= 0) {
         S2WSTAMP0(3);
@@ -516,7 +519,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         if constexpr (!fx) if (c + 1 < nb) { if (!s2w_qx_collect(a, c + 1, xpart, xt, blk_m(c + 1), QX, q_s + (size_t)(((c + 1) & 1) * 4 + 2 + xpart) * SW_MAXM)) ctrl_s[0] = 0; }
         S2W_BAR();                                         // B3: d
       }
-      issue_w(c + 1);     // (into the registers just read; the wave waits in the memory pipeline's queue while wave 8 writes the outputs)
+      if (!(A.dbg & 32) || c < 0) issue_w(c + 1);     // (into the registers just read; the wave waits in the memory pipeline's queue while wave 8 writes the outputs)
       if constexpr (!fx) s2w_qx_request(a, min(c + 2, nb - 1), xpart, xt, QX);
     }
   } else {
@@ -555,8 +558,8 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
           if (t < mB) {
             const float b0 = st.b0[t];
             const float bn = (float)(d_s[t] + (double)b0);
-            dl = (bn - b0) * (float)dscale;
-            a.b[j0 + t] = bn;
+            dl = (A.dbg & 1) ? 0.0f : (bn - b0) * (float)dscale;
+            a.b[j0 + t] = (A.dbg & 1) ? b0 : bn;
             a.d[j0 + t] = 1.0f;
             if (a.flags & SWF_VB_VEC) a.vb[j0 + t] = (float)((double)(Sb + bn * bn) / st.chi[t]);
             sum_d += 1.0;
@@ -718,7 +721,7 @@ __device__ __forceinline__ void s2w_streamer_fx(const SweepArgs &a, const S2WArg
         unsigned spins = 0;
         unsigned long long v = pre;
         for (;;) {
-          if (s2_dgranule_is(v, j)) break;
+          if (s2_dgranule_is(v, j) || (A.dbg & 4)) { if (A.dbg & 4) v = 0ull; break; }
           v = ld_agent_raw64(g);
           if (s2_dgranule_is(v, j)) break;
           if ((++spins & 63u) == 0u) {
@@ -840,7 +843,8 @@ __global__ __launch_bounds__(S2W_THREADS) void k_sweep2w(const SweepArgs a, cons
   if (a.redo_only && a.sc->redo == 0u) return;   // (the fp64 fallback of a fixed-point sweep that stayed in range)
   const int KS = FX ? A.K3 : a.K;   // streamer workgroups; then the sequencer; then every eighth workgroup a prefetcher
   if ((int)blockIdx.x > KS) { const int r = (int)blockIdx.x - KS; if ((r & 7) == 0) s2w_prefetcher(a, A, (r >> 3) - 1); return; }
-  if ((int)blockIdx.x == KS) s2_sequencer_winv<FX>(a, A);
+  if ((int)blockIdx.x == KS) { if (A.dbg & 8) return; s2_sequencer_winv<FX>(a, A); }
+  else if (A.dbg & 16) return;
   else if (threadIdx.x >= SW_THREADS) return;                            // the streamers are eight waves (a wave that has ended leaves the barriers' count)
   else if ((a.flags & SWF_DEBUG_WITHHOLD) && blockIdx.x == 0) return;   // test hook: a streamer that never shows up
   else if constexpr (FX) s2w_streamer_fx(a, A);

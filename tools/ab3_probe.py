@@ -32,7 +32,8 @@ for cfg in sys.argv[1:] or [""]:
             st = ch.state()
         except Exception:
             pass
-        print("%-40s sweep %8.3f ms  %6.3f us/block  mean_d %s  %s" % (cfg, ms, 1e3 * ms / nb, "%.4f" % st["d"].mean() if st else "n/a", P.pipeline(True)), flush=True)
+        sel = model in ("BayesB", "BayesC", "BayesCpi", "BayesDpi")
+        print("%-40s sweep %8.3f ms  %6.3f us/block  mean_d %s  %s redo %s ve %s" % (cfg, ms, 1e3 * ms / nb, "%.4f" % st["d"].mean() if st else "n/a", P.pipeline(sel), ch.redo_count(), st["ve"] if st else "n/a"), flush=True)
     finally:
         try:
             ch.close(); P.close()
