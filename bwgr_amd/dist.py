@@ -92,6 +92,18 @@ def sync_rounds(nblocks_local, blocks_per_sync, world):
     return r
 
 
+def _all_reduce(t, op=None):
+    """dist.all_reduce; a CUDA tensor under gloo (the rehearsal with more ranks than GPUs, and the CPU tests) goes through the host."""
+    import torch.distributed as dist
+    kw = {} if op is None else {"op": op}
+    if t.is_cuda and dist.get_backend() != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, **kw)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, **kw)
+
+
 def _comm_device():
     import torch
     import torch.distributed as dist
@@ -115,17 +127,17 @@ def run_iterations(engine, iters, blocks_per_sync, world, rounds=None):
             lo, hi = r * bps, min(nb, (r + 1) * bps)
             if hasattr(engine, "round_sweep"):      # the product engine keeps the round's vector arithmetic in the library
                 delta = engine.round_sweep(lo, hi)  # (lo >= hi on a rank that has run out of blocks: nothing is swept)
-                dist.all_reduce(delta)              # RCCL over xGMI: n fp64 values
+                _all_reduce(delta)                  # RCCL over xGMI: n fp64 values
                 engine.round_apply(delta)
                 continue
             e0 = engine.residual().clone()
             if lo < hi:
                 engine.sweep_blocks(lo, hi)
             delta = engine.residual() - e0
-            dist.all_reduce(delta)                  # (gloo in the CPU tests)
+            _all_reduce(delta)                      # (gloo in the CPU tests)
             engine.set_residual(e0 + delta)
         s = engine.sums()
-        dist.all_reduce(s)
+        _all_reduce(s)
         engine.end_iteration(s)
 
 
@@ -148,12 +160,13 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     from . import synth
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        if world > torch.cuda.device_count(): dist.init_process_group("gloo")   # rehearsal: ranks share devices, collectives through the host
+        else: dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
     block = args.block if args.block > 0 else 128
     lo, hi = shard_bounds(p, world, rank, block)
     X = synth.genotypes(n, hi - lo, col0=lo, device=dev)
     g = synth.phenotype(X, n, col0=lo, p_total=p)
-    dist.all_reduce(g)
+    _all_reduce(g)
     y = synth.scale_phenotype(g)
     # BWGR_FORCE_CENTRE=1: rehearse the centred float panel with one rank (bench.py's BWGR_FORCE_DIST leg)
     centre = (world > 1 or bool(os.environ.get("BWGR_FORCE_CENTRE"))) and not getattr(args, "uncentred", False)
@@ -169,7 +182,7 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     del X
     torch.cuda.empty_cache()
     msx = torch.tensor([P.stats()[2]], dtype=torch.float64, device="cuda:%d" % dev)
-    dist.all_reduce(msx)
+    _all_reduce(msx)
     eng = HipShardEngine(P, model, y, W + K, W, pi, 5.0, 0.5, synth.SEED, lo, p, float(msx.item()))
     # default: one residual all-reduce per 131 072 markers swept over ALL ranks, so the staleness window of the partitioned
     # sampler -- how many markers are updated against a residual that has not seen the other ranks' updates yet -- does not
@@ -185,7 +198,7 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     eng.chain.sync()
     dist.barrier(); torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda:%d" % dev)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    _all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     ms, launches = eng.chain.sweep_ms()
     sweep_ms_per_iter = ms * launches / K
@@ -210,7 +223,7 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     # sound = one rank (the exact chain) or centred columns: a criterion on the panel (bwgr_panel_centred: every |mean_j| <= 1e-3 sd_j), not on
     # the output.  Measured: centred, 2 / 4 / 8 shards follow the exact chain; uncentred they overshoot
     cen = torch.tensor([1 if P.centred() else 0], dtype=torch.int64, device="cuda:%d" % dev)
-    dist.all_reduce(cen, op=dist.ReduceOp.MIN)
+    _all_reduce(cen, op=dist.ReduceOp.MIN)
     out["statistically_sound"] = bool(world == 1 or int(cen.item()) == 1)
     out["centred_columns"] = bool(int(cen.item()) == 1)
     out["note"] = ("marker-sharded partitioned Gibbs sampler: NOT the reference's chain for N > 1; statistically sound on centred columns "
