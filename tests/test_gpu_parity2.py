@@ -8,6 +8,7 @@
   that is actually measured
 * the abort path (bounded spins -> BWGR_ETIMEOUT -> the panel stays usable)
 """
+import os
 import numpy as np
 import pytest
 
@@ -173,6 +174,49 @@ def test_c3_size_properties():
     e_ref = (y.double() - st["mu"] - xb).cpu().numpy()
     assert np.abs(e_ref - st["e"]).max() < 2e-5 * np.abs(e_ref).max()
     assert 0.003 < st["d"].mean() < 0.05
+
+
+def test_c5_size_properties(monkeypatch):
+    """BASELINE config 5's panel on one GPU (n = 50 000 x p = 1 000 000 int8, 50 GB; 196 slab workgroups), its own model BayesCpi (dense
+    inclusion: k_sweep2 by the device's choice at the shipped threshold) and the headline model BayesB pi = 0.99 on the same genotypes under
+    both engines (BWGR_ENG3_THR=1: k_sweep3 takes every sweep; BWGR_SWEEP=2: k_sweep2 does): after two iterations the residual identity
+    e == y - mu - X b  against an independent fp64 torch product, the inclusion rate, no range redo, and the two engines' agreement:
+    decisions equal, effects to 1e-6.  (The oracle cannot run this size; the samplers follow src/Rcpp20260726ai.cpp:858-921 / :638-699.)"""
+    import torch
+    import bwgr_amd
+    from bwgr_amd import synth
+    n, p = 50000, 1000000
+    X = synth.genotypes(n, p)
+    y = synth.scale_phenotype(synth.phenotype(X, n))
+
+    def xb_of(b_host):
+        b = torch.from_numpy(b_host).to(X.device).double()
+        xb = torch.zeros(n, dtype=torch.float64, device=X.device)
+        for j0 in range(0, p, 20000):
+            xb += X[j0:j0 + 20000, :n].double().T @ b[j0:j0 + 20000]
+        return xb
+
+    states = {}
+    for tag, model, pi, env, gen in (("cpi", "BayesCpi", 0.5, {"BWGR_ENG3_THR": "0.03"}, 3), ("b3", "BayesB", 0.99, {"BWGR_ENG3_THR": "1"}, 3),
+                                     ("b2", "BayesB", 0.99, {"BWGR_SWEEP": "2"}, 2)):
+        monkeypatch.delenv("BWGR_SWEEP", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)                    # (read when the panel is made)
+        P = bwgr_amd.Panel(X, n=n)
+        assert P.pipeline(True)["generation"] == gen
+        ch = bwgr_amd.Chain(P, model, y, it=2, bi=0, pi=pi, seed=synth.SEED)
+        ch.run(2)
+        st = ch.state()
+        nredo = ch.redo_count()
+        ch.close(); P.close()
+        assert nredo == 0, tag
+        e_ref = (y.double() - st["mu"] - xb_of(st["b"])).cpu().numpy()
+        assert np.abs(e_ref - st["e"]).max() < 2e-5 * np.abs(e_ref).max(), tag
+        states[tag] = st
+    assert 0.3 < states["cpi"]["d"].mean() < 0.7
+    assert 0.003 < states["b3"]["d"].mean() < 0.05
+    assert np.array_equal(states["b3"]["d"], states["b2"]["d"])
+    assert scaled_err(states["b3"]["b"], states["b2"]["b"]) < 1e-6 and scaled_err(states["b3"]["e"], states["b2"]["e"]) < 1e-6
 
 
 # Distance of the GPU chain from the oracle's FLOAT-FAITHFUL flavour ("f": float residual, float accumulators in eight
