@@ -944,6 +944,7 @@ struct bwgr_panel {
   int e3_D = 0;                   // fold-in lag in blocks; cross Gram arrays reach D-1 blocks back
   int K3 = 0, R3 = 0, sub3 = 0;   // streamer workgroups, rows of each, streamers per slab
   bool solo3 = true;              // a chain alone on the GPU runs 128-row streamers (BWGR_SOLO3=0: never)
+  unsigned char *gx12 = nullptr;  // 16-bit panels: an included marker's distance-1 and distance-2 rows side by side (k_near_rows); root panels own it
   void *g3x[S3_MAXD] = {};        // g3x[d-1]: cross Gram blocks of distance d in the element type k_sweep3 reads (aliases the older arrays where they fit)
   bool g3own[S3_MAXD] = {};       // allocated here (not an alias)
   int xmax = 0;                   // largest |x| of an int8 panel
@@ -1226,6 +1227,13 @@ static int sweep3_build(bwgr_panel *P) {
     P->sweep_version = 2;
     return BWGR_OK;
   }
+  {   // 16-bit panels: an included marker's distance-1 / 2 rows in one piece
+    if (g16) {
+      HIPCHK(hipMalloc(&P->gx12, (size_t)P->nblocks * m * 2 * m * 2));
+      hipLaunchKernelGGL(k_near_rows, dim3(4096), dim3(256), 0, P->stream, (const uint16_t *)P->g3x[0], (const uint16_t *)(D >= 3 ? P->g3x[1] : nullptr), (uint16_t *)P->gx12, m, (int64_t)P->nblocks);
+      HIPCHK(hipGetLastError());
+    }
+  }
   CHK(sweep3_alloc_scratch(P));
   if (want4) {
     const size_t nq = (size_t)(P->nblocks + S4_QB - 1) / S4_QB;
@@ -1254,6 +1262,7 @@ static void sweep3_args(bwgr_panel *P, const SweepArgs &a, Sweep3Args &A) {
   A.gp = root->gram16 ? (const void *)root->gramp16 : root->gramp;
   A.D = P->e3_D; A.K3 = P->K3; A.R3 = P->R3; A.sub = P->sub3; A.g16 = root->gram16 ? 1 : 0;
   A.qsum = P->qsum3; A.lists = P->lists3;
+  A.gx12 = root->gram16 ? root->gx12 : nullptr;
   A.pf = -1;
   if (const char *dv = getenv("BWGR_DBG3")) A.dbg = atoi(dv);
   if (SWEEP_DRY) return;
@@ -1400,7 +1409,8 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
   a.gate3 = sweep3_gate(P, a.flags);
   const bool fx = (a.gate3 > 0.0f) || (use_winv(P, a.flags) && P->winv && use_wfx(P));
   SnapArgs sn;
-  const bool guarded = fx && !P->debug_withhold && range_snapshot(P, a, sn);
+  static const bool no_recover = getenv("BWGR_NO_RECOVER") != nullptr;   // (timing experiments that break the chain on purpose)
+  const bool guarded = fx && !P->debug_withhold && !no_recover && range_snapshot(P, a, sn);
   launch_sweep_kernel_inner(P, a_in, false);
   if (guarded) {
     if (!SWEEP_DRY) {
@@ -1578,7 +1588,7 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   (void)hipSetDevice(P->device);
   if (!P->parent) {
     for (int d = 0; d < S3_MAXD; ++d) if (P->g3own[d]) hipFree(P->g3x[d]);
-    hipFree(P->lists4); hipFree(P->gd16); hipFree(P->fin4);
+    hipFree(P->lists4); hipFree(P->gd16); hipFree(P->fin4); hipFree(P->gx12);
     hipFree(P->xmax_dev);
     for (int d = 0; d < S2W_MAXDIST; ++d) hipFree(P->gxt[d]);
     hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->gramx3); hipFree(P->gramp16); hipFree(P->gramx16); hipFree(P->gram16_bad); hipFree(P->gramp); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev);

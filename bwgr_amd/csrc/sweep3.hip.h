@@ -44,6 +44,7 @@ static constexpr int S3_LSTRIDE = 2 * SW_MAXM + 2;    // 8-byte words of one blo
 static constexpr int S3_ND = 7;                       // signed base-256 digits of the fixed-point residual and steps (|q| < 2^55)
 static constexpr int S3_RING = S3_MAXD * SW_MAXM;     // flat ring of included markers in the sequencer's LDS (a power of two)
 static constexpr int S3_GPD_BYTES = 16384;            // LDS copy of a packed diagonal Gram block, 16-bit entries (8128 of them at m = 128)
+static constexpr int S3_ROWSLOT = 1024;               // bytes of LDS per such marker: a 64-lane x 16-byte DMA (the two rows are its first 4 m bytes)
 static constexpr int S3_NRX = 8;                      // distance-1 / 2 rows of the first S3_NRX included markers of a block land in LDS by DMA
 static constexpr int S3_OS = 12;                      // dwords per row of the int32 recombination scratch (8 used; b128 reads conflict-free)
 
@@ -59,7 +60,20 @@ struct Sweep3Args {
   uint32_t epoch;                // this launch's tag (24 bits, never 0)
   int dbg;                       // experiment switches (BWGR_DBG3)
   int pf;                        // blockIdx of the prefetcher workgroup (shares the sequencer's XCD), or -1
+  const unsigned char *gx12;     // 16-bit panels: [nblocks][m][2][m] uint16, marker k of block b against blocks b+1 and b+2 side by side (k_near_rows):
+                                 // an included marker's distance-1 and distance-2 rows in ONE LDS-DMA; nullptr: two requests from gx[0], gx[1]
 };
+
+// gx12[b][k][d-1][j] = gx[d-1][b+d][k][j] (zero past the last block)
+__global__ void k_near_rows(const uint16_t *g1, const uint16_t *g2, uint16_t *out, int m, int64_t nblocks) {
+  const int64_t total = nblocks * m * 2 * m;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(t % m), d = (int)((t / m) & 1), k = (int)((t / (2 * m)) % m);
+    const int64_t b = t / ((int64_t)2 * m * m);
+    const uint16_t *g = d ? g2 : g1;
+    out[t] = (g && b + d + 1 < nblocks) ? g[((b + d + 1) * m + k) * m + j] : (uint16_t)0;
+  }
+}
 
 // ---- fixed-point scale of one sweep.  With 2^k above both the largest |e_i| at the start of the sweep and the largest step
 // |x| * |drej_j| a marker can apply to a row, e_fixed = e * 2^sh with sh = 44 - k: eleven bits of headroom below the 55-bit
@@ -147,6 +161,10 @@ __device__ __forceinline__ void s3_dma4(const void *gsrc, const void *lds_base) 
 __device__ __forceinline__ void s3_dma4s(const unsigned char *gbase, uint32_t voff, uint32_t la) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(gbase), "s"(la) : "memory", "m0");
 }
+// 16 bytes per lane
+__device__ __forceinline__ void s3_dma16s(const unsigned char *gbase, uint32_t voff, uint32_t la) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(gbase), "s"(la) : "memory", "m0");
+}
 #pragma clang diagnostic pop
 
 __host__ __device__ inline size_t s3_streamer_lds(int R3) {
@@ -160,7 +178,7 @@ __host__ __device__ inline size_t s3_seq_lds(int D, bool g16) {
   (void)D;
   s += (size_t)S3_RING * (sizeof(double) + sizeof(long long) + sizeof(int));       // the included markers of the last D blocks
   s += (size_t)2 * 3 * 16 * SW_MAXM * (g16 ? 2 : 4);                               // far-field rows in flight
-  if (g16) s += (size_t)3 * S3_GPD_BYTES + (size_t)S3_NRX * 2 * SW_MAXM * 2;       // the packed diagonal block of three blocks, distance-1 / 2 rows of this block's included markers
+  if (g16) s += (size_t)3 * S3_GPD_BYTES + (size_t)S3_NRX * S3_ROWSLOT;       // the packed diagonal block of three blocks, distance-1 / 2 rows of this block's included markers
   return s + 256;
 }
 
@@ -461,7 +479,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   // ahead), so that an included marker's row is an LDS read inside the chain instead of an HBM miss; and the distance-1 / 2 rows
   // of the block's included markers, requested by DMA when the marker is included and consumed after the block's last round
   unsigned char *gpd_s = smem + off; if (G16) off += (size_t)3 * S3_GPD_BYTES;
-  unsigned char *rowx_s = smem + off; if (G16) off += (size_t)S3_NRX * 2 * SW_MAXM * 2;
+  unsigned char *rowx_s = smem + off; if (G16) off += (size_t)S3_NRX * S3_ROWSLOT;
   int *ctrl_s = reinterpret_cast<int *>(smem + off);   // [0] ok flag
   int *pos_s = ctrl_s + 8;                             // [b & 31]: ring position where block b's entries begin
   const unsigned char **gx_s = reinterpret_cast<const unsigned char **>(ctrl_s + 40);   // the cross Gram arrays' base addresses (a table in LDS: indexed per entry)
@@ -737,6 +755,8 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   const int tabp0 = 2 * (lane * (m - 1) - lane * (lane - 1) / 2 - lane - 1);
   const int tabp1 = 2 * ((64 + lane) * (m - 1) - (64 + lane) * (63 + lane) / 2 - (64 + lane) - 1);
   const uint32_t rolane = (uint32_t)min(lane * 4, rowbytes - 4);
+  const uint32_t rolane16 = (uint32_t)min(lane * 16, 2 * rowbytes - 16);   // (gx12: a marker's two rows are 2 * rowbytes contiguous bytes, a multiple of 16)
+  constexpr bool near12 = G16;   // (16-bit panels always carry gx12; block sizes are multiples of 16)
   const unsigned char *gpd_lane = gpd_s + 2 * lane;   // this lane's entry of a packed row, before the row's and the buffer's offsets
   int gpd_off = 0;                                     // (b % 3) * S3_GPD_BYTES, stepped once per block
   const uint32_t rowx_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)rowx_s);
@@ -745,6 +765,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   // wave 0: what the included markers of block b change in blocks b+1 and b+2 (distances 1 and 2), accumulated as they appear
   double rnext0 = 0.0, rnext1 = 0.0, rnxt20 = 0.0, rnxt21 = 0.0;
   const GT *gx0_w0 = reinterpret_cast<const GT *>(A.gx[0]) + (size_t)a.blk_begin * m * m, *gx1_w0 = reinterpret_cast<const GT *>(A.gx[1]) + (size_t)a.blk_begin * m * m;
+  const unsigned char *g12_w0 = A.gx12 + (size_t)a.blk_begin * m * 2 * rowbytes;
   for (int b = 0; b < nb; ++b) {
     const int mB = blk_m(b), blk = a.blk_begin + b;
     const bool have_next = (b + 1 < nb);
@@ -764,6 +785,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       const GT *g1 = (G16 || use1) ? gx0_w0 + (size_t)(b + 1) * (uint32_t)(m * m) : gp;
       const bool use2 = (b + 2 < nb) && D >= 3;
       const GT *g2 = (G16 || use2) ? gx1_w0 + (size_t)(b + 2) * (uint32_t)(m * m) : gp;
+      const unsigned char *g12b = g12_w0 + (size_t)b * (uint32_t)(m * 2 * rowbytes);
       const int l0 = lane, l1 = 64 + lane;
       const int l1c = min(l1, m - 1);
       // constants of this lane's two markers
@@ -803,8 +825,8 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
         for (int i_ = 0; i_ < nslot; ++i_) { \
           const double cf_ = accC[(pos0 + napp + i_) & (ring - 1)]; \
-          const uint16_t *rw1_ = reinterpret_cast<const uint16_t *>(rowx_s + (size_t)(i_ * 2) * (SW_MAXM * 2)); \
-          const uint16_t *rw2_ = reinterpret_cast<const uint16_t *>(rowx_s + (size_t)(i_ * 2 + 1) * (SW_MAXM * 2)); \
+          const uint16_t *rw1_ = reinterpret_cast<const uint16_t *>(rowx_s + (size_t)i_ * S3_ROWSLOT); \
+          const uint16_t *rw2_ = rw1_ + m; \
           if (use1) { rnext0 = fma(-(double)rw1_[min(l0, m - 1)], cf_, rnext0); rnext1 = fma(-(double)rw1_[l1c], cf_, rnext1); } \
           if (use2) { rnxt20 = fma(-(double)rw2_[min(l0, m - 1)], cf_, rnxt20); rnxt21 = fma(-(double)rw2_[l1c], cf_, rnxt21); } \
         } \
@@ -822,8 +844,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
             ga_ = gp[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gp[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)]; \
           } \
           if (__builtin_expect(nslot == S3_NRX, 0)) S3_APPLY_ROWS()   /* every slot taken: the rows so far first */ \
-          if (use1) s3_dma4s(reinterpret_cast<const unsigned char *>(g1) + (size_t)(k_ * rowbytes), rolane, rowx_la + (uint32_t)(nslot * 2) * (SW_MAXM * 2)); \
-          if (use2) s3_dma4s(reinterpret_cast<const unsigned char *>(g2) + (size_t)(k_ * rowbytes), rolane, rowx_la + (uint32_t)(nslot * 2 + 1) * (SW_MAXM * 2)); \
+          if (use1) s3_dma16s(g12b + (size_t)(k_ * 2 * rowbytes), rolane16, rowx_la + (uint32_t)nslot * S3_ROWSLOT); \
           ++nslot; } \
         } else if (!(A.dbg & 64)) {   /* 32-bit Gram entries: the rows straight from global memory */ \
           const int pr_ = prow(k_); \

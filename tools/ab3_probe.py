@@ -33,7 +33,11 @@ for cfg in sys.argv[1:] or [""]:
         except Exception:
             pass
         sel = model in ("BayesB", "BayesC", "BayesCpi", "BayesDpi")
-        print("%-40s sweep %8.3f ms  %6.3f us/block  mean_d %s  %s redo %s ve %s" % (cfg, ms, 1e3 * ms / nb, "%.4f" % st["d"].mean() if st else "n/a", P.pipeline(sel), ch.redo_count(), st["ve"] if st else "n/a"), flush=True)
+        try:
+            nredo = ch.redo_count()
+        except Exception:
+            nredo = "n/a"
+        print("%-40s sweep %8.3f ms  %6.3f us/block  mean_d %s  %s redo %s ve %s" % (cfg, ms, 1e3 * ms / nb, "%.4f" % st["d"].mean() if st else "n/a", P.pipeline(sel), nredo, st["ve"] if st else "n/a"), flush=True)
     finally:
         try:
             ch.close(); P.close()
