@@ -166,7 +166,7 @@ struct S2WArgs {
   int npf;                                   // L2 prefetch workgroups (blockIdx K + 8, K + 16, ...: the sequencer's XCD)
   int dbg;                                   // experiments (BWGR_DBGW), timing only: 1 = every step published as zero (the chain stands still), 2 = the sequencer does
                                              // not wait for the slab dots, 4 = the streamers do not wait for the steps, 8 = no sequencer, 16 = no streamers,
-                                             // 32 = W loaded for the first block only, 64 = the Gram planes loaded for the first block only
+                                             // 32 = W loaded for the first block only, 64 = the Gram planes loaded for the first block only, 128 = b, d, vb not written
 };
 
 __host__ __device__ inline size_t s2w_fx_lds(int L);
@@ -347,7 +347,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
   double *q_s = reinterpret_cast<double *>(smem + off); off += (size_t)8 * SW_MAXM * sizeof(double);      // [parity][part 0..3][marker]
     double *rhs_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
   double *d_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);                  // the un-rounded steps
-  double *delta_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);              // what the residual gets (float values)
+  off += SW_MAXM * sizeof(double);   // (unused)
   int8_t *ddig_s = reinterpret_cast<int8_t *>(smem + off); off += (size_t)(4 * 4 + 1) * S2W_DROW;        // [block & 3][digit 0..3][k]; then the zero row
   int8_t *zrow_s = ddig_s + (size_t)4 * 4 * S2W_DROW;
   double *bias_s = reinterpret_cast<double *>(smem + off); off += 4 * sizeof(double);                     // [block & 3]: 32896 * the sum of the block's fixed-point steps
@@ -394,7 +394,6 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
 
   // ---- prologue ----
   if (tid == 0) ctrl_s[0] = 1;
-  if (tid < SW_MAXM) delta_s[tid] = 0.0;
   for (int i = tid; i < (int)((4 * 4 + 1) * S2W_DROW / 4); i += S2W_THREADS) reinterpret_cast<uint32_t *>(ddig_s)[i] = 0u;
   if (tid < 4) { bias_s[tid] = 0.0; scd_s[tid] = 1.0; }
   if (wave < 4) { issue_stage(0); issue_stage(1); }
@@ -548,6 +547,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
       S2W_BAR();                                          // B3: d
       S2WSTAMP(4);
       if (wave == 8) {
+        // the part the next block's cross terms wait for: the steps, their granules for the streamers, their digits
         const StageBuf &st = stage[c % 3];
         unsigned long long *gslot = a.dgran + (size_t)(c % S2_NSLOT) * SW_MAXM;
         float dl_own[2] = {0.0f, 0.0f};
@@ -559,14 +559,8 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
             const float b0 = st.b0[t];
             const float bn = (float)(d_s[t] + (double)b0);
             dl = (A.dbg & 1) ? 0.0f : (bn - b0) * (float)dscale;
-            a.b[j0 + t] = (A.dbg & 1) ? b0 : bn;
-            a.d[j0 + t] = 1.0f;
-            if (a.flags & SWF_VB_VEC) a.vb[j0 + t] = (float)((double)(Sb + bn * bn) / st.chi[t]);
-            sum_d += 1.0;
-            sum_b2 = fma((double)bn, (double)bn, sum_b2);
           }
           dl_own[q] = dl;
-          delta_s[t] = (double)dl;
         }
         const uint32_t exmax = wave_max_u32(max((__float_as_uint(dl_own[0]) >> 23) & 0xFFu, (__float_as_uint(dl_own[1]) >> 23) & 0xFFu));
         if (lane < mB) st_agent_raw64(gslot + lane, s2_dgranule(c, exmax, dl_own[0]));
@@ -588,10 +582,26 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
         if (lane == 0) { bias_s[c & 3] = 32896.0 * (double)sq; scd_s[c & 3] = __hiloint2double((1023 - sh) << 20, 0); }
         if (lane == 0 && A.npf > 0) st_agent_u32(a.xflags + (size_t)a.K * SW_FLAG_STRIDE + 1, (uint32_t)(c + 1));   // progress, for the prefetchers
+      } else if (!(A.dbg & 128)) {
+        // ... and what nobody in the sweep waits for, on the other three waves of the group: wave 9 the effects (and the sums), wave 10
+        // the indicators, wave 11 the variances.  (stage[c % 3] and d_s are read here until the next B0: the constants of block c+3 land
+        // in this buffer after B2 of block c+1, the next product writes d_s after that barrier too.)
+        const StageBuf &st = stage[c % 3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int t = 64 * q + lane;
+          if (t < mB) {
+            const float b0 = st.b0[t];
+            const float bn = (A.dbg & 1) ? b0 : (float)(d_s[t] + (double)b0);
+            if (wave == 9) { a.b[j0 + t] = bn; sum_d += 1.0; sum_b2 = fma((double)bn, (double)bn, sum_b2); }
+            else if (wave == 10) a.d[j0 + t] = 1.0f;
+            else if (a.flags & SWF_VB_VEC) a.vb[j0 + t] = (float)((double)(Sb + bn * bn) / st.chi[t]);
+          }
+        }
       }
     }
     S2WSTAMP_FLUSH();
-    if (wave == 8) {
+    if (wave == 9) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { sum_d += __shfl_down(sum_d, o, 64); sum_b2 += __shfl_down(sum_b2, o, 64); }
       if (lane == 0) { a.sc->sum_d += sum_d; a.sc->sum_b2 += sum_b2; }
@@ -842,7 +852,7 @@ template <bool FX>
 __global__ __launch_bounds__(S2W_THREADS) void k_sweep2w(const SweepArgs a, const S2WArgs A) {
   if (a.redo_only && a.sc->redo == 0u) return;   // (the fp64 fallback of a fixed-point sweep that stayed in range)
   const int KS = FX ? A.K3 : a.K;   // streamer workgroups; then the sequencer; then every eighth workgroup a prefetcher
-  if ((int)blockIdx.x > KS) { const int r = (int)blockIdx.x - KS; if ((r & 7) == 0) s2w_prefetcher(a, A, (r >> 3) - 1); return; }
+  if ((int)blockIdx.x > KS) { const int r = (int)blockIdx.x - KS; if ((r & 7) == 0 && !(A.dbg & 8)) s2w_prefetcher(a, A, (r >> 3) - 1); return; }
   if ((int)blockIdx.x == KS) { if (A.dbg & 8) return; s2_sequencer_winv<FX>(a, A); }
   else if (A.dbg & 16) return;
   else if (threadIdx.x >= SW_THREADS) return;                            // the streamers are eight waves (a wave that has ended leaves the barriers' count)
