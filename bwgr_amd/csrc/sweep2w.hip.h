@@ -426,9 +426,10 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
   // 0-15, their right-hand sides.  MFMA roles: A = the four digit rows of the steps (rows 4-15 zero), B = a byte plane of a
   // tile's 16 Gram columns, so lane j < 16 ends up with the four digit sums of ITS marker in its four accumulator registers
   // (no cross-lane step).
-  auto phase_xr = [&](int c, int mB) {
-    const int i16 = lane & 15, kg = lane >> 4;
-    double cross0 = 0.0, cross1 = 0.0;
+  // Two parts: what does not need block c-1's steps -- the distance-2 / 3 terms and the slab dots, folded into a partial r0 right after
+  // the previous block's product (xr_early, while wave 8 writes that block's steps) -- and the distance-1 term and the right-hand sides
+  // once those steps' digits exist (xr_late, between B0 and B2: the only part on the block's critical path).
+  double rp0 = 0.0, rp1 = 0.0;   // lanes 0-15: q - (distance-2 / 3 cross terms) of the wave's two markers of the NEXT block
 #define S2W_X1(CR, r0, r1, r2, r3) { \
       s2_v4i acc0 = {0, 0, 0, 0}, acc1 = acc0; \
       acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(dv0, r0, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(dv0, r2, acc1, 0, 0, 0); \
@@ -444,26 +445,44 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
       const s2_v4i dv0 = *reinterpret_cast<const s2_v4i *>(dg), dv1 = *reinterpret_cast<const s2_v4i *>(dg + 64); \
       const double bias_ = bias_s[slot], scd_ = scd_s[slot]; \
       S2W_X1(cross0, ra0, ra1, ra2, ra3) S2W_X1(cross1, rb0, rb1, rb2, rb3) }
-    S2W_XD(1, a1p0, a1p1, a1p2, a1p3, b1p0, b1p1, b1p2, b1p3)
+  auto xr_early = [&](int c, int mB) {   // (block c >= 1; q_c was collected before the barrier that precedes this)
+    const int i16 = lane & 15, kg = lane >> 4;
+    double cross0 = 0.0, cross1 = 0.0;
     S2W_XD(2, a2p0, a2p1, a2p2, a2p3, b2p0, b2p1, b2p2, b2p3)
     S2W_XD(3, a3p0, a3p1, a3p2, a3p3, b3p0, b3p1, b3p2, b3p3)
-#undef S2W_XD
-#undef S2W_X1
+    if (lane < 16) {
+      const double *qq = q_s + (size_t)(c & 1) * 4 * SW_MAXM;
+      const int t0 = 32 * wave + lane, t1 = t0 + 16;
+      rp0 = (t0 < mB) ? ((qq[t0] + qq[SW_MAXM + t0]) + (qq[2 * SW_MAXM + t0] + qq[3 * SW_MAXM + t0])) - cross0 : 0.0;
+      rp1 = (t1 < mB) ? ((qq[t1] + qq[SW_MAXM + t1]) + (qq[2 * SW_MAXM + t1] + qq[3 * SW_MAXM + t1])) - cross1 : 0.0;
+    }
+  };
+  auto xr_late = [&](int c, int mB) {
+    const int i16 = lane & 15, kg = lane >> 4;
+    double cross0 = 0.0, cross1 = 0.0;
+    S2W_XD(1, a1p0, a1p1, a1p2, a1p3, b1p0, b1p1, b1p2, b1p3)
     if (lane < 16) {
       const StageBuf &st = stage[c % 3];
-      const double *qq = q_s + (size_t)(c & 1) * 4 * SW_MAXM;
+      if (c == 0) {   // block 0 has no earlier blocks; its slab dots arrive with the first barrier
+        const double *qq = q_s;
+        const int t0 = 32 * wave + lane, t1 = t0 + 16;
+        rp0 = (t0 < mB) ? ((qq[t0] + qq[SW_MAXM + t0]) + (qq[2 * SW_MAXM + t0] + qq[3 * SW_MAXM + t0])) : 0.0;
+        rp1 = (t1 < mB) ? ((qq[t1] + qq[SW_MAXM + t1]) + (qq[2 * SW_MAXM + t1] + qq[3 * SW_MAXM + t1])) : 0.0;
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int t = 32 * wave + 16 * u + lane;
         double rhs = 0.0;
         if (t < mB) {
-          const double r0 = ((qq[t] + qq[SW_MAXM + t]) + (qq[2 * SW_MAXM + t] + qq[3 * SW_MAXM + t])) - (u ? cross1 : cross0);
+          const double r0 = (u ? rp1 : rp0) - (u ? cross1 : cross0);
           rhs = fma(r0 + (double)st.xxb0[t], st.rden[t], st.sdz1[t]) - (double)st.b0[t];
         }
         rhs_s[t] = rhs;
       }
     }
   };
+#undef S2W_XD
+#undef S2W_X1
 
   if (wave < 4) {
     // ================= waves 0-3: cross terms and right-hand sides =================
@@ -473,13 +492,11 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
 #pragma clang loop unroll(disable)
     for (int c = -1; c < nb; ++c) {
       if (c >= 0) {
-        S2WSTAMP0(7);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the constants of blocks c, c+1 (DMA); everything in flight is a block old
         S2WSTAMP0(0);
-        S2W_BAR();                                         // B0: + q_c, the digits of block c-1
+        S2W_BAR();                                         // B0: + the digits of block c-1 (q_c came with B3 of block c-1)
         S2WSTAMP0(1);
         if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
-        phase_xr(c, blk_m(c));
+        xr_late(c, blk_m(c));
         S2WSTAMP0(2);
         S2W_BAR();                                         // B2: rhs
       }
@@ -489,6 +506,11 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         S2WSTAMP0(3);
         S2W_BAR();                                         // B3: d
       }
+      S2WSTAMP0(4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the planes of block c+1, the constants of blocks c+1, c+2 (DMA)
+      S2WSTAMP0(5);
+      if (c >= 0 && c + 1 < nb) xr_early(c + 1, blk_m(c + 1));   // (beside wave 8's outputs of block c)
+      S2WSTAMP0(7);
     }
     S2WSTAMP0_FLUSH();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
