@@ -296,6 +296,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true));   // row_bcast:31 into rows 2 and 3
   return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
+// sum over the wave of int32 values whose total fits 32 bits (the same DPP ladder; result broadcast from lane 63)
+__device__ __forceinline__ int wave_sum_i32(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true);
+  return __builtin_amdgcn_readlane(x, 63);
+}
 // signed base-256 digits of q into bytes dst[n*stride], n < ND
 template <int ND> __device__ __forceinline__ void put_digits(long long q, int8_t *dst, int stride) {
 #pragma unroll

@@ -374,16 +374,23 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
   // loads: the wait counts rely on it.
   s2_v4i a1p0, a1p1, a1p2, a1p3, a2p0, a2p1, a2p2, a2p3, a3p0, a3p1, a3p2, a3p3;   // tile 0, distance d: {plane 0, plane 1} x {k < 64, k >= 64}
   s2_v4i b1p0, b1p1, b1p2, b1p3, b2p0, b2p1, b2p2, b2p3, b3p0, b3p1, b3p2, b3p3;   // tile 1
-  auto issue_a = [&](int c) {
-    const size_t boff = (size_t)(a.blk_begin + min(c, nb - 1)) * S2W_PBYTES + (size_t)wave * 8192 + (size_t)lane * 16;
+  // (Requested together after the block's right-hand sides, the distance-2 / 3 planes first: xr_early waits for those only.  Requesting
+  // them a whole block ahead -- right after xr_early has read the previous ones -- made the sequencer alone faster, 2.53 -> 2.34 us per
+  // block, and the sweep slower, 2.77 -> 2.83: sixteen load instructions in front of B0 wait in the memory pipeline's queue behind the
+  // q polls, and B0 is on the block's critical path.)
 #define S2W_A1(d_, o_, r0, r1, r2, r3) { const unsigned char *p_ = A.gxt[(d_) - 1] + boff + (o_); \
       r0 = *reinterpret_cast<const s2_v4i *>(p_); r1 = *reinterpret_cast<const s2_v4i *>(p_ + 1024); \
       r2 = *reinterpret_cast<const s2_v4i *>(p_ + 2048); r3 = *reinterpret_cast<const s2_v4i *>(p_ + 3072); }
+  auto issue_a1 = [&](int c) {
+    const size_t boff = (size_t)(a.blk_begin + min(c, nb - 1)) * S2W_PBYTES + (size_t)wave * 8192 + (size_t)lane * 16;
     S2W_A1(1, 0, a1p0, a1p1, a1p2, a1p3) S2W_A1(1, 4096, b1p0, b1p1, b1p2, b1p3)
+  };
+  auto issue_a23 = [&](int c) {
+    const size_t boff = (size_t)(a.blk_begin + min(c, nb - 1)) * S2W_PBYTES + (size_t)wave * 8192 + (size_t)lane * 16;
     S2W_A1(2, 0, a2p0, a2p1, a2p2, a2p3) S2W_A1(2, 4096, b2p0, b2p1, b2p2, b2p3)
     S2W_A1(3, 0, a3p0, a3p1, a3p2, a3p3) S2W_A1(3, 4096, b3p0, b3p1, b3p2, b3p3)
-#undef S2W_A1
   };
+#undef S2W_A1
   auto issue_stage = [&](int c) {   // the constants of block c: six pieces
     const int cc = min(c, nb - 1);
     const unsigned char *ssrc = reinterpret_cast<const unsigned char *>(a.ps.blocks + a.blk_begin + cc) + (size_t)lane * 16;
@@ -500,14 +507,18 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         S2WSTAMP0(2);
         S2W_BAR();                                         // B2: rhs
       }
-      if (!(A.dbg & 64) || c < 0) issue_a(c + 1);       // (these waves sit in the memory pipeline's queue now, while waves 4-7 form the product)
-      issue_stage(c + 2);
+      issue_stage(c + 2);   // (two DMA instructions, then twenty-four loads: these waves sit in the memory pipeline's queue while waves 4-7 form the product)
+      issue_a23(c + 1);
+      issue_a1(c + 1);
       if (c >= 0) {
         S2WSTAMP0(3);
         S2W_BAR();                                         // B3: d
       }
       S2WSTAMP0(4);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the planes of block c+1, the constants of blocks c+1, c+2 (DMA)
+      // in flight on this wave's in-order memory counter, oldest first: the two DMA instructions (constants of block c+2; block c+1's are
+      // a block older), the sixteen distance-2 / 3 loads of block c+1, the eight distance-1 loads.  All but the last eight: the constants
+      // (no compiler-visible result to wait for) and the planes xr_early(c+1) reads; the distance-1 planes are xr_late's, a phase later.
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       S2WSTAMP0(5);
       if (c >= 0 && c + 1 < nb) xr_early(c + 1, blk_m(c + 1));   // (beside wave 8's outputs of block c)
       S2WSTAMP0(7);
@@ -590,18 +601,18 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         // the steps in block-common fixed point, |q| < 2^30, as four balanced base-256 digits: the next blocks' cross terms
         const int sh = 156 - (int)exmax;
         const double scq = __hiloint2double((1023 + sh) << 20, 0);
-        long long sq = 0;
+        int sq2 = 0;   // this lane's two fixed-point steps, |.| < 2^30 each
         int8_t *dg = ddig_s + (size_t)((c & 3) * 4) * S2W_DROW;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int t = 64 * q + lane;
           const int qi = (int)rint((double)dl_own[q] * scq);
-          sq += qi;
+          sq2 += qi;
           const uint32_t u = ((uint32_t)qi + 0x00808080u) ^ 0x00808080u;
           dg[t] = (int8_t)(u & 0xFFu); dg[S2W_DROW + t] = (int8_t)((u >> 8) & 0xFFu); dg[2 * S2W_DROW + t] = (int8_t)((u >> 16) & 0xFFu); dg[3 * S2W_DROW + t] = (int8_t)(u >> 24);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        // their sum over the block, as two DPP reductions of 16-bit halves (a 64-bit butterfly through the LDS crossbar cost ~ 1k cycles here)
+        const long long sq = ((long long)wave_sum_i32(sq2 >> 16) << 16) + (long long)wave_sum_i32(sq2 & 0xFFFF);
         if (lane == 0) { bias_s[c & 3] = 32896.0 * (double)sq; scd_s[c & 3] = __hiloint2double((1023 - sh) << 20, 0); }
         if (lane == 0 && A.npf > 0) st_agent_u32(a.xflags + (size_t)a.K * SW_FLAG_STRIDE + 1, (uint32_t)(c + 1));   // progress, for the prefetchers
       } else if (!(A.dbg & 128)) {

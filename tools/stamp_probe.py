@@ -17,8 +17,8 @@ names2 = {0: "streamer: loop top + tile issue", 9: "streamer: tile commit (vmcnt
 names = ["top-barrier", "dot", "combine+exchange", "wait for prefetch waves", "outputs+update", "spec matvec", "recurrence (wave 0)", "-", "wave1: prefetch until tile+stage stored", "wave1: residual vmcnt(0)", "wave1: t(gram loads landed)", "wave1: t(+stage landed)"]
 names2w = dict(names2)
 if os.environ.get("BWGR_WINV", "1") != "0":   # affine sweeps run k_sweep2w: its sequencer stamps wave 4 (sweep2w.hip.h)
-    names2w.update({16: "sequencer w4: wait at B0", 17: "-", 18: "sequencer w4: wait at B2 (waves 0-3: cross terms + rhs)", 19: "sequencer w4: collect q_{c+1}, request q_{c+2}", 20: "sequencer w4: wait at B3 (waves 0-3: product)", 21: "sequencer w4: outputs, granules, digits", 22: "-",
-                   24: "sequencer w0: wait for the constants (vmcnt)", 25: "sequencer w0: wait at B0", 26: "sequencer w0: cross terms + rhs", 27: "sequencer w0: plane requests", 28: "sequencer w0: wait at B2", 29: "sequencer w0: product (incl. wait for W)", 30: "sequencer w0: W + constants requests, reduce, d", 31: "sequencer w0: wait at B3 + loop"})
+    names2w.update({16: "sequencer w8: wait at B0", 17: "-", 18: "sequencer w8: wait at B2 (waves 0-3: distance-1 term + rhs)", 19: "sequencer w8: collect q_{c+1}, request q_{c+2}", 20: "sequencer w8: wait at B3 (waves 4-7: product)", 21: "sequencer w8: steps, granules, digits", 22: "-",
+                   24: "sequencer w0: (loop edge)", 25: "sequencer w0: wait at B0", 26: "sequencer w0: distance-1 term + rhs", 27: "sequencer w0: wait at B2 + plane / constant requests", 28: "sequencer w0: wait at B3", 29: "sequencer w0: wait for the distance-2/3 planes (vmcnt)", 30: "-", 31: "sequencer w0: distance-2/3 terms + q (xr_early)"})
 for key in sys.argv[1:] or ["c2", "c4s"]:
     n, p, model, pi = wl[key]
     names2 = names2 if pi else names2w
