@@ -326,6 +326,22 @@ __device__ __forceinline__ int s2w_qf_collect(const SweepArgs &a, const S2WArgs 
   return 1;
 }
 
+// x[l] + x[l ^ 16] + (the same of l ^ 32): the sum over the wave's four rows of 16 lanes, in every lane -- gfx950's row swaps
+// (v_permlane16_swap / v_permlane32_swap: VALU, no trip through the LDS crossbar); the additions are those of the xor butterfly
+__device__ __forceinline__ double s2w_rows_sum(double v) {
+  {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  }
+  {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  }
+  return v;
+}
+
 // Block c, in four phases between raw barriers (no memory-counter drain at a barrier):
 //   X  all eight waves: the cross terms  sum_{d=1..nd} G_d' delta_{c-d}  as int8 MFMA products -- two byte planes of the 16-bit
 //      Gram entries (LDS, by DMA) against the four balanced base-256 digits of the steps in block-common fixed point; wave w
@@ -544,8 +560,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         S2W_TILE(0, w0, w1) S2W_TILE(1, w2, w3) S2W_TILE(2, w4, w5) S2W_TILE(3, w6, w7) S2W_TILE(4, w8, w9)
         S2W_TILE(5, w10, w11) S2W_TILE(6, w12, w13) S2W_TILE(7, w14, w15) S2W_TILE(8, w16, w17)
 #undef S2W_TILE
-        acc_hi += __shfl_xor(acc_hi, 16, 64); acc_hi += __shfl_xor(acc_hi, 32, 64);
-        acc_lo += __shfl_xor(acc_lo, 16, 64); acc_lo += __shfl_xor(acc_lo, 32, 64);
+        acc_hi = s2w_rows_sum(acc_hi); acc_lo = s2w_rows_sum(acc_lo);
         if (cq == 0) d_s[16 * (7 - wv) + r16] = acc_hi;
         if (cq == 1) d_s[16 * wv + r16] = acc_lo;
         if constexpr (!fx) if (c + 1 < nb) { if (!s2w_qx_collect(a, c + 1, xpart, xt, blk_m(c + 1), QX, q_s + (size_t)(((c + 1) & 1) * 4 + 2 + xpart) * SW_MAXM)) ctrl_s[0] = 0; }
