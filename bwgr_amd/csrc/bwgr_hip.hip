@@ -967,7 +967,7 @@ struct bwgr_panel {
   double *winv = nullptr;         // per handle: [nblocks][S2W_WDOUBLES], written by k_affine_inv before every affine sweep
   unsigned char *gxt[S2W_MAXDIST] = {};   // the cross Gram blocks as the sequencer's MFMA operand (k_gx_planes); shared with clones
   unsigned long long *qsumw = nullptr;    // per handle: the fixed-point streamers' slab-dot sums [nblocks][SW_MAXM][2]
-  int wpf = 4, wahead = 5, wnq = 0, wlag_cap = 4;   // BWGR_WPF / BWGR_WAHEAD / BWGR_WNQ (0: by the streamer count) / BWGR_WLAG, read when the panel is made
+  int wpf = 4, wahead = 5, wnq = 0, wlag_cap = 4;   // (BWGR_WLAG=5|6: distances 4 / 5 through LDS planes -- measured slower: C4-shape BayesA 22.3 / 23.0 / 24.9 ms per sweep at depth 4 / 5 / 6)   // BWGR_WPF / BWGR_WAHEAD / BWGR_WNQ (0: by the streamer count) / BWGR_WLAG, read when the panel is made
   bool wfx_on = true;             // BWGR_WFX=0: k_sweep2's streamers under the product sequencer instead of the fixed-point ones
   int winv_nd = 0;                // distances built = the deepest lag the affine sweeps can run, minus one
   size_t ldsw_bytes = 0;
@@ -1439,12 +1439,15 @@ static void launch_sweep_kernel_inner(bwgr_panel *P, const SweepArgs &a_in, bool
   if (use_winv(P, a.flags) && P->winv) {
     S2WArgs A;
     memset(&A, 0, sizeof(A));
-    A.winv = P->winv; A.nd = std::min(a.lag - 1, (int)S2W_MAXDIST);
+    A.winv = P->winv;
+    A.fx = (use_wfx(P) && !redo) ? 1 : 0;
+    if (!A.fx) a.lag = std::min(a.lag, 4);   // (k_sweep2's streamers -- the range-recovery launch, BWGR_WFX=0 -- hold four tiles)
+    A.nd = std::min(a.lag - 1, (int)S2W_MAXDIST);
     if (const char *dv = getenv("BWGR_DBGW")) A.dbg = atoi(dv);
     for (int d = 0; d < S2W_MAXDIST; ++d) A.gxt[d] = P->gxt[d < P->winv_nd ? d : 0];
     A.npf = P->wpf;      // measured at C2: 0 -> 540, 2 -> 636, 4 -> 685 iter/s (6 and 8 no better)
     A.ahead = P->wahead;
-    A.fx = (use_wfx(P) && !redo) ? 1 : 0; A.qsum = P->qsumw; A.sub = P->R / S2W_FXR; A.K3 = P->K * A.sub;
+    A.qsum = P->qsumw; A.sub = P->R / S2W_FXR; A.K3 = P->K * A.sub;
     A.nq = P->wnq ? P->wnq : (A.K3 > 48 ? 2 : 1);   // (C2, 40 streamers: one copy 1.10 ms, two 1.21; C4 shape, 80 streamers: 27.8 / 25.6 / 27.6 ms with 1 / 2 / 4)
     if (A.fx && !SWEEP_DRY) (void)hipMemsetAsync(P->qsumw + (size_t)a.blk_begin * A.nq * 2 * SW_MAXM, 0, sizeof(unsigned long long) * A.nq * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
     // (of the 8 npf workgroups past the sequencer, the npf on its XCD prefetch; the others leave at once)
@@ -1497,7 +1500,8 @@ static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
   }
   a.lag = lag < cap ? lag : cap;
   if (use_winv(P, a.flags)) {   // the affine sweeps' product sequencer: as deep as the panel's cross Gram planes reach (BWGR_WLAG caps it)
-    a.lag = std::min(std::min(4, P->winv_nd + 1), P->wlag_cap);
+    a.lag = std::min(P->winv_nd + 1, P->wlag_cap);
+    if (!use_wfx(P)) a.lag = std::min(a.lag, 4);   // (k_sweep2's streamers hold four tiles)
     if (const char *tl = getenv("BWGR_WLAG_TIMING")) a.lag = atoi(tl);   // TIMING ONLY: deeper than the cross terms reach (wrong chain)
   }
 }
@@ -1729,9 +1733,16 @@ static int panel_build_gram(bwgr_panel *P) {
   if (!P->is_f32 && P->gram16 && P->winv_on && m <= SW_MAXM) {
     HIPCHK(hipMemsetAsync(P->gram16_bad, 0, sizeof(int), P->stream));
     int nd = 0;
+    int32_t *tmpx = nullptr;   // distances 4 and 5 (pipelines five and six blocks deep; main panels only): built here, kept as planes only
     for (int dist = 1; dist <= S2W_MAXDIST; ++dist) {
-      const int32_t *src = (const int32_t *)(dist == 1 ? P->gramx : dist == 2 ? P->gramx2 : P->gramx3);
-      if (P->nblocks <= dist || dist > P->gram_maxdist || !src) break;
+      const int32_t *src = (const int32_t *)(dist == 1 ? P->gramx : dist == 2 ? P->gramx2 : dist == 3 ? P->gramx3 : nullptr);
+      if (dist > S2W_NEARD) {
+        if (!P->want3 || P->gram_maxdist < S2W_NEARD || P->nblocks <= dist || dist > P->wlag_cap - 1) break;
+        if (!tmpx && hipMalloc(&tmpx, (size_t)P->nblocks * m * m * 4) != hipSuccess) { (void)hipGetLastError(); tmpx = nullptr; break; }
+        launch_gramx_i8(P, tmpx, dist);
+        src = tmpx;
+      }
+      if (P->nblocks <= dist || (dist <= S2W_NEARD && dist > P->gram_maxdist) || !src) break;
       if (!P->gxt[dist - 1]) HIPCHK(hipMalloc(&P->gxt[dist - 1], (size_t)P->nblocks * S2W_PBYTES));
       hipLaunchKernelGGL(k_gx_planes, dim3(4096), dim3(256), 0, P->stream, src, P->gxt[dist - 1], m, (int64_t)P->nblocks, dist, P->gram16_bad);
       HIPCHK(hipGetLastError());
@@ -1740,6 +1751,7 @@ static int panel_build_gram(bwgr_panel *P) {
     int bad = 1;
     HIPCHK(hipMemcpyAsync(&bad, P->gram16_bad, sizeof(int), hipMemcpyDeviceToHost, P->stream));
     HIPCHK(hipStreamSynchronize(P->stream));
+    if (tmpx) hipFree(tmpx);
     P->winv_nd = bad ? 0 : nd;
   }
   HIPCHK(hipStreamSynchronize(P->stream));
@@ -1843,13 +1855,13 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2w<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2w<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_affine_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  if (!P->is_f32) P->ldsw_bytes = s2w_lds_bytes(m, R, getenv("BWGR_WLAG_TIMING") ? atoi(getenv("BWGR_WLAG_TIMING")) : 4);
+  if (!P->is_f32) P->ldsw_bytes = s2w_lds_bytes(m, R, getenv("BWGR_WLAG_TIMING") ? atoi(getenv("BWGR_WLAG_TIMING")) : 6);   // (room for the deepest pipeline BWGR_WLAG can ask for)
   if (const char *wv = getenv("BWGR_WINV")) P->winv_on = !(wv[0] == '0');
   if (const char *wv = getenv("BWGR_WFX")) P->wfx_on = !(wv[0] == '0');
   if (const char *pv = getenv("BWGR_WPF")) P->wpf = std::max(0, std::min(8, atoi(pv)));
   if (const char *pv = getenv("BWGR_WAHEAD")) P->wahead = std::max(1, atoi(pv));
   if (const char *qv = getenv("BWGR_WNQ")) { const int v = atoi(qv); if (v == 1 || v == 2 || v == 4) P->wnq = v; }
-  if (const char *wl = getenv("BWGR_WLAG")) if (wl[0] >= '2' && wl[0] <= '4') P->wlag_cap = wl[0] - '0';
+  if (const char *wl = getenv("BWGR_WLAG")) if (wl[0] >= '2' && wl[0] <= '6') P->wlag_cap = wl[0] - '0';
 #undef PCHK
   (void)rc;
   *out = P;

@@ -126,7 +126,9 @@ __global__ __launch_bounds__(512) void k_affine_inv(const SweepArgs a, double *w
 // block b; pad markers hold G = 0)
 // ------------------------------------------------------------------------------------------------------------------
 static constexpr int S2W_PBYTES = 2 * SW_MAXM * SW_MAXM;            // 32 768 per block and distance
-static constexpr int S2W_MAXDIST = 3;
+static constexpr int S2W_MAXDIST = 5;   // distances 1-3 as register operands of waves 0-3, distances 4-5 (pipelines five and six blocks deep) through LDS
+static constexpr int S2W_NEARD = 3;
+static constexpr int S2W_DSLOTS = 8;   // ring of the blocks' step digits (a block's digits are read up to five blocks later, while the current block's are written)
 
 __global__ void k_gx_planes(const int32_t *src, unsigned char *dst, int m, int64_t nblocks, int dist, int *bad) {
   const int64_t total = nblocks * (S2W_PBYTES / 16);
@@ -173,8 +175,9 @@ __host__ __device__ inline size_t s2w_fx_lds(int L);
 __host__ __device__ inline size_t s2w_lds_bytes(int m, int R, int maxlag = 4) {
   size_t s = 3 * sizeof(StageBuf);
   s += (size_t)(2 * 4 + 1 + 1 + 1 + 1) * SW_MAXM * sizeof(double);   // q parts [parity][4], cross, rhs, d, delta
-  s += (size_t)(4 * 4 + 1) * S2W_DROW;                                // delta digits of the last four blocks, a row of zeros
+  s += (size_t)(S2W_DSLOTS * 4 + 1) * S2W_DROW;                       // delta digits of the last blocks, a row of zeros
   s += 256;
+  if (maxlag > S2W_NEARD + 1) s += (size_t)(maxlag - 1 - S2W_NEARD) * S2W_PBYTES;   // the far distances' planes of one block
   size_t streamer = s2i_lds_bytes(m, R, 4);
   if (s2w_fx_lds(maxlag) > streamer) streamer = s2w_fx_lds(maxlag);
   return s > streamer ? s : streamer;
@@ -364,11 +367,12 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
     double *rhs_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);
   double *d_s = reinterpret_cast<double *>(smem + off); off += SW_MAXM * sizeof(double);                  // the un-rounded steps
   off += SW_MAXM * sizeof(double);   // (unused)
-  int8_t *ddig_s = reinterpret_cast<int8_t *>(smem + off); off += (size_t)(4 * 4 + 1) * S2W_DROW;        // [block & 3][digit 0..3][k]; then the zero row
-  int8_t *zrow_s = ddig_s + (size_t)4 * 4 * S2W_DROW;
-  double *bias_s = reinterpret_cast<double *>(smem + off); off += 4 * sizeof(double);                     // [block & 3]: 32896 * the sum of the block's fixed-point steps
-  double *scd_s = reinterpret_cast<double *>(smem + off); off += 4 * sizeof(double);                      // [block & 3]: 2^-(their binary point)
-  int *ctrl_s = reinterpret_cast<int *>(smem + off);
+  int8_t *ddig_s = reinterpret_cast<int8_t *>(smem + off); off += (size_t)(S2W_DSLOTS * 4 + 1) * S2W_DROW;   // [block & 7][digit 0..3][k]; then the zero row
+  int8_t *zrow_s = ddig_s + (size_t)S2W_DSLOTS * 4 * S2W_DROW;
+  double *bias_s = reinterpret_cast<double *>(smem + off); off += S2W_DSLOTS * sizeof(double);            // [block & 7]: 32896 * the sum of the block's fixed-point steps
+  double *scd_s = reinterpret_cast<double *>(smem + off); off += S2W_DSLOTS * sizeof(double);             // [block & 7]: 2^-(their binary point)
+  int *ctrl_s = reinterpret_cast<int *>(smem + off); off += 256;
+  unsigned char *far_s = smem + off;   // [distance - 4][S2W_PBYTES]: block c+1's far planes, each wave its own 8 KB (DMA after B2 of block c, read in xr_early)
   const float Sb = a.sc->Sb;
   const double dscale = (a.flags & SWF_DELTA2) ? 2.0 : 1.0;
   constexpr int NCH = (int)(sizeof(StageBuf) / 16), SPIECES = (NCH + 63) >> 6;
@@ -417,8 +421,8 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
 
   // ---- prologue ----
   if (tid == 0) ctrl_s[0] = 1;
-  for (int i = tid; i < (int)((4 * 4 + 1) * S2W_DROW / 4); i += S2W_THREADS) reinterpret_cast<uint32_t *>(ddig_s)[i] = 0u;
-  if (tid < 4) { bias_s[tid] = 0.0; scd_s[tid] = 1.0; }
+  for (int i = tid; i < (int)((S2W_DSLOTS * 4 + 1) * S2W_DROW / 4); i += S2W_THREADS) reinterpret_cast<uint32_t *>(ddig_s)[i] = 0u;
+  if (tid < S2W_DSLOTS) { bias_s[tid] = 0.0; scd_s[tid] = 1.0; }
   if (wave < 4) { issue_stage(0); issue_stage(1); }
   __syncthreads();
   S2WPoll QP;
@@ -463,7 +467,13 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
       const double val = fma(256.0, fma(256.0, fma(256.0, t3, t2), t1), t0); \
       CR = fma(val + bias_, scd_, CR); }   /* (the planes are biased by 128: bias = (128 + 256 * 128) sum_k q_k; scd = 2^-sh) */
 #define S2W_XD(d_, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3) if (nd >= (d_) && c - (d_) >= 0) { \
-      const int slot = (c - (d_)) & 3; \
+      const int slot = (c - (d_)) & (S2W_DSLOTS - 1); \
+      const int8_t *dg = (i16 < 4 ? ddig_s + (size_t)(slot * 4 + i16) * S2W_DROW : zrow_s) + 16 * kg; \
+      const s2_v4i dv0 = *reinterpret_cast<const s2_v4i *>(dg), dv1 = *reinterpret_cast<const s2_v4i *>(dg + 64); \
+      const double bias_ = bias_s[slot], scd_ = scd_s[slot]; \
+      S2W_X1(cross0, ra0, ra1, ra2, ra3) S2W_X1(cross1, rb0, rb1, rb2, rb3) }
+#define S2W_XDR(d_, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3) if (c - (d_) >= 0) { \
+      const int slot = (c - (d_)) & (S2W_DSLOTS - 1); \
       const int8_t *dg = (i16 < 4 ? ddig_s + (size_t)(slot * 4 + i16) * S2W_DROW : zrow_s) + 16 * kg; \
       const s2_v4i dv0 = *reinterpret_cast<const s2_v4i *>(dg), dv1 = *reinterpret_cast<const s2_v4i *>(dg + 64); \
       const double bias_ = bias_s[slot], scd_ = scd_s[slot]; \
@@ -473,6 +483,14 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
     double cross0 = 0.0, cross1 = 0.0;
     S2W_XD(2, a2p0, a2p1, a2p2, a2p3, b2p0, b2p1, b2p2, b2p3)
     S2W_XD(3, a3p0, a3p1, a3p2, a3p3, b3p0, b3p1, b3p2, b3p3)
+    for (int d = S2W_NEARD + 1; d <= nd; ++d) {   // the far distances: operands from this wave's own 8 KB of the LDS copy
+      const unsigned char *fp = far_s + (size_t)(d - S2W_NEARD - 1) * S2W_PBYTES + (size_t)wave * 8192 + (size_t)lane * 16;
+      const s2_v4i f0 = *reinterpret_cast<const s2_v4i *>(fp), f1 = *reinterpret_cast<const s2_v4i *>(fp + 1024);
+      const s2_v4i f2 = *reinterpret_cast<const s2_v4i *>(fp + 2048), f3 = *reinterpret_cast<const s2_v4i *>(fp + 3072);
+      const s2_v4i g0 = *reinterpret_cast<const s2_v4i *>(fp + 4096), g1 = *reinterpret_cast<const s2_v4i *>(fp + 5120);
+      const s2_v4i g2 = *reinterpret_cast<const s2_v4i *>(fp + 6144), g3 = *reinterpret_cast<const s2_v4i *>(fp + 7168);
+      S2W_XDR(d, f0, f1, f2, f3, g0, g1, g2, g3)
+    }
     if (lane < 16) {
       const double *qq = q_s + (size_t)(c & 1) * 4 * SW_MAXM;
       const int t0 = 32 * wave + lane, t1 = t0 + 16;
@@ -505,7 +523,17 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
     }
   };
 #undef S2W_XD
+#undef S2W_XDR
 #undef S2W_X1
+  auto issue_far = [&](int c) {   // eight 1 KiB pieces per far distance: this wave's 32 markers of block c
+    const size_t boff = (size_t)(a.blk_begin + min(c, nb - 1)) * S2W_PBYTES + (size_t)wave * 8192 + (size_t)lane * 16;
+    for (int d = S2W_NEARD + 1; d <= nd; ++d) {
+      const unsigned char *src = A.gxt[d - 1] + boff;
+      unsigned char *dst = far_s + (size_t)(d - S2W_NEARD - 1) * S2W_PBYTES + (size_t)wave * 8192;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s2w_dma16(src + (size_t)k * 1024, dst + (size_t)k * 1024);
+    }
+  };
 
   if (wave < 4) {
     // ================= waves 0-3: cross terms and right-hand sides =================
@@ -523,7 +551,8 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         S2WSTAMP0(2);
         S2W_BAR();                                         // B2: rhs
       }
-      issue_stage(c + 2);   // (two DMA instructions, then twenty-four loads: these waves sit in the memory pipeline's queue while waves 4-7 form the product)
+      issue_stage(c + 2);   // (two DMA instructions -- and eight per far distance --, then twenty-four loads: these waves sit in the memory pipeline's queue while waves 4-7 form the product)
+      issue_far(c + 1);
       issue_a23(c + 1);
       issue_a1(c + 1);
       if (c >= 0) {
@@ -532,7 +561,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
       }
       S2WSTAMP0(4);
       // in flight on this wave's in-order memory counter, oldest first: the two DMA instructions (constants of block c+2; block c+1's are
-      // a block older), the sixteen distance-2 / 3 loads of block c+1, the eight distance-1 loads.  All but the last eight: the constants
+      // a block older), the far planes' DMA, the sixteen distance-2 / 3 loads of block c+1, the eight distance-1 loads.  All but the last eight: the constants
       // (no compiler-visible result to wait for) and the planes xr_early(c+1) reads; the distance-1 planes are xr_late's, a phase later.
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       S2WSTAMP0(5);
@@ -617,7 +646,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         const int sh = 156 - (int)exmax;
         const double scq = __hiloint2double((1023 + sh) << 20, 0);
         int sq2 = 0;   // this lane's two fixed-point steps, |.| < 2^30 each
-        int8_t *dg = ddig_s + (size_t)((c & 3) * 4) * S2W_DROW;
+        int8_t *dg = ddig_s + (size_t)((c & (S2W_DSLOTS - 1)) * 4) * S2W_DROW;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int t = 64 * q + lane;
@@ -628,7 +657,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         }
         // their sum over the block, as two DPP reductions of 16-bit halves (a 64-bit butterfly through the LDS crossbar cost ~ 1k cycles here)
         const long long sq = ((long long)wave_sum_i32(sq2 >> 16) << 16) + (long long)wave_sum_i32(sq2 & 0xFFFF);
-        if (lane == 0) { bias_s[c & 3] = 32896.0 * (double)sq; scd_s[c & 3] = __hiloint2double((1023 - sh) << 20, 0); }
+        if (lane == 0) { bias_s[c & (S2W_DSLOTS - 1)] = 32896.0 * (double)sq; scd_s[c & (S2W_DSLOTS - 1)] = __hiloint2double((1023 - sh) << 20, 0); }
         if (lane == 0 && A.npf > 0) st_agent_u32(a.xflags + (size_t)a.K * SW_FLAG_STRIDE + 1, (uint32_t)(c + 1));   // progress, for the prefetchers
       } else if (!(A.dbg & 128)) {
         // ... and what nobody in the sweep waits for, on the other three waves of the group: wave 9 the effects (and the sums), wave 10

@@ -438,7 +438,7 @@ def test_affine_winv_long_chain_stays_on_the_oracle(model):
     from oracle import oracle as O
     X, y = synth_small(700, 1000, seed=23)
     P = bwgr_amd.Panel(X)
-    assert P.pipeline(False)["generation"] == 4 and P.pipeline(False)["lag"] == 4
+    assert P.pipeline(False)["generation"] == 4 and P.pipeline(False)["lag"] == int(os.environ.get("BWGR_WLAG", "4"))
     ch = bwgr_amd.Chain(P, model, y, it=200, bi=50, seed=4)
     ch.run(200)
     st = ch.state()
