@@ -45,7 +45,7 @@ def test_oversubscription_is_refused_and_the_chain_survives():
     cap = P.max_concurrent(True)
     assert 1 <= cap <= 64
     handles = [P] + [P.clone() for _ in range(cap)]          # cap + 1 handles
-    iters = 24
+    iters = 48
     chains = [Chain(h, "BayesB", y, it=iters, bi=0, pi=0.99, seed=100 + i) for i, h in enumerate(handles)]
     try:
         for ch in chains[:cap]:
