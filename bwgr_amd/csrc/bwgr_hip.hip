@@ -2339,8 +2339,8 @@ extern "C" int bwgr_chain_run_pair(bwgr_chain *C0, bwgr_chain *C1, int iters) {
   if (s3p_streamer_lds(P0->R3) > (size_t)160 * 1024) return fail(BWGR_EINVAL, "chain_run_pair: the paired streamers' LDS does not fit");
   HIPCHK(hipSetDevice(P0->device));
   // everything of the pair runs on ONE stream, owned by the root panel (it outlives both handles), and both handles move onto it
-  // for good -- one cross-stream wait each, the first time: a wait per call would sit in a hardware queue that other pairs'
-  // streams share, and stall them
+  // for as long as they run in pairs -- one cross-stream wait each, the first time: a wait per call would sit in a hardware queue
+  // that other pairs' streams share, and stall them.  A handle's next sweep alone takes it back (leave_pair_stream).
   bwgr_panel *root = P0->parent ? P0->parent : P0;
   auto is_pair_stream = [&](hipStream_t st) { for (hipStream_t q : root->pair_streams) if (q == st) return true; return false; };
   hipStream_t s0 = nullptr;
