@@ -716,14 +716,14 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
 #define S3_ROLE_BARRIER() do { if (BWGR_ROLEBAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
   const int wvu = __builtin_amdgcn_readfirstlane(wave);   // the role as a scalar: real branches, every wave runs its own role's code (and barrier) only
   auto helper_phase = [&](int c) {   // block c >= 1, while wave 0 runs block c-1
-    if (wvu == 1) { if (!(A.dbg & 32768)) { if (!poll_q(c)) ctrl_s[0] = 0; } S3_ROLE_BARRIER(); }
+    if (wvu == 1) { if (!(A.dbg & 32768)) { if (!poll_q(c)) ctrl_s[0] = 0; } S3ST(2, tid == 64); S3_ROLE_BARRIER(); }
     else if (wvu <= 3) { if (!(A.dbg & 8192)) {
       // the constants of block c, requested a phase ago -- waiting for them also waits for block c's packed diagonal block, whose
       // DMA was issued before them; then the requests for block c+1 (the DMA first), which have this whole phase to land
       if (!(A.dbg & 262144)) stage_commit(c);
       if (c + 1 < nb) { if (!(A.dbg & 131072)) gpd_issue(c + 1); if (!(A.dbg & 262144)) stage_request(c + 1); }
       else if constexpr (GPD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } S3_ROLE_BARRIER(); }
+    } S3ST(2, tid == 128 || tid == 192); S3_ROLE_BARRIER(); }
     else if (wvu == 4) { S3_ROLE_BARRIER(); }   // idle: the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots
     else if (wvu <= 6) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -732,9 +732,10 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       S3ST(6, tid == 320);
       far_issue(c + 1, wave - 5);
       S3ST(7, tid == 320);
+      S3ST(2, tid == 384);
       S3_ROLE_BARRIER();
     }
-    else { if (c >= 2 && !(A.dbg & 4096)) finish_block(c - 2); touch(c + PF); S3_ROLE_BARRIER(); }
+    else { if (c >= 2 && !(A.dbg & 4096)) finish_block(c - 2); touch(c + PF); S3ST(2, tid == 448); S3_ROLE_BARRIER(); }
   };
 
   // ---- prologue: block 0 ----

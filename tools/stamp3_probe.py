@@ -18,12 +18,12 @@ wl = {"c4s": (10000, 200000, "BayesB", 0.99), "c4b": (10000, 200000, "BayesB", 0
 rows = [("streamer 0, update wave", 0, ["loop top", "fold the list of block b-D", "digits of e and drej", "barrier", "requests (drej, list) after the issue", "update MFMA + recombine", "abort check + tile commit", "next tile issue"]),
         ("streamer 0, first dots wave", 8, ["loop top", "-", "-", "barrier (incl. waiting for the update waves)", "requests (drej, list) after the issue", "dots MFMA + recombine + atomics", "abort check + tile commit", "next tile issue"]),
         ("sequencer wave 0", 16, ["loop top", "constants + r0", "rounds", "outputs + list publish", "barrier", "(inside rounds) waiting for the on-demand rows", "(included markers per block)", "-"]),
-        ("sequencer wave 1 (q poll)", 24, ["loop top", "poll + convert", "-", "-", "barrier", "-", "-", "-"]),
-        ("sequencer wave 2 (staging)", 32, ["loop top", "commit + request", "-", "-", "barrier", "-", "-", "-"]),
+        ("sequencer wave 1 (q poll)", 24, ["loop top", "wait at the block barrier (rest of the phase)", "poll + convert (until the next block's slab dots are complete)", "-", "barrier", "-", "-", "-"]),
+        ("sequencer wave 2 (staging)", 32, ["loop top", "wait at the block barrier (rest of the phase)", "commit + request", "-", "barrier", "-", "-", "-"]),
         ("sequencer wave 5 (far field)", 40, ["loop top", "(rest)", "-", "-", "barrier", "wait for last phase's rows", "consume", "issue"]),
-        ("sequencer wave 3 (staging)", 48, ["loop top", "commit + request", "-", "-", "barrier", "-", "-", "-"]),
-        ("sequencer wave 6 (far field)", 56, ["loop top", "consume + issue", "-", "-", "barrier", "-", "-", "-"]),
-        ("sequencer wave 7 (state, sums, lists)", 64, ["loop top", "finish_block", "-", "-", "barrier", "-", "-", "-"])]
+        ("sequencer wave 3 (staging)", 48, ["loop top", "wait at the block barrier (rest of the phase)", "commit + request", "-", "barrier", "-", "-", "-"]),
+        ("sequencer wave 6 (far field)", 56, ["loop top", "wait at the block barrier (rest of the phase)", "consume + issue", "-", "barrier", "-", "-", "-"]),
+        ("sequencer wave 7 (state, sums, lists)", 64, ["loop top", "wait at the block barrier (rest of the phase)", "finish_block", "-", "barrier", "-", "-", "-"])]
 for key in sys.argv[1:] or ["c4s"]:
     n, p, model, pi = wl[key]
     X = synth.genotypes(n, p); y = synth.scale_phenotype(synth.phenotype(X, n))
