@@ -163,7 +163,11 @@ __device__ __forceinline__ void s3_dma4s(const unsigned char *gbase, uint32_t vo
 }
 // 16 bytes per lane
 __device__ __forceinline__ void s3_dma16s(const unsigned char *gbase, uint32_t voff, uint32_t la) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(gbase), "s"(la) : "memory", "m0");
+  // (the base is wave-uniform; say so, for the callers whose pointer reaches here through a struct built in registers)
+  const unsigned long long gb_ = (unsigned long long)(uintptr_t)gbase;
+  const unsigned char *sb_ = reinterpret_cast<const unsigned char *>((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gb_) |
+                                                                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gb_ >> 32)) << 32));
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sb_), "s"(la) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 
@@ -788,7 +792,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       const GT *g2 = (G16 || use2) ? gx1_w0 + (size_t)(b + 2) * (uint32_t)(m * m) : gp;
       const unsigned char *g12b = g12_w0 + (size_t)b * (uint32_t)(m * 2 * rowbytes);
       const int l0 = lane, l1 = 64 + lane;
-      const int l1c = min(l1, m - 1);
+      const int l1c = min(l1, m - 1), l0c = min(l0, m - 1);
       // constants of this lane's two markers
       const float b0a = st.b0[l0], b0b = st.b0[l1], b2a = st.b2[l0], b2b = st.b2[l1], dra = st.drej[l0], drb = st.drej[l1];
       const float taa = st.tacc[l0], tab = st.tacc[l1], tra = st.trej[l0], trb = st.trej[l1];
@@ -824,12 +828,17 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       // blocks' dots -- after the block's last round, and when a block includes more markers than there are slots
 #define S3_APPLY_ROWS() { \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+        /* every LDS read of a slot unconditional and ahead of the first use (a read under "if (use1)" compiled into read, wait, convert, \
+           fma, read, wait, ...: four LDS round trips per slot on the chain's wave); a row that was not requested -- no next block -- holds \
+           stale 16-bit values and meets a zero coefficient */ \
         for (int i_ = 0; i_ < nslot; ++i_) { \
           const double cf_ = accC[(pos0 + napp + i_) & (ring - 1)]; \
           const uint16_t *rw1_ = reinterpret_cast<const uint16_t *>(rowx_s + (size_t)i_ * S3_ROWSLOT); \
           const uint16_t *rw2_ = rw1_ + m; \
-          if (use1) { rnext0 = fma(-(double)rw1_[min(l0, m - 1)], cf_, rnext0); rnext1 = fma(-(double)rw1_[l1c], cf_, rnext1); } \
-          if (use2) { rnxt20 = fma(-(double)rw2_[min(l0, m - 1)], cf_, rnxt20); rnxt21 = fma(-(double)rw2_[l1c], cf_, rnxt21); } \
+          const uint32_t x1a_ = rw1_[l0c], x1b_ = rw1_[l1c], x2a_ = rw2_[l0c], x2b_ = rw2_[l1c]; \
+          const double c1_ = use1 ? cf_ : 0.0, c2_ = use2 ? cf_ : 0.0; \
+          rnext0 = fma(-(double)x1a_, c1_, rnext0); rnext1 = fma(-(double)x1b_, c1_, rnext1); \
+          rnxt20 = fma(-(double)x2a_, c2_, rnxt20); rnxt21 = fma(-(double)x2b_, c2_, rnxt21); \
         } \
         napp += nslot; nslot = 0; }
 #define S3_INCLUDE(KOFF_, D1F_, DR_) { \
