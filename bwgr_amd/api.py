@@ -316,14 +316,15 @@ class Group:
     """One fused-sampler chain over several GPUs of this process (bwgr_group_*, include/bwgr.h): device g takes the g-th
     block-aligned marker shard of the host matrix X, the residual is replicated and re-united by RCCL all-reduces at the
     exchange rounds, one host thread drives everything.  devices=[d] is the plain exact chain on one GPU; more devices
-    run the partitioned sampler (statistical parity).  This is the path an R .Call takes to more than one GPU; the
+    run the partitioned sampler (sound on centred columns only: centre=True).  This is the path an R .Call takes to more than one GPU; the
     benchmark's one-process-per-GPU driver is bwgr_amd/dist.py."""
 
     def __init__(self, model, y, X, devices=(0,), it=1500, bi=500, pi=0.95, df=5.0, R2=0.5, seed=None, rng_mode=0, block=0,
                  markers_per_sync=0, centre=False):
         """centre=True sweeps x_j - mean(x_j) (a float panel): what makes more than one device statistically sound (on uncentred columns
-        the library refuses len(devices) > 1 unless BWGR_GROUP_ALLOW_UNCENTRED=1).  The posterior of b and hat is unchanged under the
-        flat intercept prior; result() gives mu back in the uncentred parametrisation, mu - sum_j mean_j b_j."""
+        the library refuses len(devices) > 1 unless BWGR_GROUP_ALLOW_UNCENTRED=1).  Centring is a reparametrisation under the
+        flat intercept prior (an exact Gibbs sampler would not notice; bWGR's own chain does a little: DESIGN.md section 8); result() gives mu back in
+        the uncentred parametrisation, mu - sum_j mean_j b_j."""
         X = np.asarray(X)
         assert X.ndim == 2
         self._xbar = None

@@ -17,8 +17,9 @@ SOUND ONLY ON CENTRED COLUMNS.  bWGR never centres X, so all columns are colline
 shard corrects the same stale residual mean and the summed corrections overshoot (4 shards: ve 15 against 1.45; DESIGN.md
 section 8).  On x_j - mean(x_j) the same driver follows the exact chain with 2, 4 and 8 shards (ve within 1-3 %, mean(d)
 equal, cor(hat) 0.994: tools/centred_shard_probe.py, tests/test_gpu_parity3.py::test_partitioned_sampler_on_centred_columns);
-centring leaves the posterior of b and hat unchanged under the samplers' flat intercept prior
-(/root/reference/src/Rcpp20260726ai.cpp:683-684).  bench_sharded therefore centres its shard (a float panel) unless told not to,
+centring is a reparametrisation under the samplers' flat intercept prior (/root/reference/src/Rcpp20260726ai.cpp:683-684) that an exact
+Gibbs sampler would not notice; bWGR's own chain does a little (ve 1.47 uncentred against 1.56 centred on the probe panel, DESIGN.md
+section 8), so "sound" means: follows the exact chain on the same centred panel.  bench_sharded therefore centres its shard (a float panel) unless told not to,
 and `statistically_sound` is computed from the panel (bwgr_panel_centred), not from the output.
 
 The driver is engine-agnostic: an engine exposes sweep_blocks / residual / set_residual / sums / end_iteration over

@@ -253,8 +253,10 @@ int bwgr_synth_genotypes(void *Xdev, int64_t n, int64_t p, int64_t ldx, int64_t 
  * reference's chain, and statistically SOUND ONLY ON CENTRED COLUMNS (x_j - mean(x_j); measured: 2 / 4 / 8 shards then follow the exact
  * chain's ve, mean(d) and hat; on uncentred genotypes -- what bWGR sweeps -- every shard corrects the same stale residual mean and the
  * sampler diverges: ve 15 against 1.45 with four shards).  bwgr_group_create therefore REFUSES G > 1 on uncentred columns (BWGR_EINVAL)
- * unless BWGR_GROUP_ALLOW_UNCENTRED=1 is set; bwgr_group_sound says which case a group is in.  Centring leaves the posterior of b and
- * hat unchanged under the samplers' flat intercept prior (src/Rcpp20260726ai.cpp:683-684); the intercept then absorbs sum_j mean_j b_j.  X is a HOST matrix (column-major n x p, ldx >= n), y n host floats; device g
+ * unless BWGR_GROUP_ALLOW_UNCENTRED=1 is set; bwgr_group_sound says which case a group is in.  Centring is a change
+ * of the model's parametrisation under the flat intercept prior (src/Rcpp20260726ai.cpp:683-684; the intercept absorbs sum_j mean_j b_j), which an
+ * exact Gibbs sampler would not notice; bWGR's own chain does, a little (its xx_j carry the squared means: DESIGN.md section 8 -- ve 1.47 uncentred
+ * against 1.56 centred on the probe panel), so "sound" here means: follows the exact chain on the SAME centred panel.  X is a HOST matrix (column-major n x p, ldx >= n), y n host floats; device g
  * of `devices` takes the block-aligned column shard g.  markers_per_sync: markers swept per device between two all-reduces
  * (0: 131072 / ndev).  bwgr_group_result returns the Bayes* return list over the whole panel (b, d, pval: p floats; vb: p
  * floats for BayesA/B/L/Dpi, else 1; hat: n floats).  info: {devices, exchange rounds per sweep, markers per round, RCCL in use}. */
