@@ -212,6 +212,12 @@ def test_group_refuses_several_shards_on_uncentred_columns(tpod, monkeypatch):
     rc = gc.result()
     gc.close()
     assert rc["statistically_sound"] is True and np.isfinite(rc["hat"]).all() and np.isfinite(rc["mu"])
+    # ... and it is the plain chain on the centred float panel, its intercept given back in the uncentred parametrisation
+    xbar = X.astype(np.float64).mean(0)
+    Xc = np.asfortranarray((X.astype(np.float64) - xbar).astype(np.float32))
+    pc = bwgr_amd.BayesB(y, Xc, it=4, bi=1, pi=0.9, seed=1)
+    assert np.array_equal(rc["d"], pc["d"]) and scaled_err(rc["b"], pc["b"]) < 1e-6 and scaled_err(rc["hat"], pc["hat"]) < 1e-6
+    assert abs(float(rc["mu"]) - (float(pc["mu"]) - float(xbar @ np.asarray(pc["b"], np.float64)))) < 1e-5 * max(1.0, abs(float(pc["mu"])))
     P = bwgr_amd.Panel(X)
     assert not P.centred()
     P.close()
