@@ -1178,7 +1178,7 @@ static int sweep3_build(bwgr_panel *P) {
   // (at least 2: a block's list leaves the sequencer while the next block is in its rounds)
   if (const char *dv = getenv("BWGR_D3")) { const int v = atoi(dv); if (v >= 2 && v <= S3_MAXD) D = v; }
   D = (int)std::min<int64_t>(D, std::max<int64_t>(2, P->nblocks));
-  const size_t lds = std::max(s3_streamer_lds(R3), s3_seq_lds(D, P->gram16));
+  const size_t lds = std::max(std::max(s3_streamer_lds(R3), s3_streamer_dma_lds()), s3_seq_lds(D, P->gram16));
   // the slab dots are summed as integers: sum over all rows of |x| * 128 per digit, four digits of 8 bits, 8 bits of arrival count
   if (K3 > 255 || K3 + 1 > 256 || lds > (size_t)160 * 1024 || (int64_t)P->ld * std::max(P->xmax, 1) >= (1ll << 23) || (size_t)m * R3 > (size_t)4 * 16 * SW_THREADS) {
     P->sweep_version = 2;
@@ -1265,6 +1265,10 @@ static void sweep3_args(bwgr_panel *P, const SweepArgs &a, Sweep3Args &A) {
   A.gx12 = root->gram16 ? root->gx12 : nullptr;
   A.pf = -1;
   if (const char *dv = getenv("BWGR_DBG3")) A.dbg = atoi(dv);
+  {   // 128-row streamers land their tiles by LDS-DMA (s3_streamer_dma; C4 15.0 -> 13.65 ms per sweep); BWGR_STREAM3=reg: through registers, as the 256-row ones do
+    const char *sv = getenv("BWGR_STREAM3");
+    if (!(sv && sv[0] == 'r')) A.dbg |= (1 << 22);
+  }
   if (SWEEP_DRY) return;
   P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1;
   A.epoch = P->epoch3;

@@ -171,6 +171,10 @@ __device__ __forceinline__ void s3_dma16s(const unsigned char *gbase, uint32_t v
 }
 #pragma clang diagnostic pop
 
+__host__ __device__ inline size_t s3_streamer_dma_lds() {   // (R3 = 128: four unpadded tiles)
+  const size_t Rp = 128 + 16;
+  return 4 * (size_t)SW_MAXM * 128 + 2 * 16 * Rp + 2 * 16 * (size_t)S2_DP + (size_t)64 * S3_OS * 4 * 4 + (size_t)8 * 32 * S3_OS * 4 + 64;
+}
 __host__ __device__ inline size_t s3_streamer_lds(int R3) {
   const size_t Rp = (size_t)R3 + 16;
   return 2 * (size_t)SW_MAXM * Rp + 2 * 16 * Rp + 2 * 16 * (size_t)S2_DP + (size_t)64 * S3_OS * 4 * 4 + (size_t)8 * 32 * S3_OS * 4 + 64;
@@ -453,6 +457,272 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
 #undef S3_TILE_ISSUE
 #undef S3_COMMIT1
 #undef S3_TILE_COMMIT
+}
+
+// The same streamer with its tiles landed by LDS-DMA (128-row streamers; BWGR_STREAM3=dma)
+__device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const SweepArgs &a = A.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m16 = lane & 15, grp = lane >> 4;
+  const int w = (int)blockIdx.x - 1 - ((A.pf >= 0 && (int)blockIdx.x > A.pf) ? 1 : 0);
+  const int m = a.m, R = a.R, D = A.D;
+  constexpr int R3 = 128, Rp = R3 + 16, NTB = 4;   // (Rp: the digit rows' stride; the tiles are unpadded)
+  const int slab = w / A.sub, hsub = w - slab * A.sub;
+  const int nb = a.blk_end - a.blk_begin;
+  constexpr int NU = R3 >> 6, ND = 8 - NU;   // update waves (64 rows each); the other waves form the dots
+  const int8_t *Xs = reinterpret_cast<const int8_t *>(a.X) + (size_t)slab * a.p * R + (size_t)hsub * R3;   // marker j: Xs + j * R
+  const int64_t row0 = (int64_t)slab * R + (int64_t)hsub * R3;
+  uint32_t *abortw = a.xflags + (size_t)a.K * SW_FLAG_STRIDE;
+  constexpr size_t tile_b = (size_t)SW_MAXM * R3;
+  int8_t *tile0 = reinterpret_cast<int8_t *>(smem);
+  size_t off = NTB * tile_b;
+  const uint32_t tile_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)smem);
+  int8_t *edig0 = reinterpret_cast<int8_t *>(smem + off); off += (size_t)2 * 16 * Rp;     // [parity][n][row]
+  int8_t *ddig0 = reinterpret_cast<int8_t *>(smem + off); off += (size_t)2 * 16 * S2_DP;  // [parity][n][marker]
+  int *outu = reinterpret_cast<int *>(smem + off); off += (size_t)64 * S3_OS * 4 * 4;     // [update wave][row 64][n]
+  int *outd = reinterpret_cast<int *>(smem + off); off += (size_t)8 * 32 * S3_OS * 4;     // [wave][marker 32][n]
+  uint32_t *ctl_s = reinterpret_cast<uint32_t *>(smem + off);                            // [0] failure, [1] overflow
+  const int sh = a.sc->e3_sh;
+  const double S = s3_pow2(sh), invS = s3_pow2(-sh);
+  auto blk_j0 = [&](int b) { return (a.blk_begin + b) * m; };
+  auto blk_m = [&](int b) { return min(m, a.p - (a.blk_begin + b) * m); };
+
+  for (int i = tid; i < (int)((2 * 16 * Rp + 2 * 16 * S2_DP) / 4); i += SW_THREADS) reinterpret_cast<uint32_t *>(edig0)[i] = 0u;   // edig0 and ddig0 are adjacent
+  if (tid < 16) ctl_s[tid] = 0u;
+  // the residual rows of update wave u: lane = row 64 u + lane
+  long long e_own = 0;
+  const bool upd = wave < NU;
+  if (upd) e_own = __double2ll_rn(a.e[row0 + 64 * wave + lane] * S);
+
+  // tile moves: LDS-DMA, sixteen 1 KiB pieces per tile (eight markers each), three per DOTS wave (the last two waves repeat piece 15: every
+  // dots wave issues the same number of requests, the wait counts rely on it).  The update waves issue none: their fold waits for a list
+  // word that is younger than anything they issued before, and the compiler -- which does not see the asm requests -- would wait them out.  Lane l of piece pc fills LDS slot (marker
+  // 8 pc + (l >> 3), position l & 7) with the marker's 16-byte chunk (l & 7) ^ ((l >> 3) & 7): chunk c of marker jj sits at position
+  // c ^ (jj & 7), so that sixteen markers' equal chunks fall on different banks without padding.  FOUR tile buffers: tile t + 3 is
+  // requested at the END of step t, into the buffer tile t - 1 left a whole step ago, and is first read after the barrier of step t + 3
+  // -- two block periods to land.  The requests are the LAST memory instructions a wave issues in a step, so that no wait for a younger
+  // load (the in-order counter) waits for them; before a step's barrier "all but the newest six" covers the tile the step reads.
+  const uint32_t lane_mk = (uint32_t)(lane >> 3), lane_ch = (uint32_t)((lane & 7) ^ ((lane >> 3) & 7));
+  const int j_lo = a.blk_begin * m, j_hi = min(a.p, a.blk_end * m);
+  auto tile_issue = [&](int t) {
+    const int jb = blk_j0(min(t, nb - 1));
+    const uint32_t la0 = tile_la + (uint32_t)__builtin_amdgcn_readfirstlane((int)((t & (NTB - 1)) * (int)tile_b));
+    const int wvs = __builtin_amdgcn_readfirstlane(wave);   // (a scalar: the LDS address goes into M0)
+    if (wvs < NU) return;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int pc = min(wvs - NU + ND * u, 15);
+      const int jj = min(jb + 8 * pc + (int)lane_mk, j_hi - 1);
+      const uint32_t voff = (uint32_t)(jj - j_lo) * (uint32_t)R + lane_ch * 16u;   // (a launch's slab of the panel stays below 4 GiB: checked on the host)
+      s3_dma16s(reinterpret_cast<const unsigned char *>(Xs + (size_t)j_lo * R), voff, la0 + (uint32_t)pc * 1024u);
+    }
+  };
+
+  // the included markers of block bs (relative index): e -= x_k * corr_k for this wave's rows.  `pre` holds words 0..63 of
+  // the list as requested one iteration ago (a list of up to 31 entries arrives with that single load)
+  auto fold_list = [&](int bs, unsigned long long pre) -> int {
+    const int Bs = a.blk_begin + bs;
+    const unsigned long long *L = A.lists + (size_t)Bs * S3_LSTRIDE;
+    const int8_t *col = Xs + (size_t)(Bs * m) * R + 64 * wave + lane;
+    const uint64_t t0 = wall_clock64();
+    unsigned spins = 0;
+    unsigned long long hv = __builtin_amdgcn_readfirstlane((uint32_t)pre) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(pre >> 32)) << 32);
+    while (!s3_epoch_is(hv, A.epoch)) {
+      hv = ld_agent_raw64(L);
+      hv = __builtin_amdgcn_readfirstlane((uint32_t)hv) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(hv >> 32)) << 32);
+      if (s3_epoch_is(hv, A.epoch)) break;
+      if ((++spins & 63u) == 0u) {
+        if (ld_agent_u32(abortw) != 0u) return 0;
+        if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const int cnt = (int)(uint32_t)hv;
+    for (int c0 = 0; c0 < cnt; c0 += 31) {                 // 31 entries per pass: words 1 + 2 c0 .. of the list, one per lane
+      const int nw = min(62, 2 * (cnt - c0));
+      unsigned long long wv = pre;                          // pass 0: lane i holds word i (header in lane 0)
+      bool have = (c0 == 0);
+      for (;;) {
+        const bool mine = lane >= 1 && lane <= nw;
+        if (!have) wv = mine ? ld_agent_raw64(L + 2 * c0 + lane) : 0ull;
+        if (__ballot(mine && !s3_epoch_is(wv, A.epoch)) == 0ull) break;
+        have = false;
+        if ((++spins & 63u) == 0u) {
+          if (ld_agent_u32(abortw) != 0u) return 0;
+          if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const uint32_t wlo = (uint32_t)wv, whi = (uint32_t)(wv >> 32);
+      for (int e0 = 0; e0 < nw / 2; e0 += 8) {              // eight columns in flight
+        int xb[8]; long long cq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ee = min(e0 + u, nw / 2 - 1);
+          const uint32_t a0 = __builtin_amdgcn_readlane(wlo, 1 + 2 * ee), a1 = __builtin_amdgcn_readlane(whi, 1 + 2 * ee);
+          const uint32_t b0 = __builtin_amdgcn_readlane(wlo, 2 + 2 * ee);
+          const int k = (int)(a1 & 0xFFu);
+          cq[u] = (e0 + u < nw / 2) ? (long long)(((unsigned long long)b0 << 32) | (unsigned long long)a0) : 0ll;
+          xb[u] = upd ? (int)col[(size_t)k * R] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e_own -= (long long)xb[u] * cq[u];
+      }
+    }
+    return 1;
+  };
+
+  // ---- prologue: tiles 0, 1, 2 requested ----
+  tile_issue(0); tile_issue(1); tile_issue(2);
+  float drej_pre = a.ps.blocks[a.blk_begin].drej[tid & (SW_MAXM - 1)];   // (used by the last two waves)
+  unsigned long long lpre = 0ull;
+  __syncthreads();
+  S3ST_DECL;
+  const bool st_u = (w == 0 && tid == 0), st_d = (w == 0 && tid == 64 * NU);
+
+  auto step = [&](int b) -> bool {
+    const int mB = blk_m(b), par = b & 1;
+    S3ST(0, st_u || st_d);
+    int8_t *tile = tile0 + (size_t)(b & (NTB - 1)) * tile_b;
+    int8_t *edig = edig0 + (size_t)par * 16 * Rp;
+    int8_t *ddig = ddig0 + (size_t)par * 16 * S2_DP;
+    // A: what the included markers of block b - D changed
+    if (b >= D && upd && !(A.dbg & 512)) { if (!fold_list(b - D, lpre)) ctl_s[0] = 1u; }
+    S3ST(1, st_u);
+    // B: digits of the residual rows and of this block's rejected steps
+    if (upd) {
+      if ((unsigned long long)(e_own + (1ll << 54)) >> 55) ctl_s[1] = 1u;       // left the 55-bit range
+      s3_put_digits7(e_own, edig + 64 * wave + lane, Rp);
+    } else if (tid >= SW_THREADS - SW_MAXM) {                                    // the last two waves (never update waves)
+      const double qd = (tid - (SW_THREADS - SW_MAXM) < mB) ? rint((double)drej_pre * S) : 0.0;   // (unused markers: zero steps)
+      if (!(fabs(qd) < 18014398509481984.0)) ctl_s[1] = 1u;                      // 2^54
+      s3_put_digits7((long long)qd, ddig + (tid - (SW_THREADS - SW_MAXM)), S2_DP);
+    }
+    S3ST(2, st_u);
+#if defined(BWGR_STAMPS) && BWGR_STAMPS == 2
+    S3ST(0, st_u || st_d);                      // lite: slot 0 = busy (barrier exit .. barrier entry), slot 4 = waiting at the barrier
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    S3ST(4, st_u || st_d);
+#else
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    S3ST(3, st_u || st_d);
+#endif
+    if (ctl_s[0]) { if (tid == 0) a.sc->error = 1u; return false; }
+    // C: tile b+1 (in registers for two iterations) lands in the other buffer, whose last reader was block b-1; the loads of
+    // tile b+3 go out into the registers just freed; the list of block b+1-D and the rejected steps of block b+1 are requested
+    S3ST(6, st_u || st_d);
+    {   // the small requests first (older than the tile loads on the in-order memory counter, so waiting for them does not wait
+        // for the tile), every one unconditional: a load under a branch makes the compiler drain the counter in front of it
+      const int bn1 = min(b + 1, nb - 1);
+      drej_pre = a.ps.blocks[a.blk_begin + bn1].drej[tid & (SW_MAXM - 1)];
+      lpre = ld_agent_raw64(A.lists + (size_t)(a.blk_begin + max(bn1 - D, 0)) * S3_LSTRIDE + lane);
+    }
+    S3ST(7, st_u || st_d);
+    S3ST(4, st_u || st_d);
+    if (upd) {
+      // ---- slab update with the rejected steps: out[row][n] = sum_markers x[row][marker] * digit_n(drej[marker]) ----
+      // lane (m16, grp): row quad 16 wave + m16 (rows 4 * that + k for accumulator k); k slots (dword u, byte q) of step s0 are the
+      // markers s0 + 16 u + 4 grp + q (the interleave keeps the four lane groups on different LDS banks)
+      const int rowoff = 4 * (16 * wave + m16);
+      s2_v4i acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+      for (int s0 = 0; s0 < ((A.dbg & 256) ? 0 : mB); s0 += 64) {
+        // marker s0 + 16 u + 4 grp + q: its chunk rowoff / 16 sits at position (rowoff / 16) ^ ((4 grp + q) & 7)
+        const int8_t *tp = tile + (s0 + 4 * grp) * R3 + (rowoff & 15);
+        uint32_t c[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            c[u][q] = *reinterpret_cast<const uint32_t *>(tp + (16 * u + q) * R3 + (((rowoff >> 4) ^ ((4 * grp + q) & 7)) << 4));
+        const int8_t *bp = ddig + (size_t)m16 * S2_DP + s0 + 4 * grp;
+        const s2_v4i bv = {*reinterpret_cast<const int *>(bp), *reinterpret_cast<const int *>(bp + 16),
+                           *reinterpret_cast<const int *>(bp + 32), *reinterpret_cast<const int *>(bp + 48)};
+        uint32_t rw[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t t0 = __builtin_amdgcn_perm(c[u][1], c[u][0], 0x05010400u), t1 = __builtin_amdgcn_perm(c[u][1], c[u][0], 0x07030602u);
+          const uint32_t t2 = __builtin_amdgcn_perm(c[u][3], c[u][2], 0x05010400u), t3 = __builtin_amdgcn_perm(c[u][3], c[u][2], 0x07030602u);
+          rw[0][u] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); rw[1][u] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+          rw[2][u] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); rw[3][u] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+        }
+        acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[0][0], (int)rw[0][1], (int)rw[0][2], (int)rw[0][3]}, bv, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[1][0], (int)rw[1][1], (int)rw[1][2], (int)rw[1][3]}, bv, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[2][0], (int)rw[2][1], (int)rw[2][2], (int)rw[2][3]}, bv, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[3][0], (int)rw[3][1], (int)rw[3][2], (int)rw[3][3]}, bv, acc3, 0, 0, 0);
+      }
+      int *ou = outu + (size_t)wave * 64 * S3_OS;
+      if (m16 < 8) {      // lane: digit n = m16; acc_k[reg] belongs to local row 4 (4 grp + reg) + k
+        int *op = ou + (size_t)(4 * (4 * grp)) * S3_OS + m16;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          op[(4 * reg + 0) * S3_OS] = acc0[reg]; op[(4 * reg + 1) * S3_OS] = acc1[reg];
+          op[(4 * reg + 2) * S3_OS] = acc2[reg]; op[(4 * reg + 3) * S3_OS] = acc3[reg];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes (in order; no other wave reads this scratch)
+      {
+        const int4 o0 = *reinterpret_cast<const int4 *>(ou + (size_t)lane * S3_OS);
+        const int4 o1 = *reinterpret_cast<const int4 *>(ou + (size_t)lane * S3_OS + 4);
+        long long v = (long long)o0.x + ((long long)o0.y << 8) + ((long long)o0.z << 16) + ((long long)o0.w << 24);
+        v += ((long long)o1.x << 32) + ((long long)o1.y << 40) + ((long long)o1.z << 48);
+        e_own -= v;
+      }
+      S3ST(5, st_u);
+    } else {
+      // ---- slab dots of block b against the digits of e: markers in groups of 16, groups gm and gm + ND together on wave
+      // NU + gm (the two groups' MFMAs, LDS round trips and atomics overlap) ----
+      for (int gm = wave - NU; 16 * gm < m; gm += 2 * ND) {
+        const int gm2 = gm + ND;
+        const bool two = 16 * gm2 < m;
+        const int8_t *bp = edig + (size_t)m16 * Rp + 16 * grp;
+        const int8_t *ap = tile + (size_t)(16 * gm + m16) * R3;           // (both groups' markers have jj & 7 = m16 & 7)
+        const int8_t *ap2 = tile + (size_t)(16 * (two ? gm2 : gm) + m16) * R3;
+        s2_v4i acc = {0, 0, 0, 0}, acc2 = acc;
+        for (int r = 0; r < ((A.dbg & 256) ? 0 : R3); r += 64) {
+          const s2_v4i bv = *reinterpret_cast<const s2_v4i *>(bp + r);
+          const int so = (((grp + (r >> 4)) ^ (m16 & 7)) << 4);   // rows r + 16 grp .. + 15 = chunk grp + r / 16
+          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap + so), bv, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap2 + so), bv, acc2, 0, 0, 0);
+        }
+        int *od = outd + (size_t)wave * 32 * S3_OS;
+        if (m16 < 8) {      // lane: digit n = m16 of markers 16 gm + 4 grp + reg (rows 0..15 of the scratch) and of group gm2 (rows 16..31)
+          int *op = od + (size_t)(4 * grp) * S3_OS + m16;
+          op[0] = acc[0]; op[S3_OS] = acc[1]; op[2 * S3_OS] = acc[2]; op[3 * S3_OS] = acc[3];
+          op[16 * S3_OS] = acc2[0]; op[17 * S3_OS] = acc2[1]; op[18 * S3_OS] = acc2[2]; op[19 * S3_OS] = acc2[3];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < (two ? 32 : 16)) {
+          const int4 o0 = *reinterpret_cast<const int4 *>(od + (size_t)lane * S3_OS);
+          const int4 o1 = *reinterpret_cast<const int4 *>(od + (size_t)lane * S3_OS + 4);
+          const long long lo = (long long)o0.x + ((long long)o0.y << 8) + ((long long)o0.z << 16);
+          const long long hi = (long long)o0.w + ((long long)o1.x << 8) + ((long long)o1.y << 16) + ((long long)o1.z << 24);
+          const int mk = 16 * ((lane < 16) ? gm : gm2) + (lane & 15);
+          unsigned long long *qs = A.qsum + ((size_t)(a.blk_begin + b) * SW_MAXM + mk) * 2;
+          if (!(A.dbg & 8)) {
+          __hip_atomic_fetch_add((gu64_t *)qs, (unsigned long long)((lo << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add((gu64_t *)(qs + 1), (unsigned long long)((hi << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch is read before the next pass overwrites it
+      }
+      S3ST(5, st_d);
+    }
+    tile_issue(b + 3);   // (always: the wait counts rely on it; past the end the last tile again)
+    return true;
+  };
+  for (int b = 0; b < nb; ++b) if (!step(b)) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the requests past the end)
+  S3ST_FLUSH(0, st_u); S3ST_FLUSH(8, st_d);
+  // the lists of the last D blocks
+  if (upd && !(A.dbg & 512)) for (int bs = max(0, nb - D); bs < nb; ++bs) {
+    if (!fold_list(bs, 0ull)) { ctl_s[0] = 1u; break; }
+  }
+  if (upd && ((unsigned long long)(e_own + (1ll << 54)) >> 55)) ctl_s[1] = 1u;
+  __syncthreads();
+  if (ctl_s[0]) { if (tid == 0) a.sc->error = 1u; return; }
+  if (ctl_s[1] && tid == 0) a.sc->error = 2u;
+  if (upd) a.e[row0 + 64 * wave + lane] = (double)e_own * invS;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -985,7 +1255,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep3(const Sweep3Args A) {
   if ((int)blockIdx.x == A.pf) { s3_prefetcher<GT>(A); return; }
   if (blockIdx.x == 0) { if (!(A.dbg & 1024)) s3_sequencer<GT>(A); }
   else if ((A.a.flags & SWF_DEBUG_WITHHOLD) && blockIdx.x == 1 && A.pf != 1) return;   // test hook: a streamer that never shows up
-  else if (!(A.dbg & 2048)) s3_streamer(A);   // (a second streamer whose every load was inline asm with hand-counted waits measured no faster and was removed: DESIGN 9.0)
+  else if (A.dbg & 2048) return;
+  else if ((A.dbg & (1 << 22)) && A.R3 == 128) s3_streamer_dma(A);
+  else s3_streamer(A);   // (a second streamer whose every load was inline asm with hand-counted waits measured no faster and was removed: DESIGN 9.0)
 }
 
 }  // namespace bwgr
