@@ -1178,7 +1178,7 @@ static int sweep3_build(bwgr_panel *P) {
   // (at least 2: a block's list leaves the sequencer while the next block is in its rounds)
   if (const char *dv = getenv("BWGR_D3")) { const int v = atoi(dv); if (v >= 2 && v <= S3_MAXD) D = v; }
   D = (int)std::min<int64_t>(D, std::max<int64_t>(2, P->nblocks));
-  const size_t lds = std::max(std::max(s3_streamer_lds(R3), s3_streamer_dma_lds()), s3_seq_lds(D, P->gram16));
+  const size_t lds = std::max(std::max(s3_streamer_lds(R3), std::max(s3_streamer_dma_lds(128), R3 == 256 ? s3_streamer_dma_lds(256) : (size_t)0)), s3_seq_lds(D, P->gram16));
   // the slab dots are summed as integers: sum over all rows of |x| * 128 per digit, four digits of 8 bits, 8 bits of arrival count
   if (K3 > 255 || K3 + 1 > 256 || lds > (size_t)160 * 1024 || (int64_t)P->ld * std::max(P->xmax, 1) >= (1ll << 23) || (size_t)m * R3 > (size_t)4 * 16 * SW_THREADS) {
     P->sweep_version = 2;
@@ -1268,6 +1268,7 @@ static void sweep3_args(bwgr_panel *P, const SweepArgs &a, Sweep3Args &A) {
   {   // 128-row streamers land their tiles by LDS-DMA (s3_streamer_dma; C4 15.0 -> 13.65 ms per sweep); BWGR_STREAM3=reg: through registers, as the 256-row ones do
     const char *sv = getenv("BWGR_STREAM3");
     if (!(sv && sv[0] == 'r')) A.dbg |= (1 << 22);
+    if (sv && sv[0] == 'd') A.dbg |= (1 << 23);   // (EXPERIMENT: the 256-row streamers too, three tile buffers)
   }
   if (SWEEP_DRY) return;
   P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1;

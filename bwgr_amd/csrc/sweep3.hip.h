@@ -171,9 +171,9 @@ __device__ __forceinline__ void s3_dma16s(const unsigned char *gbase, uint32_t v
 }
 #pragma clang diagnostic pop
 
-__host__ __device__ inline size_t s3_streamer_dma_lds() {   // (R3 = 128: four unpadded tiles)
-  const size_t Rp = 128 + 16;
-  return 4 * (size_t)SW_MAXM * 128 + 2 * 16 * Rp + 2 * 16 * (size_t)S2_DP + (size_t)64 * S3_OS * 4 * 4 + (size_t)8 * 32 * S3_OS * 4 + 64;
+__host__ __device__ inline size_t s3_streamer_dma_lds(int R3 = 128) {   // (four unpadded tiles at 128 rows, three at 256)
+  const size_t Rp = (size_t)R3 + 16;
+  return (R3 == 128 ? 4 : 3) * (size_t)SW_MAXM * R3 + 2 * 16 * Rp + 2 * 16 * (size_t)S2_DP + (size_t)64 * S3_OS * 4 * 4 + (size_t)8 * 32 * S3_OS * 4 + 64;
 }
 __host__ __device__ inline size_t s3_streamer_lds(int R3) {
   const size_t Rp = (size_t)R3 + 16;
@@ -460,6 +460,7 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
 }
 
 // The same streamer with its tiles landed by LDS-DMA (128-row streamers; BWGR_STREAM3=dma)
+template <int R3, int NTB>
 __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const SweepArgs &a = A.a;
@@ -467,7 +468,11 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   const int m16 = lane & 15, grp = lane >> 4;
   const int w = (int)blockIdx.x - 1 - ((A.pf >= 0 && (int)blockIdx.x > A.pf) ? 1 : 0);
   const int m = a.m, R = a.R, D = A.D;
-  constexpr int R3 = 128, Rp = R3 + 16, NTB = 4;   // (Rp: the digit rows' stride; the tiles are unpadded)
+  constexpr int Rp = R3 + 16;         // (the digit rows' stride; the tiles are unpadded)
+  constexpr int CH = R3 / 16;         // 16-byte chunks per marker
+  constexpr int MPP = 1024 / R3;      // markers per 1 KiB piece
+  constexpr int NPC = SW_MAXM / MPP;  // pieces per tile
+  static_assert(R3 == 128 || R3 == 256, "sixteen or thirty-two pieces");
   const int slab = w / A.sub, hsub = w - slab * A.sub;
   const int nb = a.blk_end - a.blk_begin;
   constexpr int NU = R3 >> 6, ND = 8 - NU;   // update waves (64 rows each); the other waves form the dots
@@ -495,26 +500,28 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   const bool upd = wave < NU;
   if (upd) e_own = __double2ll_rn(a.e[row0 + 64 * wave + lane] * S);
 
-  // tile moves: LDS-DMA, sixteen 1 KiB pieces per tile (eight markers each), three per DOTS wave (the last two waves repeat piece 15: every
-  // dots wave issues the same number of requests, the wait counts rely on it).  The update waves issue none: their fold waits for a list
+  // tile moves: LDS-DMA, NPC 1 KiB pieces per tile (MPP markers each), PPW per DOTS wave (128 rows: sixteen pieces over six waves, the last
+  // two waves repeat piece 15; 256 rows: thirty-two over four: every dots wave issues the same number of requests, the wait counts rely on it).  The update waves issue none: their fold waits for a list
   // word that is younger than anything they issued before, and the compiler -- which does not see the asm requests -- would wait them out.  Lane l of piece pc fills LDS slot (marker
   // 8 pc + (l >> 3), position l & 7) with the marker's 16-byte chunk (l & 7) ^ ((l >> 3) & 7): chunk c of marker jj sits at position
-  // c ^ (jj & 7), so that sixteen markers' equal chunks fall on different banks without padding.  FOUR tile buffers: tile t + 3 is
-  // requested at the END of step t, into the buffer tile t - 1 left a whole step ago, and is first read after the barrier of step t + 3
-  // -- two block periods to land.  The requests are the LAST memory instructions a wave issues in a step, so that no wait for a younger
-  // load (the in-order counter) waits for them; before a step's barrier "all but the newest six" covers the tile the step reads.
-  const uint32_t lane_mk = (uint32_t)(lane >> 3), lane_ch = (uint32_t)((lane & 7) ^ ((lane >> 3) & 7));
+  // c ^ (jj & (CH - 1)), so that sixteen markers' equal chunks fall on different banks without padding.  NTB tile buffers: tile t + NTB - 1
+  // is requested at the END of step t, into the buffer tile t - 1 left a whole step ago, and is first read after the barrier of step
+  // t + NTB - 1 -- NTB - 2 block periods (and the rest of a step) to land; four buffers at 128 rows, three (96 KB) at 256.  The requests are the LAST memory instructions a wave issues in a step, so that no wait for a younger
+  // load (the in-order counter) waits for them; before a step's barrier a counted wait (S3_DMA_BARRIER) covers the tile the step reads.
+  constexpr int PPW = (NPC + ND - 1) / ND;
+  const uint32_t lane_mk = (uint32_t)(lane / CH), lane_cr = (uint32_t)(lane % CH);
   const int j_lo = a.blk_begin * m, j_hi = min(a.p, a.blk_end * m);
   auto tile_issue = [&](int t) {
     const int jb = blk_j0(min(t, nb - 1));
-    const uint32_t la0 = tile_la + (uint32_t)__builtin_amdgcn_readfirstlane((int)((t & (NTB - 1)) * (int)tile_b));
+    const uint32_t la0 = tile_la + (uint32_t)__builtin_amdgcn_readfirstlane((int)((t % NTB) * (int)tile_b));
     const int wvs = __builtin_amdgcn_readfirstlane(wave);   // (a scalar: the LDS address goes into M0)
     if (wvs < NU) return;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int pc = min(wvs - NU + ND * u, 15);
-      const int jj = min(jb + 8 * pc + (int)lane_mk, j_hi - 1);
-      const uint32_t voff = (uint32_t)(jj - j_lo) * (uint32_t)R + lane_ch * 16u;   // (a launch's slab of the panel stays below 4 GiB: checked on the host)
+    for (int u = 0; u < PPW; ++u) {
+      const int pc = min(wvs - NU + ND * u, NPC - 1);
+      const int jl = MPP * pc + (int)lane_mk;                      // the marker's index in the tile
+      const int jj = min(jb + jl, j_hi - 1);
+      const uint32_t voff = (uint32_t)(jj - j_lo) * (uint32_t)R + ((lane_cr ^ ((uint32_t)jl & (uint32_t)(CH - 1))) * 16u);   // (a launch's slab of the panel stays below 4 GiB: checked on the host)
       s3_dma16s(reinterpret_cast<const unsigned char *>(Xs + (size_t)j_lo * R), voff, la0 + (uint32_t)pc * 1024u);
     }
   };
@@ -574,17 +581,23 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   };
 
   // ---- prologue: tiles 0, 1, 2 requested ----
-  tile_issue(0); tile_issue(1); tile_issue(2);
+  for (int t = 0; t < NTB - 1; ++t) tile_issue(t);
   float drej_pre = a.ps.blocks[a.blk_begin].drej[tid & (SW_MAXM - 1)];   // (used by the last two waves)
   unsigned long long lpre = 0ull;
   __syncthreads();
   S3ST_DECL;
   const bool st_u = (w == 0 && tid == 0), st_d = (w == 0 && tid == 64 * NU);
 
+  // Before a step's barrier the tile the step reads must have landed.  Loads (the DMA requests are loads) return in order among themselves,
+  // so "at most WN outstanding", with WN = the loads a dots wave issues in NTB - 2 steps (per step: two small requests and PPW pieces), holds only
+  // once every load older than those -- the step's tile among them -- is back, whatever the atomics (no order against loads) are doing; and it
+  // leaves the younger tiles in flight.  (The update waves issue no pieces: the count is harmless there.)
+  constexpr int WN = (NTB - 2) * (PPW + 2);
+#define S3_DMA_BARRIER() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"(WN) : "memory")
   auto step = [&](int b) -> bool {
     const int mB = blk_m(b), par = b & 1;
     S3ST(0, st_u || st_d);
-    int8_t *tile = tile0 + (size_t)(b & (NTB - 1)) * tile_b;
+    int8_t *tile = tile0 + (size_t)(b % NTB) * tile_b;
     int8_t *edig = edig0 + (size_t)par * 16 * Rp;
     int8_t *ddig = ddig0 + (size_t)par * 16 * S2_DP;
     // A: what the included markers of block b - D changed
@@ -602,10 +615,10 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
     S3ST(2, st_u);
 #if defined(BWGR_STAMPS) && BWGR_STAMPS == 2
     S3ST(0, st_u || st_d);                      // lite: slot 0 = busy (barrier exit .. barrier entry), slot 4 = waiting at the barrier
-    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    S3_DMA_BARRIER();
     S3ST(4, st_u || st_d);
 #else
-    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    S3_DMA_BARRIER();
     S3ST(3, st_u || st_d);
 #endif
     if (ctl_s[0]) { if (tid == 0) a.sc->error = 1u; return false; }
@@ -627,14 +640,14 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
       const int rowoff = 4 * (16 * wave + m16);
       s2_v4i acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
       for (int s0 = 0; s0 < ((A.dbg & 256) ? 0 : mB); s0 += 64) {
-        // marker s0 + 16 u + 4 grp + q: its chunk rowoff / 16 sits at position (rowoff / 16) ^ ((4 grp + q) & 7)
+        // marker s0 + 16 u + 4 grp + q: its chunk rowoff / 16 sits at position (rowoff / 16) ^ ((4 grp + q) & (CH - 1))
         const int8_t *tp = tile + (s0 + 4 * grp) * R3 + (rowoff & 15);
         uint32_t c[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            c[u][q] = *reinterpret_cast<const uint32_t *>(tp + (16 * u + q) * R3 + (((rowoff >> 4) ^ ((4 * grp + q) & 7)) << 4));
+            c[u][q] = *reinterpret_cast<const uint32_t *>(tp + (16 * u + q) * R3 + (((rowoff >> 4) ^ ((4 * grp + q) & (CH - 1))) << 4));
         const int8_t *bp = ddig + (size_t)m16 * S2_DP + s0 + 4 * grp;
         const s2_v4i bv = {*reinterpret_cast<const int *>(bp), *reinterpret_cast<const int *>(bp + 16),
                            *reinterpret_cast<const int *>(bp + 32), *reinterpret_cast<const int *>(bp + 48)};
@@ -676,12 +689,12 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
         const int gm2 = gm + ND;
         const bool two = 16 * gm2 < m;
         const int8_t *bp = edig + (size_t)m16 * Rp + 16 * grp;
-        const int8_t *ap = tile + (size_t)(16 * gm + m16) * R3;           // (both groups' markers have jj & 7 = m16 & 7)
+        const int8_t *ap = tile + (size_t)(16 * gm + m16) * R3;           // (both groups' markers have jj & 15 = m16)
         const int8_t *ap2 = tile + (size_t)(16 * (two ? gm2 : gm) + m16) * R3;
         s2_v4i acc = {0, 0, 0, 0}, acc2 = acc;
         for (int r = 0; r < ((A.dbg & 256) ? 0 : R3); r += 64) {
           const s2_v4i bv = *reinterpret_cast<const s2_v4i *>(bp + r);
-          const int so = (((grp + (r >> 4)) ^ (m16 & 7)) << 4);   // rows r + 16 grp .. + 15 = chunk grp + r / 16
+          const int so = (((grp + (r >> 4)) ^ (m16 & (CH - 1))) << 4);   // rows r + 16 grp .. + 15 = chunk grp + r / 16
           acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap + so), bv, acc, 0, 0, 0);
           acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap2 + so), bv, acc2, 0, 0, 0);
         }
@@ -708,11 +721,12 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
       }
       S3ST(5, st_d);
     }
-    tile_issue(b + 3);   // (always: the wait counts rely on it; past the end the last tile again)
+    tile_issue(b + NTB - 1);   // (always: the wait counts rely on it; past the end the last tile again)
     return true;
   };
   for (int b = 0; b < nb; ++b) if (!step(b)) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the requests past the end)
+#undef S3_DMA_BARRIER
   S3ST_FLUSH(0, st_u); S3ST_FLUSH(8, st_d);
   // the lists of the last D blocks
   if (upd && !(A.dbg & 512)) for (int bs = max(0, nb - D); bs < nb; ++bs) {
@@ -1256,7 +1270,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep3(const Sweep3Args A) {
   if (blockIdx.x == 0) { if (!(A.dbg & 1024)) s3_sequencer<GT>(A); }
   else if ((A.a.flags & SWF_DEBUG_WITHHOLD) && blockIdx.x == 1 && A.pf != 1) return;   // test hook: a streamer that never shows up
   else if (A.dbg & 2048) return;
-  else if ((A.dbg & (1 << 22)) && A.R3 == 128) s3_streamer_dma(A);
+  else if ((A.dbg & (1 << 22)) && !(A.dbg & (1 << 23)) && A.R3 == 128) s3_streamer_dma<128, 4>(A);
+  else if ((A.dbg & (1 << 23)) && A.R3 == 128) s3_streamer_dma<128, 3>(A);
   else s3_streamer(A);   // (a second streamer whose every load was inline asm with hand-counted waits measured no faster and was removed: DESIGN 9.0)
 }
 
