@@ -637,40 +637,43 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
       // ---- slab update with the rejected steps: out[row][n] = sum_markers x[row][marker] * digit_n(drej[marker]) ----
       // lane (m16, grp): row quad 16 wave + m16 (rows 4 * that + k for accumulator k); k slots (dword u, byte q) of step s0 are the
       // markers s0 + 16 u + 4 grp + q (the interleave keeps the four lane groups on different LDS banks)
-      const int rowoff = 4 * (16 * wave + m16);
+      // The A operand is x[row][marker] with the markers as the MFMA's k, and the tile is [marker][row]: gfx950's transposing LDS read
+      // (ds_read_b64_tr_b8: per sixteen lanes a block of 8 LDS rows x 16 bytes; lane 2 q + p supplies the address of row q, bytes 8 p .. 8 p + 7;
+      // lane i receives byte i of the eight rows) hands lane (m16, grp) row m16 of a 16-row chunk for eight markers at once -- two reads per
+      // operand instead of sixteen dword reads and thirty-two byte permutes.  Accumulator k holds rows 64 wave + 16 k + m16 (chunk 4 wave + k of a
+      // marker's bytes, at position chunk ^ (marker & 7) in the swizzled tile); the k slots (lane group grp, byte t of the operand) are the markers
+      // s0 + 16 grp + t, and the B operand -- the steps' digits -- is read in the same order (one b128 read).  EXEC is all ones here (a wave-uniform
+      // branch): the gather crosses lanes.
       s2_v4i acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+      const uint32_t tile_lds = tile_la + (uint32_t)((b % NTB) * (int)tile_b);
+      const uint32_t q8 = (uint32_t)((lane & 15) >> 1), p8 = (uint32_t)(lane & 1);
+      const uint32_t cw = (uint32_t)(4 * wave);
       for (int s0 = 0; s0 < ((A.dbg & 256) ? 0 : mB); s0 += 64) {
-        // marker s0 + 16 u + 4 grp + q: its chunk rowoff / 16 sits at position (rowoff / 16) ^ ((4 grp + q) & (CH - 1))
-        const int8_t *tp = tile + (s0 + 4 * grp) * R3 + (rowoff & 15);
-        uint32_t c[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            c[u][q] = *reinterpret_cast<const uint32_t *>(tp + (16 * u + q) * R3 + (((rowoff >> 4) ^ ((4 * grp + q) & (CH - 1))) << 4));
-        const int8_t *bp = ddig + (size_t)m16 * S2_DP + s0 + 4 * grp;
-        const s2_v4i bv = {*reinterpret_cast<const int *>(bp), *reinterpret_cast<const int *>(bp + 16),
-                           *reinterpret_cast<const int *>(bp + 32), *reinterpret_cast<const int *>(bp + 48)};
-        uint32_t rw[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t t0 = __builtin_amdgcn_perm(c[u][1], c[u][0], 0x05010400u), t1 = __builtin_amdgcn_perm(c[u][1], c[u][0], 0x07030602u);
-          const uint32_t t2 = __builtin_amdgcn_perm(c[u][3], c[u][2], 0x05010400u), t3 = __builtin_amdgcn_perm(c[u][3], c[u][2], 0x07030602u);
-          rw[0][u] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); rw[1][u] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
-          rw[2][u] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); rw[3][u] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
-        }
-        acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[0][0], (int)rw[0][1], (int)rw[0][2], (int)rw[0][3]}, bv, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[1][0], (int)rw[1][1], (int)rw[1][2], (int)rw[1][3]}, bv, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[2][0], (int)rw[2][1], (int)rw[2][2], (int)rw[2][3]}, bv, acc2, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{(int)rw[3][0], (int)rw[3][1], (int)rw[3][2], (int)rw[3][3]}, bv, acc3, 0, 0, 0);
+        const uint32_t rowA = tile_lds + (uint32_t)(s0 + 16 * grp + (int)q8) * (uint32_t)R3 + 8u * p8;   // markers s0 + 16 grp + q8 and + 8 (both have marker & 7 = q8)
+        const uint32_t a0 = rowA + ((((cw + 0u) ^ q8) & (uint32_t)(CH - 1)) << 4), a1 = rowA + ((((cw + 1u) ^ q8) & (uint32_t)(CH - 1)) << 4);
+        const uint32_t a2 = rowA + ((((cw + 2u) ^ q8) & (uint32_t)(CH - 1)) << 4), a3 = rowA + ((((cw + 3u) ^ q8) & (uint32_t)(CH - 1)) << 4);
+        typedef int s3_v2i __attribute__((ext_vector_type(2)));
+        s3_v2i x0, x1, x2, x3, y0, y1, y2, y3;
+        asm volatile("ds_read_b64_tr_b8 %0, %8\n\tds_read_b64_tr_b8 %4, %8 offset:1024\n\t"
+                     "ds_read_b64_tr_b8 %1, %9\n\tds_read_b64_tr_b8 %5, %9 offset:1024\n\t"
+                     "ds_read_b64_tr_b8 %2, %10\n\tds_read_b64_tr_b8 %6, %10 offset:1024\n\t"
+                     "ds_read_b64_tr_b8 %3, %11\n\tds_read_b64_tr_b8 %7, %11 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+        static_assert(R3 == 128, "offset:1024 = eight markers of 128 bytes");
+        const s2_v4i bv = *reinterpret_cast<const s2_v4i *>(ddig + (size_t)m16 * S2_DP + s0 + 16 * grp);
+        acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{x0[0], x0[1], y0[0], y0[1]}, bv, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{x1[0], x1[1], y1[0], y1[1]}, bv, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{x2[0], x2[1], y2[0], y2[1]}, bv, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(s2_v4i{x3[0], x3[1], y3[0], y3[1]}, bv, acc3, 0, 0, 0);
       }
       int *ou = outu + (size_t)wave * 64 * S3_OS;
-      if (m16 < 8) {      // lane: digit n = m16; acc_k[reg] belongs to local row 4 (4 grp + reg) + k
-        int *op = ou + (size_t)(4 * (4 * grp)) * S3_OS + m16;
+      if (m16 < 8) {      // lane: digit n = m16; acc_k[reg] belongs to local row 16 k + 4 grp + reg
+        int *op = ou + (size_t)(4 * grp) * S3_OS + m16;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          op[(4 * reg + 0) * S3_OS] = acc0[reg]; op[(4 * reg + 1) * S3_OS] = acc1[reg];
-          op[(4 * reg + 2) * S3_OS] = acc2[reg]; op[(4 * reg + 3) * S3_OS] = acc3[reg];
+          op[(reg + 0) * S3_OS] = acc0[reg]; op[(reg + 16) * S3_OS] = acc1[reg];
+          op[(reg + 32) * S3_OS] = acc2[reg]; op[(reg + 48) * S3_OS] = acc3[reg];
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes (in order; no other wave reads this scratch)
