@@ -622,6 +622,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
     S3ST(3, st_u || st_d);
 #endif
     if (ctl_s[0]) { if (tid == 0) a.sc->error = 1u; return false; }
+    tile_issue(b + NTB - 1);   // (always: the wait counts rely on it; past the end the last tile again)
     // C: tile b+1 (in registers for two iterations) lands in the other buffer, whose last reader was block b-1; the loads of
     // tile b+3 go out into the registers just freed; the list of block b+1-D and the rejected steps of block b+1 are requested
     S3ST(6, st_u || st_d);
@@ -724,7 +725,6 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
       }
       S3ST(5, st_d);
     }
-    tile_issue(b + NTB - 1);   // (always: the wait counts rely on it; past the end the last tile again)
     return true;
   };
   for (int b = 0; b < nb; ++b) if (!step(b)) return;
