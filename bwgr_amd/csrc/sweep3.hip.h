@@ -1102,11 +1102,14 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
         const double D1_ = (double)D1F_; \
         const double diffd_ = fma((GJ_), (D2S_) - D1_ * D1_, (2.0 * (R_)) * (D1_ - (D2_)));   /* |e2|^2 - |e1|^2 */ \
         const float x_ = Cc * (float)diffd_; \
-        const bool sa_ = x_ < (TA_), sr_ = x_ > (TR_); \
-        ACC_ = sa_; \
-        if (__builtin_expect(__ballot(!(sa_ || sr_)) != 0ull, 0)) { \
+        /* the decisions as scalar masks (two compares straight into SGPR pairs; a per-lane bool made the compiler shuttle it through \
+           v_cndmask / v_cmp and EXEC-masked regions every round) */ \
+        const unsigned long long ma_ = __ballot(x_ < (TA_)); \
+        const unsigned long long mu_ = ~(ma_ | __ballot(x_ > (TR_)));   /* the lanes between the two thresholds (a NaN too): the exact test decides */ \
+        ACC_ = ma_; \
+        if (__builtin_expect(mu_ != 0ull, 0)) { \
           const bool ex_ = lane_accept_exact(diffd_, a.marker0 + (uint32_t)(blk * m + (MKOFF_) + lane), a.flags, Cc, odds, one_minus_pi, a.rng, a.iter); \
-          ACC_ = sa_ ? true : (sr_ ? false : ex_); \
+          ACC_ |= __ballot(ex_) & mu_; \
         } }
       // An included marker k = KOFF_ + js: its step beyond the speculated one, corr = (b1 - b0) - drej (both floats, exact in
       // fp64; the streamers fold in the same difference on the fixed-point grid, 2^-44 of the scale away), and its Gram rows, read
@@ -1163,28 +1166,28 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       // exact speculative rounds, first over markers 0..63, then 64..127: every lane assumes "nobody before me is included"
       if (!(A.dbg & 128)) {
         const int cnt0 = min(64, mB);
-        int front = 0;
+        unsigned long long live0 = (cnt0 >= 64) ? ~0ull : ((1ull << cnt0) - 1ull);   // lanes not yet passed
         for (;;) {
-          float d1f; bool acc;
+          float d1f; unsigned long long acc;
           S3_EVAL(r0, xba, rda, sza, b0a, D2a, D2sa, gja, taa, tra, 0, d1f, acc)
-          const unsigned long long bal = __ballot(acc && lane >= front && lane < cnt0);
+          const unsigned long long bal = acc & live0;
           if (bal == 0ull) break;
-          const int js = __ffsll((long long)bal) - 1;
-          front = js + 1;
+          const int js = (int)__builtin_ctzll(bal);
+          live0 &= (~1ull << js);
           am0 |= 1ull << js;
           S3_INCLUDE(0, d1f, dra)
         }
       }
       if (mB > 64 && (!(A.dbg & 128))) {
         const int cnt1 = mB - 64;
-        int front = 0;
+        unsigned long long live1 = (cnt1 >= 64) ? ~0ull : ((1ull << cnt1) - 1ull);
         for (;;) {
-          float d1f; bool acc;
+          float d1f; unsigned long long acc;
           S3_EVAL(r1, xbb, rdb, szb, b0b, D2b, D2sb, gjb, tab, trb, 64, d1f, acc)
-          const unsigned long long bal = __ballot(acc && lane >= front && lane < cnt1);
+          const unsigned long long bal = acc & live1;
           if (bal == 0ull) break;
-          const int js = __ffsll((long long)bal) - 1;
-          front = js + 1;
+          const int js = (int)__builtin_ctzll(bal);
+          live1 &= (~1ull << js);
           am1 |= 1ull << js;
           S3_INCLUDE(64, d1f, drb)
         }
