@@ -747,6 +747,12 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
 // ------------------------------------------------------------------------------------------------------------------
 template <typename GT>
 __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
+  // the experiment switches (BWGR_DBG3) cost instructions and branches inside the rounds: compiled in only with -DBWGR_EXPERIMENTS (tools/ab3_probe.py builds that library)
+#ifdef BWGR_EXPERIMENTS
+  const int SDBG = A.dbg;
+#else
+  constexpr int SDBG = 0;
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const SweepArgs &a = A.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -839,7 +845,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     unsigned long long l0 = n0 ? pq_l0 : need, h0 = n0 ? pq_h0 : need, l1 = n1 ? pq_l1 : need, h1 = n1 ? pq_h1 : need;
     for (;;) {
       if ((l0 & 0xFFull) == need && (h0 & 0xFFull) == need && (l1 & 0xFFull) == need && (h1 & 0xFFull) == need) break;
-      if (A.dbg & 8) break;   // (timing experiment only: the streamers publish nothing)
+      if (SDBG & 8) break;   // (timing experiment only: the streamers publish nothing)
       if ((++spins & 63u) == 0u) {
         if (ld_agent_u32(abortw) != 0u) return 0;
         if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
@@ -887,7 +893,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   double f_cf = 0.0;                 // lane i: its coefficient
   auto far_issue = [&](int c, int hw) {
     f_cnt = 0; f_n = 0;
-    if (c < 3 || D < 4 || c >= nb || (A.dbg & 32)) return;
+    if (c < 3 || D < 4 || c >= nb || (SDBG & 32)) return;
     f_p0 = pos_s[max(c - D + 1, 0) & 31];
     f_cnt = (pos_s[(c - 2) & 31] - f_p0) & (ring - 1);   // [f_p0, +f_cnt): blocks c-D+1 .. c-3
     f_n = (f_cnt > hw) ? min(NFL, (f_cnt - hw + NFW - 1) / NFW) : 0;
@@ -936,7 +942,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   constexpr int PF = 8;
   uint32_t pf0 = 0u, pf1 = 0u, pf2 = 0u, pf3 = 0u, pf4 = 0u, pf5 = 0u;
   auto touch = [&](int c) {
-    if (c >= nb || !(A.dbg & 2)) return;   // (off by default: measured slower at C4; BWGR_DBG3=2 turns the touches on)
+    if (c >= nb || !(SDBG & 2)) return;   // (off by default: measured slower at C4; BWGR_DBG3=2 turns the touches on)
     const int blk = a.blk_begin + c;
     const unsigned char *gpb = reinterpret_cast<const unsigned char *>(gp_all + (size_t)blk * pstride);
     const size_t gpbytes = (size_t)pstride * sizeof(GT), gxbytes = (size_t)m * m * sizeof(GT);
@@ -1007,12 +1013,12 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
 #define S3_ROLE_BARRIER() do { if (BWGR_ROLEBAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
   const int wvu = __builtin_amdgcn_readfirstlane(wave);   // the role as a scalar: real branches, every wave runs its own role's code (and barrier) only
   auto helper_phase = [&](int c) {   // block c >= 1, while wave 0 runs block c-1
-    if (wvu == 1) { if (!(A.dbg & 32768)) { if (!poll_q(c)) ctrl_s[0] = 0; } S3ST(2, tid == 64); S3_ROLE_BARRIER(); }
-    else if (wvu <= 3) { if (!(A.dbg & 8192)) {
+    if (wvu == 1) { if (!(SDBG & 32768)) { if (!poll_q(c)) ctrl_s[0] = 0; } S3ST(2, tid == 64); S3_ROLE_BARRIER(); }
+    else if (wvu <= 3) { if (!(SDBG & 8192)) {
       // the constants of block c, requested a phase ago -- waiting for them also waits for block c's packed diagonal block, whose
       // DMA was issued before them; then the requests for block c+1 (the DMA first), which have this whole phase to land
-      if (!(A.dbg & 262144)) stage_commit(c);
-      if (c + 1 < nb) { if (!(A.dbg & 131072)) gpd_issue(c + 1); if (!(A.dbg & 262144)) stage_request(c + 1); }
+      if (!(SDBG & 262144)) stage_commit(c);
+      if (c + 1 < nb) { if (!(SDBG & 131072)) gpd_issue(c + 1); if (!(SDBG & 262144)) stage_request(c + 1); }
       else if constexpr (GPD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } S3ST(2, tid == 128 || tid == 192); S3_ROLE_BARRIER(); }
     else if (wvu == 4) { S3_ROLE_BARRIER(); }   // idle: the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots
@@ -1026,7 +1032,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       S3ST(2, tid == 384);
       S3_ROLE_BARRIER();
     }
-    else { if (c >= 2 && !(A.dbg & 4096)) finish_block(c - 2); touch(c + PF); S3ST(2, tid == 448); S3_ROLE_BARRIER(); }
+    else { if (c >= 2 && !(SDBG & 4096)) finish_block(c - 2); touch(c + PF); S3ST(2, tid == 448); S3_ROLE_BARRIER(); }
   };
 
   // ---- prologue: block 0 ----
@@ -1053,7 +1059,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   int gpd_off = 0;                                     // (b % 3) * S3_GPD_BYTES, stepped once per block
   const uint32_t rowx_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)rowx_s);
   const bool altb2 = (a.flags & SWF_ALT_B2) != 0;
-  if (wave == 0 && !(A.dbg & 1)) __builtin_amdgcn_s_setprio(3);   // the chain's wave goes first wherever it shares an issue port
+  if (wave == 0 && !(SDBG & 1)) __builtin_amdgcn_s_setprio(3);   // the chain's wave goes first wherever it shares an issue port
   // wave 0: what the included markers of block b change in blocks b+1 and b+2 (distances 1 and 2), accumulated as they appear
   double rnext0 = 0.0, rnext1 = 0.0, rnxt20 = 0.0, rnxt21 = 0.0;
   const GT *gx0_w0 = reinterpret_cast<const GT *>(A.gx[0]) + (size_t)a.blk_begin * m * m, *gx1_w0 = reinterpret_cast<const GT *>(A.gx[1]) + (size_t)a.blk_begin * m * m;
@@ -1062,7 +1068,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     const int mB = blk_m(b), blk = a.blk_begin + b;
     const bool have_next = (b + 1 < nb);
     S3ST(0, sq0 || sq1 || sq2 || sq4 || sq3 || sq6 || sq7);
-    if (wvu == 0 && !(A.dbg & 16384)) {
+    if (wvu == 0 && !(SDBG & 16384)) {
       // Wave 0 is one long dependent chain, so everything here is counted in instructions.  Dead lanes of a ragged last block need
       // no masks: k_prestage fills their constants so that they reject for certain, and their q, spec and far terms are zero.
       const StageBuf &st = stage[b & 1];
@@ -1135,7 +1141,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
         const int k_ = (KOFF_) + js; \
         GT ga_ = (GT)1, gb_ = (GT)1; \
         if constexpr (G16) { \
-          if (!(A.dbg & 64)) { \
+          if (!(SDBG & 64)) { \
           if constexpr (GPD) { \
             const unsigned char *gpl_ = gpd_lane + gpd_off + __builtin_amdgcn_readlane((KOFF_) ? tabp1 : tabp0, js); \
             ga_ = *reinterpret_cast<const GT *>(gpl_); gb_ = *reinterpret_cast<const GT *>(gpl_ + 128);   /* (lanes at or before k_: masked below) */ \
@@ -1146,7 +1152,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
           if (__builtin_expect(nslot == S3_NRX, 0)) S3_APPLY_ROWS()   /* every slot taken: the rows so far first */ \
           if (use1) s3_dma16s(g12b + (size_t)(k_ * 2 * rowbytes), rolane16, rowx_la + (uint32_t)nslot * S3_ROWSLOT); \
           ++nslot; } \
-        } else if (!(A.dbg & 64)) {   /* 32-bit Gram entries: the rows straight from global memory */ \
+        } else if (!(SDBG & 64)) {   /* 32-bit Gram entries: the rows straight from global memory */ \
           const int pr_ = prow(k_); \
           ga_ = gp[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gp[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)];   /* (the last row is empty) */ \
         } \
@@ -1156,7 +1162,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
         ++nacc; \
         r0 = fma(-(double)((l0 > k_) ? ga_ : (GT)0), corr_, r0); \
         r1 = fma(-(double)((l1 > k_ && l1 < m) ? gb_ : (GT)0), corr_, r1); \
-        if constexpr (!G16) { if (!(A.dbg & 64)) { \
+        if constexpr (!G16) { if (!(SDBG & 64)) { \
           const GT *row_ = g1 + (use1 ? (size_t)k_ * m : (size_t)0);   /* (without a next block: a harmless in-bounds read) */ \
           const GT xa_ = row_[use1 ? min(l0, m - 1) : 0], xb_ = row_[use1 ? l1c : 0]; \
           const GT *row2_ = g2 + (use2 ? (size_t)k_ * m : (size_t)0); \
@@ -1164,7 +1170,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
           if (use1) { rnext0 = fma(-(double)xa_, corr_, rnext0); rnext1 = fma(-(double)xb_, corr_, rnext1); } \
           if (use2) { rnxt20 = fma(-(double)ya_, corr_, rnxt20); rnxt21 = fma(-(double)yb_, corr_, rnxt21); } } } }
       // exact speculative rounds, first over markers 0..63, then 64..127: every lane assumes "nobody before me is included"
-      if (!(A.dbg & 128)) {
+      if (!(SDBG & 128)) {
         const int cnt0 = min(64, mB);
         unsigned long long live0 = (cnt0 >= 64) ? ~0ull : ((1ull << cnt0) - 1ull);   // lanes not yet passed
         for (;;) {
@@ -1178,7 +1184,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
           S3_INCLUDE(0, d1f, dra)
         }
       }
-      if (mB > 64 && (!(A.dbg & 128))) {
+      if (mB > 64 && (!(SDBG & 128))) {
         const int cnt1 = mB - 64;
         unsigned long long live1 = (cnt1 >= 64) ? ~0ull : ((1ull << cnt1) - 1ull);
         for (;;) {

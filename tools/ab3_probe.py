@@ -1,8 +1,15 @@
 """Diagnostic: sweep time of k_sweep3 under the BWGR_DBG3 experiment switches (some of them break the chain on purpose:
-timing only) and under BWGR_D3 / BWGR_R3.  Usage: ab3_probe.py "VAR=val,VAR=val" ... (each argument one configuration)."""
+timing only; they are compiled into a library of their own, built here with -DBWGR_EXPERIMENTS) and under BWGR_D3 / BWGR_R3.  Usage: ab3_probe.py "VAR=val,VAR=val" ... (each argument one configuration)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import subprocess
+from bwgr_amd import build as B
+so = os.path.join(ROOT, "gpurun_out", "libbwgr_hip_exp.so")     # the experiment switches live in a build of their own (-DBWGR_EXPERIMENTS)
+os.makedirs(os.path.dirname(so), exist_ok=True)
+if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in B.DEPS):
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DBWGR_EXPERIMENTS", "-o", so] + B.SOURCES)
+B.LIB = so
 import torch, bwgr_amd
 from bwgr_amd import synth
 n, p = 10000, int(os.environ.get("AB_P", "200000"))
