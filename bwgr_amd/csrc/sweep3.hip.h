@@ -194,6 +194,11 @@ __host__ __device__ inline size_t s3_seq_lds(int D, bool g16) {
 // streamer
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
+#ifdef BWGR_EXPERIMENTS
+  const int SDBG = A.dbg;
+#else
+  constexpr int SDBG = 0;   // (the experiment switches: -DBWGR_EXPERIMENTS)
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const SweepArgs &a = A.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -316,7 +321,7 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
     int8_t *edig = edig0 + (size_t)par * 16 * Rp;
     int8_t *ddig = ddig0 + (size_t)par * 16 * S2_DP;
     // A: what the included markers of block b - D changed
-    if (b >= D && upd && !(A.dbg & 512)) { if (!fold_list(b - D, lpre)) ctl_s[0] = 1u; }
+    if (b >= D && upd && !(SDBG & 512)) { if (!fold_list(b - D, lpre)) ctl_s[0] = 1u; }
     S3ST(1, st_u);
     // B: digits of the residual rows and of this block's rejected steps
     if (upd) {
@@ -348,7 +353,7 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
       lpre = ld_agent_raw64(A.lists + (size_t)(a.blk_begin + max(bn1 - D, 0)) * S3_LSTRIDE + lane);
     }
     S3ST(7, st_u || st_d);
-    if (b + 3 < nb && !(A.dbg & 16)) S3_TILE_ISSUE(b + 3);
+    if (b + 3 < nb && !(SDBG & 16)) S3_TILE_ISSUE(b + 3);
     S3ST(4, st_u || st_d);
     if (upd) {
       // ---- slab update with the rejected steps: out[row][n] = sum_markers x[row][marker] * digit_n(drej[marker]) ----
@@ -356,7 +361,7 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
       // markers s0 + 16 u + 4 grp + q (the interleave keeps the four lane groups on different LDS banks)
       const int rowoff = 4 * (16 * wave + m16);
       s2_v4i acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-      for (int s0 = 0; s0 < ((A.dbg & 256) ? 0 : mB); s0 += 64) {
+      for (int s0 = 0; s0 < ((SDBG & 256) ? 0 : mB); s0 += 64) {
         const int8_t *tp = tile + __mul24(s0 + 4 * grp, Rp) + rowoff;
         uint32_t c[4][4];
 #pragma unroll
@@ -408,7 +413,7 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
         const int8_t *ap = tile + (size_t)(16 * gm + m16) * Rp + 16 * grp;
         const int8_t *ap2 = tile + (size_t)(16 * (two ? gm2 : gm) + m16) * Rp + 16 * grp;
         s2_v4i acc = {0, 0, 0, 0}, acc2 = acc;
-        for (int r = 0; r < ((A.dbg & 256) ? 0 : R3); r += 64) {
+        for (int r = 0; r < ((SDBG & 256) ? 0 : R3); r += 64) {
           const s2_v4i bv = *reinterpret_cast<const s2_v4i *>(bp + r);
           acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap + r), bv, acc, 0, 0, 0);
           acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap2 + r), bv, acc2, 0, 0, 0);
@@ -427,7 +432,7 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
           const long long hi = (long long)o0.w + ((long long)o1.x << 8) + ((long long)o1.y << 16) + ((long long)o1.z << 24);
           const int mk = 16 * ((lane < 16) ? gm : gm2) + (lane & 15);
           unsigned long long *qs = A.qsum + ((size_t)(a.blk_begin + b) * SW_MAXM + mk) * 2;
-          if (!(A.dbg & 8)) {
+          if (!(SDBG & 8)) {
           __hip_atomic_fetch_add((gu64_t *)qs, (unsigned long long)((lo << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_fetch_add((gu64_t *)(qs + 1), (unsigned long long)((hi << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -444,7 +449,7 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
   }
   S3ST_FLUSH(0, st_u); S3ST_FLUSH(8, st_d);
   // the lists of the last D blocks
-  if (upd && !(A.dbg & 512)) for (int bs = max(0, nb - D); bs < nb; ++bs) {
+  if (upd && !(SDBG & 512)) for (int bs = max(0, nb - D); bs < nb; ++bs) {
     if (!fold_list(bs, 0ull)) { ctl_s[0] = 1u; break; }
   }
   if (upd && ((unsigned long long)(e_own + (1ll << 54)) >> 55)) ctl_s[1] = 1u;
@@ -462,6 +467,11 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
 // The same streamer with its tiles landed by LDS-DMA (128-row streamers; BWGR_STREAM3=dma)
 template <int R3, int NTB>
 __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
+#ifdef BWGR_EXPERIMENTS
+  const int SDBG = A.dbg;
+#else
+  constexpr int SDBG = 0;   // (the experiment switches: -DBWGR_EXPERIMENTS)
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const SweepArgs &a = A.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -601,7 +611,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
     int8_t *edig = edig0 + (size_t)par * 16 * Rp;
     int8_t *ddig = ddig0 + (size_t)par * 16 * S2_DP;
     // A: what the included markers of block b - D changed
-    if (b >= D && upd && !(A.dbg & 512)) { if (!fold_list(b - D, lpre)) ctl_s[0] = 1u; }
+    if (b >= D && upd && !(SDBG & 512)) { if (!fold_list(b - D, lpre)) ctl_s[0] = 1u; }
     S3ST(1, st_u);
     // B: digits of the residual rows and of this block's rejected steps
     if (upd) {
@@ -649,7 +659,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
       const uint32_t tile_lds = tile_la + (uint32_t)((b % NTB) * (int)tile_b);
       const uint32_t q8 = (uint32_t)((lane & 15) >> 1), p8 = (uint32_t)(lane & 1);
       const uint32_t cw = (uint32_t)(4 * wave);
-      for (int s0 = 0; s0 < ((A.dbg & 256) ? 0 : mB); s0 += 64) {
+      for (int s0 = 0; s0 < ((SDBG & 256) ? 0 : mB); s0 += 64) {
         const uint32_t rowA = tile_lds + (uint32_t)(s0 + 16 * grp + (int)q8) * (uint32_t)R3 + 8u * p8;   // markers s0 + 16 grp + q8 and + 8 (both have marker & 7 = q8)
         const uint32_t a0 = rowA + ((((cw + 0u) ^ q8) & (uint32_t)(CH - 1)) << 4), a1 = rowA + ((((cw + 1u) ^ q8) & (uint32_t)(CH - 1)) << 4);
         const uint32_t a2 = rowA + ((((cw + 2u) ^ q8) & (uint32_t)(CH - 1)) << 4), a3 = rowA + ((((cw + 3u) ^ q8) & (uint32_t)(CH - 1)) << 4);
@@ -696,7 +706,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
         const int8_t *ap = tile + (size_t)(16 * gm + m16) * R3;           // (both groups' markers have jj & 15 = m16)
         const int8_t *ap2 = tile + (size_t)(16 * (two ? gm2 : gm) + m16) * R3;
         s2_v4i acc = {0, 0, 0, 0}, acc2 = acc;
-        for (int r = 0; r < ((A.dbg & 256) ? 0 : R3); r += 64) {
+        for (int r = 0; r < ((SDBG & 256) ? 0 : R3); r += 64) {
           const s2_v4i bv = *reinterpret_cast<const s2_v4i *>(bp + r);
           const int so = (((grp + (r >> 4)) ^ (m16 & (CH - 1))) << 4);   // rows r + 16 grp .. + 15 = chunk grp + r / 16
           acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap + so), bv, acc, 0, 0, 0);
@@ -716,7 +726,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
           const long long hi = (long long)o0.w + ((long long)o1.x << 8) + ((long long)o1.y << 16) + ((long long)o1.z << 24);
           const int mk = 16 * ((lane < 16) ? gm : gm2) + (lane & 15);
           unsigned long long *qs = A.qsum + ((size_t)(a.blk_begin + b) * SW_MAXM + mk) * 2;
-          if (!(A.dbg & 8)) {
+          if (!(SDBG & 8)) {
           __hip_atomic_fetch_add((gu64_t *)qs, (unsigned long long)((lo << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_fetch_add((gu64_t *)(qs + 1), (unsigned long long)((hi << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -732,7 +742,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
 #undef S3_DMA_BARRIER
   S3ST_FLUSH(0, st_u); S3ST_FLUSH(8, st_d);
   // the lists of the last D blocks
-  if (upd && !(A.dbg & 512)) for (int bs = max(0, nb - D); bs < nb; ++bs) {
+  if (upd && !(SDBG & 512)) for (int bs = max(0, nb - D); bs < nb; ++bs) {
     if (!fold_list(bs, 0ull)) { ctl_s[0] = 1u; break; }
   }
   if (upd && ((unsigned long long)(e_own + (1ll << 54)) >> 55)) ctl_s[1] = 1u;
@@ -1150,7 +1160,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
             ga_ = gp[min(pr_ + max(l0 - k_ - 1, 0), pstride - 1)]; gb_ = gp[min(pr_ + max(l1c - k_ - 1, 0), pstride - 1)]; \
           } \
           if (__builtin_expect(nslot == S3_NRX, 0)) S3_APPLY_ROWS()   /* every slot taken: the rows so far first */ \
-          if (use1) s3_dma16s(g12b + (size_t)(k_ * 2 * rowbytes), rolane16, rowx_la + (uint32_t)nslot * S3_ROWSLOT); \
+          if (use1) s3_dma16s(g12b, rolane16 + (uint32_t)(k_ * 2 * rowbytes), rowx_la + (uint32_t)nslot * S3_ROWSLOT); \
           ++nslot; } \
         } else if (!(SDBG & 64)) {   /* 32-bit Gram entries: the rows straight from global memory */ \
           const int pr_ = prow(k_); \
