@@ -274,7 +274,7 @@ def main():
     # (a chain that has the GPU to itself runs k_sweep3 with 128-row streamers, two to a slab: bwgr_hip.hip, launch_sweep3)
     solo3 = pl["generation"] == 3 and os.environ.get("BWGR_SOLO3", "1") != "0" and P.slab_rows == 256 and 2 * P.nwg + 1 <= 256 and not os.environ.get("BWGR_R3")
     traffic, traffic_source = None, None
-    for name in ("r03f_pmc_%s.json" % args.workload, "r03e_pmc_%s.json" % args.workload, "r03d_pmc_%s.json" % args.workload, "r03c_pmc_%s.json" % args.workload, "r03b_pmc_%s.json" % args.workload, "r03_pmc_%s.json" % args.workload, "r02_pmc_c4.json", "r01_pmc_c4.json"):
+    for name in ("r03g_pmc_%s.json" % args.workload, "r03f_pmc_%s.json" % args.workload, "r03e_pmc_%s.json" % args.workload, "r03d_pmc_%s.json" % args.workload, "r03c_pmc_%s.json" % args.workload, "r03b_pmc_%s.json" % args.workload, "r03_pmc_%s.json" % args.workload, "r02_pmc_c4.json", "r01_pmc_c4.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             if pm["workload"] == args.workload and pm["n"] == n and pm["p"] == p and kernel.split("<")[0] in pm.get("kernel", "k_sweep2<int8>").split("<")[0].split("::")[-1].split():
