@@ -187,6 +187,12 @@ __host__ __device__ inline size_t s2w_lds_bytes(int m, int R, int maxlag = 4) {
 // sequencer
 // ------------------------------------------------------------------------------------------------------------------
 #define S2W_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// the experiment switches (BWGR_DBGW) are compiled in only with -DBWGR_EXPERIMENTS (tools/ab3_probe.py builds that library)
+#ifdef BWGR_EXPERIMENTS
+#define S2W_DBG(A_) ((A_).dbg)
+#else
+#define S2W_DBG(A_) 0
+#endif
 #ifdef BWGR_STAMPS
 #define S2WSTAMP(k) do { if (tid == 512) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph2[k] += t_ - tl2; tl2 = t_; } } while (0)
 #define S2WSTAMP_FLUSH() do { if (tid == 512 && a.stamps) for (int k_ = 0; k_ < 8; ++k_) a.stamps[16 + k_] += ph2[k_]; } while (0)
@@ -316,7 +322,7 @@ __device__ __forceinline__ int s2w_qf_collect(const SweepArgs &a, const S2WArgs 
   const uint64_t t0 = wall_clock64();
   unsigned spins = 0;
   for (;;) {
-    const bool ok = (t >= mB) || ((v & 0xFFull) == need) || (A.dbg & 2);
+    const bool ok = (t >= mB) || ((v & 0xFFull) == need) || (S2W_DBG(A) & 2);
     if (__ballot(!ok) == 0ull) break;
     if ((++spins & 63u) == 0u) {
       if (ld_agent_u32(abortw) != 0u) return 0;
@@ -595,7 +601,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         if constexpr (!fx) if (c + 1 < nb) { if (!s2w_qx_collect(a, c + 1, xpart, xt, blk_m(c + 1), QX, q_s + (size_t)(((c + 1) & 1) * 4 + 2 + xpart) * SW_MAXM)) ctrl_s[0] = 0; }
         S2W_BAR();                                         // B3: d
       }
-      if (!(A.dbg & 32) || c < 0) issue_w(c + 1);     // (into the registers just read; the wave waits in the memory pipeline's queue while wave 8 writes the outputs)
+      if (!(S2W_DBG(A) & 32) || c < 0) issue_w(c + 1);     // (into the registers just read; the wave waits in the memory pipeline's queue while wave 8 writes the outputs)
       if constexpr (!fx) s2w_qx_request(a, min(c + 2, nb - 1), xpart, xt, QX);
     }
   } else {
@@ -635,7 +641,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
           if (t < mB) {
             const float b0 = st.b0[t];
             const float bn = (float)(d_s[t] + (double)b0);
-            dl = (A.dbg & 1) ? 0.0f : (bn - b0) * (float)dscale;
+            dl = (S2W_DBG(A) & 1) ? 0.0f : (bn - b0) * (float)dscale;
           }
           dl_own[q] = dl;
         }
@@ -659,7 +665,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
         const long long sq = ((long long)wave_sum_i32(sq2 >> 16) << 16) + (long long)wave_sum_i32(sq2 & 0xFFFF);
         if (lane == 0) { bias_s[c & (S2W_DSLOTS - 1)] = 32896.0 * (double)sq; scd_s[c & (S2W_DSLOTS - 1)] = __hiloint2double((1023 - sh) << 20, 0); }
         if (lane == 0 && A.npf > 0) st_agent_u32(a.xflags + (size_t)a.K * SW_FLAG_STRIDE + 1, (uint32_t)(c + 1));   // progress, for the prefetchers
-      } else if (!(A.dbg & 128)) {
+      } else if (!(S2W_DBG(A) & 128)) {
         // ... and what nobody in the sweep waits for, on the other three waves of the group: wave 9 the effects (and the sums), wave 10
         // the indicators, wave 11 the variances.  (stage[c % 3] and d_s are read here until the next B0: the constants of block c+3 land
         // in this buffer after B2 of block c+1, the next product writes d_s after that barrier too.)
@@ -669,7 +675,7 @@ __device__ __forceinline__ void s2_sequencer_winv(const SweepArgs &a, const S2WA
           const int t = 64 * q + lane;
           if (t < mB) {
             const float b0 = st.b0[t];
-            const float bn = (A.dbg & 1) ? b0 : (float)(d_s[t] + (double)b0);
+            const float bn = (S2W_DBG(A) & 1) ? b0 : (float)(d_s[t] + (double)b0);
             if (wave == 9) { a.b[j0 + t] = bn; sum_d += 1.0; sum_b2 = fma((double)bn, (double)bn, sum_b2); }
             else if (wave == 10) a.d[j0 + t] = 1.0f;
             else if (a.flags & SWF_VB_VEC) a.vb[j0 + t] = (float)((double)(Sb + bn * bn) / st.chi[t]);
@@ -808,7 +814,7 @@ __device__ __forceinline__ void s2w_streamer_fx(const SweepArgs &a, const S2WArg
         unsigned spins = 0;
         unsigned long long v = pre;
         for (;;) {
-          if (s2_dgranule_is(v, j) || (A.dbg & 4)) { if (A.dbg & 4) v = 0ull; break; }
+          if (s2_dgranule_is(v, j) || (S2W_DBG(A) & 4)) { if (S2W_DBG(A) & 4) v = 0ull; break; }
           v = ld_agent_raw64(g);
           if (s2_dgranule_is(v, j)) break;
           if ((++spins & 63u) == 0u) {
@@ -929,9 +935,9 @@ template <bool FX>
 __global__ __launch_bounds__(S2W_THREADS) void k_sweep2w(const SweepArgs a, const S2WArgs A) {
   if (a.redo_only && a.sc->redo == 0u) return;   // (the fp64 fallback of a fixed-point sweep that stayed in range)
   const int KS = FX ? A.K3 : a.K;   // streamer workgroups; then the sequencer; then every eighth workgroup a prefetcher
-  if ((int)blockIdx.x > KS) { const int r = (int)blockIdx.x - KS; if ((r & 7) == 0 && !(A.dbg & 8)) s2w_prefetcher(a, A, (r >> 3) - 1); return; }
-  if ((int)blockIdx.x == KS) { if (A.dbg & 8) return; s2_sequencer_winv<FX>(a, A); }
-  else if (A.dbg & 16) return;
+  if ((int)blockIdx.x > KS) { const int r = (int)blockIdx.x - KS; if ((r & 7) == 0 && !(S2W_DBG(A) & 8)) s2w_prefetcher(a, A, (r >> 3) - 1); return; }
+  if ((int)blockIdx.x == KS) { if (S2W_DBG(A) & 8) return; s2_sequencer_winv<FX>(a, A); }
+  else if (S2W_DBG(A) & 16) return;
   else if (threadIdx.x >= SW_THREADS) return;                            // the streamers are eight waves (a wave that has ended leaves the barriers' count)
   else if ((a.flags & SWF_DEBUG_WITHHOLD) && blockIdx.x == 0) return;   // test hook: a streamer that never shows up
   else if constexpr (FX) s2w_streamer_fx(a, A);
