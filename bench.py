@@ -140,6 +140,91 @@ def concurrent_leg(P, model, y, pi, nch, K, W, n, p):
             h.close()
 
 
+def pmc_traffic(workload, n, p, kernel):
+    """HBM bytes per launch from the newest committed rocprofv3 --pmc summary of this workload and kernel (profiles/rNN*_pmc_<workload>.json;
+    it cannot be read inside this process).  Returns (bytes, source) or (None, None)."""
+    import glob
+    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % workload)), reverse=True)
+    for path in names:
+        try:
+            pm = json.load(open(path))
+            if pm["workload"] == workload and pm["n"] == n and pm["p"] == p and kernel.split("<")[0] in pm.get("kernel", "k_sweep2<int8>").split("<")[0].split("::")[-1].split():
+                return pm["traffic_bytes_per_launch"], "profiles/%s (an earlier rocprofv3 --pmc pass of this kernel%s, not measured in this run)" % (
+                    os.path.basename(path), ", commit %s" % pm["commit"] if pm.get("commit") else "")
+        except Exception:
+            pass
+    return None, None
+
+
+def single_leg(workload, K, W, dev, args, keep):
+    """One exact chain of `workload` alone on the GPU: W untimed iterations, K timed between synchronizes, the sweep kernel's mean launch
+    time from hipEvents on its stream.  keep: return the panel and inputs for the legs that follow (the caller closes them)."""
+    import torch
+    import bwgr_amd
+    from bwgr_amd import synth
+    n, p, model, pi = WORKLOADS[workload]
+    t_setup = time.perf_counter()
+    X = synth.genotypes(n, p, device=dev)
+    g = synth.phenotype(X, n)
+    y = synth.scale_phenotype(g)
+    Xs_host = None
+    if keep and not args.no_cpu:
+        ps = min(args.cpu_slice, p)
+        Xs_host = X[:ps, :n].cpu().numpy().T   # (n, ps) view, column-major
+    P = bwgr_amd.Panel(X, n=n, device=dev, block=args.block, nwg=args.nwg)
+    del X
+    torch.cuda.empty_cache()
+    ch = bwgr_amd.Chain(P, model, y, it=W + K, bi=W, pi=pi, df=5, R2=0.5, seed=synth.SEED)
+    setup_s = time.perf_counter() - t_setup
+    ch.run(W)
+    ch.sync()
+    ch.sweep_ms()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ch.run(K)
+    ch.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    sweep_ms, launches = ch.sweep_ms()
+    st = ch.state()
+    elapsed = t1 - t0
+    alg_bytes = float(n) * float(p) * 1.0      # SURVEY 8(d): every genotype byte read once per sweep
+    pl = P.pipeline(bool(pi) or model in ("BayesCpi", "BayesDpi"))
+    mean_d = float(st["d"].mean())
+    if pl["generation"] == 3 and mean_d >= float(os.environ.get("BWGR_ENG3_THR", "0.03")):
+        # the device picks the selection sweeps' engine from the chain's inclusion rate: above the threshold k_sweep2 ran them
+        pl = {"generation": 2, "lag": int(os.environ.get("BWGR_LAG", "3")), "feeders": 0}
+    kernel = {4: "k_sweep2w", 3: "k_sweep3<uint%d>" % pl.get("gram_bits", 16), 2: "k_sweep2<int8>", 1: "k_sweep<int8>"}[pl["generation"]]
+    # (a chain that has the GPU to itself runs k_sweep3 with 128-row streamers, two to a slab: bwgr_hip.hip, launch_sweep3)
+    solo3 = pl["generation"] == 3 and os.environ.get("BWGR_SOLO3", "1") != "0" and P.slab_rows == 256 and 2 * P.nwg + 1 <= 256 and not os.environ.get("BWGR_R3")
+    traffic, traffic_source = pmc_traffic(workload, n, p, kernel)
+    achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+    out = {
+        "metric": "MCMC iter/sec (full marker sweep)", "value": K / elapsed, "unit": "iter/s", "n_gpus": 1,
+        "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 scalars, fixed-point / f64 residual, int8 genotypes", "data": "synthetic",
+        "config": {"workload": "%s: synthetic n=%d x p=%d int8, %s%s, exact chain (blocked sweep, block=%d, %d slabs "
+                               "x %d rows + 1 sequencer%s)" % (workload, n, p, model,
+                                                          " pi=%.2f (%.1f%% of the markers in the model at the last sweep)" % (pi, 100.0 * mean_d) if pi else "", P.block, P.nwg, P.slab_rows,
+                                                          (" + %d q feeders" % pl["feeders"] if pl["feeders"] else "")
+                                                          + (", the chain alone on the GPU: %d streamers x 128 rows" % (2 * P.nwg) if solo3 else "")
+                                                          + ", engine generation %d, lag %d blocks" % (pl["generation"], pl["lag"])),
+                   "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": 1},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel,
+                     "kernel_ms": sweep_ms, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes},
+        "setup_s": setup_s,
+        "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d": mean_d},
+    }
+    ch.close()
+    if keep:
+        return out, P, y, Xs_host, pl
+    P.close()
+    del P, y
+    torch.cuda.empty_cache()
+    return {k: out[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "setup_s", "chain_check")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +242,7 @@ def main():
                     "kept for measurements)")
     ap.add_argument("--pairs", type=int, default=0, help="pairs of chains in the paired-chains leg (0: as many as fit)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c3 legs that follow the headline workload (`workloads` in the JSON line)")
     ap.add_argument("--cpu-slice", type=int, default=20000)
     args = ap.parse_args()
 
@@ -237,71 +323,7 @@ def main():
         return
 
     # ---- single GPU ----
-    t_setup = time.perf_counter()
-    X = synth.genotypes(n, p, device=dev)
-    g = synth.phenotype(X, n)
-    y = synth.scale_phenotype(g)
-    Xs_host = None
-    if not args.no_cpu:
-        ps = min(args.cpu_slice, p)
-        Xs_host = X[:ps, :n].cpu().numpy().T   # (n, ps) view, column-major
-    P = bwgr_amd.Panel(X, n=n, device=dev, block=args.block, nwg=args.nwg)
-    del X
-    torch.cuda.empty_cache()
-    ch = bwgr_amd.Chain(P, model, y, it=W + K, bi=W, pi=pi, df=5, R2=0.5, seed=synth.SEED)
-    setup_s = time.perf_counter() - t_setup
-    ch.run(W)
-    ch.sync()
-    ch.sweep_ms()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ch.run(K)
-    ch.sync()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    sweep_ms, launches = ch.sweep_ms()
-    st = ch.state()
-    elapsed = t1 - t0
-    alg_bytes = float(n) * float(p) * 1.0      # every genotype byte read once per sweep
-    # HBM traffic per launch comes from separate rocprofv3 --pmc passes (it cannot be read inside this process); the
-    # corrected figure is committed under profiles/ and quoted only for the workload it was measured on
-    pl = P.pipeline(bool(pi) or model in ("BayesCpi", "BayesDpi"))
-    mean_d = float(st["d"].mean())
-    if pl["generation"] == 3 and mean_d >= float(os.environ.get("BWGR_ENG3_THR", "0.03")):
-        # the device picks the selection sweeps' engine from the chain's inclusion rate: above the threshold k_sweep2 ran them
-        pl = {"generation": 2, "lag": int(os.environ.get("BWGR_LAG", "3")), "feeders": 0}
-    kernel = {4: "k_sweep2w", 3: "k_sweep3<uint%d>" % pl.get("gram_bits", 16), 2: "k_sweep2<int8>", 1: "k_sweep<int8>"}[pl["generation"]]
-    # (a chain that has the GPU to itself runs k_sweep3 with 128-row streamers, two to a slab: bwgr_hip.hip, launch_sweep3)
-    solo3 = pl["generation"] == 3 and os.environ.get("BWGR_SOLO3", "1") != "0" and P.slab_rows == 256 and 2 * P.nwg + 1 <= 256 and not os.environ.get("BWGR_R3")
-    traffic, traffic_source = None, None
-    for name in ("r03g_pmc_%s.json" % args.workload, "r03f_pmc_%s.json" % args.workload, "r03e_pmc_%s.json" % args.workload, "r03d_pmc_%s.json" % args.workload, "r03c_pmc_%s.json" % args.workload, "r03b_pmc_%s.json" % args.workload, "r03_pmc_%s.json" % args.workload, "r02_pmc_c4.json", "r01_pmc_c4.json"):
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if pm["workload"] == args.workload and pm["n"] == n and pm["p"] == p and kernel.split("<")[0] in pm.get("kernel", "k_sweep2<int8>").split("<")[0].split("::")[-1].split():
-                traffic, traffic_source = pm["traffic_bytes_per_launch"], "profiles/%s (an earlier rocprofv3 --pmc pass of this kernel%s, not measured in this run)" % (
-                    name, ", commit %s" % pm["commit"] if pm.get("commit") else "")
-                break
-        except Exception:
-            pass
-    achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
-    out = {
-        "metric": "MCMC iter/sec (full marker sweep)", "value": K / elapsed, "unit": "iter/s", "n_gpus": 1,
-        "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 scalars, fixed-point / f64 residual, int8 genotypes", "data": "synthetic",
-        "config": {"workload": "%s: synthetic n=%d x p=%d int8, %s%s, exact chain (blocked sweep, block=%d, %d slabs "
-                               "x %d rows + 1 sequencer%s)" % (args.workload, n, p, model,
-                                                          " pi=%.2f (%.1f%% of the markers in the model at the last sweep)" % (pi, 100.0 * mean_d) if pi else "", P.block, P.nwg, P.slab_rows,
-                                                          (" + %d q feeders" % pl["feeders"] if pl["feeders"] else "")
-                                                          + (", the chain alone on the GPU: %d streamers x 128 rows" % (2 * P.nwg) if solo3 else "")
-                                                          + ", engine generation %d, lag %d blocks" % (pl["generation"], pl["lag"])),
-                   "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": 1},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel,
-                     "kernel_ms": sweep_ms, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes},
-        "setup_s": setup_s,
-        "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d": mean_d},
-    }
-    ch.close()
+    out, P, y, Xs_host, pl = single_leg(args.workload, K, W, dev, args, keep=True)
     nch = args.chains if args.chains > 0 else P.max_concurrent(bool(pi))
     nch = min(nch, P.max_concurrent(bool(pi)))
     if nch > 1:
@@ -320,6 +342,17 @@ def main():
         out["cpu_baseline"] = cpu_baseline(Xs_host, y.cpu().numpy(), model, pi, p)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     P.close()
+    del P, y
+    torch.cuda.empty_cache()
+    # BASELINE configs 2 and 3 on the same box, same timing discipline (a barrier-free single GPU: synchronize on both sides, K steps
+    # timed exactly, kernel time by hipEvents on the kernel's stream): driver-visible beside the headline, each with its own roofline
+    if not args.no_extra and args.workload == "c4":
+        out["workloads"] = {}
+        for wl in ("c2", "c3"):
+            try:
+                out["workloads"][wl] = single_leg(wl, max(K, 10) * (5 if wl == "c2" else 1), max(W, 2), dev, args, keep=False)   # (c2 is 1 ms per step: more of them)
+            except Exception as ex:
+                out["workloads"][wl] = {"error": str(ex)}
     print(json.dumps(out))
 
 

@@ -29,7 +29,10 @@ def lib():
     # finds "No HIP GPUs".  A caller that uses both imports torch first (bench.py, bwgr_amd.dist and bwgr_amd.synth do), or sets
     # BWGR_PRELOAD_TORCH=1 to have it imported here.  The library itself does not need torch.
     if "torch" not in sys.modules and os.environ.get("BWGR_PRELOAD_TORCH", "0") == "1":
-        import torch  # noqa: F401
+        try:
+            import torch  # noqa: F401
+        except ImportError:   # a box without torch: the library does not need it
+            pass
     L = C.CDLL(path)
     L.bwgr_last_error.restype = C.c_char_p
     vp, i64, u64, u32, i32, f32, f64 = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_int, C.c_float, C.c_double
@@ -43,6 +46,7 @@ def lib():
     L.bwgr_panel_max_concurrent.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.bwgr_panel_max_pairs.argtypes = [vp, C.POINTER(C.c_int)]
     L.bwgr_debug_occupancy_fits.argtypes = [i32, i32, i32, i32, C.POINTER(i32)]
+    L.bwgr_debug_stream3_dma.argtypes = [i64, i64]
     L.bwgr_panel_pipeline.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.bwgr_panel_stats.argtypes = [vp, c_f, c_f, c_f]
     L.bwgr_kmup.argtypes = [vp, c_f, c_f, c_f, c_f, c_f, f32, f32, u64, u32, i32]
@@ -98,7 +102,7 @@ def device_count():
 
 
 EXPORTS = ["bwgr_abi_version", "bwgr_last_error", "bwgr_device_count", "bwgr_panel_create", "bwgr_panel_destroy",
-           "bwgr_panel_set_stream", "bwgr_panel_info", "bwgr_panel_pipeline", "bwgr_panel_clone", "bwgr_em", "bwgr_em_order", "bwgr_panel_max_concurrent", "bwgr_panel_max_pairs", "bwgr_debug_occupancy_fits", "bwgr_panel_stats", "bwgr_kmup", "bwgr_kmup2", "bwgr_chain_create",
+           "bwgr_panel_set_stream", "bwgr_panel_info", "bwgr_panel_pipeline", "bwgr_panel_clone", "bwgr_em", "bwgr_em_order", "bwgr_panel_max_concurrent", "bwgr_panel_max_pairs", "bwgr_debug_occupancy_fits", "bwgr_debug_stream3_dma", "bwgr_panel_stats", "bwgr_kmup", "bwgr_kmup2", "bwgr_chain_create",
            "bwgr_chain_create_sharded", "bwgr_chain_sweep_blocks", "bwgr_chain_round_sweep", "bwgr_chain_round_apply", "bwgr_chain_get_sums_dev", "bwgr_chain_end_iteration_dev", "bwgr_chain_get_sums", "bwgr_chain_end_iteration",
            "bwgr_chain_destroy", "bwgr_chain_run", "bwgr_chain_run_pair", "bwgr_chain_sync", "bwgr_chain_iterations", "bwgr_chain_result",
            "bwgr_chain_state", "bwgr_chain_sweep_ms", "bwgr_chain_redo_count", "bwgr_group_sound", "bwgr_panel_centred", "bwgr_bayes", "bwgr_bayes2", "bwgr_wgr", "bwgr_wgr_ex", "bwgr_synth_genotypes",

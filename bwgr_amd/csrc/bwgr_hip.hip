@@ -18,7 +18,6 @@
 #include "sweep3.hip.h"
 #include "sweep2w.hip.h"
 #include "sweep3p.hip.h"
-#include "sweep4.hip.h"
 #include <stdlib.h>
 
 using namespace bwgr;
@@ -882,7 +881,7 @@ __global__ void k_debug_variates(Rng g, int kind, double nu, uint32_t marker0, u
 
 // ------------------------------------------------------------------------------------------------
 // host objects
-// ---- a fixed-point sweep (k_sweep3 / k_sweep4 / k_sweep2w's fixed-point streamers) that leaves its range is redone on the fp64 residual:
+// ---- a fixed-point sweep (k_sweep3 / k_sweep2w's fixed-point streamers) that leaves its range is redone on the fp64 residual:
 // the state it starts from is kept (12 bytes per marker and the residual: 12 MB against a 10 GB read at C4), and when the range flag
 // comes back the state is restored, the flag cleared and sc->redo set, which lets the fp64 launches queued behind (redo_only) run ----
 namespace {
@@ -952,16 +951,7 @@ struct bwgr_panel {
   unsigned long long *qsum3 = nullptr, *lists3 = nullptr;   // per handle (clones have their own)
   uint32_t epoch3 = 0;
   size_t lds3_bytes = 0;
-  // k_sweep4 (sweep4.hip.h): the trajectory engine with super-block streamers and the eight-wave token sequencer -- a chain alone on
-  // the GPU, int8 panel, 128-marker blocks, 16-bit Gram entries; every other sparse selection sweep stays with k_sweep3
-  bool e4_ready = false;
-  bool sweep4_on = false;         // BWGR_SWEEP4=1 enables it (off while it is slower than k_sweep3)
-  int e4_DQ = S4_MAXDQ, e4_SS = 4;
-  unsigned long long *lists4 = nullptr;   // root panels only
-  double *fin4 = nullptr;                 // k_sweep4_finish's partial sums
   double *snap_e = nullptr; float *snap_b = nullptr, *snap_d = nullptr, *snap_vb = nullptr;   // state before a fixed-point sweep (range recovery)
-  uint16_t *gd16 = nullptr;               // [nblocks][128][128] the diagonal Gram blocks in full, 16-bit (rows land in the sequencer's LDS by DMA: whole aligned rows)
-  size_t lds4_bytes = 0;
   // the affine models' block solve as a triangular product (sweep2w.hip.h)
   bool winv_on = true;            // BWGR_WINV=0: the serial recurrence of k_sweep2's sequencer instead
   double *winv = nullptr;         // per handle: [nblocks][S2W_WDOUBLES], written by k_affine_inv before every affine sweep
@@ -1189,13 +1179,7 @@ static int sweep3_build(bwgr_panel *P) {
   if (const char *tv = getenv("BWGR_ENG3_THR")) { const float v = (float)atof(tv); if (v > 0.0f) P->eng3_thr = v; }
   const size_t blk_elems = (size_t)P->nblocks * m * m;
   const bool g16 = P->gram16;
-  // k_sweep4: 128-row streamers on 128-marker blocks with 16-bit Gram entries; its cross Gram arrays reach 4 DQ - 1 blocks back
-  P->e4_ready = false;
-  if (const char *s4 = getenv("BWGR_SWEEP4")) P->sweep4_on = s4[0] == '1';
-  if (const char *dq = getenv("BWGR_DQ4")) { const int v = atoi(dq); if (v >= 2 && v <= S4_MAXDQ) P->e4_DQ = v; }
-  const bool want4 = P->sweep4_on && g16 && m == SW_MAXM && (P->R % 128) == 0 && P->K * (P->R / 128) <= 255 && P->K * (P->R / 128) + 2 <= 256 &&
-                     (uint64_t)P->p * (uint64_t)P->R < (1ull << 32) && s4_streamer_lds(128, P->e4_SS) <= (size_t)160 * 1024 && !P->parent;
-  const int Dbuild = want4 ? std::max(D, S4_QB * P->e4_DQ) : D;
+  const int Dbuild = D;
   int32_t *tmp = nullptr;
   for (int d = 1; d < Dbuild; ++d) {
     if (P->nblocks <= d) { P->g3x[d - 1] = nullptr; continue; }
@@ -1235,17 +1219,6 @@ static int sweep3_build(bwgr_panel *P) {
     }
   }
   CHK(sweep3_alloc_scratch(P));
-  if (want4) {
-    const size_t nq = (size_t)(P->nblocks + S4_QB - 1) / S4_QB;
-    HIPCHK(hipMalloc(&P->gd16, (size_t)P->nblocks * m * m * 2));
-    hipLaunchKernelGGL(k_gram_narrow, dim3(2048), dim3(256), 0, P->stream, (const int32_t *)P->gram, P->gd16, (int64_t)P->nblocks * m * m, P->gram16_bad);   // (the diagonal entries are among the packed ones already checked)
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMalloc(&P->lists4, sizeof(unsigned long long) * S4_LSTRIDE * nq));
-    HIPCHK(hipMemsetAsync(P->lists4, 0, sizeof(unsigned long long) * S4_LSTRIDE * nq, P->stream));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    P->lds4_bytes = std::max(std::max(s4_streamer_lds(128, P->e4_SS), s4_seq_lds()), s4c_seq_lds());
-    P->e4_ready = true;
-  }
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<int32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3p<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1253,6 +1226,9 @@ static int sweep3_build(bwgr_panel *P) {
   P->e3_ready = true;
   return BWGR_OK;
 }
+// the DMA streamer's lane offsets are 32-bit: (columns of the launch) * (rows of a slab) bytes must stay below 4 GiB
+static bool stream3_dma_fits(int64_t ncols, int64_t R) { return ncols >= 0 && R > 0 && (uint64_t)ncols * (uint64_t)R < (1ull << 32); }
+extern "C" int bwgr_debug_stream3_dma(int64_t ncols, int64_t R) { return stream3_dma_fits(ncols, R) ? 1 : 0; }
 // what one launch of k_sweep3 / k_sweep3p needs beside the sweep's own arguments; zeroes the launch's slab-dot sums, takes a new epoch
 static void sweep3_args(bwgr_panel *P, const SweepArgs &a, Sweep3Args &A) {
   memset(&A, 0, sizeof(A));
@@ -1264,55 +1240,25 @@ static void sweep3_args(bwgr_panel *P, const SweepArgs &a, Sweep3Args &A) {
   A.qsum = P->qsum3; A.lists = P->lists3;
   A.gx12 = root->gram16 ? root->gx12 : nullptr;
   A.pf = -1;
-  if (const char *dv = getenv("BWGR_DBG3")) A.dbg = atoi(dv);
+#ifdef BWGR_EXPERIMENTS
+  if (const char *dv = getenv("BWGR_DBG3")) A.dbg = atoi(dv);   // (timing switches, some of which break the chain: the experiment build only)
+#endif
   {   // 128-row streamers land their tiles by LDS-DMA (s3_streamer_dma; C4 15.0 -> 13.65 ms per sweep); BWGR_STREAM3=reg: through registers, as the 256-row ones do
+    // The DMA streamer forms a tile piece's source as a 32-bit lane offset from the launch's first column (no 64-bit vector arithmetic): only
+    // launches whose column range spans less than 4 GiB of one slab take it (p * R < 2^32: 16.7 M markers at R = 256); wider ones keep the
+    // register path, whose offsets are size_t.  bwgr_debug_stream3_dma() exposes the rule to the CPU tests.
     const char *sv = getenv("BWGR_STREAM3");
-    if (!(sv && sv[0] == 'r')) A.dbg |= (1 << 22);
-    if (sv && sv[0] == 'd') A.dbg |= (1 << 23);   // (EXPERIMENT: the 256-row streamers too, three tile buffers)
+    const int64_t j_lo = (int64_t)a.blk_begin * a.m, j_hi = std::min<int64_t>(P->p, (int64_t)a.blk_end * a.m);
+    const bool fits32 = stream3_dma_fits(j_hi - j_lo, P->R);
+    if (!(sv && sv[0] == 'r') && fits32) A.dbg |= (1 << 22);
+    if (sv && sv[0] == 'd' && fits32) A.dbg |= (1 << 23);   // (EXPERIMENT: the 256-row streamers too, three tile buffers)
   }
   if (SWEEP_DRY) return;
   P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1;
   A.epoch = P->epoch3;
   (void)hipMemsetAsync(P->qsum3 + (size_t)a.blk_begin * 2 * SW_MAXM, 0, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
 }
-// k_sweep4 takes a sparse selection sweep when the chain has the GPU to itself and the range starts on a quad boundary (k_spec4's
-// in-super-block terms are laid out from block 0 of the panel); what it needs beside the sweep's own arguments
-static bool use_sweep4(const bwgr_panel *P, const SweepArgs &a) {
-  return P->e4_ready && !P->parent && P->nclones == 0 && P->lists4 && (a.blk_begin % S4_QB) == 0 && !P->force3;
-}
-static void launch_sweep4(bwgr_panel *P, const SweepArgs &a) {
-  Sweep4Args A;
-  memset(&A, 0, sizeof(A));
-  A.a = a;
-  for (int d = 0; d < S3_MAXD; ++d) A.gx[d] = P->g3x[d];
-  A.gp = P->gramp16; A.gd = P->gd16;
-  A.DQ = P->e4_DQ; A.SS = P->e4_SS; A.R3 = 128; A.sub = P->R / 128; A.K3 = P->K * A.sub;
-  A.qsum = P->qsum3; A.lists = P->lists4;
-  if (!SWEEP_DRY) { P->epoch3 = (P->epoch3 + 1) & 0xFFFFFFu; if (P->epoch3 == 0) P->epoch3 = 1; }
-  A.epoch = P->epoch3;
-  if (const char *dv = getenv("BWGR_DBG4")) A.dbg = atoi(dv);
-  A.seq = 1;   // (1: the token walk over eight waves -- the faster of the two so far; 2: the chain wave with helpers)
-  if (const char *sv = getenv("BWGR_SEQ4")) A.seq = (sv[0] == '2') ? 2 : 1;
-  if (!SWEEP_DRY) (void)hipMemsetAsync(P->qsum3 + (size_t)a.blk_begin * 2 * SW_MAXM, 0, sizeof(unsigned long long) * 2 * SW_MAXM * (size_t)(a.blk_end - a.blk_begin), P->stream);
-  // L2 prefetcher workgroups on the sequencer's XCD (workgroup indices that are multiples of 8): BWGR_PF4 = how many (default 4)
-  int npf = 4;
-  if (const char *pv = getenv("BWGR_PF4")) npf = std::max(0, std::min(8, atoi(pv)));
-  while (npf > 0 && (8 * npf >= 1 + A.K3 + npf || 1 + A.K3 + npf > 256)) --npf;
-  A.npf = npf;
-  const dim3 grid(1 + A.K3 + npf), blk(SW_THREADS);
-  if (A.seq == 2 && !SWEEP_DRY) {   // the chain wave writes the included markers' b and d = 1 only
-    const int j0 = a.blk_begin * a.m, j1 = (int)std::min<int64_t>(P->p, (int64_t)a.blk_end * a.m);
-    (void)hipMemsetAsync(a.d + j0, 0, sizeof(float) * (size_t)(j1 - j0), P->stream);
-  }
-  SPIN_LAUNCH(k_sweep4<4>, grid, blk, P->lds4_bytes, P->stream, A);
-  if (A.seq == 2 && !SWEEP_DRY) {
-    if (!P->fin4) (void)hipMalloc(&P->fin4, sizeof(double) * 2 * 256);
-    hipLaunchKernelGGL(k_sweep4_finish, dim3(256), dim3(256), 0, P->stream, a, P->fin4);
-    hipLaunchKernelGGL(k_sweep4_finish2, dim3(1), dim3(64), 0, P->stream, a, (const double *)P->fin4, 256);
-  }
-}
 static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
-  if (use_sweep4(P, a)) { launch_sweep4(P, a); return; }
   Sweep3Args A;
   sweep3_args(P, a, A);
   // one more workgroup, on the sequencer's XCD (workgroups with equal index mod 8 share an XCD), warms that XCD's L2 with what the
@@ -1367,14 +1313,6 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
   if (s3) {   // the sweep's fixed-point scale, then the in-block speculative terms on that grid
     int xbits = 0; while ((1 << xbits) < std::max(1, (P->parent ? P->parent : P)->xmax)) ++xbits;
     hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, xbits, a.gate3, sh_add);
-    if (P->e4_ready && (a.blk_begin % S4_QB) == 0) {   // k_spec3's terms plus k_sweep4's in-super-block ones and the rounds' radii: either engine may follow
-      Sweep4Args A4;
-      memset(&A4, 0, sizeof(A4));
-      A4.a = a; A4.SS = P->e4_SS;
-      const bwgr_panel *root = P->parent ? P->parent : P;
-      for (int d = 0; d < S3_MAXD; ++d) A4.gx[d] = root->g3x[d];
-      hipLaunchKernelGGL(k_spec4, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, A4, a.blk_begin);
-    } else
     hipLaunchKernelGGL(k_spec3, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin);
     if (std::isinf(a.gate3)) return;
   }
@@ -1414,7 +1352,11 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
   a.gate3 = sweep3_gate(P, a.flags);
   const bool fx = (a.gate3 > 0.0f) || (use_winv(P, a.flags) && P->winv && use_wfx(P));
   SnapArgs sn;
-  static const bool no_recover = getenv("BWGR_NO_RECOVER") != nullptr;   // (timing experiments that break the chain on purpose)
+#ifdef BWGR_EXPERIMENTS
+  static const bool no_recover = getenv("BWGR_NO_RECOVER") != nullptr;   // (timing experiments that break the chain on purpose: the experiment build only)
+#else
+  constexpr bool no_recover = false;
+#endif
   const bool guarded = fx && !P->debug_withhold && !no_recover && range_snapshot(P, a, sn);
   launch_sweep_kernel_inner(P, a_in, false);
   if (guarded) {
@@ -1448,7 +1390,9 @@ static void launch_sweep_kernel_inner(bwgr_panel *P, const SweepArgs &a_in, bool
     A.fx = (use_wfx(P) && !redo) ? 1 : 0;
     if (!A.fx) a.lag = std::min(a.lag, 4);   // (k_sweep2's streamers -- the range-recovery launch, BWGR_WFX=0 -- hold four tiles)
     A.nd = std::min(a.lag - 1, (int)S2W_MAXDIST);
+#ifdef BWGR_EXPERIMENTS
     if (const char *dv = getenv("BWGR_DBGW")) A.dbg = atoi(dv);
+#endif
     for (int d = 0; d < S2W_MAXDIST; ++d) A.gxt[d] = P->gxt[d < P->winv_nd ? d : 0];
     A.npf = P->wpf;      // measured at C2: 0 -> 540, 2 -> 636, 4 -> 685 iter/s (6 and 8 no better)
     A.ahead = P->wahead;
@@ -1507,7 +1451,9 @@ static void choose_lag(const bwgr_panel *P, SweepArgs &a) {
   if (use_winv(P, a.flags)) {   // the affine sweeps' product sequencer: as deep as the panel's cross Gram planes reach (BWGR_WLAG caps it)
     a.lag = std::min(P->winv_nd + 1, P->wlag_cap);
     if (!use_wfx(P)) a.lag = std::min(a.lag, 4);   // (k_sweep2's streamers hold four tiles)
+#ifdef BWGR_EXPERIMENTS
     if (const char *tl = getenv("BWGR_WLAG_TIMING")) a.lag = atoi(tl);   // TIMING ONLY: deeper than the cross terms reach (wrong chain)
+#endif
   }
 }
 // A handle that a pair run moved onto the pair's stream goes back to the stream it had (its own, or the caller's) when it next sweeps alone:
@@ -1597,7 +1543,7 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   (void)hipSetDevice(P->device);
   if (!P->parent) {
     for (int d = 0; d < S3_MAXD; ++d) if (P->g3own[d]) hipFree(P->g3x[d]);
-    hipFree(P->lists4); hipFree(P->gd16); hipFree(P->fin4); hipFree(P->gx12);
+    hipFree(P->gx12);
     hipFree(P->xmax_dev);
     for (int d = 0; d < S2W_MAXDIST; ++d) hipFree(P->gxt[d]);
     hipFree(P->X); hipFree(P->gram); hipFree(P->gramx); hipFree(P->gramx2); hipFree(P->gramx3); hipFree(P->gramp16); hipFree(P->gramx16); hipFree(P->gram16_bad); hipFree(P->gramp); hipFree(P->xx); hipFree(P->vx); hipFree(P->msx_dev);
@@ -1860,7 +1806,11 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2w<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep2w<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   PCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_affine_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  if (!P->is_f32) P->ldsw_bytes = s2w_lds_bytes(m, R, getenv("BWGR_WLAG_TIMING") ? atoi(getenv("BWGR_WLAG_TIMING")) : 6);   // (room for the deepest pipeline BWGR_WLAG can ask for)
+#ifdef BWGR_EXPERIMENTS
+  if (!P->is_f32) P->ldsw_bytes = s2w_lds_bytes(m, R, getenv("BWGR_WLAG_TIMING") ? atoi(getenv("BWGR_WLAG_TIMING")) : 6);
+#else
+  if (!P->is_f32) P->ldsw_bytes = s2w_lds_bytes(m, R, 6);
+#endif   // (room for the deepest pipeline BWGR_WLAG can ask for)
   if (const char *wv = getenv("BWGR_WINV")) P->winv_on = !(wv[0] == '0');
   if (const char *wv = getenv("BWGR_WFX")) P->wfx_on = !(wv[0] == '0');
   if (const char *pv = getenv("BWGR_WPF")) P->wpf = std::max(0, std::min(8, atoi(pv)));
@@ -1914,7 +1864,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   P->parent = root; P->nclones = 0; P->nchains = 0; P->own_stream = nullptr; P->stream = nullptr; P->ps_owner = nullptr; P->ps_iter = -1;
   P->pair_streams.clear();   // (the root's: a clone owns none)
   P->pre_pair_stream = nullptr; P->pre_pair_set = false; P->guard_ev = nullptr; P->guard_cus = 0; P->guard_stream = nullptr; P->guard_listed = false;
-  P->qsum3 = P->lists3 = nullptr; P->lists4 = nullptr; P->gd16 = nullptr; P->fin4 = nullptr; P->epoch3 = 0;
+  P->qsum3 = P->lists3 = nullptr; P->epoch3 = 0;
   P->snap_e = nullptr; P->snap_b = P->snap_d = P->snap_vb = nullptr; P->xmax_dev = nullptr; P->winv = nullptr; P->qsumw = nullptr;
   P->xspec2 = P->xspec3 = nullptr; P->ps = {}; P->xpart = P->qpart = nullptr; P->dgran = nullptr; P->xflags = nullptr; P->xchg = nullptr; P->stamps = nullptr;
   root->nclones++;

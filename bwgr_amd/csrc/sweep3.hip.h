@@ -531,7 +531,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
       const int pc = min(wvs - NU + ND * u, NPC - 1);
       const int jl = MPP * pc + (int)lane_mk;                      // the marker's index in the tile
       const int jj = min(jb + jl, j_hi - 1);
-      const uint32_t voff = (uint32_t)(jj - j_lo) * (uint32_t)R + ((lane_cr ^ ((uint32_t)jl & (uint32_t)(CH - 1))) * 16u);   // (a launch's slab of the panel stays below 4 GiB: checked on the host)
+      const uint32_t voff = (uint32_t)(jj - j_lo) * (uint32_t)R + ((lane_cr ^ ((uint32_t)jl & (uint32_t)(CH - 1))) * 16u);   // (a launch's slab of the panel stays below 4 GiB: sweep3_args selects this streamer only then)
       s3_dma16s(reinterpret_cast<const unsigned char *>(Xs + (size_t)j_lo * R), voff, la0 + (uint32_t)pc * 1024u);
     }
   };
@@ -590,10 +590,15 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
     return 1;
   };
 
-  // ---- prologue: tiles 0, 1, 2 requested ----
+  // ---- prologue: tiles 0 .. NTB - 2 requested and waited for.  The counted wait in front of a step's barrier (S3_DMA_BARRIER) proves tile b landed
+  // only when at least WN younger loads have been issued, which holds from step NTB - 1 on (per step a dots wave issues PPW pieces and two small
+  // loads: younger than tile b at the barrier of step b are (NTB - 1 - b) * PPW prologue pieces less tile b's own, one prologue load and b * (PPW + 2)
+  // loop loads -- 7 at step 0, 9 at step 1, 12 from step 2 on for <128, 4>, against WN = 10).  The prologue's __syncthreads() compiles to
+  // lgkmcnt(0) + s_barrier and drains no DMA, so the prologue tiles are drained here, once per launch. ----
   for (int t = 0; t < NTB - 1; ++t) tile_issue(t);
   float drej_pre = a.ps.blocks[a.blk_begin].drej[tid & (SW_MAXM - 1)];   // (used by the last two waves)
   unsigned long long lpre = 0ull;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   S3ST_DECL;
   const bool st_u = (w == 0 && tid == 0), st_d = (w == 0 && tid == 64 * NU);

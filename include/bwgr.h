@@ -34,8 +34,11 @@ enum bwgr_status {
   BWGR_ENOMEM = 3,
   BWGR_ETIMEOUT = 4, /* an in-kernel workgroup exchange gave up (bounded spin) */
   BWGR_ENODEV = 5,   /* no usable GPU */
-  BWGR_ERANGE = 6    /* the residual grew more than eightfold within one sweep (the fixed-point range of the selection
-                        models' sweep engine): the chain has diverged; its state is invalid */
+  BWGR_ERANGE = 6    /* a fixed-point sweep left its range and could NOT be redone.  Since round 3 a sweep of the single-chain entry
+                        points that leaves the range is redone on the fp64 residual from the state it started with and the chain goes
+                        on (bwgr_chain_redo_count says how often); this status remains for the paths without that recovery: a pair
+                        sweep (bwgr_chain_run_pair -- run the two chains unpaired instead; the host layer's fit_many does), the debug
+                        abort hook, and a recovery whose snapshot could not be allocated.  The chain's state is then invalid. */
 };
 enum bwgr_xtype { BWGR_X_I8 = 0, BWGR_X_F32 = 1, BWGR_X_F64 = 2 }; /* F64 (an R numeric matrix) is narrowed
                                                                      to float on upload, as the Rcpp glue does
@@ -87,6 +90,10 @@ int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src);
 int bwgr_panel_max_concurrent(const bwgr_panel *P, int selection, int *count);
 int bwgr_panel_max_pairs(const bwgr_panel *P, int *pairs);
 int bwgr_debug_occupancy_fits(int grid, int per_cu, int cus, int busy, int *need);
+/* host arithmetic of one more launch rule: the LDS-DMA streamers of k_sweep3 address a launch's columns by 32-bit lane offsets, so a
+ * launch over `ncols` columns of `slab_rows`-row slabs takes them only while ncols * slab_rows < 2^32 (else the register-path streamers
+ * with 64-bit offsets).  Returns 1 / 0. */
+int bwgr_debug_stream3_dma(int64_t ncols, int64_t slab_rows);
 /* geometry actually chosen: info[0]=n, [1]=p, [2]=ld (padded rows), [3]=block, [4]=nwg, [5]=slab rows,
  * [6]=bytes of X resident, [7]=bytes of Gram resident */
 int bwgr_panel_info(const bwgr_panel *P, int64_t info[8]);

@@ -16,6 +16,18 @@ os.environ.setdefault("BWGR_ENG3_THR", "1")
 os.environ.setdefault("BWGR_PRELOAD_TORCH", "1")
 
 
+@pytest.fixture(params=["forced", "shipped"])
+def engine_threshold(request, monkeypatch):
+    """The core parity matrix runs twice: with k_sweep3 forced for every selection sweep (the suite's default, above) and at the SHIPPED
+    device-side engine gate (BWGR_ENG3_THR unset: k_sweep3 below 3 % of the markers in the model, k_sweep2 above).  The variable is read when
+    a panel is made, so tests that take this fixture build their panels after it."""
+    if request.param == "shipped":
+        monkeypatch.delenv("BWGR_ENG3_THR", raising=False)
+    else:
+        monkeypatch.setenv("BWGR_ENG3_THR", "1")
+    return request.param
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

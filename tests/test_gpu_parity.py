@@ -44,7 +44,7 @@ def test_panel_stats_tpod(tpod):
 
 @pytest.mark.parametrize("pi", [0.0, 0.3])
 @pytest.mark.parametrize("block,nwg", [(0, 0), (16, 1), (64, 1)])
-def test_kmup_sweep_tpod(tpod, pi, block, nwg):
+def test_kmup_sweep_tpod(tpod, pi, block, nwg, engine_threshold):
     import bwgr_amd
     from oracle import oracle as O
     X, y = tpod["gen"], tpod["y"]
@@ -64,7 +64,7 @@ def test_kmup_sweep_tpod(tpod, pi, block, nwg):
 
 
 @pytest.mark.parametrize("model", ALL_MODELS)
-def test_short_chain_tpod(tpod, model):
+def test_short_chain_tpod(tpod, model, engine_threshold):
     import bwgr_amd
     from oracle import oracle as O
     X, y = tpod["gen"], tpod["y"]
@@ -86,7 +86,7 @@ def test_short_chain_tpod(tpod, model):
 
 
 @pytest.mark.parametrize("model,nwg,block", [("BayesA", 2, 32), ("BayesB", 3, 64), ("BayesRR", 4, 128), ("BayesCpi", 2, 48)])
-def test_short_chain_multi_workgroup(model, nwg, block):
+def test_short_chain_multi_workgroup(model, nwg, block, engine_threshold):
     """Row slabs across several workgroups: exercises the in-kernel all-gather of slab partials."""
     import bwgr_amd
     from oracle import oracle as O
@@ -137,7 +137,7 @@ def test_float_panel_chains(model):
 # wgr() settings of man/wgr.Rd:82: BRR (defaults), BayesA (iv), BayesB (iv, pi>0), BayesC (pi>0), BayesL (de)
 @pytest.mark.parametrize("name,kw", [("BRR", {}), ("BayesA", {"iv": True}), ("BayesB", {"iv": True, "pi": 0.5}),
                                      ("BayesC", {"pi": 0.5}), ("BayesL", {"de": True}), ("thin", {"th": 3, "bi": 4})])
-def test_wgr_tpod(tpod, name, kw):
+def test_wgr_tpod(tpod, name, kw, engine_threshold):
     import bwgr_amd
     from oracle import oracle as O
     X, y = tpod["gen"], tpod["y"]

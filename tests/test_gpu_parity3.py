@@ -3,7 +3,6 @@
 * the fixed-point engines leaving their range: the sweep is redone on the fp64 residual and the chain stays the oracle's
   (the reference's update, src/Rcpp20260726ai.cpp:681, cannot fail)
 * KMUP calls whose residual is zero or tiny against the steps (the affine engine's scale used to come from max|e| alone)
-* k_sweep4 (opt-in), both sequencer forms, against the oracle
 * the parity matrix at the SHIPPED engine threshold (the suite otherwise forces k_sweep3 everywhere)
 """
 import numpy as np
@@ -81,30 +80,6 @@ def test_kmup_with_a_zero_or_tiny_residual(tpod, pi, escale):
     o = O.kmup(X, b, d, xx, e, L, 0.04, pi, seed=17, it=2)
     assert scaled_err(g["b"], o["b"]) < TOL and scaled_err(g["e"], o["e"]) < TOL
     assert np.array_equal(g["d"], o["d"])
-
-
-@pytest.mark.parametrize("seq", ["1", "2"])
-@pytest.mark.parametrize("model,pi,data", [("BayesB", 0.9, "tpod"), ("BayesCpi", 0.0, "tpod"), ("BayesB", 0.97, "synth"), ("BayesDpi", 0.0, "synth")])
-def test_sweep4_against_the_oracle(tpod, model, pi, data, seq, monkeypatch):
-    """k_sweep4 (opt-in, BWGR_SWEEP4=1): the super-block streamers with either sequencer form -- the token walk over eight waves
-    (BWGR_SEQ4=1) and the chain wave with helpers (BWGR_SEQ4=2) -- run the oracle's chain: sparse and dense inclusion, a ragged last
-    quad (tpod: three blocks; synth: 1 000 x 1 700, fourteen blocks, eight slab streamers)."""
-    import bwgr_amd
-    from oracle import oracle as O
-    monkeypatch.setenv("BWGR_SWEEP4", "1")
-    monkeypatch.setenv("BWGR_SEQ4", seq)
-    if data == "tpod":
-        X, y = tpod["gen"], tpod["y"]
-    else:
-        X, y = synth_small(1000, 1700, seed=31)
-    P = bwgr_amd.Panel(X)
-    ch = bwgr_amd.Chain(P, model, y, it=8, bi=2, pi=pi, seed=9)
-    ch.run(8)
-    st = ch.state()
-    ch.close(); P.close()
-    o = O.bayes(model, y, X, it=8, bi=2, pi=pi, seed=9)["last"]
-    assert np.array_equal(st["d"], o["d"])
-    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
 
 
 @pytest.mark.parametrize("model,pi", [("BayesB", 0.9), ("BayesB", 0.99), ("BayesC", 0.95), ("BayesCpi", 0.0), ("BayesDpi", 0.0)])

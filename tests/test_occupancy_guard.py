@@ -32,6 +32,18 @@ def test_guard_arithmetic():
     assert _fits(0, 1, 256, 0)[0] != OK and _fits(10, 1, 0, 0)[0] != OK and _fits(10, 1, 256, -1)[0] != OK
 
 
+def test_dma_streamer_is_chosen_only_below_4gib_of_columns():
+    """k_sweep3's LDS-DMA streamers address a launch's columns by 32-bit lane offsets (sweep3.hip.h, tile_issue): the host selects them only
+    while columns x slab rows < 2^32 and falls back to the register-path streamers (64-bit offsets) beyond -- a WGS-size panel such as
+    2 000 x 20 M fits the GPU and must not wrap."""
+    f = _lib.lib().bwgr_debug_stream3_dma
+    assert f(1_000_000, 256) == 1                 # C4: 2.56e8
+    assert f(16_777_215, 256) == 1 and f(16_777_216, 256) == 0      # the edge at R = 256
+    assert f(20_000_000, 256) == 0                # the WGS-size panel
+    assert f(20_000_000, 128) == 1 and f(33_554_432, 128) == 0
+    assert f(0, 256) == 1 and f(-1, 256) == 0 and f(10, 0) == 0
+
+
 @pytest.mark.gpu
 def test_oversubscription_is_refused_and_the_chain_survives():
     """cap = bwgr_panel_max_concurrent chains in flight on clones of one panel; one more is refused (BWGR_EINVAL, nothing enqueued), and
