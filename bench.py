@@ -240,6 +240,8 @@ def main():
                     "residual all-reduce) instead of N replica chains; statistically unsound on uncentred genotypes, see DESIGN.md section 8")
     ap.add_argument("--uncentred", action="store_true", help="--sharded on the raw int8 genotypes (statistically UNSOUND for N > 1: DESIGN.md section 8; "
                     "kept for measurements)")
+    ap.add_argument("--centre-explicit", action="store_true", help="--sharded: centre into a float32 copy of the shard (round 3's path, 4 bytes per genotype) instead of "
+                    "sweeping the int8 shard as implicitly centred columns")
     ap.add_argument("--pairs", type=int, default=0, help="pairs of chains in the paired-chains leg (0: as many as fit)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c3 legs that follow the headline workload (`workloads` in the JSON line)")

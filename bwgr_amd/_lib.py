@@ -71,6 +71,7 @@ def lib():
     L.bwgr_chain_redo_count.argtypes = [vp, C.POINTER(i32)]
     L.bwgr_group_sound.argtypes = [vp, C.POINTER(i32)]
     L.bwgr_panel_centred.argtypes = [vp, C.POINTER(i32)]
+    L.bwgr_panel_set_centred.argtypes = [vp, i32]
     L.bwgr_bayes.argtypes = [vp, i32, c_f, f32, f32, f32, f32, f32, u64, i32] + [c_f] * 10
     L.bwgr_bayes2.argtypes = [vp, vp, i32, c_f, f32, f32, f32, f32, f32, u64, i32] + [c_f] * 10
     L.bwgr_wgr.argtypes = [vp, c_d, i32, i32, i32, i32, i32, f64, f64, f64, u64, i32] + [c_d] * 7
@@ -79,6 +80,7 @@ def lib():
     L.bwgr_debug_variates.argtypes = [i32, u64, i32, f64, u32, u32, u32, i32, c_d]
     L.bwgr_debug_withhold.argtypes = [vp, i32]
     L.bwgr_group_create.argtypes = [C.POINTER(vp), i32, C.POINTER(i32), vp, i32, i64, i64, i64, i32, c_f, i32, f32, f32, f32, f32, f32, u64, i32, i64]
+    L.bwgr_group_create_centred.argtypes = L.bwgr_group_create.argtypes
     L.bwgr_group_run.argtypes = [vp, i32]
     L.bwgr_group_sync.argtypes = [vp]
     L.bwgr_group_info.argtypes = [vp, C.POINTER(i64)]
@@ -105,6 +107,6 @@ EXPORTS = ["bwgr_abi_version", "bwgr_last_error", "bwgr_device_count", "bwgr_pan
            "bwgr_panel_set_stream", "bwgr_panel_info", "bwgr_panel_pipeline", "bwgr_panel_clone", "bwgr_em", "bwgr_em_order", "bwgr_panel_max_concurrent", "bwgr_panel_max_pairs", "bwgr_debug_occupancy_fits", "bwgr_debug_stream3_dma", "bwgr_panel_stats", "bwgr_kmup", "bwgr_kmup2", "bwgr_chain_create",
            "bwgr_chain_create_sharded", "bwgr_chain_sweep_blocks", "bwgr_chain_round_sweep", "bwgr_chain_round_apply", "bwgr_chain_get_sums_dev", "bwgr_chain_end_iteration_dev", "bwgr_chain_get_sums", "bwgr_chain_end_iteration",
            "bwgr_chain_destroy", "bwgr_chain_run", "bwgr_chain_run_pair", "bwgr_chain_sync", "bwgr_chain_iterations", "bwgr_chain_result",
-           "bwgr_chain_state", "bwgr_chain_sweep_ms", "bwgr_chain_redo_count", "bwgr_group_sound", "bwgr_panel_centred", "bwgr_bayes", "bwgr_bayes2", "bwgr_wgr", "bwgr_wgr_ex", "bwgr_synth_genotypes",
-           "bwgr_debug_variates", "bwgr_debug_withhold", "bwgr_sample_rows", "bwgr_group_create", "bwgr_group_run", "bwgr_group_sync",
+           "bwgr_chain_state", "bwgr_chain_sweep_ms", "bwgr_chain_redo_count", "bwgr_group_sound", "bwgr_panel_centred", "bwgr_panel_set_centred", "bwgr_bayes", "bwgr_bayes2", "bwgr_wgr", "bwgr_wgr_ex", "bwgr_synth_genotypes",
+           "bwgr_debug_variates", "bwgr_debug_withhold", "bwgr_sample_rows", "bwgr_group_create", "bwgr_group_create_centred", "bwgr_group_run", "bwgr_group_sync",
            "bwgr_group_info", "bwgr_group_result", "bwgr_group_destroy"]

@@ -117,6 +117,13 @@ class Panel:
         check(_lib.lib().bwgr_panel_centred(self._h, C.byref(k)))
         return bool(k.value)
 
+    def set_centred(self, on=True):
+        """Sweep the implicitly centred columns x_j - mean(x_j) of this int8 panel from now on (bwgr_panel_set_centred): the genotypes stay
+        int8 in HBM and the kernels those of the raw columns; the fused chains (Chain, BayesB / C / Cpi / Dpi) then run the reference's sweep on
+        the centred columns, stats() returns their squared norms and centred() is True -- what the marker-sharded sampler needs."""
+        check(_lib.lib().bwgr_panel_set_centred(self._h, int(bool(on))))
+        return self
+
     def pipeline(self, selection):
         """How a sweep over this panel is pipelined: dict(generation, lag, feeders, gram_bits) (bwgr_panel_pipeline)."""
         info = (C.c_int * 4)()
@@ -328,10 +335,16 @@ class Group:
         X = np.asarray(X)
         assert X.ndim == 2
         self._xbar = None
+        implicit = False
         if centre:
             Xd = X.astype(np.float64)
             self._xbar = Xd.mean(0)
-            X = (Xd - self._xbar).astype(np.float32)
+            # integer genotypes: the library centres them IMPLICITLY (int8 stays int8 in HBM, k_sweep3 sweeps it: bwgr_group_create_centred) for the
+            # selection models; otherwise (float columns, affine models) an explicitly centred float panel
+            implicit = (centre != "explicit" and model in ("BayesB", "BayesC", "BayesCpi", "BayesDpi") and X.size > 0 and bool(np.all(X == np.rint(X)))
+                        and X.min() >= -128 and X.max() <= 127)
+            if not implicit:
+                X = (Xd - self._xbar).astype(np.float32)
         if X.dtype != np.int8:
             fits = bool(X.size == 0 or (X.min() >= -128 and X.max() <= 127))
             if fits and (np.issubdtype(X.dtype, np.integer) or np.all(X == np.rint(X))):
@@ -346,7 +359,9 @@ class Group:
         xtype = {np.dtype(np.int8): X_I8, np.dtype(np.float32): X_F32, np.dtype(np.float64): X_F64}[self._X.dtype]
         devs = (C.c_int * len(devices))(*[int(d) for d in devices])
         self._h = C.c_void_p()
-        check(_lib.lib().bwgr_group_create(C.byref(self._h), len(devices), devs, self._X.ctypes.data_as(C.c_void_p), xtype, self.n,
+        self.implicit_centring = implicit
+        create = _lib.lib().bwgr_group_create_centred if implicit else _lib.lib().bwgr_group_create
+        check(create(C.byref(self._h), len(devices), devs, self._X.ctypes.data_as(C.c_void_p), xtype, self.n,
                                             self.p, self.n, int(block), _fp(self._y), MODELS[model], float(it), float(bi), float(pi),
                                             float(df), float(R2), C.c_uint64(_seed(seed)), int(rng_mode), int(markers_per_sync)))
 

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <mutex>
 #include <utility>
+#include <type_traits>
 #include "../../include/bwgr.h"
 #include "rng.hip.h"
 #include "sweep.hip.h"
@@ -109,6 +110,31 @@ __global__ void k_stats(const XT *X, int R, int n, int p, float *xx, float *vx) 
   for (int i = lane; i < n; i += 64) { const float dev = xval(X, xoff(i, j, R, p)) - mean; const float sq = dev * dev; sv += (double)sq; }
   sv = wave_sum(sv);
   if (lane == 0) { xx[j] = (float)s2; vx[j] = (float)(sv / (double)(float)(n - 1)); }
+}
+
+// ---- implicit centring of an int8 panel (bwgr_panel_set_centred): s_j = sum_i x_ij exactly, and the centred column's squared norm
+// sum_i (x_ij - s_j / n)^2 = sum x^2 - s_j^2 / n from exact integer sums, rounded to float once (the reference would form it from the centred
+// float column, X.colwise().squaredNorm(), src/Rcpp20260726ai.cpp:593-594); one wave per column ----
+__global__ void k_colsum_i8(const int8_t *X, int R, int n, int p, int32_t *csum, float *xxc) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j >= p) return;
+  long long s1 = 0, s2 = 0;
+  for (int i = lane; i < n; i += 64) { const int v = (int)X[xoff(i, j, R, p)]; s1 += v; s2 += v * v; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); }
+  if (lane == 0) { csum[j] = (int32_t)s1; xxc[j] = (float)((double)s2 - (double)s1 * (double)s1 / (double)n); }
+}
+// sum_j s_j coef_j / n  (one workgroup, fixed order): what the centred columns take off X * coef
+__global__ __launch_bounds__(1024) void k_cen_dot(const int32_t *csum, const float *coef, int64_t p, double ninv, double *out) {
+  __shared__ double red[1024];
+  const int t = threadIdx.x;
+  double s = 0.0;
+  for (int64_t j = t; j < p; j += 1024) s = fma((double)csum[j], (double)coef[j], s);
+  red[t] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  if (t == 0) *out = red[0] * ninv;
 }
 
 // deterministic two-stage sum of a float vector into a double
@@ -588,10 +614,10 @@ __global__ __launch_bounds__(256) void k_gemv_part_i8(const int8_t *X, int64_t l
 #pragma unroll
   for (int k = 0; k < 16; ++k) o[k] = acc[k];
 }
-__global__ void k_hat_finish(const double *part, int64_t ld, int nchunks, int n, float MU, float *hat) {
+__global__ void k_hat_finish(const double *part, int64_t ld, int nchunks, int n, float MU, float *hat, const double *cen_off = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double s = 0;
+  double s = cen_off ? -*cen_off : 0.0;   // (implicitly centred columns: X_c B = X B - sum_j mean_j B_j)
   for (int c = 0; c < nchunks; ++c) s += part[(int64_t)c * ld + i];
   const float f = (float)s;
   hat[i] = f + MU;
@@ -965,11 +991,18 @@ struct bwgr_panel {
   bool force3 = false;            // a pair run (bwgr_chain_run_pair): every selection sweep is k_sweep3's, whatever the inclusion rate
   float eng3_thr = 0.03f;         // k_sweep3 takes the sweeps whose chains hold fewer than this share of markers in the model (BWGR_ENG3_THR);
                                   // measured crossover at n = 10 000: us per block at 1.4 / 3.7 / 5.8 / 10.9 % inclusion: k_sweep3 2.26 / 3.73 / 5.56 / 12.1, k_sweep2 3.07 / 3.29 / 3.60 / 4.69
+  // implicitly centred columns (bwgr_panel_set_centred; int8 panels with k_sweep3): the column sums, the centred |x_j - mean_j|^2 as floats (what
+  // a chain's xx is then), both owned by the root panel; per handle the running block sums of s_k * drej_k of the current iteration
+  bool cen = false;
+  int32_t *csum = nullptr; float *xxc = nullptr;
+  double *cpre = nullptr;
   hipStream_t own_stream = nullptr;
   // occupancy guard: the compute units this handle's enqueued sweeps hold while they run, the stream they run on, and an event behind the last of them
   hipStream_t pre_pair_stream = nullptr; bool pre_pair_set = false;   // the stream this handle ran on before a pair run moved it (restored by its next sweep alone)
   hipEvent_t guard_ev = nullptr; int guard_cus = 0; hipStream_t guard_stream = nullptr; bool guard_listed = false;
 };
+
+static bool panel_cen(const bwgr_panel *P) { return (P->parent ? P->parent : P)->cen; }
 
 struct bwgr_chain {
   bwgr_panel *P = nullptr;
@@ -1219,8 +1252,10 @@ static int sweep3_build(bwgr_panel *P) {
     }
   }
   CHK(sweep3_alloc_scratch(P));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<int32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<uint16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<int32_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<uint16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3<int32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3p<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep3p<int32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   P->e3_ready = true;
@@ -1274,14 +1309,21 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
   const bool pf_on = (pv ? pv[0] == '1' : solo) && A.K3 + 2 <= 256;
   A.pf = pf_on ? ((A.K3 + 2 > 8) ? 8 : A.K3 + 1) : -1;
   const dim3 grid(A.K3 + 1 + (pf_on ? 1 : 0)), blk(SW_THREADS);
-  if (A.g16) SPIN_LAUNCH(k_sweep3<uint16_t>, grid, blk, P->lds3_bytes, P->stream, A);
-  else SPIN_LAUNCH(k_sweep3<int32_t>, grid, blk, P->lds3_bytes, P->stream, A);
+  const bool cen = (a.flags & SWF_CENTRE) != 0;
+  if (cen && !SWEEP_DRY) hipLaunchKernelGGL(k_cen_begin, dim3(1), dim3(1024), 0, P->stream, a);
+  if (A.g16) { if (cen) SPIN_LAUNCH((k_sweep3<uint16_t, true>), grid, blk, P->lds3_bytes, P->stream, A); else SPIN_LAUNCH((k_sweep3<uint16_t, false>), grid, blk, P->lds3_bytes, P->stream, A); }
+  else { if (cen) SPIN_LAUNCH((k_sweep3<int32_t, true>), grid, blk, P->lds3_bytes, P->stream, A); else SPIN_LAUNCH((k_sweep3<int32_t, false>), grid, blk, P->lds3_bytes, P->stream, A); }
+  if (cen && !SWEEP_DRY) hipLaunchKernelGGL(k_cen_end, dim3(64), dim3(256), 0, P->stream, a);
 }
 
 // The selection models' sweeps on a panel that has k_sweep3: the device picks the engine from the chain's current inclusion
 // rate (ChainScalars::inc_rate against the panel's threshold), so both engines' kernels are enqueued and one side leaves at once
 // (a few microseconds per iteration); a threshold >= 1 means k_sweep3 always and the other side is not enqueued at all.
-static float sweep3_gate(const bwgr_panel *P, int flags) { return use_sweep3(P, flags) ? ((P->eng3_thr >= 1.0f || P->force3) ? INFINITY : P->eng3_thr) : 0.0f; }
+static float sweep3_gate(const bwgr_panel *P, int flags) {
+  if (!use_sweep3(P, flags)) return 0.0f;
+  if (flags & SWF_CENTRE) return INFINITY;   // implicitly centred sweeps are k_sweep3's at every inclusion rate (k_sweep2 sweeps the raw columns)
+  return (P->eng3_thr >= 1.0f || P->force3) ? INFINITY : P->eng3_thr;
+}
 
 // The affine sweeps of an int8 panel with 16-bit Gram staging run k_sweep2w: the block solve as a product with the inverse
 // k_affine_inv forms before the sweep (sweep2w.hip.h).
@@ -1313,6 +1355,10 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
   if (s3) {   // the sweep's fixed-point scale, then the in-block speculative terms on that grid
     int xbits = 0; while ((1 << xbits) < std::max(1, (P->parent ? P->parent : P)->xmax)) ++xbits;
     hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, xbits, a.gate3, sh_add);
+    if (a.flags & SWF_CENTRE) {   // the rejected steps' share of sum(e_stored), block by block (the whole panel: launch_prestage is called with every block)
+      hipLaunchKernelGGL(k_cen_tot, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin);
+      hipLaunchKernelGGL(k_cen_scan, dim3(1), dim3(1024), 0, P->stream, a, (int)P->nblocks);
+    }
     hipLaunchKernelGGL(k_spec3, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin);
     if (std::isinf(a.gate3)) return;
   }
@@ -1357,7 +1403,8 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
 #else
   constexpr bool no_recover = false;
 #endif
-  const bool guarded = fx && !P->debug_withhold && !no_recover && range_snapshot(P, a, sn);
+  // (an implicitly centred sweep that leaves the range is reported, BWGR_ERANGE: the fp64 engine that redoes a sweep sweeps the raw columns)
+  const bool guarded = fx && !P->debug_withhold && !no_recover && !(a.flags & SWF_CENTRE) && range_snapshot(P, a, sn);
   launch_sweep_kernel_inner(P, a_in, false);
   if (guarded) {
     if (!SWEEP_DRY) {
@@ -1553,6 +1600,7 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   // the scratch a sweep writes: speculative cross terms, pre-staged constants, exchange words
   hipFree(P->qsum3); hipFree(P->lists3); hipFree(P->winv); hipFree(P->qsumw);
   hipFree(P->snap_e); hipFree(P->snap_b); hipFree(P->snap_d); hipFree(P->snap_vb);
+  hipFree(P->cpre); if (!P->parent) { hipFree(P->csum); hipFree(P->xxc); }
   hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->ps.quick); hipFree(P->xpart); hipFree(P->xchg); hipFree(P->stamps);
   guard_forget(P);
   if (P->own_stream) hipStreamDestroy(P->own_stream);
@@ -1958,7 +2006,7 @@ extern "C" int bwgr_panel_pipeline(const bwgr_panel *P, int selection, int info[
 extern "C" int bwgr_panel_stats(bwgr_panel *P, float *xx, float *vx, float *MSx) {
   if (!P) return fail(BWGR_EINVAL, "null panel");
   HIPCHK(hipSetDevice(P->device));
-  if (xx) HIPCHK(d2h(P->stream, xx, P->xx, sizeof(float) * P->p));
+  if (xx) HIPCHK(d2h(P->stream, xx, panel_cen(P) ? (P->parent ? P->parent : P)->xxc : P->xx, sizeof(float) * P->p));   // (centred panel: the centred columns' norms)
   if (vx) HIPCHK(d2h(P->stream, vx, P->vx, sizeof(float) * P->p));
   if (MSx) *MSx = P->MSx;
   return BWGR_OK;
@@ -2023,6 +2071,7 @@ static int kmup_sweep(bwgr_panel *PS, float *b, float *d, const float *xx, const
 
 extern "C" int bwgr_kmup(bwgr_panel *P, float *b, float *d, const float *xx, float *e, const float *L, float Ve,
                          float pi, uint64_t seed, uint32_t iter, int rng_mode) {
+  if (P && panel_cen(P)) return fail(BWGR_EINVAL, "kmup: this panel sweeps implicitly centred columns (bwgr_panel_set_centred), which only the fused chains do; call bwgr_panel_set_centred(P, 0) first");
   if (!P || !b || !d || !xx || !e || !L) return fail(BWGR_EINVAL, "kmup: null pointer");
   HIPCHK(hipSetDevice(P->device));
   DevBufs bufs;
@@ -2044,6 +2093,7 @@ extern "C" int bwgr_kmup(bwgr_panel *P, float *b, float *d, const float *xx, flo
 // e_out receives the nuse residuals of the subsample (:76); E (n0 entries) is not modified.
 extern "C" int bwgr_kmup2(bwgr_panel *P, const int *Use, int64_t nuse, float *b, float *d, const float *xx, const float *E,
                           float *e_out, const float *L, float Ve, float pi, uint64_t seed, uint32_t iter, int rng_mode) {
+  if (P && panel_cen(P)) return fail(BWGR_EINVAL, "kmup2: this panel sweeps implicitly centred columns (bwgr_panel_set_centred), which only the fused chains do; call bwgr_panel_set_centred(P, 0) first");
   if (!P || !Use || !b || !d || !xx || !E || !e_out || !L) return fail(BWGR_EINVAL, "kmup2: null pointer");
   if (nuse < 2 || nuse > 0x7FFFFF00ll) return fail(BWGR_EINVAL, "kmup2: need 2 <= length(Use) < 2^31 (got %lld)", (long long)nuse);
   for (int64_t k = 0; k < nuse; ++k)
@@ -2098,6 +2148,11 @@ extern "C" int bwgr_chain_create_sharded(bwgr_chain **out, bwgr_panel *P, int mo
   if (model < BWGR_BAYESA || model > BWGR_BAYESDPI) return fail(BWGR_EINVAL, "chain_create: bad model %d", model);
   if (marker0 < 0 || p_total < marker0 + P->p || p_total > 0xFFFFFFF0ll) return fail(BWGR_EINVAL, "chain_create: bad shard [%lld,+%lld) of %lld", (long long)marker0, (long long)P->p, (long long)p_total);
   HIPCHK(hipSetDevice(P->device));
+  if (panel_cen(P)) {
+    if (!has_d(model) || !use_sweep3(P, SWF_SELECT))
+      return fail(BWGR_EINVAL, "chain_create: an implicitly centred panel (bwgr_panel_set_centred) runs the selection models BayesB / C / Cpi / Dpi on k_sweep3 only");
+    if (!P->cpre) HIPCHK(hipMalloc(&P->cpre, sizeof(double) * ((size_t)P->nblocks + 1)));
+  }
   bwgr_chain *C = new bwgr_chain();
   C->P = P; P->nchains++; C->model = model; C->itf = it; C->bif = bi; C->iit = (int)it; C->ibi = (int)bi;
   C->pi = pi; C->df = df; C->R2 = R2; C->seed = seed; C->rng_mode = rng_mode;
@@ -2140,6 +2195,10 @@ static void chain_args(const bwgr_chain *C, int blk_begin, int blk_end, SweepArg
   if (per_marker_vb(model)) fl |= SWF_LAM_VEC | SWF_VB_VEC;
   a.flags = fl | C->flags_extra;
   a.e = C->e; a.b = C->b; a.d = C->d; a.vb = C->vb; a.xx = P->xx; a.lam = C->lam; a.sc = C->sc;
+  if (panel_cen(P)) {   // implicitly centred columns: the centred squared norms, the column sums, this handle's running block sums
+    const bwgr_panel *root = P->parent ? P->parent : P;
+    a.flags |= SWF_CENTRE; a.xx = root->xxc; a.csum = root->csum; a.cpre = P->cpre; a.ninv = 1.0 / (double)P->n;
+  }
   a.iter = (uint32_t)C->done; a.marker0 = (uint32_t)C->marker0; a.rng = make_rng(C->seed, C->rng_mode);
 }
 
@@ -2282,6 +2341,7 @@ extern "C" int bwgr_chain_run(bwgr_chain *C, int iters) {
 // bit-identical to a run of its own.  (No reference counterpart: the callers that fit many models on one X -- mcmcCV's loop,
 // /root/reference/R/cv.R:113-216 -- are where it plugs in.)
 extern "C" int bwgr_chain_run_pair(bwgr_chain *C0, bwgr_chain *C1, int iters) {
+  if (C0 && C0->P && panel_cen(C0->P)) return fail(BWGR_EINVAL, "chain_run_pair: this panel sweeps implicitly centred columns (bwgr_panel_set_centred), which only the fused chains do; call bwgr_panel_set_centred(P, 0) first");
   if (!C0 || !C1 || C0 == C1) return fail(BWGR_EINVAL, "chain_run_pair: two distinct chains");
   bwgr_panel *P0 = C0->P, *P1 = C1->P;
   const bwgr_panel *r0 = P0->parent ? P0->parent : P0, *r1 = P1->parent ? P1->parent : P1;
@@ -2439,13 +2499,20 @@ static void gemv_launch(bwgr_panel *P, const CT *coef_dev, int nchunks, int cpc,
 
 // hat = X*B + MU   (src/Rcpp20260726ai.cpp:629-630), fp64 accumulation, deterministic two-stage
 template <typename CT>
-static int gemv_hat(bwgr_panel *P, const CT *coef_dev, float MU, float *hat_dev) {
+static int gemv_hat(bwgr_panel *P, const CT *coef_dev, float MU, float *hat_dev, bool centred = false) {
   const int nchunks = gemv_chunks(P);
   const int cpc = (int)((P->p + nchunks - 1) / nchunks);
   double *part = nullptr;
-  HIPCHK(hipMalloc(&part, sizeof(double) * (size_t)nchunks * P->ld));
+  HIPCHK(hipMalloc(&part, sizeof(double) * ((size_t)nchunks * P->ld + 1)));
   gemv_launch<CT>(P, coef_dev, nchunks, cpc, part);
-  hipLaunchKernelGGL(k_hat_finish, dim3((unsigned)((P->n + 255) / 256)), dim3(256), 0, P->stream, part, P->ld, nchunks, (int)P->n, MU, hat_dev);
+  double *cen_off = nullptr;
+  if constexpr (std::is_same<CT, float>::value) {
+    if (centred) {   // X_c B = X B - sum_j mean_j B_j
+      cen_off = part + (size_t)nchunks * P->ld;
+      hipLaunchKernelGGL(k_cen_dot, dim3(1), dim3(1024), 0, P->stream, (P->parent ? P->parent : P)->csum, coef_dev, P->p, 1.0 / (double)P->n, cen_off);
+    }
+  }
+  hipLaunchKernelGGL(k_hat_finish, dim3((unsigned)((P->n + 255) / 256)), dim3(256), 0, P->stream, part, P->ld, nchunks, (int)P->n, MU, hat_dev, (const double *)cen_off);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(P->stream));
   HIPCHK(hipFree(part));
@@ -2501,7 +2568,7 @@ extern "C" int bwgr_chain_result(bwgr_chain *C, float *mu, float *b, float *d, f
   if (hat) {
     float *hat_dev = nullptr;
     HIPCHK(hipMalloc(&hat_dev, sizeof(float) * P->n));
-    int rc = gemv_hat<float>(P, C->B, MU, hat_dev);
+    int rc = gemv_hat<float>(P, C->B, MU, hat_dev, panel_cen(P));
     if (rc == BWGR_OK) HIPCHK(d2h(P->stream, hat, hat_dev, sizeof(float) * P->n));
     hipFree(hat_dev);
     CHK(rc);
@@ -2524,6 +2591,7 @@ extern "C" int bwgr_bayes(bwgr_panel *P, int model, const float *y, float it, fl
 extern "C" int bwgr_bayes2(bwgr_panel *P1, bwgr_panel *P2, int base_model, const float *y, float it, float bi, float pi, float df,
                            float R2, uint64_t seed, int rng_mode, float *mu, float *b1, float *d1, float *vb1, float *b2,
                            float *d2, float *vb2, float *ve, float *hat, float *h2) {
+  if ((P1 && panel_cen(P1)) || (P2 && panel_cen(P2))) return fail(BWGR_EINVAL, "bayes2: this panel sweeps implicitly centred columns (bwgr_panel_set_centred), which only the fused chains do; call bwgr_panel_set_centred(P, 0) first");
   if (!P1 || !P2 || !y) return fail(BWGR_EINVAL, "bayes2: null pointer");
   if (base_model != BWGR_BAYESA && base_model != BWGR_BAYESB && base_model != BWGR_BAYESRR)
     return fail(BWGR_EINVAL, "bayes2: base model must be BayesA, BayesB or BayesRR (got %d)", base_model);
@@ -2670,6 +2738,7 @@ extern "C" int bwgr_wgr(bwgr_panel *P, const double *y, int it, int bi, int th, 
 extern "C" int bwgr_wgr_ex(bwgr_panel *P, const double *y, int it, int bi, int th, int iv, int de, double pi, double df, double R2,
                            uint64_t seed, int rng_mode, const double *U, const double *V, int64_t pk, double bag, int rp,
                            double *mu, double *b, double *Vb, double *d, double *Ve, double *hat, double *cxx, double *u, double *Vk) {
+  if (P && panel_cen(P)) return fail(BWGR_EINVAL, "wgr: this panel sweeps implicitly centred columns (bwgr_panel_set_centred), which only the fused chains do; call bwgr_panel_set_centred(P, 0) first");
   if (!P || !y) return fail(BWGR_EINVAL, "wgr: null pointer");
   if (!U || pk <= 0) { U = nullptr; pk = 0; }
   if (U && !V) return fail(BWGR_EINVAL, "wgr: eigenvalues missing");
@@ -2912,8 +2981,35 @@ __global__ void k_uncentred(const float *xx, const float *vx, int64_t p, double 
   if (any) *flag = 1;
 }
 }  // namespace
+// Sweep the IMPLICITLY centred columns x_j - mean(x_j) of an int8 panel from now on (on != 0) or the raw columns again (on == 0): nothing is
+// converted or copied -- the genotypes stay int8, the streamers, Gram arrays and MFMA tiles stay those of the raw columns, and the sequencer of
+// k_sweep3 carries the scalar terms (sweep3.hip.h, "implicitly centred sweeps").  What changes for the callers: bwgr_panel_stats returns the centred
+// columns' squared norms, the fused chains (bwgr_chain_*, bwgr_bayes, bwgr_group_*) run the reference's sweep on the centred columns
+// (src/Rcpp20260726ai.cpp:668-682 with X_j - mean_j for X_j; selection models on k_sweep3 only), hat = X_c B + mu, and bwgr_panel_centred answers 1 -- which is
+// what makes the marker-sharded sampler of several devices sound without a float copy of the panel.  Refused while chains are alive.
+extern "C" int bwgr_panel_set_centred(bwgr_panel *P, int on) {
+  if (!P) return fail(BWGR_EINVAL, "null panel");
+  if (P->parent) return fail(BWGR_EINVAL, "panel_set_centred: set it on the root panel (clones follow it)");
+  if (P->nchains > 0) return fail(BWGR_EINVAL, "panel_set_centred: %d chains are alive on this panel", P->nchains);
+  HIPCHK(hipSetDevice(P->device));
+  if (!on) { P->cen = false; return BWGR_OK; }
+  if (P->is_f32) return fail(BWGR_EINVAL, "panel_set_centred: float panels are swept as given (centre the columns before the upload)");
+  if (!use_sweep3(P, SWF_SELECT)) return fail(BWGR_EINVAL, "panel_set_centred: this panel has no k_sweep3 (geometry or Gram range): the implicitly centred sweep is k_sweep3's");
+  if (!P->csum) {
+    HIPCHK(hipMalloc(&P->csum, sizeof(int32_t) * (size_t)P->p));
+    HIPCHK(hipMalloc(&P->xxc, sizeof(float) * (size_t)P->p));
+    const int wpb = 4;
+    hipLaunchKernelGGL(k_colsum_i8, dim3((unsigned)((P->p + wpb - 1) / wpb)), dim3(64 * wpb), 0, P->stream, (const int8_t *)P->X, P->R, (int)P->n, (int)P->p, P->csum, P->xxc);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(P->stream));
+  }
+  P->cen = true;
+  return BWGR_OK;
+}
+
 extern "C" int bwgr_panel_centred(bwgr_panel *P, int *centred) {
   if (!P || !centred) return fail(BWGR_EINVAL, "null pointer");
+  if (panel_cen(P)) { *centred = 1; return BWGR_OK; }   // implicitly centred: exactly
   HIPCHK(hipSetDevice(P->device));
   int *flag = nullptr, h = 0;
   HIPCHK(hipMalloc(&flag, sizeof(int)));
@@ -2926,10 +3022,11 @@ extern "C" int bwgr_panel_centred(bwgr_panel *P, int *centred) {
 }
 extern "C" int bwgr_group_sound(const bwgr_group *Gp, int *sound);
 
-extern "C" int bwgr_group_create(bwgr_group **out, int ndev, const int *devices, const void *X, int xtype, int64_t n, int64_t p,
-                                 int64_t ldx, int block, const float *y, int model, float it, float bi, float pi, float df, float R2,
-                                 uint64_t seed, int rng_mode, int64_t markers_per_sync) {
+static int group_create_impl(bwgr_group **out, int ndev, const int *devices, const void *X, int xtype, int64_t n, int64_t p,
+                             int64_t ldx, int block, const float *y, int model, float it, float bi, float pi, float df, float R2,
+                             uint64_t seed, int rng_mode, int64_t markers_per_sync, int centre) {
   if (!out || !devices || !X || !y) return fail(BWGR_EINVAL, "group_create: null pointer");
+  if (centre && xtype != BWGR_X_I8) return fail(BWGR_EINVAL, "group_create_centred: implicit centring is for int8 genotypes (centre float columns before the call)");
   *out = nullptr;
   if (ndev < 1 || ndev > 64) return fail(BWGR_EINVAL, "group_create: ndev = %d", ndev);
   if (xtype != BWGR_X_I8 && xtype != BWGR_X_F32 && xtype != BWGR_X_F64) return fail(BWGR_EINVAL, "group_create: bad xtype %d", xtype);
@@ -2949,6 +3046,7 @@ extern "C" int bwgr_group_create(bwgr_group **out, int ndev, const int *devices,
     Gp->lo.push_back(lo); Gp->hi.push_back(hi);
     int rc = bwgr_panel_create(&Gp->P[g], reinterpret_cast<const unsigned char *>(X) + (size_t)lo * (size_t)ldx * esz, xtype, BWGR_HOST, n, hi - lo, ldx, devices[g], m, 0);
     if (rc != BWGR_OK) return bail(rc);
+    if (centre) { rc = bwgr_panel_set_centred(Gp->P[g], 1); if (rc != BWGR_OK) return bail(rc); }   // the shard's own column means (rows are not sharded)
     msx += (double)Gp->P[g]->MSx;
     int cen = 1;
     rc = bwgr_panel_centred(Gp->P[g], &cen);
@@ -2989,6 +3087,17 @@ extern "C" int bwgr_group_create(bwgr_group **out, int ndev, const int *devices,
   return BWGR_OK;
 }
 
+extern "C" int bwgr_group_create(bwgr_group **out, int ndev, const int *devices, const void *X, int xtype, int64_t n, int64_t p,
+                                 int64_t ldx, int block, const float *y, int model, float it, float bi, float pi, float df, float R2,
+                                 uint64_t seed, int rng_mode, int64_t markers_per_sync) {
+  return group_create_impl(out, ndev, devices, X, xtype, n, p, ldx, block, y, model, it, bi, pi, df, R2, seed, rng_mode, markers_per_sync, 0);
+}
+// ... on the implicitly centred columns of an int8 matrix (bwgr_panel_set_centred on every shard): sound with several devices, int8 in HBM
+extern "C" int bwgr_group_create_centred(bwgr_group **out, int ndev, const int *devices, const void *X, int xtype, int64_t n, int64_t p,
+                                         int64_t ldx, int block, const float *y, int model, float it, float bi, float pi, float df, float R2,
+                                         uint64_t seed, int rng_mode, int64_t markers_per_sync) {
+  return group_create_impl(out, ndev, devices, X, xtype, n, p, ldx, block, y, model, it, bi, pi, df, R2, seed, rng_mode, markers_per_sync, 1);
+}
 static int group_allreduce(bwgr_group *Gp, std::vector<double *> &buf, size_t count) {
   int nr = g_rccl.GroupStart();
   for (int g = 0; g < Gp->G && nr == 0; ++g)
@@ -3264,6 +3373,7 @@ extern "C" int bwgr_em_order(int64_t p, int upto, int32_t *order) {
 
 extern "C" int bwgr_em(bwgr_panel *P, int model, const float *y, float df, float R2, float par, const float *D, int maxit_in,
                        float *mu, float *b, float *d, float *hat, float *vbvec, float *scal, int *iters) {
+  if (P && panel_cen(P)) return fail(BWGR_EINVAL, "em: this panel sweeps implicitly centred columns (bwgr_panel_set_centred), which only the fused chains do; call bwgr_panel_set_centred(P, 0) first");
   if (!P || !y || !b || !scal) return fail(BWGR_EINVAL, "em: null pointer");
   if (model < BWGR_EM_RR || model > BWGR_EM_LASSO) return fail(BWGR_EINVAL, "em: bad model %d", model);
   if (D && model != BWGR_EM_ML) return fail(BWGR_EINVAL, "em: marker weights D belong to emML only");

@@ -49,7 +49,10 @@ enum : int {
   SWF_EM_ANY = SWF_EM_SEL | SWF_EM_EN | SWF_EM_BL | SWF_EM_LASSO,
   SWF_SERIAL = 1 << 19,          // affine sweep that must keep the lane-ordered recurrence (wgr's de: Vb_j = |b_j| sqrt(Ve/MSx) feeds rounding-level
                                  // differences of b back into the next sweep's shrinkage, amplified; R/wgr.R:118)
-  SWF_DEBUG_WITHHOLD = 1 << 20   // test hook (bwgr_debug_withhold): slab workgroup 0 leaves at once, so every wait on it must time out
+  SWF_DEBUG_WITHHOLD = 1 << 20,  // test hook (bwgr_debug_withhold): slab workgroup 0 leaves at once, so every wait on it must time out
+  SWF_CENTRE = 1 << 21           // the sweep is over the IMPLICITLY CENTRED columns x_j - mean(x_j) of an int8 panel (bwgr_panel_set_centred): the streamers
+                                 // keep sweeping the raw int8 columns (e_stored = e - shift * 1), the sequencer adds the scalar terms: with s_j = colsum,
+                                 // (x_j - s_j/n 1)' e = x_j' e_stored - (s_j/n) sum(e_stored), and sum(e_stored) moves by -s_k delta_k per marker
 };
 
 // scalars produced on the device by the per-iteration tail kernel (or filled by the host for KMUP)
@@ -69,6 +72,9 @@ struct ChainScalars {
                                 // behind it with SweepArgs::redo_only run the same sweep on the fp64 residual (k_range_recover ... k_redo_clear)
   double snap_sum_d, snap_sum_b2;   // sum_d / sum_b2 before that sweep
   uint32_t nredo;               // sweeps redone so far (bwgr_chain_redo_count)
+  // implicitly centred sweeps (SWF_CENTRE): u0 = -(sum(e) at the start of the launch + cpre[blk_begin]) / n, written by k_cen_begin before the
+  // sweep kernel; cen_c = sum over the launch's included markers of (s_k / n) corr_k, written by the sequencer; k_cen_end turns e_stored back into e
+  double cen_u0, cen_c;
 };
 
 // per-marker constants of one sweep, produced chip-wide by k_prestage before the sweep kernel starts (they depend on
@@ -119,6 +125,9 @@ struct SweepArgs {
   int redo_only;                // this launch is the fp64 fallback of a fixed-point sweep: it runs only when sc->redo is set
   float gate3;                  // > 0: both engines of the selection models are launched and the device picks one -- k_sweep3 (and its
                                 // k_escale / k_spec3) runs when sc->inc_rate < gate3, k_sweep2 (and k_spec) otherwise; 0: no gating
+  // SWF_CENTRE: the panel's column sums (p int32), the running sums cpre[b] = sum over the markers of blocks < b of s_k * (rejected step on the
+  // sweep's fixed-point grid) with cpre[nblocks] the total (k_cen_tot / k_cen_scan, per iteration), and 1 / n
+  const int32_t *csum; double *cpre; double ninv;
 };
 
 template <typename XT> struct XTraits;

@@ -102,8 +102,63 @@ __global__ __launch_bounds__(1024) void k_escale(const double *e, int64_t ld, Ch
 }
 __device__ __forceinline__ double s3_pow2(int k) { return __hiloint2double((1023 + k) << 20, 0); }   // 2^k, |k| < 1022
 
+// ---- implicitly centred sweeps (SWF_CENTRE; the reference's own sweep on centred columns, src/Rcpp20260726ai.cpp:668-682 with X_j -> X_j - mean_j) ----
+// With s_j = sum_i x_ij and e = e_stored + shift * 1 (shift = sum over the markers swept so far of (s_k / n) delta_k),
+//   (x_j - (s_j / n) 1)' e = x_j' e_stored - (s_j / n) E,   E = sum(e_stored) = E_0 - sum_{k < j} s_k delta_k,
+// so the streamers, the Gram arrays and the lists stay those of the raw int8 columns and the sequencer adds scalars: the rejected steps' part of
+// E is known before the sweep (cpre: running block sums; the in-block part goes into spec), the included markers' part is one running scalar.
+// k_cen_tot: cpre[b + 1] = sum over block b of s_k * drej_k on the sweep's grid;  k_cen_scan: the inclusive scan, cpre[0] = 0
+__global__ __launch_bounds__(128) void k_cen_tot(const SweepArgs a, int blk_begin) {
+  if (!(a.sc->inc_rate < a.gate3)) return;
+  const int blk = blk_begin + blockIdx.x, j = threadIdx.x, m = a.m;
+  const int mB = min(m, a.p - blk * m);
+  const int sh = a.sc->e3_sh;
+  const double S = s3_pow2(sh), invS = s3_pow2(-sh);
+  __shared__ double red[128];
+  red[j] = (j < mB) ? (double)a.csum[blk * m + j] * (rint((double)a.ps.blocks[blk].drej[j] * S) * invS) : 0.0;
+  __syncthreads();
+  for (int o = 64; o > 0; o >>= 1) { if (j < o) red[j] += red[j + o]; __syncthreads(); }   // (a fixed tree: the same bits on every run)
+  if (j == 0) a.cpre[blk + 1] = red[0];
+}
+__global__ __launch_bounds__(1024) void k_cen_scan(const SweepArgs a, int nblocks) {
+  if (!(a.sc->inc_rate < a.gate3)) return;
+  __shared__ double part[1024];
+  const int t = threadIdx.x, per = (nblocks + 1023) / 1024;
+  const int b0 = min(nblocks, t * per), b1 = min(nblocks, b0 + per);
+  double s = 0.0;
+  for (int b = b0; b < b1; ++b) s += a.cpre[b + 1];
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) { double run = 0.0; for (int i = 0; i < 1024; ++i) { const double v = part[i]; part[i] = run; run += v; } }   // (serial: 1 024 adds, once per iteration)
+  __syncthreads();
+  double run = part[t];
+  for (int b = b0; b < b1; ++b) { run += a.cpre[b + 1]; a.cpre[b + 1] = run; }
+  if (t == 0) a.cpre[0] = 0.0;
+}
+// before a centred launch over [blk_begin, blk_end): u0 = -(sum(e) + cpre[blk_begin]) / n  (one workgroup; the residual's padded rows are zero)
+__global__ __launch_bounds__(1024) void k_cen_begin(const SweepArgs a) {
+  if (!(a.sc->inc_rate < a.gate3)) return;
+  __shared__ double red[1024];
+  const int t = threadIdx.x;
+  double s = 0.0;
+  for (int64_t i = t; i < a.ld; i += 1024) s += a.e[i];
+  red[t] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  if (t == 0) { a.sc->cen_u0 = -(red[0] + a.cpre[a.blk_begin]) * a.ninv; a.sc->cen_c = 0.0; }
+}
+// after it: e = e_stored + shift on the n real rows, shift = (cpre[blk_end] - cpre[blk_begin]) / n + cen_c  (not after a sweep that left the range:
+// the recovery restores the state)
+__global__ void k_cen_end(const SweepArgs a) {
+  if (!(a.sc->inc_rate < a.gate3) || a.sc->error != 0u) return;
+  const double shift = (a.cpre[a.blk_end] - a.cpre[a.blk_begin]) * a.ninv + a.sc->cen_c;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) a.e[i] += shift;
+}
+
 // k_spec3: spec_j = sum_{k<j, same block} G_kj * drej_k with drej on the sweep's fixed-point grid (what the streamers apply),
 // and the Gram diagonal.  One workgroup of 128 threads per block, thread = marker j, four partial sums.
+// SWF_CENTRE: spec_j -= (s_j / n) * (cpre[blk] + sum_{k<j, same block} s_k drej_k) -- the rejected steps' share of -(s_j / n) E -- and the
+// Gram-diagonal slot carries {G_jj, s_j} as two 32-bit integers (the sequencer forms G_jj - s_j^2 / n).
 __global__ __launch_bounds__(128) void k_spec3(const SweepArgs a, int blk_begin) {
   if (!(a.sc->inc_rate < a.gate3)) return;   // this sweep is k_sweep2's
   const int blk = blk_begin + blockIdx.x, j = threadIdx.x, m = a.m;
@@ -111,11 +166,15 @@ __global__ __launch_bounds__(128) void k_spec3(const SweepArgs a, int blk_begin)
   const int32_t *G = reinterpret_cast<const int32_t *>(a.gram) + (size_t)blk * m * m;
   SpecBuf &sp = a.ps.spec[blk];
   __shared__ double dr[128];
+  __shared__ double cs[128];
+  const bool cen = (a.flags & SWF_CENTRE) != 0;
   const int sh = a.sc->e3_sh;
   const double S = s3_pow2(sh), invS = s3_pow2(-sh);
   dr[j] = (j < mB) ? rint((double)a.ps.blocks[blk].drej[j] * S) * invS : 0.0;
+  const int sj = (cen && j < mB) ? a.csum[blk * m + j] : 0;
+  cs[j] = (double)sj * dr[j];
   __syncthreads();
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, gjj = 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, gjj = 0.0, ib = 0.0;
   if (j < mB) {
     gjj = (double)G[(size_t)j * m + j];
     int k = 0;
@@ -126,8 +185,14 @@ __global__ __launch_bounds__(128) void k_spec3(const SweepArgs a, int blk_begin)
       s3 = fma((double)G[(size_t)(k + 3) * m + j], dr[k + 3], s3);
     }
     for (; k < j; ++k) s0 = fma((double)G[(size_t)k * m + j], dr[k], s0);
+    if (cen) for (int k2 = 0; k2 < j; ++k2) ib += cs[k2];
   }
-  sp.spec[j] = (s0 + s1) + (s2 + s3); sp.xspec[j] = 0.0; sp.gjj[j] = gjj;
+  double spec = (s0 + s1) + (s2 + s3);
+  if (cen) {
+    spec -= ((double)sj * a.ninv) * (a.cpre[blk] + ib);
+    gjj = __hiloint2double(sj, (j < mB) ? (int)G[(size_t)j * m + j] : 0);
+  }
+  sp.spec[j] = spec; sp.xspec[j] = 0.0; sp.gjj[j] = gjj;
 }
 
 // The seven signed base-256 digits of q (|q| < 2^55) as bytes: adding 0x80 to each of the seven low bytes turns the signed digits
@@ -760,7 +825,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
 // ------------------------------------------------------------------------------------------------------------------
 // sequencer
 // ------------------------------------------------------------------------------------------------------------------
-template <typename GT>
+template <typename GT, bool CEN = false>
 __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   // the experiment switches (BWGR_DBG3) cost instructions and branches inside the rounds: compiled in only with -DBWGR_EXPERIMENTS (tools/ab3_probe.py builds that library)
 #ifdef BWGR_EXPERIMENTS
@@ -1077,6 +1142,12 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   if (wave == 0 && !(SDBG & 1)) __builtin_amdgcn_s_setprio(3);   // the chain's wave goes first wherever it shares an issue port
   // wave 0: what the included markers of block b change in blocks b+1 and b+2 (distances 1 and 2), accumulated as they appear
   double rnext0 = 0.0, rnext1 = 0.0, rnxt20 = 0.0, rnxt21 = 0.0;
+  // implicitly centred columns (CEN): wave 0 carries U = -(E_0 + cpre[first block]) / n + sum over the included markers so far of (s_k / n) corr_k;
+  // a lane's centred dot is its raw one plus s_j * U (the rejected steps' share sits in the staged spec), an included marker's row G_kj becomes
+  // G_kj - s_j s_k / n for the later lanes of its own block, and every later block sees it through U
+  const double ninv = a.ninv;
+  const double cen_u0 = CEN ? a.sc->cen_u0 : 0.0;
+  double cenU = cen_u0;
   const GT *gx0_w0 = reinterpret_cast<const GT *>(A.gx[0]) + (size_t)a.blk_begin * m * m, *gx1_w0 = reinterpret_cast<const GT *>(A.gx[1]) + (size_t)a.blk_begin * m * m;
   const unsigned char *g12_w0 = A.gx12 + (size_t)a.blk_begin * m * 2 * rowbytes;
   for (int b = 0; b < nb; ++b) {
@@ -1106,9 +1177,17 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       const float taa = st.tacc[l0], tab = st.tacc[l1], tra = st.trej[l0], trb = st.trej[l1];
       const double xba = (double)st.xxb0[l0], xbb = (double)st.xxb0[l1];
       const double rda = st.rden[l0], rdb = st.rden[l1], sza = st.sdz1[l0], szb = st.sdz1[l1];
-      const double gja = sps[SW_MAXM + l0], gjb = sps[SW_MAXM + l1];
+      double gja = sps[SW_MAXM + l0], gjb = sps[SW_MAXM + l1];
       double r0 = ((qd[l0] - sps[l0]) - (fd[l0] + fd[SW_MAXM + l0])) + rnext0;
       double r1 = ((qd[l1] - sps[l1]) - (fd[l1] + fd[SW_MAXM + l1])) + rnext1;
+      int csa = 0, csb = 0;
+      double sA = 0.0, sB = 0.0;
+      if constexpr (CEN) {   // the Gram-diagonal slot holds {G_jj, s_j} as two 32-bit integers (k_spec3)
+        csa = __double2hiint(gja); csb = __double2hiint(gjb);
+        sA = (double)csa; sB = (double)csb;
+        gja = (double)(uint32_t)__double2loint(gja) - sA * sA * ninv; gjb = (double)(uint32_t)__double2loint(gjb) - sB * sB * ninv;
+        r0 = fma(sA, cenU, r0); r1 = fma(sB, cenU, r1);
+      }
       const double D2a = (double)((altb2 ? b2a : 0.0f) - b0a), D2b = (double)((altb2 ? b2b : 0.0f) - b0b);   // the alternative's step
       const double D2sa = D2a * D2a, D2sb = D2b * D2b;
       rnext0 = rnxt20; rnext1 = rnxt21; rnxt20 = 0.0; rnxt21 = 0.0;
@@ -1175,8 +1254,15 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
         const double corr_ = (double)dacc_ - (double)drj_; \
         if (lane == 0) { const int sl_ = (pos0 + nacc) & (ring - 1); accK[sl_] = k_ | (b << 8); accC[sl_] = corr_; accS[sl_] = make_float2(dacc_, drj_); } \
         ++nacc; \
+        if constexpr (CEN) { \
+          const double xk_ = (double)__builtin_amdgcn_readlane((KOFF_) ? csb : csa, js) * ninv;   /* mean of column k */ \
+          cenU = fma(xk_, corr_, cenU); \
+          r0 = fma(-((l0 > k_) ? ((double)ga_ - sA * xk_) : 0.0), corr_, r0); \
+          r1 = fma(-((l1 > k_ && l1 < m) ? ((double)gb_ - sB * xk_) : 0.0), corr_, r1); \
+        } else { \
         r0 = fma(-(double)((l0 > k_) ? ga_ : (GT)0), corr_, r0); \
         r1 = fma(-(double)((l1 > k_ && l1 < m) ? gb_ : (GT)0), corr_, r1); \
+        } \
         if constexpr (!G16) { if (!(SDBG & 64)) { \
           const GT *row_ = g1 + (use1 ? (size_t)k_ * m : (size_t)0);   /* (without a next block: a harmless in-bounds read) */ \
           const GT xa_ = row_[use1 ? min(l0, m - 1) : 0], xb_ = row_[use1 ? l1c : 0]; \
@@ -1241,6 +1327,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
   }
   S3ST_FLUSH(16, sq0); S3ST_FLUSH(24, sq1); S3ST_FLUSH(32, sq2); S3ST_FLUSH(40, sq4); S3ST_FLUSH(48, sq3); S3ST_FLUSH(56, sq6); S3ST_FLUSH(64, sq7);
+  if constexpr (CEN) { if (tid == 0) a.sc->cen_c = cenU - cen_u0; }   // the included markers' share of the shift (k_cen_end)
   if (wave == 7) {   // the last two blocks
     if (nb >= 2) finish_block(nb - 2);
     finish_block(nb - 1);
@@ -1290,11 +1377,11 @@ __device__ __forceinline__ void s3_prefetcher(const Sweep3Args &A) {
   if (sink == 0x9E3779B9u && a.stamps) a.stamps[255] = sink;   // (keeps the loads alive)
 }
 
-template <typename GT>
+template <typename GT, bool CEN = false>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep3(const Sweep3Args A) {
   if (!(A.a.sc->inc_rate < A.a.gate3)) return;   // this sweep is k_sweep2's (dense inclusion: every workgroup sees the same scalar)
   if ((int)blockIdx.x == A.pf) { s3_prefetcher<GT>(A); return; }
-  if (blockIdx.x == 0) { if (!(A.dbg & 1024)) s3_sequencer<GT>(A); }
+  if (blockIdx.x == 0) { if (!(A.dbg & 1024)) s3_sequencer<GT, CEN>(A); }
   else if ((A.a.flags & SWF_DEBUG_WITHHOLD) && blockIdx.x == 1 && A.pf != 1) return;   // test hook: a streamer that never shows up
   else if (A.dbg & 2048) return;
   else if ((A.dbg & (1 << 22)) && !(A.dbg & (1 << 23)) && A.R3 == 128) s3_streamer_dma<128, 4>(A);

@@ -19,8 +19,10 @@ section 8).  On x_j - mean(x_j) the same driver follows the exact chain with 2, 
 equal, cor(hat) 0.994: tools/centred_shard_probe.py, tests/test_gpu_parity3.py::test_partitioned_sampler_on_centred_columns);
 centring is a reparametrisation under the samplers' flat intercept prior (/root/reference/src/Rcpp20260726ai.cpp:683-684) that an exact
 Gibbs sampler would not notice; bWGR's own chain does a little (ve 1.47 uncentred against 1.56 centred on the probe panel, DESIGN.md
-section 8), so "sound" means: follows the exact chain on the same centred panel.  bench_sharded therefore centres its shard (a float panel) unless told not to,
-and `statistically_sound` is computed from the panel (bwgr_panel_centred), not from the output.
+section 8), so "sound" means: follows the exact chain on the same centred panel.  bench_sharded therefore centres its shard unless told not to --
+IMPLICITLY since round 4 (bwgr_panel_set_centred: the genotypes stay int8 in HBM, k_sweep3 sweeps them and its sequencer carries the scalar terms;
+`--centre-explicit` keeps round 3's float copy of the centred columns) -- and `statistically_sound` is computed from the panel (bwgr_panel_centred),
+not from the output.
 
 The driver is engine-agnostic: an engine exposes sweep_blocks / residual / set_residual / sums / end_iteration over
 torch tensors.  The product engine is HipShardEngine (bwgr_amd.Chain on the GPU).  tests/test_dist_gloo.py drives the
@@ -169,9 +171,10 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     g = synth.phenotype(X, n, col0=lo, p_total=p)
     _all_reduce(g)
     y = synth.scale_phenotype(g)
-    # BWGR_FORCE_CENTRE=1: rehearse the centred float panel with one rank (bench.py's BWGR_FORCE_DIST leg)
+    # BWGR_FORCE_CENTRE=1: rehearse the centred panel with one rank (bench.py's BWGR_FORCE_DIST leg)
     centre = (world > 1 or bool(os.environ.get("BWGR_FORCE_CENTRE"))) and not getattr(args, "uncentred", False)
-    if centre:   # x_j - mean(x_j) as a float panel (column-major n x p_local on the device, in column chunks to bound the temporaries)
+    explicit = centre and (getattr(args, "centre_explicit", False) or model not in ("BayesB", "BayesC", "BayesCpi", "BayesDpi"))
+    if explicit:   # x_j - mean(x_j) as a float panel (column-major n x p_local on the device, in column chunks to bound the temporaries)
         Xf = torch.empty((hi - lo, n), dtype=torch.float32, device=X.device)     # (p_local, n): row j = column j, no row padding
         for c0 in range(0, hi - lo, 8192):
             blk_ = X[c0:c0 + 8192, :n].to(torch.float32)
@@ -182,6 +185,8 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     P = bwgr_amd.Panel(X, n=n, device=dev, block=block, nwg=args.nwg)
     del X
     torch.cuda.empty_cache()
+    if centre and not explicit:
+        P.set_centred(True)      # implicit: int8 in HBM, the shard's own column means (rows are not sharded)
     msx = torch.tensor([P.stats()[2]], dtype=torch.float64, device="cuda:%d" % dev)
     _all_reduce(msx)
     eng = HipShardEngine(P, model, y, W + K, W, pi, 5.0, 0.5, synth.SEED, lo, p, float(msx.item()))
@@ -204,20 +209,20 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     ms, launches = eng.chain.sweep_ms()
     sweep_ms_per_iter = ms * launches / K
     st = eng.chain.state()
-    alg = float(n) * float(hi - lo) * (4.0 if centre else 1.0)
+    alg = float(n) * float(hi - lo) * (4.0 if explicit else 1.0)
     ach = alg / (sweep_ms_per_iter * 1e-3) / 1e9
     out = {
         "metric": "MCMC iter/sec (full marker sweep)", "value": K / elapsed, "unit": "iter/s", "n_gpus": world, "steps": K,
         "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32 scalars, f64 residual/accumulation, %s genotypes" % ("centred f32" if centre else "int8"), "data": "synthetic",
+        "dtype": "f32 scalars, f64 residual/accumulation, %s genotypes" % ("centred f32" if explicit else ("int8, implicitly centred" if centre else "int8")), "data": "synthetic",
         "config": {"workload": "%s: synthetic n=%d x p=%d %s, %s%s, markers sharded over %d GPUs (%d per rank), residual "
                                "all-reduce (n fp64) every %d markers per rank = %d per sweep; partitioned Gibbs (statistical "
-                               "parity for N>1)" % (args.workload, n, p, "int8 centred to f32 columns" if centre else "int8", model,
+                               "parity for N>1)" % (args.workload, n, p, "int8 centred to f32 columns" if explicit else ("int8 swept as implicitly centred columns" if centre else "int8"), model,
                                                     " pi=%.2f" % pi if pi else "", world, hi - lo, bps * P.block, rounds),
                    "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": 1, "block": P.block,
                    "slab_workgroups": P.nwg, "sync_rounds_per_sweep": rounds},
         "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                     "kernel": "%s (rank 0, all launches of one sweep summed)" % ("k_sweep2<float>" if centre else "k_sweep2<int8> / k_sweep3"), "kernel_ms": sweep_ms_per_iter,
+                     "kernel": "%s (rank 0, all launches of one sweep summed)" % ("k_sweep2<float>" if explicit else ("k_sweep3<uint16, centred>" if centre else "k_sweep2<int8> / k_sweep3")), "kernel_ms": sweep_ms_per_iter,
                      "launches": launches, "algorithmic_bytes_per_launch": alg},
         "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d_rank0": float(st["d"].mean())},
     }
@@ -229,7 +234,9 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     out["centred_columns"] = bool(int(cen.item()) == 1)
     out["note"] = ("marker-sharded partitioned Gibbs sampler: NOT the reference's chain for N > 1; statistically sound on centred columns "
                    "(tests/test_gpu_parity3.py::test_partitioned_sampler_on_centred_columns: 2, 4, 8 shards against the exact chain), unsound on "
-                   "uncentred genotypes (tests/test_gpu_parity2.py::test_partitioned_sampler_characterisation, DESIGN.md section 8); centred shards "
-                   "are float panels (4 bytes per genotype), so `roofline` here is priced on 4 n p bytes")
+                   "uncentred genotypes (tests/test_gpu_parity2.py::test_partitioned_sampler_characterisation, DESIGN.md section 8); "
+                   + ("explicitly centred shards are float panels (4 bytes per genotype), so `roofline` here is priced on 4 n p bytes" if explicit else
+                      "the shards are int8 panels swept as implicitly centred columns (bwgr_panel_set_centred): `roofline` is priced on n p bytes"))
+    out["centring"] = "explicit-f32" if explicit else ("implicit-int8" if centre else "none")
     dist.destroy_process_group()
     return out

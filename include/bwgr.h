@@ -271,11 +271,28 @@ typedef struct bwgr_group bwgr_group;
 int bwgr_group_create(bwgr_group **out, int ndev, const int *devices, const void *X, int xtype, int64_t n, int64_t p, int64_t ldx,
                       int block, const float *y, int model, float it, float bi, float pi, float df, float R2, uint64_t seed,
                       int rng_mode, int64_t markers_per_sync);
+/* the same on the IMPLICITLY centred columns of an int8 matrix (bwgr_panel_set_centred on every shard: the genotypes stay int8, k_sweep3 sweeps them):
+ * sound with several devices; selection models only; the intercept returned is that of the centred parametrisation (mu_c = mu + sum_j mean_j b_j) */
+int bwgr_group_create_centred(bwgr_group **out, int ndev, const int *devices, const void *X, int xtype, int64_t n, int64_t p, int64_t ldx,
+                              int block, const float *y, int model, float it, float bi, float pi, float df, float R2, uint64_t seed,
+                              int rng_mode, int64_t markers_per_sync);
 int bwgr_group_run(bwgr_group *G, int iters);
 int bwgr_group_sync(bwgr_group *G);
 int bwgr_group_info(const bwgr_group *G, int64_t info[4]);
 int bwgr_group_sound(const bwgr_group *G, int *sound);      /* 1: one device (exact chain) or centred columns; 0: G > 1 on uncentred columns */
-int bwgr_panel_centred(bwgr_panel *P, int *centred);        /* 1 when every column's |mean| <= 1e-3 sd (from the panel's own statistics) */
+int bwgr_panel_centred(bwgr_panel *P, int *centred);        /* 1 when every column's |mean| <= 1e-3 sd (from the panel's own statistics), or after
+                                                               bwgr_panel_set_centred(P, 1) */
+/* Implicit centring of an int8 panel (no reference counterpart: bWGR sweeps whatever columns it is given, src/Rcpp20260726ai.cpp:668-682; centring
+ * is the caller's preprocessing there).  on != 0: from now on the fused chains on this panel and its clones (bwgr_chain_*, bwgr_bayes, the chains
+ * bwgr_group_* builds) sweep the columns x_j - mean(x_j) -- the same chain as on an explicitly centred float copy of the panel, to the float
+ * rounding of that copy's entries -- while the genotypes stay int8 in HBM and every kernel keeps reading the raw columns: with s_j = sum_i x_ij and
+ * the residual carried as e_stored = e - shift * 1,  (x_j - s_j/n 1)'e = x_j'e_stored - (s_j/n) sum(e_stored), and sum(e_stored) moves by -s_k delta_k
+ * per marker: scalars on the sequencer, nothing on the streamers.  bwgr_panel_stats then returns xx_j = |x_j - mean_j|^2 (vx, MSx do not change),
+ * hat = X_c B + mu, bwgr_panel_centred answers 1, and the group entry points accept several devices.  Selection models (BayesB / C /
+ * Cpi / Dpi) on panels that have k_sweep3; other models and the non-chain entry points (KMUP, wgr, EM, two-effect samplers, pairs) return BWGR_EINVAL
+ * on a centred panel.  A centred sweep that leaves the fixed-point range returns BWGR_ERANGE (its fp64 redo engine sweeps raw columns).  Refused while
+ * chains are alive on the panel; on == 0 switches back. */
+int bwgr_panel_set_centred(bwgr_panel *P, int on);
 int bwgr_group_result(bwgr_group *G, float *mu, float *b, float *d, float *hat, float *vb, float *ve, float *h2, float *MSx,
                       float *pi_out, float *pval);
 int bwgr_group_destroy(bwgr_group *G);

@@ -104,14 +104,18 @@ def test_short_chains_under_the_shipped_engine_threshold(tpod, model, pi, monkey
 
 
 # ---- the marker-sharded partitioned sampler ----
-def _sharded_run(XX, y, G, markers_per_round, it, bi, pi, seed, msx):
-    """G in-process shards of one panel on one GPU, driven exactly as bwgr_amd/dist.py drives one rank per GPU."""
+def _sharded_run(XX, y, G, markers_per_round, it, bi, pi, seed, msx, implicit=False):
+    """G in-process shards of one panel on one GPU, driven exactly as bwgr_amd/dist.py drives one rank per GPU.  implicit: int8 shards swept as
+    implicitly centred columns (bwgr_panel_set_centred), as bench.py --sharded does."""
     import torch
     import bwgr_amd
     from bwgr_amd.dist import HipShardEngine, shard_bounds
     p = XX.shape[1]
     spans = [shard_bounds(p, G, r, 128) for r in range(G)]
     panels = [bwgr_amd.Panel(np.asfortranarray(XX[:, lo:hi])) for lo, hi in spans]
+    if implicit:
+        for P in panels:
+            P.set_centred(True)
     engs = [HipShardEngine(panels[r], "BayesB", y, it, bi, pi, 5.0, 0.5, seed, spans[r][0], p, msx) for r in range(G)]
     bps = max(1, markers_per_round // panels[0].block)
     rounds = max((e.nblocks + bps - 1) // bps for e in engs)
@@ -135,6 +139,102 @@ def _sharded_run(XX, y, G, markers_per_round, it, bi, pi, seed, msx):
     return out
 
 
+# ---- implicitly centred int8 panels (bwgr_panel_set_centred) ----
+def _centred_f32(X):
+    Xd = X.astype(np.float64)
+    return np.asfortranarray((Xd - Xd.mean(0)).astype(np.float32))
+
+
+@pytest.mark.parametrize("model,pi", [("BayesB", 0.9), ("BayesB", 0.99), ("BayesC", 0.9), ("BayesCpi", 0.0), ("BayesDpi", 0.0)])
+@pytest.mark.parametrize("data", ["tpod", "synth"])
+def test_implicit_centring_is_the_chain_on_the_centred_columns(tpod, model, pi, data):
+    """An int8 panel swept as implicitly centred columns (the genotypes stay int8; the sequencer of k_sweep3 carries the scalar terms) runs the
+    reference's sweep (src/Rcpp20260726ai.cpp:668-682) on x_j - mean(x_j): against the ORACLE on the explicitly centred float matrix, and against
+    the GPU's own chain on that float panel (the fp32 engine): b, e, hat, ve to 1e-6, inclusion decisions equal.  (The float copy rounds every
+    centred entry to 24 bits; the implicit form is exact -- the two agree to that rounding.)  tpod: three blocks, one slab; synth: 700 x 900,
+    eight blocks with a ragged last one, three slabs."""
+    import bwgr_amd
+    from oracle import oracle as O
+    if data == "tpod":
+        X, y = tpod["gen"], tpod["y"]
+        kw = {}
+    else:
+        X, y = synth_small(700, 900, seed=3)
+        kw = {"nwg": 3}
+    Xc = _centred_f32(X)
+    it, bi = 10, 2
+    P = bwgr_amd.Panel(X, **kw).set_centred(True)
+    assert P.centred()
+    xx, vx, msx = P.stats()
+    oxx, ovx, omsx = O.stats(Xc)
+    assert scaled_err(xx, oxx) < 2e-7 and _rel(msx, omsx) < 1e-6
+    ch = bwgr_amd.Chain(P, model, y, it=it, bi=bi, pi=pi, seed=41)
+    ch.run(it)
+    g = ch.result(); st = ch.state()
+    ch.close(); P.close()
+    o = O.bayes(model, y, Xc, it=it, bi=bi, pi=pi, seed=41)
+    assert np.array_equal(g["d"], o["d"]) and np.array_equal(st["d"], o["last"]["d"])
+    assert scaled_err(g["b"], o["b"]) < TOL and scaled_err(g["hat"], o["hat"]) < TOL
+    # (on centred columns the intercept is the mean of y -- zero for the synthetic phenotype --: compared on the scale of y)
+    assert _rel(g["ve"], o["ve"]) < TOL and abs(float(g["mu"]) - float(o["mu"])) < TOL * max(abs(float(o["mu"])), float(np.std(y)))
+    assert scaled_err(st["e"], o["last"]["e"]) < TOL and scaled_err(st["b"], o["last"]["b"]) < TOL
+    # ... and the GPU's chain on the explicitly centred float panel (what round 3's sharded leg swept)
+    f = getattr(bwgr_amd, model)(y, Xc, it=it, bi=bi, seed=41, **({"pi": pi} if model in ("BayesB", "BayesC") else {}))
+    assert np.array_equal(g["d"], f["d"]) and scaled_err(g["b"], f["b"]) < TOL and scaled_err(g["hat"], f["hat"]) < TOL and _rel(g["ve"], f["ve"]) < TOL
+
+
+def test_implicit_centring_in_ranges_and_rounds(tpod):
+    """The sharded stepping on an implicitly centred panel: sweeping the panel in block ranges (sweep_blocks) and in exchange rounds
+    (round_sweep / round_apply with one shard) is the chain run(1) runs, bit for bit -- the centring scalars (sum of the residual at the start of a
+    range, the running block sums) are per range."""
+    import torch
+    import bwgr_amd
+    X, y = synth_small(500, 1100, seed=8)
+    res = []
+    for mode in ("run", "ranges", "rounds"):
+        P = bwgr_amd.Panel(X).set_centred(True)
+        ch = bwgr_amd.Chain(P, "BayesB", y, it=6, bi=1, pi=0.9, seed=5)
+        nb = ch.nblocks
+        for _ in range(6):
+            if mode == "run":
+                ch.run(1)
+            elif mode == "ranges":
+                for lo in range(0, nb, 3):
+                    ch.sweep_blocks(lo, min(nb, lo + 3))
+                ch.end_iteration(None)
+            else:
+                delta = torch.empty(P.ld, dtype=torch.float64, device="cuda:0")
+                for lo in range(0, nb, 4):
+                    ch.round_sweep(lo, min(nb, lo + 4), delta)
+                    ch.round_apply(delta)
+                ch.end_iteration(None)
+        st = ch.state()
+        res.append(st)
+        ch.close(); P.close()
+    for st in res[1:]:
+        assert np.array_equal(st["d"], res[0]["d"])
+        assert scaled_err(st["b"], res[0]["b"]) < 1e-9 and scaled_err(st["e"], res[0]["e"]) < 1e-9 and _rel(st["ve"], res[0]["ve"]) < 1e-9
+
+
+def test_centred_panel_refuses_what_it_cannot_sweep(tpod):
+    import bwgr_amd
+    X, y = tpod["gen"], tpod["y"]
+    P = bwgr_amd.Panel(X).set_centred(True)
+    with pytest.raises(bwgr_amd.BwgrError):
+        bwgr_amd.Chain(P, "BayesA", y, it=4, bi=1, seed=1)          # affine models sweep raw columns (k_sweep2w)
+    with pytest.raises(bwgr_amd.BwgrError):
+        bwgr_amd.KMUP(P, np.zeros(P.p), np.ones(P.p), np.ones(P.p), y - y.mean(), np.ones(P.p), 0.03, 0.5, seed=1)
+    ch = bwgr_amd.Chain(P, "BayesB", y, it=4, bi=1, pi=0.9, seed=1)
+    with pytest.raises(bwgr_amd.BwgrError):
+        P.set_centred(False)                                         # not while a chain is alive
+    ch.close()
+    P.set_centred(False)
+    assert not P.centred()
+    g = bwgr_amd.BayesA(y, P, it=4, bi=1, seed=1)                    # the raw columns again
+    assert np.isfinite(g["b"]).all()
+    P.close()
+
+
 def test_partitioned_sampler_on_centred_columns():
     """VERDICT r2 item 2.  The marker-sharded sampler is a different chain from the reference for more than one shard, so its
     parity is statistical.  On the uncentred genotypes bWGR sweeps it is unsound (test_gpu_parity2.py::
@@ -153,17 +253,21 @@ def test_partitioned_sampler_on_centred_columns():
     Xc = np.asfortranarray((X.astype(np.float64) - X.astype(np.float64).mean(0)).astype(np.float32))
     a = bwgr_amd.BayesB(y, Xc, it=it, bi=bi, pi=pi, seed=31)
     au = bwgr_amd.BayesB(y, X, it=it, bi=bi, pi=pi, seed=31)
+    # G = 1 through the implicit form is the exact centred chain (to the float copy's rounding)
+    one = _sharded_run(X, y, 1, 1 << 30, it, bi, pi, 31, msx, implicit=True)
+    assert one["centred"] and np.array_equal(one["d"], a["d"]) and scaled_err(one["b"], a["b"]) < 1e-5 and _rel(one["ve"], a["ve"]) < 1e-5
     for G, mpr in ((2, 2048), (4, 1024), (8, 512)):
-        s_ = _sharded_run(Xc, y, G, mpr, it, bi, pi, 31, msx)
         u_ = _sharded_run(X, y, G, mpr, it, bi, pi, 31, msx)
-        ch, cb = np.corrcoef(s_["hat"], a["hat"])[0, 1], np.corrcoef(s_["b"], a["b"])[0, 1]
-        print("%d shards x %d markers per round, centred: ve %.4f (exact %.4f) mean d %.4f (%.4f) cor(hat) %.4f cor(b) %.4f | uncentred: ve %.3f "
-              "(exact %.4f) cor(hat) %.3f" % (G, mpr, s_["ve"], a["ve"], s_["d"].mean(), a["d"].mean(), ch, cb, u_["ve"], au["ve"],
-                                             np.corrcoef(u_["hat"], au["hat"])[0, 1]))
-        assert s_["centred"] and not u_["centred"]
-        assert _rel(s_["ve"], a["ve"]) < 0.05, (G, s_["ve"], a["ve"])
-        assert abs(float(s_["d"].mean()) - float(a["d"].mean())) < 0.003
-        assert ch >= 0.98 and cb >= 0.97, (G, ch, cb)
+        for form in ("fp32-explicit", "int8-implicit"):
+            s_ = _sharded_run(Xc, y, G, mpr, it, bi, pi, 31, msx) if form == "fp32-explicit" else _sharded_run(X, y, G, mpr, it, bi, pi, 31, msx, implicit=True)
+            ch, cb = np.corrcoef(s_["hat"], a["hat"])[0, 1], np.corrcoef(s_["b"], a["b"])[0, 1]
+            print("%d shards x %d markers per round, centred (%s): ve %.4f (exact %.4f) mean d %.4f (%.4f) cor(hat) %.4f cor(b) %.4f | uncentred: ve %.3f "
+                  "(exact %.4f) cor(hat) %.3f" % (G, mpr, form, s_["ve"], a["ve"], s_["d"].mean(), a["d"].mean(), ch, cb, u_["ve"], au["ve"],
+                                                 np.corrcoef(u_["hat"], au["hat"])[0, 1]))
+            assert s_["centred"] and not u_["centred"]
+            assert _rel(s_["ve"], a["ve"]) < 0.05, (G, form, s_["ve"], a["ve"])
+            assert abs(float(s_["d"].mean()) - float(a["d"].mean())) < 0.003
+            assert ch >= 0.98 and cb >= 0.97, (G, form, ch, cb)
 
 
 def test_group_refuses_several_shards_on_uncentred_columns(tpod, monkeypatch):
