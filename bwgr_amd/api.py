@@ -341,7 +341,7 @@ class Group:
             self._xbar = Xd.mean(0)
             # integer genotypes: the library centres them IMPLICITLY (int8 stays int8 in HBM, k_sweep3 sweeps it: bwgr_group_create_centred) for the
             # selection models; otherwise (float columns, affine models) an explicitly centred float panel
-            implicit = (centre != "explicit" and model in ("BayesB", "BayesC", "BayesCpi", "BayesDpi") and X.size > 0 and bool(np.all(X == np.rint(X)))
+            implicit = (centre != "explicit" and (model in ("BayesB", "BayesC") or (centre == "implicit" and model in ("BayesCpi", "BayesDpi"))) and X.size > 0 and bool(np.all(X == np.rint(X)))
                         and X.min() >= -128 and X.max() <= 127)
             if not implicit:
                 X = (Xd - self._xbar).astype(np.float32)

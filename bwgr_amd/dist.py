@@ -173,7 +173,9 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     y = synth.scale_phenotype(g)
     # BWGR_FORCE_CENTRE=1: rehearse the centred panel with one rank (bench.py's BWGR_FORCE_DIST leg)
     centre = (world > 1 or bool(os.environ.get("BWGR_FORCE_CENTRE"))) and not getattr(args, "uncentred", False)
-    explicit = centre and (getattr(args, "centre_explicit", False) or model not in ("BayesB", "BayesC", "BayesCpi", "BayesDpi"))
+    # (implicit centring is k_sweep3's, the engine of the sparse selection chains; the dense ones -- BayesCpi / Dpi keep about half the markers in
+    # the model -- and the affine models keep the float copy, which k_sweep2 / k_sweep2w sweep)
+    explicit = centre and (getattr(args, "centre_explicit", False) or model not in ("BayesB", "BayesC"))
     if explicit:   # x_j - mean(x_j) as a float panel (column-major n x p_local on the device, in column chunks to bound the temporaries)
         Xf = torch.empty((hi - lo, n), dtype=torch.float32, device=X.device)     # (p_local, n): row j = column j, no row padding
         for c0 in range(0, hi - lo, 8192):
