@@ -225,6 +225,39 @@ def single_leg(workload, K, W, dev, args, keep):
     return {k: out[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "setup_s", "chain_check")}
 
 
+def intra_gpu_shards_leg(model, pi, S, K, W, n, p, dev):
+    """The partitioned sampler's shards SIDE BY SIDE ON THIS ONE GPU (Group(devices=[dev] * S), include/bwgr.h "shards side by side on one GPU"):
+    S marker shards of the same panel, each an int8 panel swept as implicitly centred columns (bwgr_panel_set_centred) by its own k_sweep3 launch
+    on its own stream and compute units, residual deltas summed at the exchange rounds by a kernel.  One exact chain is a latency-bound pipeline
+    on a third of the chip; this is the north-star's marker-sharded independent-block sampler filling the rest.  NOT the reference's chain
+    (statistical parity: tests/test_gpu_parity3.py::test_shards_side_by_side_on_one_gpu, ::test_partitioned_sampler_on_centred_columns), so it
+    is reported beside the headline, never as it."""
+    import torch
+    import bwgr_amd
+    from bwgr_amd import synth
+    X = synth.genotypes(n, p, device=dev)
+    y = synth.scale_phenotype(synth.phenotype(X, n))
+    g = bwgr_amd.Group(model, y, X, devices=[dev] * S, it=W + K, bi=W, pi=pi, df=5, R2=0.5, seed=synth.SEED, centre=True, n=n)
+    try:
+        g.run(W); g.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g.run(K); g.sync(); torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        info = g.info()
+        r = g.result()
+        rate = K / el
+        return {"shards": S, "value": rate, "unit": "iter/s", "ms_per_step": 1e3 * el / K, "genotype_GBps": rate * float(n) * float(p) / 1e9,
+                "frac_of_hbm_peak": rate * float(n) * float(p) / 1e9 / HBM_PEAK_GBS, "rounds_per_sweep": info["rounds_per_sweep"],
+                "markers_per_round": info["markers_per_round"], "centring": "implicit-int8", "statistically_sound": bool(r["statistically_sound"]),
+                "chain_check": {"ve": float(r["ve"]), "mean_d": float(r["d"].mean())},
+                "note": "partitioned (independent-block) Gibbs sampler over %d marker shards of one panel on ONE GPU: a different chain from the reference's, "
+                        "statistically sound on centred columns; every genotype byte is read once per iteration" % S}
+    finally:
+        g.close()
+        del X
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,6 +275,8 @@ def main():
                     "kept for measurements)")
     ap.add_argument("--centre-explicit", action="store_true", help="--sharded: centre into a float32 copy of the shard (round 3's path, 4 bytes per genotype) instead of "
                     "sweeping the int8 shard as implicitly centred columns")
+    ap.add_argument("--shards", type=int, default=3, help="extra leg at N=1: the partitioned sampler's marker shards side by side on the one GPU, implicitly centred "
+                    "int8 (reported as intra_gpu_shards; 0 or 1 = skip)")
     ap.add_argument("--pairs", type=int, default=0, help="pairs of chains in the paired-chains leg (0: as many as fit)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c3 legs that follow the headline workload (`workloads` in the JSON line)")
@@ -346,6 +381,11 @@ def main():
     P.close()
     del P, y
     torch.cuda.empty_cache()
+    if args.shards > 1 and args.workload in ("c3", "c4") and model in ("BayesB", "BayesC"):
+        try:
+            out["intra_gpu_shards"] = intra_gpu_shards_leg(model, pi, args.shards, K, W, n, p, dev)
+        except Exception as ex:
+            out["intra_gpu_shards"] = {"shards": args.shards, "error": str(ex)}
     # BASELINE configs 2 and 3 on the same box, same timing discipline (a barrier-free single GPU: synchronize on both sides, K steps
     # timed exactly, kernel time by hipEvents on the kernel's stream): driver-visible beside the headline, each with its own roofline
     if not args.no_extra and args.workload == "c4":

@@ -80,7 +80,7 @@ def lib():
     L.bwgr_debug_variates.argtypes = [i32, u64, i32, f64, u32, u32, u32, i32, c_d]
     L.bwgr_debug_withhold.argtypes = [vp, i32]
     L.bwgr_group_create.argtypes = [C.POINTER(vp), i32, C.POINTER(i32), vp, i32, i64, i64, i64, i32, c_f, i32, f32, f32, f32, f32, f32, u64, i32, i64]
-    L.bwgr_group_create_centred.argtypes = L.bwgr_group_create.argtypes
+    L.bwgr_group_create_centred.argtypes = list(L.bwgr_group_create.argtypes) + [i32]
     L.bwgr_group_run.argtypes = [vp, i32]
     L.bwgr_group_sync.argtypes = [vp]
     L.bwgr_group_info.argtypes = [vp, C.POINTER(i64)]

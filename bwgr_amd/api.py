@@ -327,43 +327,68 @@ class Group:
     benchmark's one-process-per-GPU driver is bwgr_amd/dist.py."""
 
     def __init__(self, model, y, X, devices=(0,), it=1500, bi=500, pi=0.95, df=5.0, R2=0.5, seed=None, rng_mode=0, block=0,
-                 markers_per_sync=0, centre=False):
-        """centre=True sweeps x_j - mean(x_j) (a float panel): what makes more than one device statistically sound (on uncentred columns
-        the library refuses len(devices) > 1 unless BWGR_GROUP_ALLOW_UNCENTRED=1).  Centring is a reparametrisation under the
-        flat intercept prior (an exact Gibbs sampler would not notice; bWGR's own chain does a little: DESIGN.md section 8); result() gives mu back in
-        the uncentred parametrisation, mu - sum_j mean_j b_j."""
-        X = np.asarray(X)
-        assert X.ndim == 2
+                 markers_per_sync=0, centre=False, n=None):
+        """centre=True sweeps x_j - mean(x_j): what makes more than one shard statistically sound (on uncentred columns the library refuses
+        len(devices) > 1 unless BWGR_GROUP_ALLOW_UNCENTRED=1).  Integer genotypes under BayesB / BayesC are centred IMPLICITLY (the panel stays int8
+        in HBM, k_sweep3 sweeps it: bwgr_group_create_centred; centre="implicit" asks for it under BayesCpi / Dpi too, centre="explicit" for the float
+        copy); float columns and the other models get an explicitly centred float panel.  Centring is a reparametrisation under the flat intercept
+        prior (an exact Gibbs sampler would not notice; bWGR's own chain does a little: DESIGN.md section 8); result() gives mu back in the uncentred
+        parametrisation, mu - sum_j mean_j b_j.
+        devices may name ONE device several times: the shards then run side by side on that GPU (streams of their own, a sum kernel per exchange
+        round, no RCCL).  X may then also be a torch int8 CUDA tensor of shape (p, ldx) on that device (row j = column j of X; n rows of it used)."""
         self._xbar = None
+        self._keep = None
         implicit = False
-        if centre:
-            Xd = X.astype(np.float64)
-            self._xbar = Xd.mean(0)
-            # integer genotypes: the library centres them IMPLICITLY (int8 stays int8 in HBM, k_sweep3 sweeps it: bwgr_group_create_centred) for the
-            # selection models; otherwise (float columns, affine models) an explicitly centred float panel
-            implicit = (centre != "explicit" and (model in ("BayesB", "BayesC") or (centre == "implicit" and model in ("BayesCpi", "BayesDpi"))) and X.size > 0 and bool(np.all(X == np.rint(X)))
-                        and X.min() >= -128 and X.max() <= 127)
-            if not implicit:
-                X = (Xd - self._xbar).astype(np.float32)
-        if X.dtype != np.int8:
-            fits = bool(X.size == 0 or (X.min() >= -128 and X.max() <= 127))
-            if fits and (np.issubdtype(X.dtype, np.integer) or np.all(X == np.rint(X))):
-                X = X.astype(np.int8)
-            elif X.dtype not in (np.float32, np.float64):
-                X = X.astype(np.float64)
-        self._X = np.asfortranarray(X)
-        self.n, self.p = self._X.shape
+        memloc = HOST
+        if hasattr(X, "data_ptr"):     # device-resident int8 genotypes, shards of that one device, implicit centring
+            import torch
+            assert X.is_cuda and X.dim() == 2 and X.is_contiguous() and X.dtype == torch.int8, "device X: a contiguous (p, ldx) int8 CUDA tensor"
+            assert centre and centre != "explicit", "device X: implicitly centred shards (centre=True)"
+            assert all(int(d) == (X.device.index or 0) for d in devices), "device X serves shards of its own device only"
+            p_, ldx = X.shape
+            self.n, self.p = int(ldx if n is None else n), int(p_)
+            xb = torch.empty(p_, dtype=torch.float64, device=X.device)
+            for c0 in range(0, p_, 65536):
+                xb[c0:c0 + 65536] = X[c0:c0 + 65536, :self.n].sum(dim=1, dtype=torch.int64).to(torch.float64) / self.n
+            self._xbar = xb.cpu().numpy()
+            torch.cuda.synchronize(X.device)
+            self._keep = X
+            implicit, memloc, xtype, xptr = True, DEVICE, X_I8, C.c_void_p(X.data_ptr())
+        else:
+            X = np.asarray(X)
+            assert X.ndim == 2
+            if centre:
+                Xd = X.astype(np.float64)
+                self._xbar = Xd.mean(0)
+                implicit = (centre != "explicit" and (model in ("BayesB", "BayesC") or (centre == "implicit" and model in ("BayesCpi", "BayesDpi"))) and X.size > 0
+                            and bool(np.all(X == np.rint(X))) and X.min() >= -128 and X.max() <= 127)
+                if not implicit:
+                    X = (Xd - self._xbar).astype(np.float32)
+            if X.dtype != np.int8:
+                fits = bool(X.size == 0 or (X.min() >= -128 and X.max() <= 127))
+                if fits and (np.issubdtype(X.dtype, np.integer) or np.all(X == np.rint(X))):
+                    X = X.astype(np.int8)
+                elif X.dtype not in (np.float32, np.float64):
+                    X = X.astype(np.float64)
+            self._X = np.asfortranarray(X)
+            self.n, self.p = self._X.shape
+            ldx = self.n
+            xtype = {np.dtype(np.int8): X_I8, np.dtype(np.float32): X_F32, np.dtype(np.float64): X_F64}[self._X.dtype]
+            xptr = self._X.ctypes.data_as(C.c_void_p)
         self.model = model
+        if hasattr(y, "data_ptr"):
+            y = y.detach().cpu().numpy()
         self._y = np.ascontiguousarray(y, np.float32)
         assert self._y.size == self.n
-        xtype = {np.dtype(np.int8): X_I8, np.dtype(np.float32): X_F32, np.dtype(np.float64): X_F64}[self._X.dtype]
         devs = (C.c_int * len(devices))(*[int(d) for d in devices])
         self._h = C.c_void_p()
         self.implicit_centring = implicit
-        create = _lib.lib().bwgr_group_create_centred if implicit else _lib.lib().bwgr_group_create
-        check(create(C.byref(self._h), len(devices), devs, self._X.ctypes.data_as(C.c_void_p), xtype, self.n,
-                                            self.p, self.n, int(block), _fp(self._y), MODELS[model], float(it), float(bi), float(pi),
-                                            float(df), float(R2), C.c_uint64(_seed(seed)), int(rng_mode), int(markers_per_sync)))
+        args = [C.byref(self._h), len(devices), devs, xptr, xtype, self.n, self.p, int(ldx), int(block), _fp(self._y), MODELS[model], float(it), float(bi),
+                float(pi), float(df), float(R2), C.c_uint64(_seed(seed)), int(rng_mode), int(markers_per_sync)]
+        if implicit:
+            check(_lib.lib().bwgr_group_create_centred(*(args + [memloc])))
+        else:
+            check(_lib.lib().bwgr_group_create(*args))
 
     def info(self):
         v = (C.c_int64 * 4)()

@@ -2948,6 +2948,16 @@ struct bwgr_group {
   bool use_comm = false;
   bool centred = true;        // every shard's columns are centred (bwgr_panel_centred): what makes G > 1 statistically sound
   float MSx_total = 0;
+  // several shards on ONE device (every entry of `devices` equal): the shards' sweeps run side by side on their own streams, each on its own
+  // compute units, and an exchange round is a sum kernel between events -- no RCCL.  One exact chain is a latency-bound pipeline that fills a
+  // third of the chip; the partitioned sampler's shards fill the rest.
+  bool same_dev = false;
+  std::vector<hipStream_t> streams;      // owned
+  std::vector<hipEvent_t> ev_sweep;      // [g]: shard g's round_sweep (or sums) is enqueued up to here
+  hipEvent_t ev_sum[2] = {nullptr, nullptr};
+  double *total[2] = {nullptr, nullptr}; // the summed residual deltas of a round, by round parity (ld doubles each); total_sums likewise (2 doubles)
+  double *total_sums[2] = {nullptr, nullptr};
+  uint64_t round_no = 0;
 };
 
 extern "C" int bwgr_group_destroy(bwgr_group *Gp) {
@@ -2960,6 +2970,11 @@ extern "C" int bwgr_group_destroy(bwgr_group *Gp) {
     if (Gp->P[g]) bwgr_panel_destroy(Gp->P[g]);
   }
   if (Gp->use_comm) for (bwgr_ncclComm_t c : Gp->comm) if (c) g_rccl.CommDestroy(c);
+  if (Gp->same_dev) {
+    for (hipEvent_t e : Gp->ev_sweep) if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; ++k) { if (Gp->ev_sum[k]) (void)hipEventDestroy(Gp->ev_sum[k]); hipFree(Gp->total[k]); hipFree(Gp->total_sums[k]); }
+    for (hipStream_t q : Gp->streams) if (q) (void)hipStreamDestroy(q);
+  }
   delete Gp;
   return BWGR_OK;
 }
@@ -3024,11 +3039,17 @@ extern "C" int bwgr_group_sound(const bwgr_group *Gp, int *sound);
 
 static int group_create_impl(bwgr_group **out, int ndev, const int *devices, const void *X, int xtype, int64_t n, int64_t p,
                              int64_t ldx, int block, const float *y, int model, float it, float bi, float pi, float df, float R2,
-                             uint64_t seed, int rng_mode, int64_t markers_per_sync, int centre) {
+                             uint64_t seed, int rng_mode, int64_t markers_per_sync, int centre, int memloc = BWGR_HOST) {
   if (!out || !devices || !X || !y) return fail(BWGR_EINVAL, "group_create: null pointer");
+  if (memloc != BWGR_HOST && memloc != BWGR_DEVICE) return fail(BWGR_EINVAL, "group_create: bad memloc %d", memloc);
+  if (memloc == BWGR_DEVICE && ndev > 1 && !std::all_of(devices, devices + ndev, [&](int d) { return d == devices[0]; }))
+    return fail(BWGR_EINVAL, "group_create: a device-resident X serves shards of that one device only");
   if (centre && xtype != BWGR_X_I8) return fail(BWGR_EINVAL, "group_create_centred: implicit centring is for int8 genotypes (centre float columns before the call)");
   *out = nullptr;
   if (ndev < 1 || ndev > 64) return fail(BWGR_EINVAL, "group_create: ndev = %d", ndev);
+  for (int g = 1; g < ndev; ++g) for (int h = 0; h < g; ++h)
+    if (devices[g] == devices[h] && !std::all_of(devices, devices + ndev, [&](int d) { return d == devices[0]; }))
+      return fail(BWGR_EINVAL, "group_create: a device may appear once, or every shard sits on the same device (shards side by side on one GPU)");
   if (xtype != BWGR_X_I8 && xtype != BWGR_X_F32 && xtype != BWGR_X_F64) return fail(BWGR_EINVAL, "group_create: bad xtype %d", xtype);
   const int mmax = (xtype == BWGR_X_I8) ? SW_MAXM : 64;
   const int m = block > 0 ? block : mmax;
@@ -3037,6 +3058,7 @@ static int group_create_impl(bwgr_group **out, int ndev, const int *devices, con
   bwgr_group *Gp = new bwgr_group();
   Gp->G = ndev; Gp->model = model; Gp->n = n; Gp->p = p; Gp->block = m;
   Gp->dev.assign(devices, devices + ndev);
+  Gp->same_dev = ndev > 1 && std::all_of(devices, devices + ndev, [&](int d) { return d == devices[0]; });
   Gp->P.assign(ndev, nullptr); Gp->C.assign(ndev, nullptr); Gp->delta.assign(ndev, nullptr); Gp->sums.assign(ndev, nullptr);
   auto bail = [&](int code) { bwgr_group_destroy(Gp); return code; };
   const size_t esz = (xtype == BWGR_X_I8) ? 1 : (xtype == BWGR_X_F32 ? 4 : 8);
@@ -3044,8 +3066,15 @@ static int group_create_impl(bwgr_group **out, int ndev, const int *devices, con
   for (int g = 0; g < ndev; ++g) {
     const int64_t lo = std::min<int64_t>(p, (int64_t)g * per * m), hi = std::min<int64_t>(p, (int64_t)(g + 1) * per * m);
     Gp->lo.push_back(lo); Gp->hi.push_back(hi);
-    int rc = bwgr_panel_create(&Gp->P[g], reinterpret_cast<const unsigned char *>(X) + (size_t)lo * (size_t)ldx * esz, xtype, BWGR_HOST, n, hi - lo, ldx, devices[g], m, 0);
+    int rc = bwgr_panel_create(&Gp->P[g], reinterpret_cast<const unsigned char *>(X) + (size_t)lo * (size_t)ldx * esz, xtype, memloc, n, hi - lo, ldx, devices[g], m, 0);
     if (rc != BWGR_OK) return bail(rc);
+    if (Gp->same_dev) {   // shards of one device: each on a stream of its own; from three shards on, 256-row streamers (K3 + 1 units a shard instead of 2 K3 + 2)
+      hipStream_t q = nullptr;
+      if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) return bail(fail(BWGR_EHIP, "group_create: hipStreamCreate failed"));
+      Gp->streams.push_back(q);
+      Gp->P[g]->stream = q;
+      if (ndev > 2) Gp->P[g]->solo3 = false;
+    }
     if (centre) { rc = bwgr_panel_set_centred(Gp->P[g], 1); if (rc != BWGR_OK) return bail(rc); }   // the shard's own column means (rows are not sharded)
     msx += (double)Gp->P[g]->MSx;
     int cen = 1;
@@ -3075,7 +3104,16 @@ static int group_create_impl(bwgr_group **out, int ndev, const int *devices, con
   for (int g = 0; g < ndev; ++g) nbmax = std::max<int64_t>(nbmax, Gp->P[g]->nblocks);
   Gp->rounds = (int)((nbmax + Gp->bps - 1) / Gp->bps);
   const char *fc = getenv("BWGR_GROUP_FORCE_COMM");   // (tests: exercise the RCCL path with a single device)
-  Gp->use_comm = ndev > 1 || (fc && fc[0] == '1');
+  Gp->use_comm = (ndev > 1 && !Gp->same_dev) || (fc && fc[0] == '1' && !Gp->same_dev);
+  if (Gp->same_dev) {
+    if (hipSetDevice(devices[0]) != hipSuccess) return bail(fail(BWGR_EHIP, "group_create: hipSetDevice failed"));
+    Gp->ev_sweep.assign(ndev, nullptr);
+    for (int g = 0; g < ndev; ++g) if (hipEventCreateWithFlags(&Gp->ev_sweep[g], hipEventDisableTiming) != hipSuccess) return bail(fail(BWGR_EHIP, "group_create: hipEventCreate failed"));
+    for (int k = 0; k < 2; ++k) {
+      if (hipEventCreateWithFlags(&Gp->ev_sum[k], hipEventDisableTiming) != hipSuccess || hipMalloc(&Gp->total[k], sizeof(double) * (size_t)Gp->P[0]->ld) != hipSuccess ||
+          hipMalloc(&Gp->total_sums[k], sizeof(double) * 2) != hipSuccess) return bail(fail(BWGR_ENOMEM, "group_create: device allocation failed"));
+    }
+  }
   if (Gp->use_comm) {
     int rc = rccl_load();
     if (rc != BWGR_OK) return bail(rc);
@@ -3095,8 +3133,8 @@ extern "C" int bwgr_group_create(bwgr_group **out, int ndev, const int *devices,
 // ... on the implicitly centred columns of an int8 matrix (bwgr_panel_set_centred on every shard): sound with several devices, int8 in HBM
 extern "C" int bwgr_group_create_centred(bwgr_group **out, int ndev, const int *devices, const void *X, int xtype, int64_t n, int64_t p,
                                          int64_t ldx, int block, const float *y, int model, float it, float bi, float pi, float df, float R2,
-                                         uint64_t seed, int rng_mode, int64_t markers_per_sync) {
-  return group_create_impl(out, ndev, devices, X, xtype, n, p, ldx, block, y, model, it, bi, pi, df, R2, seed, rng_mode, markers_per_sync, 1);
+                                         uint64_t seed, int rng_mode, int64_t markers_per_sync, int memloc) {
+  return group_create_impl(out, ndev, devices, X, xtype, n, p, ldx, block, y, model, it, bi, pi, df, R2, seed, rng_mode, markers_per_sync, 1, memloc);
 }
 static int group_allreduce(bwgr_group *Gp, std::vector<double *> &buf, size_t count) {
   int nr = g_rccl.GroupStart();
@@ -3114,9 +3152,55 @@ extern "C" int bwgr_group_sound(const bwgr_group *Gp, int *sound) {
   return BWGR_OK;
 }
 
+namespace {
+struct SumPtrs { const double *src[64]; };
+__global__ void k_group_sum(const SumPtrs s, int G, double *out, int64_t count) {   // out = sum over the shards, in shard order (the same bits on every run)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    double t = 0.0;
+    for (int g = 0; g < G; ++g) t += s.src[g][i];
+    out[i] = t;
+  }
+}
+}  // namespace
+// one exchange among the shards of one device: every shard's stream has produced buf[g]; stream 0 sums them into `total` (by round parity, so
+// that the readers of the previous round are never overwritten: a buffer's next writer waits for events that every reader's stream records later)
+static int group_local_sum(bwgr_group *Gp, std::vector<double *> &buf, size_t count, double *const total[2], double **out) {
+  const int k = (int)(Gp->round_no++ & 1u);
+  SumPtrs sp;
+  for (int g = 0; g < Gp->G; ++g) { sp.src[g] = buf[g]; HIPCHK(hipEventRecord(Gp->ev_sweep[g], Gp->streams[g])); }
+  for (int g = 1; g < Gp->G; ++g) HIPCHK(hipStreamWaitEvent(Gp->streams[0], Gp->ev_sweep[g], 0));
+  hipLaunchKernelGGL(k_group_sum, dim3((unsigned)std::min<size_t>(64, (count + 255) / 256)), dim3(256), 0, Gp->streams[0], sp, Gp->G, total[k], (int64_t)count);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(Gp->ev_sum[k], Gp->streams[0]));
+  for (int g = 1; g < Gp->G; ++g) HIPCHK(hipStreamWaitEvent(Gp->streams[g], Gp->ev_sum[k], 0));
+  *out = total[k];
+  return BWGR_OK;
+}
+static int group_run_same_device(bwgr_group *Gp, int iters) {
+  HIPCHK(hipSetDevice(Gp->dev[0]));
+  for (int k = 0; k < iters; ++k) {
+    for (int r = 0; r < Gp->rounds; ++r) {
+      for (int g = 0; g < Gp->G; ++g) {
+        const int nb = (int)Gp->P[g]->nblocks;
+        const int lo = std::min(nb, r * Gp->bps), hi = std::min(nb, (r + 1) * Gp->bps);
+        CHK(bwgr_chain_round_sweep(Gp->C[g], lo, hi, Gp->delta[g]));
+      }
+      double *tot = nullptr;
+      CHK(group_local_sum(Gp, Gp->delta, (size_t)Gp->P[0]->ld, Gp->total, &tot));
+      for (int g = 0; g < Gp->G; ++g) CHK(bwgr_chain_round_apply(Gp->C[g], tot));
+    }
+    for (int g = 0; g < Gp->G; ++g) CHK(bwgr_chain_get_sums_dev(Gp->C[g], Gp->sums[g]));
+    double *tot2 = nullptr;
+    CHK(group_local_sum(Gp, Gp->sums, 2, Gp->total_sums, &tot2));
+    for (int g = 0; g < Gp->G; ++g) CHK(bwgr_chain_end_iteration_dev(Gp->C[g], tot2));
+  }
+  return BWGR_OK;
+}
+
 extern "C" int bwgr_group_run(bwgr_group *Gp, int iters) {
   if (!Gp) return fail(BWGR_EINVAL, "null group");
   if (iters < 0) return fail(BWGR_EINVAL, "group_run: iters < 0");
+  if (Gp->same_dev) return group_run_same_device(Gp, iters);
   if (!Gp->use_comm) return bwgr_chain_run(Gp->C[0], iters);   // one device: the plain exact chain
   for (int k = 0; k < iters; ++k) {
     for (int r = 0; r < Gp->rounds; ++r) {

@@ -272,10 +272,14 @@ int bwgr_group_create(bwgr_group **out, int ndev, const int *devices, const void
                       int block, const float *y, int model, float it, float bi, float pi, float df, float R2, uint64_t seed,
                       int rng_mode, int64_t markers_per_sync);
 /* the same on the IMPLICITLY centred columns of an int8 matrix (bwgr_panel_set_centred on every shard: the genotypes stay int8, k_sweep3 sweeps them):
- * sound with several devices; selection models only; the intercept returned is that of the centred parametrisation (mu_c = mu + sum_j mean_j b_j) */
+ * sound with several devices; selection models only; the intercept returned is that of the centred parametrisation (mu_c = mu + sum_j mean_j b_j).
+ * memloc: where X lives (BWGR_DEVICE: only when every shard sits on that device).
+ * SHARDS SIDE BY SIDE ON ONE GPU: `devices` may name the same device ndev times (both create calls).  One exact chain is a latency-bound pipeline
+ * that occupies a third of the chip; the shards of the partitioned sampler then run their sweeps concurrently on streams of their own, each on its own
+ * compute units, and an exchange round is a sum kernel between events (no RCCL).  Same sampler, same soundness rule (centred columns) as across GPUs. */
 int bwgr_group_create_centred(bwgr_group **out, int ndev, const int *devices, const void *X, int xtype, int64_t n, int64_t p, int64_t ldx,
                               int block, const float *y, int model, float it, float bi, float pi, float df, float R2, uint64_t seed,
-                              int rng_mode, int64_t markers_per_sync);
+                              int rng_mode, int64_t markers_per_sync, int memloc);
 int bwgr_group_run(bwgr_group *G, int iters);
 int bwgr_group_sync(bwgr_group *G);
 int bwgr_group_info(const bwgr_group *G, int64_t info[4]);

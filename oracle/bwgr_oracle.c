@@ -190,6 +190,20 @@ double FN(oracle_variate)(uint64_t seed, int mode, int kind, double nu, uint32_t
   return orng_chisq(&g, nu, marker, iter, purpose);
 }
 
+/* ORNG_RSTREAM (bwgr_rstream.h, UNVERIFIED restatement of R's stream): set.seed(seed), and single draws for the self-tests --
+ * kind 0 unif_rand, 1 norm_rand, 2 exp_rand, 3 rgamma(par, 1), 4 rchisq(par), 5 rbinom(1, par).  Each flavour of this file has its own stream. */
+void FN(oracle_rstream_seed)(uint32_t seed) { ors_set_seed(seed); }
+double FN(oracle_rstream_draw)(int kind, double par) {
+  switch (kind) {
+    case 0: return ors_unif_rand();
+    case 1: return ors_norm_rand();
+    case 2: return ors_exp_rand();
+    case 3: return ors_rgamma(par, 1.0);
+    case 4: return ors_rchisq(par);
+    default: return (double)ors_rbinom1(par);
+  }
+}
+
 /* ---- KMUP: one Gibbs sweep, /root/reference/src/Rcpp20260726ai.cpp:12-38 ----------------------
  * stable = 0: literal cj/(cj+dj) (underflows to 0/0 = NaN for 0.5*|e|^2/sqrt(Ve) >~ 103, then
  *             every marker takes the else branch, :25-31);
@@ -228,7 +242,7 @@ int FN(oracle_kmup)(const float *X, int64_t n, int64_t p, int64_t ldx, float *b,
         pj = cj / (cj + dj);                                                     /* :27 */
       }
       /* R::rbinom(1,pj)==1 ; NaN pj compares false, like rbinom's NaN return */
-      if (orng_uniform(&g, mk, iter, ORNG_U, 0) < (double)pj) {                  /* :28 */
+      if (orng_bernoulli(&g, (double)pj, mk, iter)) {                  /* :28 */
         b[j] = b1; d[j] = 1; memcpy(e, e1, sizeof(E_T) * n);                     /* :29 */
       } else {
         b[j] = b2; d[j] = 0; memcpy(e, e2, sizeof(E_T) * n);                     /* :31 */
@@ -305,7 +319,7 @@ int FN(oracle_kmup2)(const float *X, int64_t n0, int64_t p, int64_t ldx, const i
         dj = (pi)*f_exp(C * e_sqnorm(e2, n));                                    /* :65 */
         pj = cj / (cj + dj);                                                     /* :66 */
       }
-      if (orng_uniform(&g, mk, iter, ORNG_U, 0) < (double)pj) { b[j] = b1; d[j] = 1; memcpy(e0, e1, sizeof(E_T) * n); }   /* :67-68 */
+      if (orng_bernoulli(&g, (double)pj, mk, iter)) { b[j] = b1; d[j] = 1; memcpy(e0, e1, sizeof(E_T) * n); }   /* :67-68 */
       else { b[j] = b2; d[j] = 0; memcpy(e0, e2, sizeof(E_T) * n); }             /* :70 */
     } else { d[j] = 1; b[j] = b1; memcpy(e0, e1, sizeof(E_T) * n); }             /* :73 */
   }
@@ -385,7 +399,7 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
           LR = Pi0 * f_exp(C * diff);
         }
         pj = 1.0f / (1.0f + LR);
-        if (orng_uniform(&g, mk, itx, ORNG_U, 0) < (double)pj) {
+        if (orng_bernoulli(&g, (double)pj, mk, itx)) {
           b[j] = b1; d[j] = 1;
         } else {
           b[j] = draw_norm(0.0f, sqrtf(ve / den), orng_normal(&g, mk, itx, ORNG_Z2, 0)); d[j] = 0;
@@ -407,7 +421,7 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
           LR = Pi0 * f_exp(C * diff);
         }
         pj = 1.0f / (1.0f + LR);
-        if (orng_uniform(&g, mk, itx, ORNG_U, 0) < (double)pj) { b[j] = b1; d[j] = 1; }
+        if (orng_bernoulli(&g, (double)pj, mk, itx)) { b[j] = b1; d[j] = 1; }
         else { b[j] = b2; d[j] = 0; }
         v_axpy(e, xj, b[j] - b0, n);
         break;
@@ -424,7 +438,7 @@ int FN(oracle_bayes)(int model, const float *y, const float *X, int64_t n, int64
           pj = (1 - pi) * f_exp(C * diff);
         }
         if (pj > 1) pj = 1;
-        if (orng_uniform(&g, mk, itx, ORNG_U, 0) < (double)pj) { b[j] = b1; d[j] = 1; }
+        if (orng_bernoulli(&g, (double)pj, mk, itx)) { b[j] = b1; d[j] = 1; }
         else { b[j] = b2; d[j] = 0; }
         vbv[j] = (float)((double)(Sb + b[j] * b[j]) / orng_chisq(&g, (double)(df + 1), mk, itx, ORNG_CHI));
         v_axpy(e, xj, b[j] - b0, n);
@@ -565,7 +579,7 @@ int FN(oracle_bayes2)(int model2, const float *y, const float *X1, int64_t p1, c
           const float diff = e_sqnorm(e2, n) - e_sqnorm(e1, n);
 #endif
           const float pj = 1.0f / (1.0f + Pi0 * f_exp(C * diff));
-          if (orng_uniform(&g, mk, itx, ORNG_U, 0) < (double)pj) { b[k][j] = b1; d[k][j] = 1; }
+          if (orng_bernoulli(&g, (double)pj, mk, itx)) { b[k][j] = b1; d[k][j] = 1; }
           else { b[k][j] = b2; d[k][j] = 0; }
         } else {
           b[k][j] = b1;                                                 /* :1031, :1196 */

@@ -21,6 +21,7 @@
 #define BWGR_ORACLE_RNG_H
 #include <stdint.h>
 #include <math.h>
+#include "bwgr_rstream.h"   /* ORNG_RSTREAM: an UNVERIFIED restatement of R's serial stream, for users who have R (see that header) */
 
 /* purposes (third counter word) */
 enum {
@@ -40,6 +41,9 @@ enum {
 #define ORNG_PHILOX 0
 #define ORNG_DEGENERATE 1  /* z = 0, chi-square = its mean, u = 0.5: turns the sampler into
                               deterministic Gauss-Seidel for the analytic invariants */
+#define ORNG_RSTREAM 2     /* R's own serial stream (Mersenne-Twister, inversion normals, nmath's rgamma / rbinom), drawn in the order the
+                              oracle's code -- and so the reference's -- asks for variates; counters are ignored; seed it with
+                              oracle_rstream_seed() = set.seed() before the call.  UNVERIFIED: no R in the build image (bwgr_rstream.h) */
 
 typedef struct { uint64_t seed; int mode; } orng_t;
 
@@ -73,6 +77,7 @@ static inline void orng_block(const orng_t *g, uint32_t marker, uint32_t iter, u
 
 static inline double orng_uniform(const orng_t *g, uint32_t marker, uint32_t iter, uint32_t purpose, uint32_t k) {
   if (g->mode == ORNG_DEGENERATE) return 0.5;
+  if (g->mode == ORNG_RSTREAM) return ors_unif_rand();
   uint32_t x[4]; orng_block(g, marker, iter, purpose, k, x);
   return orng_u53(x[0], x[1]);
 }
@@ -80,6 +85,7 @@ static inline double orng_uniform(const orng_t *g, uint32_t marker, uint32_t ite
 /* Box-Muller (cosine branch), one normal per Philox block */
 static inline double orng_normal(const orng_t *g, uint32_t marker, uint32_t iter, uint32_t purpose, uint32_t k) {
   if (g->mode == ORNG_DEGENERATE) return 0.0;
+  if (g->mode == ORNG_RSTREAM) return ors_norm_rand();
   uint32_t x[4]; orng_block(g, marker, iter, purpose, k, x);
   double u1 = orng_u53(x[0], x[1]);
   double u2 = orng_u53(x[2], x[3]);
@@ -111,7 +117,15 @@ static inline double orng_gamma(const orng_t *g, double a, uint32_t marker, uint
 }
 
 static inline double orng_chisq(const orng_t *g, double nu, uint32_t marker, uint32_t iter, uint32_t purpose) {
+  if (g->mode == ORNG_RSTREAM) return ors_rchisq(nu);   /* R::rchisq(nu) = rgamma(nu / 2, 2) */
   return 2.0 * orng_gamma(g, 0.5 * nu, marker, iter, purpose);
+}
+
+/* the Bernoulli inclusion draw: `R::rbinom(1, pj) == 1` (/root/reference/src/Rcpp20260726ai.cpp:28, :675 ...).  Contract: u < pj on the marker's
+ * ORNG_U uniform (a NaN pj compares false, as rbinom's NaN == 1 does); R stream: nmath's inversion rbinom, one uniform */
+static inline int orng_bernoulli(const orng_t *g, double pj, uint32_t marker, uint32_t iter) {
+  if (g->mode == ORNG_RSTREAM) return ors_rbinom1(pj);
+  return orng_uniform(g, marker, iter, ORNG_U, 0) < pj;
 }
 
 #endif

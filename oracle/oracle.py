@@ -20,7 +20,7 @@ _libs = {}
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = [os.path.join(_HERE, f) for f in ("bwgr_oracle.c", "bwgr_rng.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("bwgr_oracle.c", "bwgr_rng.h", "bwgr_rstream.h", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
     return so
@@ -59,6 +59,20 @@ def variate(seed, kind, marker, it, purpose, k=0, nu=0.0, mode=0):
     kinds = {"normal": 0, "uniform": 1, "chisq": 2}
     return f(C.c_uint64(seed), C.c_int(mode), C.c_int(kinds[kind]), C.c_double(nu), C.c_uint32(marker),
              C.c_uint32(it), C.c_uint32(purpose), C.c_uint32(k))
+
+
+RSTREAM = 2   # rng_mode: R's own serial stream (oracle/bwgr_rstream.h -- an UNVERIFIED restatement; seed it with rstream_seed = set.seed)
+
+
+def rstream_seed(seed, flavour="w", fast=False):
+    """set.seed(seed) of the R-stream back-end (rng_mode=RSTREAM); each flavour of the C file keeps its own stream."""
+    getattr(lib(fast), "oracle_rstream_seed_" + flavour)(C.c_uint32(int(seed) & 0xFFFFFFFF))
+
+
+def rstream_draw(kind, par=0.0, flavour="w"):
+    """One draw from the R-stream back-end: kind in unif, norm, exp, gamma (shape par), chisq (df par), binom1 (probability par)."""
+    f = getattr(lib(), "oracle_rstream_draw_" + flavour); f.restype = C.c_double
+    return f(C.c_int({"unif": 0, "norm": 1, "exp": 2, "gamma": 3, "chisq": 4, "binom1": 5}[kind]), C.c_double(par))
 
 
 def stats(X, flavour="w"):

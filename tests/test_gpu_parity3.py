@@ -270,6 +270,39 @@ def test_partitioned_sampler_on_centred_columns():
             assert ch >= 0.98 and cb >= 0.97, (G, form, ch, cb)
 
 
+def test_shards_side_by_side_on_one_gpu():
+    """Group(devices=[0] * S): the shards of the partitioned sampler on ONE device, sweeping concurrently on streams of their own with a sum kernel
+    per exchange round (no RCCL).  It is the sampler _sharded_run drives shard after shard: the same chain to rounding (six iterations: the deltas
+    are summed in the same shard order), and over 160 iterations it follows the exact centred chain like the shards of test_partitioned_sampler_on_centred_columns."""
+    import bwgr_amd
+    from oracle import oracle as O
+    n, p, pi = 800, 16384, 0.95
+    X, y = synth_small(n, p, seed=23, causal=0.01)
+    y = y.astype(np.float32)
+    msx = float(O.stats(X)[2])
+    for S, mpr in ((2, 2048), (4, 1024)):
+        g = bwgr_amd.Group("BayesB", y, X, devices=[0] * S, it=6, bi=1, pi=pi, seed=31, centre=True, markers_per_sync=mpr)
+        assert g.implicit_centring and g.info()["rccl"] == 0 and g.info()["devices"] == S
+        g.run(6)
+        r = g.result()
+        g.close()
+        s_ = _sharded_run(X, y, S, mpr, 6, 1, pi, 31, msx, implicit=True)
+        assert np.array_equal(r["d"], s_["d"]) and scaled_err(r["b"], s_["b"]) < 1e-6 and _rel(r["ve"], s_["ve"]) < 1e-6
+        assert r["statistically_sound"] is True
+    it, bi = 160, 40
+    Xc = _centred_f32(X)
+    a = bwgr_amd.BayesB(y, Xc, it=it, bi=bi, pi=pi, seed=31)
+    g = bwgr_amd.Group("BayesB", y, X, devices=[0, 0, 0, 0], it=it, bi=bi, pi=pi, seed=31, centre=True, markers_per_sync=1024)
+    g.run(it)
+    r = g.result()
+    g.close()
+    ch, cb = np.corrcoef(r["hat"], a["hat"])[0, 1], np.corrcoef(r["b"], a["b"])[0, 1]
+    print("4 shards side by side on one GPU: ve %.4f (exact %.4f) mean d %.4f (%.4f) cor(hat) %.4f cor(b) %.4f" % (r["ve"], a["ve"], r["d"].mean(), a["d"].mean(), ch, cb))
+    assert _rel(r["ve"], a["ve"]) < 0.05 and abs(float(r["d"].mean()) - float(a["d"].mean())) < 0.003 and ch >= 0.98 and cb >= 0.97
+    with pytest.raises(bwgr_amd.BwgrError):
+        bwgr_amd.Group("BayesB", y, X, devices=[0, 0], it=4, bi=1, pi=pi, seed=1)   # uncentred: refused like several devices
+
+
 def test_group_refuses_several_shards_on_uncentred_columns(tpod, monkeypatch):
     """bwgr_group_create with more than one shard on uncentred columns is an error unless BWGR_GROUP_ALLOW_UNCENTRED=1 (a caller
     must not get the unsound sampler silently); centred columns and a single device are accepted, and bwgr_group_sound / Group.result()

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 python3 bench.py > $OUT/${TAG}_bench_c4.json 2> $OUT/${TAG}_bench_c4.err
 echo "bench done"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o ${TAG} --output-format csv -- python3 $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu --no-extra --chains 1 > $OUT/${TAG}_bench_c4_under_rocprof.json 2> $OUT/${TAG}_rocprof.err
+rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o ${TAG} --output-format csv -- python3 $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu --no-extra --shards 0 --chains 1 > $OUT/${TAG}_bench_c4_under_rocprof.json 2> $OUT/${TAG}_rocprof.err
 echo "stats done"
 # the concurrent-chains leg on its own (kernel durations with five sweeps side by side)
 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_cc -o ${TAG}cc --output-format csv -- python3 $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu > $OUT/${TAG}_bench_c4_concurrent_under_rocprof.json 2>> $OUT/${TAG}_rocprof.err
@@ -24,9 +24,9 @@ find $OUT/prof_stats_em -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_em_c2_
 find $OUT/prof_stats_em -name "*kernel_trace.csv" -delete
 echo "em stats done"
 fi
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_fetch -o ${TAG} --output-format csv -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu --no-extra --chains 1 > $OUT/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_fetch -o ${TAG} --output-format csv -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu --no-extra --shards 0 --chains 1 > $OUT/${TAG}_pmc_fetch.log 2>&1
 echo "fetch done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write -o ${TAG} --output-format csv -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu --no-extra --chains 1 > $OUT/${TAG}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write -o ${TAG} --output-format csv -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu --no-extra --shards 0 --chains 1 > $OUT/${TAG}_pmc_write.log 2>&1
 echo "write done"
 cd $OLDPWD
 python3 tools/pmc_summary.py $OUT/prof_fetch $OUT/prof_write $OUT/${TAG}_pmc_c4.json c4 10000 1000000 > /dev/null

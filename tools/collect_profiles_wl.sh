@@ -10,18 +10,18 @@ REPO=$PWD
 mkdir -p $OUT
 export TMPDIR=/tmp
 if [ -z "$PMC_ONLY" ]; then
-python3 bench.py --workload $WL --chains 1 --no-extra ${BENCH_EXTRA} > $OUT/${TAG}_bench_${WL}.json 2> $OUT/${TAG}_bench_${WL}.err
+python3 bench.py --workload $WL --chains 1 --no-extra --shards 0 ${BENCH_EXTRA} > $OUT/${TAG}_bench_${WL}.json 2> $OUT/${TAG}_bench_${WL}.err
 echo "$WL bench done"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_${WL} -o ${TAG}${WL} --output-format csv -- python3 $REPO/bench.py --workload $WL --steps 10 --warmup 2 --no-cpu --no-extra --chains 1 > $OUT/${TAG}_bench_${WL}_under_rocprof.json 2> $OUT/${TAG}_rocprof_${WL}.err
+rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_${WL} -o ${TAG}${WL} --output-format csv -- python3 $REPO/bench.py --workload $WL --steps 10 --warmup 2 --no-cpu --no-extra --shards 0 --chains 1 > $OUT/${TAG}_bench_${WL}_under_rocprof.json 2> $OUT/${TAG}_rocprof_${WL}.err
 find $OUT/prof_stats_${WL} -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_bench_${WL}_kernel_stats.csv \;
 rm -rf $OUT/prof_stats_${WL}
 echo "$WL stats done"
 fi
 cd /tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_fetch_${WL} -o ${TAG} --output-format csv -- python3 $REPO/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu --no-extra --chains 1 > $OUT/${TAG}_pmc_fetch_${WL}.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_fetch_${WL} -o ${TAG} --output-format csv -- python3 $REPO/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu --no-extra --shards 0 --chains 1 > $OUT/${TAG}_pmc_fetch_${WL}.log 2>&1
 echo "$WL fetch done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write_${WL} -o ${TAG} --output-format csv -- python3 $REPO/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu --no-extra --chains 1 > $OUT/${TAG}_pmc_write_${WL}.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write_${WL} -o ${TAG} --output-format csv -- python3 $REPO/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu --no-extra --shards 0 --chains 1 > $OUT/${TAG}_pmc_write_${WL}.log 2>&1
 echo "$WL write done"
 cd $REPO
 python3 tools/pmc_summary.py $OUT/prof_fetch_${WL} $OUT/prof_write_${WL} $OUT/${TAG}_pmc_${WL}.json $WL $N $P > /dev/null
