@@ -1346,14 +1346,19 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
 template <typename GT>
 __device__ __forceinline__ void s3_prefetcher(const Sweep3Args &A) {
   const SweepArgs &a = A.a;
-  const int tid = threadIdx.x, m = a.m, nb = a.blk_end - a.blk_begin;
-  constexpr int AHEAD = 12;
+  const int tid = threadIdx.x, nb = a.blk_end - a.blk_begin;
+  // Four blocks per trip, their touches in flight together, one poll per trip: a trip costs one poll round trip plus one HBM round trip, so the
+  // prefetcher keeps ahead of a sequencer that takes a block every 1.2 - 1.6 us.  (One block per trip -- a poll and a dependent load wave each --
+  // took about 2 us a block: the prefetcher fell behind the sequencer it serves, whose staging loads then missed L2 again.)
+  constexpr int AHEAD = 16, NPB = 4;
   uint32_t *abortw = a.xflags + (size_t)a.K * SW_FLAG_STRIDE;
-  const size_t gpbytes = (size_t)a.pstride * sizeof(GT), gxbytes = (size_t)m * m * sizeof(GT);
+  const size_t gpbytes = (size_t)a.pstride * sizeof(GT);
   uint32_t sink = 0u;
-  for (int c = 0; c < nb; ++c) {
-    if (c >= AHEAD) {   // wait (one lane polls) until the sequencer has published the list of block c - AHEAD
-      const unsigned long long *L = A.lists + (size_t)(a.blk_begin + c - AHEAD) * S3_LSTRIDE;
+  const size_t o = (size_t)tid * 128;
+  for (int c0 = 0; c0 < nb; c0 += NPB) {
+    const int clast = min(c0 + NPB, nb) - 1;
+    if (clast >= AHEAD) {   // wait (one lane polls) until the sequencer has published the list of block clast - AHEAD
+      const unsigned long long *L = A.lists + (size_t)(a.blk_begin + clast - AHEAD) * S3_LSTRIDE;
       const uint64_t t0 = wall_clock64();
       unsigned spins = 0;
       for (;;) {
@@ -1362,17 +1367,21 @@ __device__ __forceinline__ void s3_prefetcher(const Sweep3Args &A) {
         __builtin_amdgcn_s_sleep(4);
       }
     }
-    // what the staging waves will ask for: the block's constants, speculative terms and packed diagonal Gram block, one dword per
-    // 128-byte line (their loads are HBM misses ~2 us away on the sequencer's CU, and they must be back within one block period)
-    const int blk = a.blk_begin + c;
-    const unsigned char *gpb = reinterpret_cast<const unsigned char *>(A.gp) + (size_t)blk * gpbytes;
-    const unsigned char *stb = reinterpret_cast<const unsigned char *>(a.ps.blocks + blk);
-    const unsigned char *spb = reinterpret_cast<const unsigned char *>(a.ps.spec + blk);
-    const size_t o = (size_t)tid * 128;
-    if (o < sizeof(StageBuf)) sink += *reinterpret_cast<const uint32_t *>(stb + o);
-    if (o < sizeof(SpecBuf)) sink += *reinterpret_cast<const uint32_t *>(spb + o);
-    if (o < gpbytes) sink += *reinterpret_cast<const uint32_t *>(gpb + o);
-    (void)gxbytes;
+    // what the staging waves will ask for: the blocks' constants, speculative terms and packed diagonal Gram blocks, one dword per 128-byte line
+    // (their loads are HBM misses ~2 us away on the sequencer's CU, and they must be back within one block period)
+    uint32_t v[NPB][3];
+#pragma unroll
+    for (int u = 0; u < NPB; ++u) {
+      const int blk = a.blk_begin + min(c0 + u, nb - 1);
+      const unsigned char *gpb = reinterpret_cast<const unsigned char *>(A.gp) + (size_t)blk * gpbytes;
+      const unsigned char *stb = reinterpret_cast<const unsigned char *>(a.ps.blocks + blk);
+      const unsigned char *spb = reinterpret_cast<const unsigned char *>(a.ps.spec + blk);
+      v[u][0] = *reinterpret_cast<const uint32_t *>(stb + min(o, sizeof(StageBuf) - 4));
+      v[u][1] = *reinterpret_cast<const uint32_t *>(spb + min(o, sizeof(SpecBuf) - 4));
+      v[u][2] = *reinterpret_cast<const uint32_t *>(gpb + min(o, gpbytes - 4));
+    }
+#pragma unroll
+    for (int u = 0; u < NPB; ++u) sink += v[u][0] + v[u][1] + v[u][2];
   }
   if (sink == 0x9E3779B9u && a.stamps) a.stamps[255] = sink;   // (keeps the loads alive)
 }
