@@ -9,12 +9,13 @@ from bwgr_amd import build as B
 so = os.path.join(ROOT, "gpurun_out", "libbwgr_hip_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 LITE = os.environ.get("STAMPS_LITE", "0")   # 0: every stamp; 1: busy / waiting per role; 2: only the sequencer's wave 0, busy / waiting
-subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DBWGR_STAMPS=%d" % (1 + int(LITE)), "-o", so] + B.SOURCES)
+EXP = ["-DBWGR_EXPERIMENTS"] if os.environ.get("STAMP_EXP") else []   # (with the BWGR_DBG3 switches: roles off, sequencer alone, ...)
+subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + EXP + ["-DBWGR_STAMPS=%d" % (1 + int(LITE)), "-o", so] + B.SOURCES)
 B.LIB = so
 import numpy as np, torch
 import bwgr_amd
 from bwgr_amd import synth, _lib
-wl = {"c4s": (10000, 200000, "BayesB", 0.99), "c4b": (10000, 200000, "BayesB", 0.95), "c4d": (10000, 100000, "BayesCpi", 0.5)}
+wl = {"c4x": (10000, int(os.environ.get("AB_P", "500000")), "BayesB", 0.99), "c4s": (10000, 200000, "BayesB", 0.99), "c4b": (10000, 200000, "BayesB", 0.95), "c4d": (10000, 100000, "BayesCpi", 0.5)}
 rows = [("streamer 0, update wave", 0, ["loop top", "fold the list of block b-D", "digits of e and drej", "barrier", "requests (drej, list) after the issue", "update MFMA + recombine", "abort check + tile commit", "next tile issue"]),
         ("streamer 0, first dots wave", 8, ["loop top", "-", "-", "barrier (incl. waiting for the update waves)", "requests (drej, list) after the issue", "dots MFMA + recombine + atomics", "abort check + tile commit", "next tile issue"]),
         ("sequencer wave 0", 16, ["loop top", "constants + r0", "rounds", "outputs + list publish", "barrier", "(inside rounds) waiting for the on-demand rows", "(included markers per block)", "-"]),
