@@ -329,9 +329,9 @@ class Group:
     def __init__(self, model, y, X, devices=(0,), it=1500, bi=500, pi=0.95, df=5.0, R2=0.5, seed=None, rng_mode=0, block=0,
                  markers_per_sync=0, centre=False, n=None):
         """centre=True sweeps x_j - mean(x_j): what makes more than one shard statistically sound (on uncentred columns the library refuses
-        len(devices) > 1 unless BWGR_GROUP_ALLOW_UNCENTRED=1).  Integer genotypes under BayesB / BayesC are centred IMPLICITLY (the panel stays int8
-        in HBM, k_sweep3 sweeps it: bwgr_group_create_centred; centre="implicit" asks for it under BayesCpi / Dpi too, centre="explicit" for the float
-        copy); float columns and the other models get an explicitly centred float panel.  Centring is a reparametrisation under the flat intercept
+        len(devices) > 1 unless BWGR_GROUP_ALLOW_UNCENTRED=1).  Integer genotypes under the selection models (BayesB / C / Cpi / Dpi) are centred
+        IMPLICITLY (the panel stays int8 in HBM: bwgr_group_create_centred; centre="explicit" asks for the float copy); float columns and the affine
+        models get an explicitly centred float panel.  Centring is a reparametrisation under the flat intercept
         prior (an exact Gibbs sampler would not notice; bWGR's own chain does a little: DESIGN.md section 8); result() gives mu back in the uncentred
         parametrisation, mu - sum_j mean_j b_j.
         devices may name ONE device several times: the shards then run side by side on that GPU (streams of their own, a sum kernel per exchange
@@ -360,7 +360,7 @@ class Group:
             if centre:
                 Xd = X.astype(np.float64)
                 self._xbar = Xd.mean(0)
-                implicit = (centre != "explicit" and (model in ("BayesB", "BayesC") or (centre == "implicit" and model in ("BayesCpi", "BayesDpi"))) and X.size > 0
+                implicit = (centre != "explicit" and model in ("BayesB", "BayesC", "BayesCpi", "BayesDpi") and X.size > 0
                             and bool(np.all(X == np.rint(X))) and X.min() >= -128 and X.max() <= 127)
                 if not implicit:
                     X = (Xd - self._xbar).astype(np.float32)

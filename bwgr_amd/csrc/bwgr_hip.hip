@@ -1310,10 +1310,10 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
   A.pf = pf_on ? ((A.K3 + 2 > 8) ? 8 : A.K3 + 1) : -1;
   const dim3 grid(A.K3 + 1 + (pf_on ? 1 : 0)), blk(SW_THREADS);
   const bool cen = (a.flags & SWF_CENTRE) != 0;
-  if (cen && !SWEEP_DRY) hipLaunchKernelGGL(k_cen_begin, dim3(1), dim3(1024), 0, P->stream, a);
+  if (cen && !SWEEP_DRY) hipLaunchKernelGGL(k_cen_begin, dim3(1), dim3(1024), 0, P->stream, a, 0);
   if (A.g16) { if (cen) SPIN_LAUNCH((k_sweep3<uint16_t, true>), grid, blk, P->lds3_bytes, P->stream, A); else SPIN_LAUNCH((k_sweep3<uint16_t, false>), grid, blk, P->lds3_bytes, P->stream, A); }
   else { if (cen) SPIN_LAUNCH((k_sweep3<int32_t, true>), grid, blk, P->lds3_bytes, P->stream, A); else SPIN_LAUNCH((k_sweep3<int32_t, false>), grid, blk, P->lds3_bytes, P->stream, A); }
-  if (cen && !SWEEP_DRY) hipLaunchKernelGGL(k_cen_end, dim3(64), dim3(256), 0, P->stream, a);
+  if (cen && !SWEEP_DRY) hipLaunchKernelGGL(k_cen_end, dim3(64), dim3(256), 0, P->stream, a, 0);
 }
 
 // The selection models' sweeps on a panel that has k_sweep3: the device picks the engine from the chain's current inclusion
@@ -1321,7 +1321,6 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
 // (a few microseconds per iteration); a threshold >= 1 means k_sweep3 always and the other side is not enqueued at all.
 static float sweep3_gate(const bwgr_panel *P, int flags) {
   if (!use_sweep3(P, flags)) return 0.0f;
-  if (flags & SWF_CENTRE) return INFINITY;   // implicitly centred sweeps are k_sweep3's at every inclusion rate (k_sweep2 sweeps the raw columns)
   return (P->eng3_thr >= 1.0f || P->force3) ? INFINITY : P->eng3_thr;
 }
 
@@ -1356,8 +1355,8 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
     int xbits = 0; while ((1 << xbits) < std::max(1, (P->parent ? P->parent : P)->xmax)) ++xbits;
     hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, xbits, a.gate3, sh_add);
     if (a.flags & SWF_CENTRE) {   // the rejected steps' share of sum(e_stored), block by block (the whole panel: launch_prestage is called with every block)
-      hipLaunchKernelGGL(k_cen_tot, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin);
-      hipLaunchKernelGGL(k_cen_scan, dim3(1), dim3(1024), 0, P->stream, a, (int)P->nblocks);
+      hipLaunchKernelGGL(k_cen_tot, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin, 0);
+      hipLaunchKernelGGL(k_cen_scan, dim3(1), dim3(1024), 0, P->stream, a, (int)P->nblocks, 0);
     }
     hipLaunchKernelGGL(k_spec3, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin);
     if (std::isinf(a.gate3)) return;
@@ -1373,6 +1372,10 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
   if (P->sweep_version >= 2) {
     const int sel = (a.flags & SWF_SELECT) ? 1 : 0;
     const unsigned nb = (unsigned)(a.blk_end - a.blk_begin);
+    if ((a.flags & SWF_CENTRE) && sel) {   // the fp64 engine's share of an implicitly centred iteration (the float steps themselves; runs on k_sweep2's side of the gate)
+      hipLaunchKernelGGL(k_cen_tot, dim3(nb), dim3(128), 0, P->stream, a, a.blk_begin, 1);
+      hipLaunchKernelGGL(k_cen_scan, dim3(1), dim3(1024), 0, P->stream, a, (int)P->nblocks, 1);
+    }
     if (P->is_f32) hipLaunchKernelGGL(k_spec<double>, dim3(nb), dim3(128), 0, P->stream, a, a.blk_begin, sel);
     else hipLaunchKernelGGL(k_spec<int32_t>, dim3(nb), dim3(128), 0, P->stream, a, a.blk_begin, sel);
   }
@@ -1403,8 +1406,7 @@ static void launch_sweep_kernel(bwgr_panel *P, const SweepArgs &a_in) {
 #else
   constexpr bool no_recover = false;
 #endif
-  // (an implicitly centred sweep that leaves the range is reported, BWGR_ERANGE: the fp64 engine that redoes a sweep sweeps the raw columns)
-  const bool guarded = fx && !P->debug_withhold && !no_recover && !(a.flags & SWF_CENTRE) && range_snapshot(P, a, sn);
+  const bool guarded = fx && !P->debug_withhold && !no_recover && range_snapshot(P, a, sn);
   launch_sweep_kernel_inner(P, a_in, false);
   if (guarded) {
     if (!SWEEP_DRY) {
@@ -1423,6 +1425,11 @@ static void launch_sweep_kernel_inner(bwgr_panel *P, const SweepArgs &a_in, bool
   a.redo_only = redo ? 1 : 0;
   if (redo && P->sweep_version >= 2 && !use_winv(P, a.flags)) {   // the fp64 engine's speculative terms (k_spec) of the state just restored
     const int sel = (a.flags & SWF_SELECT) ? 1 : 0;
+    if (!SWEEP_DRY && (a.flags & SWF_CENTRE) && sel) {   // the running block sums on the float steps (the fixed-point launch left them on its grid): every block, then the scan
+      SweepArgs all = a; all.blk_begin = 0; all.blk_end = (int)P->nblocks;
+      hipLaunchKernelGGL(k_cen_tot, dim3((unsigned)P->nblocks), dim3(128), 0, P->stream, all, 0, 2);
+      hipLaunchKernelGGL(k_cen_scan, dim3(1), dim3(1024), 0, P->stream, all, (int)P->nblocks, 2);
+    }
     if (!SWEEP_DRY) hipLaunchKernelGGL(k_spec<int32_t>, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin, sel);
   }
   if (a.gate3 > 0.0f) { launch_sweep3(P, a); if (std::isinf(a.gate3)) return; }
@@ -1453,6 +1460,9 @@ static void launch_sweep_kernel_inner(bwgr_panel *P, const SweepArgs &a_in, bool
   }
   if (P->sweep_version >= 2) {
     const dim3 grid(P->K + 1 + a.nfeed), blk(SW_THREADS);
+    const bool cen2 = (a.flags & SWF_CENTRE) && sel && !P->is_f32 && !SWEEP_DRY;
+    struct CenEnd { bool on; hipStream_t st; SweepArgs a; int mode; ~CenEnd() { if (on) hipLaunchKernelGGL(k_cen_end, dim3(64), dim3(256), 0, st, a, mode); } } cen_end{cen2, P->stream, a, redo ? 2 : 1};
+    if (cen2) hipLaunchKernelGGL(k_cen_begin, dim3(1), dim3(1024), 0, P->stream, a, redo ? 2 : 1);
     if (P->is_f32) {
       if (sel) SPIN_LAUNCH((k_sweep2<float, true>), grid, blk, P->lds2_bytes, P->stream, a);
       else SPIN_LAUNCH((k_sweep2<float, false>), grid, blk, P->lds2_bytes, P->stream, a);
@@ -2150,7 +2160,7 @@ extern "C" int bwgr_chain_create_sharded(bwgr_chain **out, bwgr_panel *P, int mo
   HIPCHK(hipSetDevice(P->device));
   if (panel_cen(P)) {
     if (!has_d(model) || !use_sweep3(P, SWF_SELECT))
-      return fail(BWGR_EINVAL, "chain_create: an implicitly centred panel (bwgr_panel_set_centred) runs the selection models BayesB / C / Cpi / Dpi on k_sweep3 only");
+      return fail(BWGR_EINVAL, "chain_create: an implicitly centred panel (bwgr_panel_set_centred) runs the selection models BayesB / C / Cpi / Dpi only");
     if (!P->cpre) HIPCHK(hipMalloc(&P->cpre, sizeof(double) * ((size_t)P->nblocks + 1)));
   }
   bwgr_chain *C = new bwgr_chain();

@@ -446,10 +446,13 @@ __device__ __forceinline__ void lane_quick(const LaneConst &c, int flags, float 
 // count, not their dependent chain: the loop below is written for few instructions -- the packed row's offset from a lane-indexed
 // table by one v_readlane instead of the triangular-number arithmetic, one exit test, the correction formed per lane before the
 // lane is known, the sliver's code out of line.)
-template <typename GT>
+// CEN (SWF_CENTRE, implicitly centred columns): cs = the two lanes' column sums s_j, cenU the running scalar -(E_0 + ...)/n + sum over the included
+// markers of (s_k / n) corr_k (see sweep3.hip.h, "implicitly centred sweeps"); an included marker's packed row G_kj acts as G_kj - s_j s_k / n.
+template <typename GT, bool CEN = false>
 __device__ __forceinline__ void quick_rounds(double (&r)[2], const LaneConst (&lc)[2], const double (&zc)[2], const double (&ha)[2], const double (&hr)[2],
                                              unsigned long long (&accmask)[2], const GT *gp, int m, int mB,
-                                             int lane, int flags, float Cc, float odds, float one_minus_pi, const Rng &rng, uint32_t iter) {
+                                             int lane, int flags, float Cc, float odds, float one_minus_pi, const Rng &rng, uint32_t iter,
+                                             const double *cs = nullptr, double ninv = 0.0, double *cenU = nullptr) {
   const int ngrp = (mB + 63) >> 6;
   const GT *gl = gp + lane;
 #pragma unroll
@@ -486,6 +489,15 @@ __device__ __forceinline__ void quick_rounds(double (&r)[2], const LaneConst (&l
       qr_apply:
         corr = readlane_f64(cd, js);
         am |= (1ull << js);
+        if constexpr (CEN) {
+          const double xk = readlane_f64(cs[q], js) * ninv;   // mean of column k
+          *cenU = fma(xk, corr, *cenU);
+          gm0 = (lane > js) ? ((double)g0 - cs[q] * xk) : 0.0;
+          rq = fma(-gm0, corr, rq);
+          z = fma(-gm0, corr, z);
+          if (q == 0) ro = fma(-((double)g1 - cs[1] * xk), corr, ro);
+          goto qr_top;
+        }
         gm0 = (double)((lane > js) ? g0 : (GT)0);
         rq = fma(-gm0, corr, rq);
         z = fma(-gm0, corr, z);
@@ -518,8 +530,18 @@ __global__ __launch_bounds__(128) void k_spec(const SweepArgs a, int blk_begin, 
   drp[j] = (blk > blk_begin) ? a.ps.blocks[blk - 1].drej[j] : 0.0f;   // previous block is always a full block
   __syncthreads();
   double s = 0.0, xs = 0.0, gjj = 0.0;
+  const bool cen = (a.flags & SWF_CENTRE) != 0 && select;   // implicitly centred columns (sweep3.hip.h): the rejected steps' share of -(s_j / n) sum(e) goes into spec,
+  __shared__ double cs_s[128];                                // the Gram diagonal becomes |x_j - mean_j|^2; cpre: k_cen_tot / k_cen_scan on the UNROUNDED steps
+  const double sj = (cen && j < mB) ? (double)a.csum[blk * m + j] : 0.0;
+  if (cen) { cs_s[j] = sj * (double)dr[j]; __syncthreads(); }
   if (j < mB) {
     gjj = (double)G[(size_t)j * m + j];
+    if (cen) {
+      double ib = 0.0;
+      for (int k = 0; k < j; ++k) ib += cs_s[k];
+      s = -(sj * a.ninv) * (a.cpre[blk] + ib);   // (spec is subtracted from the dot: + (s_j / n) * the rejected steps' share of the drop of sum(e))
+      gjj -= sj * sj * a.ninv;
+    }
     if (select) {
       for (int k = 0; k < j; ++k) s = fma((double)G[(size_t)k * m + j], (double)dr[k], s);
       if (blk > blk_begin) {

@@ -740,6 +740,14 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) { nzc[g] = quick[0].zc[64 * g + lane]; nha[g] = quick[0].ha[64 * g + lane]; nhr[g] = quick[0].hr[64 * g + lane]; }
   }
+  // implicitly centred columns (SWF_CENTRE, selection sweeps of int8 panels; sweep3.hip.h "implicitly centred sweeps"): the lanes' column sums of the
+  // next block, read a block ahead, and wave 0's running scalar
+  const bool cen = SELECT && sizeof(XT) == 1 && (a.flags & SWF_CENTRE) != 0;
+  const double ninv = a.ninv, cen_u0 = cen ? a.sc->cen_u0 : 0.0;
+  double cenU = cen_u0;
+  auto cs_load = [&](int b, int q) -> double { const int jj = (a.blk_begin + b) * m + 64 * q + lane; return (cen && 64 * q + lane < min(m, a.p - (a.blk_begin + b) * m)) ? (double)a.csum[min(jj, a.p - 1)] : 0.0; };
+  double ncs[2] = {0.0, 0.0};
+  if (cen && wave == 0) { ncs[0] = cs_load(0, 0); ncs[1] = cs_load(0, 1); }
   // helper threads' prefetch registers (plain named locals: an aggregate would end up in scratch memory)
   static_assert(PCH <= 5 && XCH <= 10, "named prefetch registers cover 5 + 10 chunks per helper thread");
   constexpr int NCH = (int)(sizeof(StageBuf) / 16), NSP = (int)(sizeof(SpecBuf) / 16);
@@ -795,6 +803,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
         const int t = 64 * q + lane;
         const bool live = t < mB;
         r[q] = live ? (SELECT ? (r0_s[t] - sb.spec[t]) : r0_s[t]) : 0.0;
+        if constexpr (SELECT && sizeof(XT) == 1) { if (cen) r[q] = fma(ncs[q], cenU, r[q]); }
         lc[q].b0 = live ? st.b0[t] : 0.0f; lc[q].xxb0 = live ? st.xxb0[t] : 0.0f;
         lc[q].b2 = live ? st.b2[t] : 0.0f; lc[q].drej = live ? st.drej[t] : 0.0f;
         lc[q].rden = live ? st.rden[t] : 1.0; lc[q].sdz1 = live ? st.sdz1[t] : 0.0;
@@ -903,7 +912,16 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
 #pragma unroll
               for (int g = 0; g < 2; ++g) lane_quick(lc[g], a.flags, Cc, zc[g], ha[g], hr[g]);
             }
-            quick_rounds(r, lc, zc, ha, hr, accmask, gp, m, mB, lane, a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
+            bool done_cen = false;
+            if constexpr (SELECT && sizeof(XT) == 1) {
+              if (cen) {
+                const double cs[2] = {ncs[0], ncs[1]};
+                if (have_next) { ncs[0] = cs_load(b + 1, 0); ncs[1] = cs_load(b + 1, 1); }
+                quick_rounds<GT, true>(r, lc, zc, ha, hr, accmask, gp, m, mB, lane, a.flags, Cc, odds, one_minus_pi, a.rng, a.iter, cs, ninv, &cenU);
+                done_cen = true;
+              }
+            }
+            if (!done_cen) quick_rounds(r, lc, zc, ha, hr, accmask, gp, m, mB, lane, a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
           }
         }
       }
@@ -1077,7 +1095,7 @@ __device__ __forceinline__ void s2_sequencer(const SweepArgs &a) {
   if (wave == 0) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { sum_d += __shfl_down(sum_d, o, 64); sum_b2 += __shfl_down(sum_b2, o, 64); }
-    if (lane == 0) { a.sc->sum_d += sum_d; a.sc->sum_b2 += sum_b2; }
+    if (lane == 0) { a.sc->sum_d += sum_d; a.sc->sum_b2 += sum_b2; if (cen) a.sc->cen_c = cenU - cen_u0; }
   }
 }
 
@@ -1332,13 +1350,20 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
   }
   double sum_d = 0.0, sum_b2 = 0.0;
   double rnext[2] = {0.0, 0.0};
+  // implicitly centred columns (SWF_CENTRE; sweep3.hip.h "implicitly centred sweeps"): the lanes' column sums of the next block, read a block ahead like
+  // the radii below, and wave 0's running scalar
+  const bool cen = (a.flags & SWF_CENTRE) != 0;
+  const double ninv = a.ninv, cen_u0 = cen ? a.sc->cen_u0 : 0.0;
+  double cenU = cen_u0;
+  double ncs[2] = {0.0, 0.0};
+  auto cs_load = [&](int b, int q) -> double { const int jj = (a.blk_begin + b) * m + 64 * q + lane; return (cen && 64 * q + lane < blk_m(b)) ? (double)a.csum[min(jj, a.p - 1)] : 0.0; };
   // the rounds' centres and radii (k_spec's QuickBuf) of the next block: wave 0 reads them itself, a block ahead, into registers
   double nzc[2] = {0.0, 0.0}, nha[2] = {INFINITY, INFINITY}, nhr[2] = {-1.0, -1.0};
   const QuickBuf *quick = a.ps.quick ? a.ps.quick + a.blk_begin : nullptr;
   if (wave == 0) {
     const double *ps = Q16_QS(0);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) rnext[q] = ps[64 * q + lane];
+    for (int q = 0; q < 2; ++q) { rnext[q] = ps[64 * q + lane]; ncs[q] = cs_load(0, q); }
     if (quick) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) { nzc[q] = quick[0].zc[64 * q + lane]; nha[q] = quick[0].ha[64 * q + lane]; nhr[q] = quick[0].hr[64 * q + lane]; }
@@ -1375,6 +1400,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
         for (int q = 0; q < 2; ++q) {
           const bool live = 64 * q + lane < mB;
           r[q] = live ? (rnext[q] - spc[q]) : 0.0;
+          if (cen) r[q] = fma(ncs[q], cenU, r[q]);   // (dead lanes: a zero column sum)
           lc[q].b0 = live ? fb0[q] : 0.0f; lc[q].xxb0 = live ? fxx[q] : 0.0f;
           lc[q].b2 = live ? fb2[q] : 0.0f; lc[q].drej = live ? fdr[q] : 0.0f;
           lc[q].rden = live ? rd[q] : 1.0; lc[q].sdz1 = live ? sz[q] : 0.0;
@@ -1396,6 +1422,11 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) lane_quick(lc[q], a.flags, Cc, zc[q], ha[q], hr[q]);
       }
+      if (cen) {
+        const double cs[2] = {ncs[0], ncs[1]};
+        if (have_next) { ncs[0] = cs_load(b + 1, 0); ncs[1] = cs_load(b + 1, 1); }
+        quick_rounds<GT, true>(r, lc, zc, ha, hr, accmask, gp, m, mB, lane, a.flags, Cc, odds, one_minus_pi, a.rng, a.iter, cs, ninv, &cenU);
+      } else
       quick_rounds(r, lc, zc, ha, hr, accmask, gp, m, mB, lane, a.flags, Cc, odds, one_minus_pi, a.rng, a.iter);
       S2STAMP(6);
       // outputs; delta_b goes out at once as {epoch, float} granules (one 8-byte write-through store per marker)
@@ -1508,7 +1539,7 @@ __device__ __forceinline__ void s2_sequencer_sel16(const SweepArgs &a) {
   if (wave == 0) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { sum_d += __shfl_down(sum_d, o, 64); sum_b2 += __shfl_down(sum_b2, o, 64); }
-    if (lane == 0) { a.sc->sum_d += sum_d; a.sc->sum_b2 += sum_b2; }
+    if (lane == 0) { a.sc->sum_d += sum_d; a.sc->sum_b2 += sum_b2; if (cen) a.sc->cen_c = cenU - cen_u0; }
   }
 }
 

@@ -107,21 +107,31 @@ __device__ __forceinline__ double s3_pow2(int k) { return __hiloint2double((1023
 //   (x_j - (s_j / n) 1)' e = x_j' e_stored - (s_j / n) E,   E = sum(e_stored) = E_0 - sum_{k < j} s_k delta_k,
 // so the streamers, the Gram arrays and the lists stay those of the raw int8 columns and the sequencer adds scalars: the rejected steps' part of
 // E is known before the sweep (cpre: running block sums; the in-block part goes into spec), the included markers' part is one running scalar.
-// k_cen_tot: cpre[b + 1] = sum over block b of s_k * drej_k on the sweep's grid;  k_cen_scan: the inclusive scan, cpre[0] = 0
-__global__ __launch_bounds__(128) void k_cen_tot(const SweepArgs a, int blk_begin) {
-  if (!(a.sc->inc_rate < a.gate3)) return;
+// Which engine a centring helper serves (every launch of an iteration is enqueued; the device decides which side runs):
+//   mode 0: k_sweep3 (rejected steps on the sweep's fixed-point grid)  -- when the chain's inclusion rate is below the gate
+//   mode 1: k_sweep2 (the float steps themselves)                     -- the other side of the gate, or no gate at all
+//   mode 2: k_sweep2 redoing a fixed-point sweep that left its range   -- when sc->redo is set
+__device__ __forceinline__ bool cen_active(const SweepArgs &a, int mode) {
+  if (mode == 2) return a.sc->redo != 0u;
+  const bool three = a.gate3 > 0.0f && a.sc->inc_rate < a.gate3;
+  return mode == 0 ? three : !three;
+}
+// k_cen_tot: cpre[b + 1] = sum over block b of s_k * drej_k (mode 0: on the sweep's grid);  k_cen_scan: the inclusive scan, cpre[0] = 0
+__global__ __launch_bounds__(128) void k_cen_tot(const SweepArgs a, int blk_begin, int mode) {
+  if (!cen_active(a, mode)) return;
   const int blk = blk_begin + blockIdx.x, j = threadIdx.x, m = a.m;
   const int mB = min(m, a.p - blk * m);
   const int sh = a.sc->e3_sh;
-  const double S = s3_pow2(sh), invS = s3_pow2(-sh);
+  const double S = s3_pow2(mode == 0 ? sh : 0), invS = s3_pow2(mode == 0 ? -sh : 0);
   __shared__ double red[128];
-  red[j] = (j < mB) ? (double)a.csum[blk * m + j] * (rint((double)a.ps.blocks[blk].drej[j] * S) * invS) : 0.0;
+  const double dj = (j < mB) ? (double)a.ps.blocks[blk].drej[j] : 0.0;
+  red[j] = (j < mB) ? (double)a.csum[blk * m + j] * (mode == 0 ? rint(dj * S) * invS : dj) : 0.0;
   __syncthreads();
   for (int o = 64; o > 0; o >>= 1) { if (j < o) red[j] += red[j + o]; __syncthreads(); }   // (a fixed tree: the same bits on every run)
   if (j == 0) a.cpre[blk + 1] = red[0];
 }
-__global__ __launch_bounds__(1024) void k_cen_scan(const SweepArgs a, int nblocks) {
-  if (!(a.sc->inc_rate < a.gate3)) return;
+__global__ __launch_bounds__(1024) void k_cen_scan(const SweepArgs a, int nblocks, int mode) {
+  if (!cen_active(a, mode)) return;
   __shared__ double part[1024];
   const int t = threadIdx.x, per = (nblocks + 1023) / 1024;
   const int b0 = min(nblocks, t * per), b1 = min(nblocks, b0 + per);
@@ -136,8 +146,8 @@ __global__ __launch_bounds__(1024) void k_cen_scan(const SweepArgs a, int nblock
   if (t == 0) a.cpre[0] = 0.0;
 }
 // before a centred launch over [blk_begin, blk_end): u0 = -(sum(e) + cpre[blk_begin]) / n  (one workgroup; the residual's padded rows are zero)
-__global__ __launch_bounds__(1024) void k_cen_begin(const SweepArgs a) {
-  if (!(a.sc->inc_rate < a.gate3)) return;
+__global__ __launch_bounds__(1024) void k_cen_begin(const SweepArgs a, int mode) {
+  if (!cen_active(a, mode)) return;
   __shared__ double red[1024];
   const int t = threadIdx.x;
   double s = 0.0;
@@ -149,8 +159,8 @@ __global__ __launch_bounds__(1024) void k_cen_begin(const SweepArgs a) {
 }
 // after it: e = e_stored + shift on the n real rows, shift = (cpre[blk_end] - cpre[blk_begin]) / n + cen_c  (not after a sweep that left the range:
 // the recovery restores the state)
-__global__ void k_cen_end(const SweepArgs a) {
-  if (!(a.sc->inc_rate < a.gate3) || a.sc->error != 0u) return;
+__global__ void k_cen_end(const SweepArgs a, int mode) {
+  if (!cen_active(a, mode) || a.sc->error != 0u) return;
   const double shift = (a.cpre[a.blk_end] - a.cpre[a.blk_begin]) * a.ninv + a.sc->cen_c;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) a.e[i] += shift;
 }

@@ -173,9 +173,9 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
     y = synth.scale_phenotype(g)
     # BWGR_FORCE_CENTRE=1: rehearse the centred panel with one rank (bench.py's BWGR_FORCE_DIST leg)
     centre = (world > 1 or bool(os.environ.get("BWGR_FORCE_CENTRE"))) and not getattr(args, "uncentred", False)
-    # (implicit centring is k_sweep3's, the engine of the sparse selection chains; the dense ones -- BayesCpi / Dpi keep about half the markers in
-    # the model -- and the affine models keep the float copy, which k_sweep2 / k_sweep2w sweep)
-    explicit = centre and (getattr(args, "centre_explicit", False) or model not in ("BayesB", "BayesC"))
+    # (implicit centring covers the selection models on both of their engines, k_sweep3 and k_sweep2; the affine models keep the float copy, which
+    # k_sweep2w / k_sweep2 sweep)
+    explicit = centre and (getattr(args, "centre_explicit", False) or model not in ("BayesB", "BayesC", "BayesCpi", "BayesDpi"))
     if explicit:   # x_j - mean(x_j) as a float panel (column-major n x p_local on the device, in column chunks to bound the temporaries)
         Xf = torch.empty((hi - lo, n), dtype=torch.float32, device=X.device)     # (p_local, n): row j = column j, no row padding
         for c0 in range(0, hi - lo, 8192):
@@ -224,7 +224,7 @@ def bench_sharded(args, n, p, model, pi, K, W, rank, world, dev):
                    "n": n, "p": p, "model": model, "pi": pi, "df": 5, "R2": 0.5, "chains": 1, "block": P.block,
                    "slab_workgroups": P.nwg, "sync_rounds_per_sweep": rounds},
         "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                     "kernel": "%s (rank 0, all launches of one sweep summed)" % ("k_sweep2<float>" if explicit else ("k_sweep3<uint16, centred>" if centre else "k_sweep2<int8> / k_sweep3")), "kernel_ms": sweep_ms_per_iter,
+                     "kernel": "%s (rank 0, all launches of one sweep summed)" % ("k_sweep2<float>" if explicit else ("k_sweep3 / k_sweep2<int8>, implicitly centred" if centre else "k_sweep2<int8> / k_sweep3")), "kernel_ms": sweep_ms_per_iter,
                      "launches": launches, "algorithmic_bytes_per_launch": alg},
         "chain_check": {"ve": st["ve"], "mu": st["mu"], "mean_d_rank0": float(st["d"].mean())},
     }

@@ -293,9 +293,9 @@ int bwgr_panel_centred(bwgr_panel *P, int *centred);        /* 1 when every colu
  * the residual carried as e_stored = e - shift * 1,  (x_j - s_j/n 1)'e = x_j'e_stored - (s_j/n) sum(e_stored), and sum(e_stored) moves by -s_k delta_k
  * per marker: scalars on the sequencer, nothing on the streamers.  bwgr_panel_stats then returns xx_j = |x_j - mean_j|^2 (vx, MSx do not change),
  * hat = X_c B + mu, bwgr_panel_centred answers 1, and the group entry points accept several devices.  Selection models (BayesB / C /
- * Cpi / Dpi) on panels that have k_sweep3; other models and the non-chain entry points (KMUP, wgr, EM, two-effect samplers, pairs) return BWGR_EINVAL
- * on a centred panel.  A centred sweep that leaves the fixed-point range returns BWGR_ERANGE (its fp64 redo engine sweeps raw columns).  Refused while
- * chains are alive on the panel; on == 0 switches back. */
+ * Cpi / Dpi) on int8 panels that have k_sweep3, at every inclusion rate (both of their engines carry the terms, and so does the fp64 redo of a sweep
+ * that leaves the fixed-point range); the affine models and the non-chain entry points (KMUP, wgr, EM, two-effect samplers, pairs) return BWGR_EINVAL
+ * on a centred panel.  Refused while chains are alive on the panel; on == 0 switches back. */
 int bwgr_panel_set_centred(bwgr_panel *P, int on);
 int bwgr_group_result(bwgr_group *G, float *mu, float *b, float *d, float *hat, float *vb, float *ve, float *h2, float *MSx,
                       float *pi_out, float *pval);

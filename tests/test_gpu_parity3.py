@@ -147,12 +147,13 @@ def _centred_f32(X):
 
 @pytest.mark.parametrize("model,pi", [("BayesB", 0.9), ("BayesB", 0.99), ("BayesC", 0.9), ("BayesCpi", 0.0), ("BayesDpi", 0.0)])
 @pytest.mark.parametrize("data", ["tpod", "synth"])
-def test_implicit_centring_is_the_chain_on_the_centred_columns(tpod, model, pi, data):
+def test_implicit_centring_is_the_chain_on_the_centred_columns(tpod, model, pi, data, engine_threshold):
     """An int8 panel swept as implicitly centred columns (the genotypes stay int8; the sequencer of k_sweep3 carries the scalar terms) runs the
     reference's sweep (src/Rcpp20260726ai.cpp:668-682) on x_j - mean(x_j): against the ORACLE on the explicitly centred float matrix, and against
     the GPU's own chain on that float panel (the fp32 engine): b, e, hat, ve to 1e-6, inclusion decisions equal.  (The float copy rounds every
     centred entry to 24 bits; the implicit form is exact -- the two agree to that rounding.)  tpod: three blocks, one slab; synth: 700 x 900,
-    eight blocks with a ragged last one, three slabs."""
+    eight blocks with a ragged last one, three slabs.  Twice: every sweep on k_sweep3, and at the shipped engine gate, where the chains above 3 %
+    inclusion -- all but BayesB pi = 0.99 -- run k_sweep2, whose sequencers carry the same scalar terms."""
     import bwgr_amd
     from oracle import oracle as O
     if data == "tpod":
@@ -181,6 +182,38 @@ def test_implicit_centring_is_the_chain_on_the_centred_columns(tpod, model, pi, 
     # ... and the GPU's chain on the explicitly centred float panel (what round 3's sharded leg swept)
     f = getattr(bwgr_amd, model)(y, Xc, it=it, bi=bi, seed=41, **({"pi": pi} if model in ("BayesB", "BayesC") else {}))
     assert np.array_equal(g["d"], f["d"]) and scaled_err(g["b"], f["b"]) < TOL and scaled_err(g["hat"], f["hat"]) < TOL and _rel(g["ve"], f["ve"]) < TOL
+
+
+@pytest.mark.parametrize("gram16", ["1", "0"])
+@pytest.mark.parametrize("model,pi", [("BayesB", 0.95), ("BayesCpi", 0.0)])
+def test_implicit_centring_redo_and_32_bit_gram(model, pi, gram16, monkeypatch):
+    """(i) A centred fixed-point sweep that leaves its range is redone on the fp64 engine -- on the centred columns too (BWGR_DEBUG_SH_ADD forces
+    every k_sweep3 sweep out of range); (ii) panels whose Gram entries need 32 bits (BWGR_GRAM16=0 stands in for n > 16 383: config 5's 50 000 rows)
+    take k_sweep3<int32> and k_sweep2's generic sequencer.  Both against the oracle on the centred float matrix."""
+    import bwgr_amd
+    from oracle import oracle as O
+    monkeypatch.setenv("BWGR_GRAM16", gram16)
+    monkeypatch.setenv("BWGR_DEBUG_SH_ADD", "14")
+    X, y = synth_small(600, 1100, seed=12)
+    Xc = _centred_f32(X)
+    P = bwgr_amd.Panel(X).set_centred(True)
+    ch = bwgr_amd.Chain(P, model, y, it=6, bi=1, pi=pi, seed=3)
+    ch.run(6)
+    st = ch.state(); nredo = ch.redo_count()
+    ch.close(); P.close()
+    assert nredo == 6
+    o = O.bayes(model, y, Xc, it=6, bi=1, pi=pi, seed=3)["last"]
+    assert np.array_equal(st["d"], o["d"])
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
+    monkeypatch.delenv("BWGR_DEBUG_SH_ADD")
+    monkeypatch.delenv("BWGR_ENG3_THR", raising=False)       # the shipped gate: BayesCpi's sweeps are k_sweep2's (generic sequencer when gram16 == "0")
+    P = bwgr_amd.Panel(X).set_centred(True)
+    ch = bwgr_amd.Chain(P, model, y, it=6, bi=1, pi=pi, seed=3)
+    ch.run(6)
+    st = ch.state(); nredo = ch.redo_count()
+    ch.close(); P.close()
+    assert nredo == 0 and np.array_equal(st["d"], o["d"])
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL and _rel(st["ve"], o["ve"]) < TOL
 
 
 def test_implicit_centring_in_ranges_and_rounds(tpod):
