@@ -369,3 +369,50 @@ def test_group_refuses_several_shards_on_uncentred_columns(tpod, monkeypatch):
     Pc = bwgr_amd.Panel(np.asfortranarray((X.astype(np.float64) - X.astype(np.float64).mean(0)).astype(np.float32)))
     assert Pc.centred()
     Pc.close()
+
+
+# ---- the mixed(alg = ...) consumer contract (R/mix.R:70-94; VERDICT r3 "missing" 5) ----
+@pytest.mark.parametrize("model", ["BayesB", "BayesRR", "BayesCpi"])
+def test_samplers_called_the_way_mixed_calls_its_alg(tpod, model):
+    """mixed()'s structured-random step, gws(), calls its `alg` as  h = alg(e0[comn], X[[i]][comn, ], ...)  -- POSITIONAL (y, X), a row SUBSET of the
+    genotype matrix per call, per-level means as the phenotype -- and then reads h$hat (one value per row passed) and h$b (R/mix.R:78-79, :93).  The host
+    mirror is called the same way, iteration after iteration of the outer loop with a changing phenotype, and must return the oracle's lists: same names
+    at those positions, same numbers."""
+    import bwgr_amd
+    from oracle import oracle as O
+    X, y, fam = tpod["gen"], tpod["y"], np.asarray(tpod["fam"]).ravel()
+    rs = np.random.RandomState(3)
+    alg = getattr(bwgr_amd, model)
+    e = y - y.mean()
+    for outer in range(3):
+        comn = np.sort(rs.choice(X.shape[0], 150, replace=False))           # the levels present this time
+        e0 = (e + 0.05 * outer * (fam == 1))[comn]
+        e0 = e0 - e0.mean()
+        h = alg(e0, X[comn, :], 12, 3, **({"seed": 7 + outer}))               # positional y, X, it, bi: gws passes `...` through
+        o = O.bayes(model, e0, np.asfortranarray(X[comn, :]), it=12, bi=3, pi=0.95, seed=7 + outer)
+        assert "hat" in h and "b" in h and h["hat"].shape == (150,) and h["b"].shape == (X.shape[1],)
+        assert list(h.keys())[:2] == ["mu", "b"]
+        assert scaled_err(h["hat"], o["hat"]) < TOL and scaled_err(h["b"], o["b"]) < TOL
+        e = e - 0.1 * np.bincount(comn, weights=h["hat"], minlength=X.shape[0])   # the outer loop moves the residual on
+
+
+# ---- row sharding is exact (SURVEY section 8 e2; src/Rcpp20260726ai.cpp:18-36 is the recurrence that must not change) ----
+def test_row_shards_give_the_same_chain_bit_for_bit():
+    """the chain on G shards of ROWS must be the one-shard chain, bit for bit.  That is what k_sweep3's streamers are -- every streamer
+    workgroup owns a slab of rows, forms its slab's share of the dots and of the residual update, and the shares are combined as exact integers
+    (fixed-point residual, 64-bit integer atomics: any order, same bits).  One, two, three and six row shards of a 700-row panel (each again cut into
+    128- or 256-row streamers): b, d, e, ve identical to the last bit."""
+    import bwgr_amd
+    X, y = synth_small(700, 900, seed=3)
+    ref = None
+    for nwg in (1, 2, 3, 6):
+        P = bwgr_amd.Panel(X, nwg=nwg)
+        assert P.nwg == nwg
+        ch = bwgr_amd.Chain(P, "BayesB", y, it=8, bi=2, pi=0.9, seed=17)
+        ch.run(8)
+        st = ch.state()
+        ch.close(); P.close()
+        if ref is None:
+            ref = st
+        else:
+            assert np.array_equal(st["d"], ref["d"]) and np.array_equal(st["b"], ref["b"]) and np.array_equal(st["e"], ref["e"]) and st["ve"] == ref["ve"], nwg

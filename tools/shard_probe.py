@@ -12,7 +12,8 @@ from bwgr_amd import synth, dist as bdist
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 MODE = sys.argv[2] if len(sys.argv) > 2 else "implicit"
-n, p = 10000, 1000000
+n, p = int(os.environ.get("SP_N", "10000")), 1000000           # SP_N=50000 SP_MODEL=BayesCpi SP_PI=0.5: config 5's panel and model
+MODEL, PI = os.environ.get("SP_MODEL", "BayesB"), float(os.environ.get("SP_PI", "0.99"))
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 lo, hi = bdist.shard_bounds(p, G, 0, 128)
 X = synth.genotypes(n, hi - lo, col0=lo, device=0)
@@ -21,11 +22,11 @@ P = bwgr_amd.Panel(X, n=n, device=0, block=128); del X
 if MODE == "implicit":
     P.set_centred(True)
 msx = P.stats()[2] * G
-K, W = 30, 5
-eng = bdist.HipShardEngine(P, "BayesB", y, 2 * (W + K), 0, 0.99, 5.0, 0.5, synth.SEED, lo, p, msx)
+K, W = int(os.environ.get("SP_K", "30")), 5
+eng = bdist.HipShardEngine(P, MODEL, y, 2 * (W + K), 0, PI, 5.0, 0.5, synth.SEED, lo, p, msx)
 bps = max(1, max(P.block, 131072 // G) // P.block)
 rounds = (eng.nblocks + bps - 1) // bps
-out = {"G": G, "p_local": hi - lo, "rounds_per_sweep": rounds, "centring": MODE}
+out = {"G": G, "n": n, "model": MODEL, "p_local": hi - lo, "rounds_per_sweep": rounds, "centring": MODE}
 def exchange(iters):
     nb = eng.nblocks
     for _ in range(iters):
@@ -40,7 +41,7 @@ out["ms_per_iteration_with_rounds"] = round(1e3 * (time.perf_counter() - t0) / K
 ms, launches = eng.chain.sweep_ms(); out["sweep_kernel_ms_per_iteration"] = round(ms * launches / (W + K), 3)
 out["chain_check"] = {k: (float(v.mean()) if k == "d" else float(v)) for k, v in eng.chain.state().items() if k in ("ve", "mu", "d")}
 eng.chain.close()
-ch = bwgr_amd.Chain(P, "BayesB", y, it=W + K, bi=0, pi=0.99, seed=synth.SEED)
+ch = bwgr_amd.Chain(P, MODEL, y, it=W + K, bi=0, pi=PI, seed=synth.SEED)
 ch.run(W); ch.sync(); torch.cuda.synchronize(); t0 = time.perf_counter(); ch.run(K); ch.sync(); torch.cuda.synchronize()
 out["ms_per_iteration_plain_chain"] = round(1e3 * (time.perf_counter() - t0) / K, 3)
 print(json.dumps(out)); dist.destroy_process_group()
