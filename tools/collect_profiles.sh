@@ -13,7 +13,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o ${TAG} --output-format csv -- python3 $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu --no-extra --shards 0 --chains 1 > $OUT/${TAG}_bench_c4_under_rocprof.json 2> $OUT/${TAG}_rocprof.err
 echo "stats done"
 # the concurrent-chains leg on its own (kernel durations with five sweeps side by side)
-rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_cc -o ${TAG}cc --output-format csv -- python3 $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu > $OUT/${TAG}_bench_c4_concurrent_under_rocprof.json 2>> $OUT/${TAG}_rocprof.err
+rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_cc -o ${TAG}cc --output-format csv -- python3 $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu --no-extra --shards 0 > $OUT/${TAG}_bench_c4_concurrent_under_rocprof.json 2>> $OUT/${TAG}_rocprof.err
 find $OUT/prof_stats_cc -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_bench_c4_concurrent_kernel_stats.csv \;
 find $OUT/prof_stats_cc -name "*kernel_trace.csv" -delete
 echo "concurrent stats done"
