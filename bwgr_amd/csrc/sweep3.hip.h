@@ -47,6 +47,7 @@ static constexpr int S3_GPD_BYTES = 16384;            // LDS copy of a packed di
 static constexpr int S3_ROWSLOT = 1024;               // bytes of LDS per such marker: a 64-lane x 16-byte DMA (the two rows are its first 4 m bytes)
 static constexpr int S3_NRX = 8;                      // distance-1 / 2 rows of the first S3_NRX included markers of a block land in LDS by DMA
 static constexpr int S3_OS = 12;                      // dwords per row of the int32 recombination scratch (8 used; b128 reads conflict-free)
+static constexpr int S3_QRAW_BYTES = SW_MAXM * 16;    // a block's slab-dot sums as the streamers' atomics leave them: two 8-byte words per marker
 
 struct Sweep3Args {
   SweepArgs a;
@@ -244,6 +245,13 @@ __device__ __forceinline__ void s3_dma16s(const unsigned char *gbase, uint32_t v
                                                                     ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gb_ >> 32)) << 32));
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sb_), "s"(la) : "memory", "m0");
 }
+// ... bypassing this CU's L1 (sc1): words that other CUs' atomics complete
+__device__ __forceinline__ void s3_dma16s_sc1(const unsigned char *gbase, uint32_t voff, uint32_t la) {
+  const unsigned long long gb_ = (unsigned long long)(uintptr_t)gbase;
+  const unsigned char *sb_ = reinterpret_cast<const unsigned char *>((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gb_) |
+                                                                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gb_ >> 32)) << 32));
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" : : "v"(voff), "s"(sb_), "s"(la) : "memory", "m0");
+}
 #pragma clang diagnostic pop
 
 __host__ __device__ inline size_t s3_streamer_dma_lds(int R3 = 128) {   // (four unpadded tiles at 128 rows, three at 256)
@@ -262,6 +270,7 @@ __host__ __device__ inline size_t s3_seq_lds(int D, bool g16) {
   s += (size_t)S3_RING * (sizeof(double) + sizeof(long long) + sizeof(int));       // the included markers of the last D blocks
   s += (size_t)2 * 3 * 16 * SW_MAXM * (g16 ? 2 : 4);                               // far-field rows in flight
   if (g16) s += (size_t)3 * S3_GPD_BYTES + (size_t)S3_NRX * S3_ROWSLOT;       // the packed diagonal block of three blocks, distance-1 / 2 rows of this block's included markers
+  s += (size_t)3 * S3_QRAW_BYTES;                                                  // the slab-dot sums of three blocks as they land (two phases ahead)
   return s + 256;
 }
 
@@ -867,6 +876,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   // of the block's included markers, requested by DMA when the marker is included and consumed after the block's last round
   unsigned char *gpd_s = smem + off; if (G16) off += (size_t)3 * S3_GPD_BYTES;
   unsigned char *rowx_s = smem + off; if (G16) off += (size_t)S3_NRX * S3_ROWSLOT;
+  unsigned char *qraw_s = smem + off; off += (size_t)3 * S3_QRAW_BYTES;   // [block % 3]: the block's slab-dot words, landed by LDS-DMA two phases before they are adopted
   int *ctrl_s = reinterpret_cast<int *>(smem + off);   // [0] ok flag
   int *pos_s = ctrl_s + 8;                             // [b & 31]: ring position where block b's entries begin
   const unsigned char **gx_s = reinterpret_cast<const unsigned char **>(ctrl_s + 40);   // the cross Gram arrays' base addresses (a table in LDS: indexed per entry)
@@ -919,35 +929,45 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   // wave 1: the K3 slab dots of block c, summed by the streamers' atomics; two markers per lane.  The four words a lane needs are
   // requested one phase ahead (pq_*): the streamers run blocks ahead of the sequencer, so in steady state the words are complete
   // when they are first looked at and no memory round trip sits in the block period.
-  unsigned long long pq_l0 = 0ull, pq_h0 = 0ull, pq_l1 = 0ull, pq_h1 = 0ull;
-  auto poll_request = [&](int c) {   // unconditional loads (clamped block and marker)
-    const unsigned long long *g = A.qsum + (size_t)(a.blk_begin + min(c, nb - 1)) * SW_MAXM * 2;
-    pq_l0 = ld_agent_raw64(g + 2 * lane); pq_h0 = ld_agent_raw64(g + 2 * lane + 1);
-    pq_l1 = ld_agent_raw64(g + 2 * (64 + lane)); pq_h1 = ld_agent_raw64(g + 2 * (64 + lane) + 1);
+  // The 2 KB of a block's words are requested by two LDS-DMA pieces (sc1: past this CU's L1) TWO phases before the block is adopted: one phase
+  // ahead -- round 3, through registers -- the period could not drop below that round trip (the words live at the memory side: the streamers'
+  // atomics are performed there), and every helper role's request -> consume chain was one phase long (profiles/NOTES.md, round 4).  The counted
+  // wait leaves the younger block's two pieces in flight; an incomplete sum (the streamers are D blocks ahead: rare) falls back to polling.
+  const uint32_t qraw_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)qraw_s);
+  auto poll_request = [&](int c) {   // (clamped block: the requests past the end re-read the last block)
+    const unsigned char *g = reinterpret_cast<const unsigned char *>(A.qsum + (size_t)(a.blk_begin + min(c, nb - 1)) * SW_MAXM * 2);
+    const uint32_t la = qraw_la + (uint32_t)((c % 3) * S3_QRAW_BYTES);
+    s3_dma16s_sc1(g, (uint32_t)lane * 16u, la);
+    s3_dma16s_sc1(g, 1024u + (uint32_t)lane * 16u, la + 1024u);
   };
   auto poll_q = [&](int c) -> int {
     const int mBc = blk_m(c);
     const unsigned long long *g = A.qsum + (size_t)(a.blk_begin + c) * SW_MAXM * 2;
     const unsigned long long need = (unsigned long long)A.K3;
     const bool n0 = lane < mBc, n1 = 64 + lane < mBc;
-    const uint64_t t0 = wall_clock64();
-    unsigned spins = 0;
-    unsigned long long l0 = n0 ? pq_l0 : need, h0 = n0 ? pq_h0 : need, l1 = n1 ? pq_l1 : need, h1 = n1 ? pq_h1 : need;
-    for (;;) {
-      if ((l0 & 0xFFull) == need && (h0 & 0xFFull) == need && (l1 & 0xFFull) == need && (h1 & 0xFFull) == need) break;
-      if (SDBG & 8) break;   // (timing experiment only: the streamers publish nothing)
-      if ((++spins & 63u) == 0u) {
-        if (ld_agent_u32(abortw) != 0u) return 0;
-        if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // block c's two pieces (two phases old) have landed; block c + 1's may still be in flight
+    const ulonglong2 v0 = reinterpret_cast<const ulonglong2 *>(qraw_s + (size_t)(c % 3) * S3_QRAW_BYTES)[lane];
+    const ulonglong2 v1 = reinterpret_cast<const ulonglong2 *>(qraw_s + (size_t)(c % 3) * S3_QRAW_BYTES)[64 + lane];
+    unsigned long long l0 = n0 ? v0.x : need, h0 = n0 ? v0.y : need, l1 = n1 ? v1.x : need, h1 = n1 ? v1.y : need;
+    if (__builtin_expect(__ballot(!((l0 & 0xFFull) == need && (h0 & 0xFFull) == need && (l1 & 0xFFull) == need && (h1 & 0xFFull) == need)) != 0ull, 0)) {
+      const uint64_t t0 = wall_clock64();
+      unsigned spins = 0;
+      for (;;) {
+        if ((l0 & 0xFFull) == need && (h0 & 0xFFull) == need && (l1 & 0xFFull) == need && (h1 & 0xFFull) == need) break;
+        if (SDBG & 8) break;   // (timing experiment only: the streamers publish nothing)
+        if ((++spins & 63u) == 0u) {
+          if (ld_agent_u32(abortw) != 0u) return 0;
+          if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if (n0) { l0 = ld_agent_raw64(g + 2 * lane); h0 = ld_agent_raw64(g + 2 * lane + 1); }
+        if (n1) { l1 = ld_agent_raw64(g + 2 * (64 + lane)); h1 = ld_agent_raw64(g + 2 * (64 + lane) + 1); }
       }
-      __builtin_amdgcn_s_sleep(1);
-      if (n0) { l0 = ld_agent_raw64(g + 2 * lane); h0 = ld_agent_raw64(g + 2 * lane + 1); }
-      if (n1) { l1 = ld_agent_raw64(g + 2 * (64 + lane)); h1 = ld_agent_raw64(g + 2 * (64 + lane) + 1); }
     }
     double *qd = q_s + (size_t)(c & 1) * SW_MAXM;
     qd[lane] = n0 ? fma((double)((long long)h0 >> 8), 16777216.0, (double)((long long)l0 >> 8)) * invS : 0.0;
     qd[64 + lane] = n1 ? fma((double)((long long)h1 >> 8), 16777216.0, (double)((long long)l1 >> 8)) * invS : 0.0;
-    poll_request(c + 1);
+    poll_request(c + 2);
     return 1;
   };
   // The included markers of all blocks live in one flat ring of D * SW_MAXM entries {k | source block << 8, corr, corr on the grid}
@@ -1129,12 +1149,12 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   if (tid < 40) ctrl_s[tid] = (tid == 0) ? 1 : 0;   // (pos_s: block 0's entries begin at ring position 0)
   if (tid >= 64 && tid < 64 + S3_MAXD) gx_s[tid - 64] = reinterpret_cast<const unsigned char *>(A.gx[tid - 64]);
   __syncthreads();
-  if (wave == 1) { poll_request(0); if (!poll_q(0)) ctrl_s[0] = 0; }
+  if (wave == 1) { poll_request(0); poll_request(1); if (!poll_q(0)) ctrl_s[0] = 0; }
   else if (wave == 2 || wave == 3) { gpd_issue(0); stage_request(0); stage_commit(0); if constexpr (G16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (nb > 1) { gpd_issue(1); stage_request(1); } }
   else if (wave >= 5 && wave <= 6) { far_consume(0, wave - 5); far_issue(1, wave - 5); }
   else if (wave == 7) { for (int c = 0; c < PF; ++c) touch(c); chi_request(0); }
   __syncthreads();
-  if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
+  if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
 
   const bool sq0 = (tid == 0), sq1 = (tid == 64), sq2 = (tid == 128), sq4 = (tid == 320), sq3 = (tid == 192), sq6 = (tid == 384), sq7 = (tid == 448);
   // wave 0's included-marker path, counted in instructions: the packed row's byte offset from a lane-indexed table by one v_readlane
@@ -1334,10 +1354,11 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     // __syncthreads() would drain the far-field rows that are meant to stay in flight across it.)
     if (!BWGR_ROLEBAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     S3ST(4, sq0 || sq1 || sq2 || sq4 || sq3 || sq6 || sq7);
-    if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; return; }
+    if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }   // (no DMA may land after the workgroup has gone)
   }
   S3ST_FLUSH(16, sq0); S3ST_FLUSH(24, sq1); S3ST_FLUSH(32, sq2); S3ST_FLUSH(40, sq4); S3ST_FLUSH(48, sq3); S3ST_FLUSH(56, sq6); S3ST_FLUSH(64, sq7);
   if constexpr (CEN) { if (tid == 0) a.sc->cen_c = cenU - cen_u0; }   // the included markers' share of the shift (k_cen_end)
+  if (wave == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the poll wave's requests past the end)
   if (wave == 7) {   // the last two blocks
     if (nb >= 2) finish_block(nb - 2);
     finish_block(nb - 1);
