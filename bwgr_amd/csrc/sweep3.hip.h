@@ -263,12 +263,12 @@ __host__ __device__ inline size_t s3_streamer_lds(int R3) {
   return 2 * (size_t)SW_MAXM * Rp + 2 * 16 * Rp + 2 * 16 * (size_t)S2_DP + (size_t)64 * S3_OS * 4 * 4 + (size_t)8 * 32 * S3_OS * 4 + 64;
 }
 __host__ __device__ inline size_t s3_seq_lds(int D, bool g16) {
-  size_t s = 2 * sizeof(StageBuf) + 2 * 2 * SW_MAXM * sizeof(double);            // constants, spec + gjj
+  size_t s = 3 * sizeof(StageBuf) + 3 * 2 * SW_MAXM * sizeof(double);            // constants, spec + gjj: rings of three blocks (landed by DMA)
   s += 2 * SW_MAXM * sizeof(double) + 2 * 3 * SW_MAXM * sizeof(double);          // q sums, far-field partial sums (three waves)
   s += 2 * 3 * SW_MAXM * sizeof(float);                                          // state of a block
   (void)D;
   s += (size_t)S3_RING * (sizeof(double) + sizeof(long long) + sizeof(int));       // the included markers of the last D blocks
-  s += (size_t)2 * 3 * 16 * SW_MAXM * (g16 ? 2 : 4);                               // far-field rows in flight
+  s += (size_t)2 * 2 * 16 * SW_MAXM * (g16 ? 2 : 4);                               // far-field rows in flight (two waves)
   if (g16) s += (size_t)3 * S3_GPD_BYTES + (size_t)S3_NRX * S3_ROWSLOT;       // the packed diagonal block of three blocks, distance-1 / 2 rows of this block's included markers
   s += (size_t)3 * S3_QRAW_BYTES;                                                  // the slab-dot sums of three blocks as they land (two phases ahead)
   return s + 256;
@@ -857,15 +857,15 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = a.m, nb = a.blk_end - a.blk_begin, D = A.D, pstride = a.pstride;
   size_t off = 0;
-  StageBuf *stage = reinterpret_cast<StageBuf *>(smem + off); off += 2 * sizeof(StageBuf);
-  double *spec_s = reinterpret_cast<double *>(smem + off); off += (size_t)2 * 2 * SW_MAXM * sizeof(double);   // [parity][spec | gjj][marker]
+  StageBuf *stage = reinterpret_cast<StageBuf *>(smem + off); off += 3 * sizeof(StageBuf);                        // [block % 3]
+  double *spec_s = reinterpret_cast<double *>(smem + off); off += (size_t)3 * 2 * SW_MAXM * sizeof(double);   // [block % 3][spec | gjj][marker]
   double *q_s = reinterpret_cast<double *>(smem + off); off += (size_t)2 * SW_MAXM * sizeof(double);
   double *far_s = reinterpret_cast<double *>(smem + off); off += (size_t)2 * 3 * SW_MAXM * sizeof(double);    // [parity][far wave][marker]
   float *state_s = reinterpret_cast<float *>(smem + off); off += (size_t)2 * 3 * SW_MAXM * sizeof(float);    // [parity][b | d][marker]
   double *accC = reinterpret_cast<double *>(smem + off); off += (size_t)S3_RING * sizeof(double);         // included markers of the last D blocks: what marker k changed beyond drej
   float2 *accS = reinterpret_cast<float2 *>(smem + off); off += (size_t)S3_RING * sizeof(float2);          // ... as the two float steps {included, rejected}
   int *accK = reinterpret_cast<int *>(smem + off); off += (size_t)S3_RING * sizeof(int);                    // k | source block << 8
-  unsigned char *rowf_s = smem + off; off += (size_t)2 * 3 * 16 * SW_MAXM * sizeof(GT);                     // far-field rows landing by LDS-DMA [parity][wave][row]
+  unsigned char *rowf_s = smem + off; off += (size_t)2 * 2 * 16 * SW_MAXM * sizeof(GT);                     // far-field rows landing by LDS-DMA [parity][wave][row]
   constexpr bool G16 = (sizeof(GT) == 2);
 #ifndef BWGR_GPD3
 #define BWGR_GPD3 1
@@ -892,40 +892,34 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   static_assert(NCH + 128 == 512, "four 16-byte chunks for each lane of the two staging waves");
 
   // ---- the helpers' work for block c (relative): everything that does not depend on block c-1's rounds ----
-  uint4 sg0 = make_uint4(0, 0, 0, 0), sg1 = sg0, sg2 = sg0, sg3 = sg0;   // staging waves: block c's chunks, requested one phase earlier
-  // (selects, not branches: where exec-masked branches join, the compiler puts an s_waitcnt vmcnt(0) in front of its register copies,
-  // and a staging wave would wait out the loads it has just issued)
-  auto stage_src = [&](int c, int ch) -> const uint4 * {
-    const int blk = a.blk_begin + c;
-    const uintptr_t p0 = (uintptr_t)(reinterpret_cast<const uint4 *>(a.ps.blocks + blk) + ch);
-    const uintptr_t p1 = (uintptr_t)(reinterpret_cast<const uint4 *>(a.ps.spec[blk].spec) + (ch - NCH));
-    const uintptr_t p2 = (uintptr_t)(reinterpret_cast<const uint4 *>(a.ps.spec[blk].gjj) + (ch - NCH - 64));
-    return reinterpret_cast<const uint4 *>(ch < NCH ? p0 : (ch < NCH + 64 ? p1 : p2));
-  };
-  auto stage_dst = [&](int c, int ch) -> uint4 * {
-    const uintptr_t d0 = (uintptr_t)(reinterpret_cast<uint4 *>(&stage[c & 1]) + ch);
-    const uintptr_t d1 = (uintptr_t)(reinterpret_cast<uint4 *>(spec_s + (size_t)(c & 1) * 2 * SW_MAXM) + (ch - NCH));   // spec (64 chunks) then gjj (64 chunks), contiguous
-    return reinterpret_cast<uint4 *>(ch < NCH ? d0 : d1);
-  };
-  auto stage_request = [&](int c) {   // waves 2-3
-    const int t = tid - 128;
-    sg0 = *stage_src(c, t); sg1 = *stage_src(c, t + 128); sg2 = *stage_src(c, t + 256); sg3 = *stage_src(c, t + 384);
-  };
-  auto stage_commit = [&](int c) {
-    const int t = tid - 128;
-    *stage_dst(c, t) = sg0; *stage_dst(c, t + 128) = sg1; *stage_dst(c, t + 256) = sg2; *stage_dst(c, t + 384) = sg3;
-  };
-  auto gpd_issue = [&](int c) {   // waves 2-3, 16-bit panels: block c's packed diagonal block, 1 KiB pieces alternating between the two waves
+  // Waves 2-3, staging.  Everything block c needs that does not depend on the chain -- its constants (StageBuf, 6 KB), speculative terms and Gram
+  // diagonal (2 KB) and, 16-bit panels, its packed diagonal Gram block (16 KB) -- lands by LDS-DMA straight in rings of three blocks: requested while
+  // wave 0 runs block c - 2, waited for (a counted wait, behind the requests for block c + 1) before the barrier that ends block c - 1.  No registers in
+  // flight, no commit phase, two phases for a request to land.  (Round 3 moved the constants through registers, requested in one phase and stored in
+  // the next: one phase to land, and every such round trip that is longer than the period IS the period -- profiles/NOTES.md, round 4.)
+  // Each wave issues S3_STG_PIECES pieces per block, whatever the block size (sources clamped inside the block's data): the wait count relies on it.
+  constexpr int S3_STG_PIECES = 4 + (GPD ? 8 : 0);
+  const uint32_t stage_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)stage);
+  const uint32_t spec_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)spec_s);
+  static_assert(sizeof(StageBuf) == 6 * 1024, "six 1 KiB pieces of constants");
+  auto stage_issue = [&](int c) {
+    const int blk = a.blk_begin + min(c, nb - 1), slot = c % 3, wv2 = __builtin_amdgcn_readfirstlane(wave) - 2;
+    const unsigned char *stb = reinterpret_cast<const unsigned char *>(a.ps.blocks + blk);
+    const unsigned char *spb = reinterpret_cast<const unsigned char *>(a.ps.spec + blk);
+    const uint32_t lo16 = (uint32_t)lane * 16u;
+    // pieces 0-5: the constants; 6: spec; 7: the Gram diagonal (SpecBuf: spec at 0, gjj at 2 KB) -- even pieces on wave 2, odd ones on wave 3
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { const int pc = wv2 + 2 * u; s3_dma16s(stb, (uint32_t)pc * 1024u + lo16, stage_la + (uint32_t)slot * (uint32_t)sizeof(StageBuf) + (uint32_t)pc * 1024u); }
+    s3_dma16s(spb, (uint32_t)wv2 * 2048u + lo16, spec_la + (uint32_t)slot * 2048u + (uint32_t)wv2 * 1024u);
     if constexpr (GPD) {
-      const int gpbytes = pstride * 2;
-      const unsigned char *src = reinterpret_cast<const unsigned char *>(gp_all + (size_t)(a.blk_begin + c) * pstride);
-      unsigned char *dst = gpd_s + (size_t)(c % 3) * S3_GPD_BYTES;
-      for (int pc = wave - 2; pc * 1024 < gpbytes; pc += 2) {
-        const int o = pc * 1024 + lane * 16;
-        if (o + 16 <= gpbytes) s3_dma16(src + o, dst + pc * 1024);   // (pstride is a multiple of 8 entries: whole 16-byte chunks)
-      }
+      const int gpbytes = pstride * 2;   // (pstride is a multiple of 8 entries: whole 16-byte chunks)
+      const unsigned char *src = reinterpret_cast<const unsigned char *>(gp_all + (size_t)blk * pstride);
+      const uint32_t gla = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)gpd_s) + (uint32_t)slot * (uint32_t)S3_GPD_BYTES;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int pc = wv2 + 2 * u; s3_dma16s(src, (uint32_t)min(pc * 1024 + lane * 16, gpbytes - 16), gla + (uint32_t)pc * 1024u); }
     }
   };
+#define S3_STG_WAIT() asm volatile("s_waitcnt vmcnt(%0)" : : "n"(S3_STG_PIECES) : "memory")   /* all but the block just requested have landed */
   // wave 1: the K3 slab dots of block c, summed by the streamers' atomics; two markers per lane.  The four words a lane needs are
   // requested one phase ahead (pq_*): the streamers run blocks ahead of the sequencer, so in steady state the words are complete
   // when they are first looked at and no memory round trip sits in the block period.
@@ -1012,7 +1006,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       f_ptr = (f_n > 0) ? (unsigned long long)far_src(c, sl) : 0ull;
       f_cf = (lane < f_n) ? accC[sl] : 0.0;
     }
-    unsigned char *dst = rowf_s + (size_t)(((c & 1) * 3 + hw) * NFL) * ROWB;
+    unsigned char *dst = rowf_s + (size_t)(((c & 1) * 2 + hw) * NFL) * ROWB;
     for (int n = 0; n < f_n; ++n) {
       const unsigned char *src = reinterpret_cast<const unsigned char *>(
           (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f_ptr, n) |
@@ -1026,7 +1020,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   auto far_consume = [&](int c, int hw) {
     double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows requested one phase ago
-    const unsigned char *src = rowf_s + (size_t)(((c & 1) * 3 + hw) * NFL) * ROWB;
+    const unsigned char *src = rowf_s + (size_t)(((c & 1) * 2 + hw) * NFL) * ROWB;
     int n = 0;
     for (; n + 2 <= f_n; n += 2) {                      // two rows per trip: their LDS reads overlap
       far_add(reinterpret_cast<const uint32_t *>(src + (size_t)n * ROWB), readlane_f64(f_cf, n), s0, s1);
@@ -1125,11 +1119,10 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   auto helper_phase = [&](int c) {   // block c >= 1, while wave 0 runs block c-1
     if (wvu == 1) { if (!(SDBG & 32768)) { if (!poll_q(c)) ctrl_s[0] = 0; } S3ST(2, tid == 64); S3_ROLE_BARRIER(); }
     else if (wvu <= 3) { if (!(SDBG & 8192)) {
-      // the constants of block c, requested a phase ago -- waiting for them also waits for block c's packed diagonal block, whose
-      // DMA was issued before them; then the requests for block c+1 (the DMA first), which have this whole phase to land
-      if (!(SDBG & 262144)) stage_commit(c);
-      if (c + 1 < nb) { if (!(SDBG & 131072)) gpd_issue(c + 1); if (!(SDBG & 262144)) stage_request(c + 1); }
-      else if constexpr (GPD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the requests for block c + 1 (always: past the end the last block again, the wait counts rely on it), then the wait for block c's, which were
+      // issued a phase ago and are used by wave 0 after this phase's barrier
+      stage_issue(c + 1);
+      S3_STG_WAIT();
     } S3ST(2, tid == 128 || tid == 192); S3_ROLE_BARRIER(); }
     else if (wvu == 4) { S3_ROLE_BARRIER(); }   // idle: the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots
     else if (wvu <= 6) {
@@ -1150,7 +1143,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   if (tid >= 64 && tid < 64 + S3_MAXD) gx_s[tid - 64] = reinterpret_cast<const unsigned char *>(A.gx[tid - 64]);
   __syncthreads();
   if (wave == 1) { poll_request(0); poll_request(1); if (!poll_q(0)) ctrl_s[0] = 0; }
-  else if (wave == 2 || wave == 3) { gpd_issue(0); stage_request(0); stage_commit(0); if constexpr (G16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (nb > 1) { gpd_issue(1); stage_request(1); } }
+  else if (wave == 2 || wave == 3) { stage_issue(0); stage_issue(1); S3_STG_WAIT(); }
   else if (wave >= 5 && wave <= 6) { far_consume(0, wave - 5); far_issue(1, wave - 5); }
   else if (wave == 7) { for (int c = 0; c < PF; ++c) touch(c); chi_request(0); }
   __syncthreads();
@@ -1187,8 +1180,8 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     if (wvu == 0 && !(SDBG & 16384)) {
       // Wave 0 is one long dependent chain, so everything here is counted in instructions.  Dead lanes of a ragged last block need
       // no masks: k_prestage fills their constants so that they reject for certain, and their q, spec and far terms are zero.
-      const StageBuf &st = stage[b & 1];
-      const double *sps = spec_s + (size_t)(b & 1) * 2 * SW_MAXM;
+      const StageBuf &st = stage[b % 3];
+      const double *sps = spec_s + (size_t)(b % 3) * 2 * SW_MAXM;
       const double *qd = q_s + (size_t)(b & 1) * SW_MAXM;
       const double *fd = far_s + (size_t)(b & 1) * 3 * SW_MAXM;
       const int pos0 = pos_s[b & 31];
@@ -1358,7 +1351,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   }
   S3ST_FLUSH(16, sq0); S3ST_FLUSH(24, sq1); S3ST_FLUSH(32, sq2); S3ST_FLUSH(40, sq4); S3ST_FLUSH(48, sq3); S3ST_FLUSH(56, sq6); S3ST_FLUSH(64, sq7);
   if constexpr (CEN) { if (tid == 0) a.sc->cen_c = cenU - cen_u0; }   // the included markers' share of the shift (k_cen_end)
-  if (wave == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the poll wave's requests past the end)
+  if (wave >= 1 && wave <= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the poll and staging waves' requests past the end)
   if (wave == 7) {   // the last two blocks
     if (nb >= 2) finish_block(nb - 2);
     finish_block(nb - 1);
