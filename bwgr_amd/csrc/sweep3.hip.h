@@ -256,7 +256,7 @@ __device__ __forceinline__ void s3_dma16s_sc1(const unsigned char *gbase, uint32
 
 __host__ __device__ inline size_t s3_streamer_dma_lds(int R3 = 128) {   // (four unpadded tiles at 128 rows, three at 256)
   const size_t Rp = (size_t)R3 + 16;
-  return (R3 == 128 ? 4 : 3) * (size_t)SW_MAXM * R3 + 2 * 16 * Rp + 2 * 16 * (size_t)S2_DP + (size_t)64 * S3_OS * 4 * 4 + (size_t)8 * 32 * S3_OS * 4 + 64;
+  return (R3 == 128 ? 4 : 3) * (size_t)SW_MAXM * R3 + 2 * 16 * Rp + 2 * 16 * (size_t)S2_DP + (size_t)64 * S3_OS * 4 * 4 + (size_t)8 * 32 * S3_OS * 4 + 64 + (size_t)4 * SW_MAXM * 4;
 }
 __host__ __device__ inline size_t s3_streamer_lds(int R3) {
   const size_t Rp = (size_t)R3 + 16;
@@ -581,7 +581,9 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   int8_t *ddig0 = reinterpret_cast<int8_t *>(smem + off); off += (size_t)2 * 16 * S2_DP;  // [parity][n][marker]
   int *outu = reinterpret_cast<int *>(smem + off); off += (size_t)64 * S3_OS * 4 * 4;     // [update wave][row 64][n]
   int *outd = reinterpret_cast<int *>(smem + off); off += (size_t)8 * 32 * S3_OS * 4;     // [wave][marker 32][n]
-  uint32_t *ctl_s = reinterpret_cast<uint32_t *>(smem + off);                            // [0] failure, [1] overflow
+  uint32_t *ctl_s = reinterpret_cast<uint32_t *>(smem + off); off += 64;                 // [0] failure, [1] overflow
+  float *drej_s = reinterpret_cast<float *>(smem + off);                                 // [block % NTB][marker]: the blocks' rejected steps, landed by DMA with the tiles
+  const uint32_t drej_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)drej_s);
   const int sh = a.sc->e3_sh;
   const double S = s3_pow2(sh), invS = s3_pow2(-sh);
   auto blk_j0 = [&](int b) { return (a.blk_begin + b) * m; };
@@ -602,22 +604,36 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   // is requested at the END of step t, into the buffer tile t - 1 left a whole step ago, and is first read after the barrier of step
   // t + NTB - 1 -- NTB - 2 block periods (and the rest of a step) to land; four buffers at 128 rows, three (96 KB) at 256.  The requests are the LAST memory instructions a wave issues in a step, so that no wait for a younger
   // load (the in-order counter) waits for them; before a step's barrier a counted wait (S3_DMA_BARRIER) covers the tile the step reads.
-  constexpr int PPW = (NPC + ND - 1) / ND;
+  // Roles by what a wave keeps on its (in-order) memory counter -- round 4: update waves 0-1 (the list words, compiler-managed waits); dots waves 2-5
+  // (no load at all: their atomics are fire-and-forget, nothing ever waits behind them); DMA waves 6-7 (nothing but LDS-DMA requests, eight tile
+  // pieces and the next block's rejected steps each per step, behind ONE counted wait).  Round 3 had all six non-update waves issue pieces, small
+  // loads AND atomics: the counted wait then also waited for atomics (2 800 cycles under load), and the compiler's own wait for the small loads
+  // drained the pieces a wave had just issued -- streamers alone 1.34 us per block, 1.03 with the atomics switched off.
+  static_assert(NU == 2, "waves 0-1 update, 2-5 dots, 6-7 DMA");
+  constexpr int NDOT = 4, PPW = NPC / 2;       // pieces per DMA wave and tile
+  constexpr int LPS = PPW + 2;                 // DMA requests per DMA wave and step: the tile's pieces and two 256-byte halves of a block's rejected steps
   const uint32_t lane_mk = (uint32_t)(lane / CH), lane_cr = (uint32_t)(lane % CH);
   const int j_lo = a.blk_begin * m, j_hi = min(a.p, a.blk_end * m);
-  auto tile_issue = [&](int t) {
+  const int wvs = __builtin_amdgcn_readfirstlane(wave);   // (a scalar: the LDS address goes into M0)
+  auto drej_issue = [&](int t) {   // block t's rejected steps (clamped past the end), both DMA waves the same two requests: equal counts, the same bytes
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(a.ps.blocks[a.blk_begin + max(0, min(t, nb - 1))].drej);
+    const uint32_t la = drej_la + (uint32_t)((max(t, 0) % NTB) * SW_MAXM * 4);
+    s3_dma4s(src, (uint32_t)lane * 4u, la);
+    s3_dma4s(src, 256u + (uint32_t)lane * 4u, la + 256u);
+  };
+  auto tile_issue = [&](int t) {   // set t = tile t and the rejected steps of block t + 1 (they are digitised BEFORE the barrier of step t + 1)
+    if (wvs < 6) return;
     const int jb = blk_j0(min(t, nb - 1));
     const uint32_t la0 = tile_la + (uint32_t)__builtin_amdgcn_readfirstlane((int)((t % NTB) * (int)tile_b));
-    const int wvs = __builtin_amdgcn_readfirstlane(wave);   // (a scalar: the LDS address goes into M0)
-    if (wvs < NU) return;
 #pragma unroll
     for (int u = 0; u < PPW; ++u) {
-      const int pc = min(wvs - NU + ND * u, NPC - 1);
+      const int pc = (wvs - 6) + 2 * u;
       const int jl = MPP * pc + (int)lane_mk;                      // the marker's index in the tile
       const int jj = min(jb + jl, j_hi - 1);
       const uint32_t voff = (uint32_t)(jj - j_lo) * (uint32_t)R + ((lane_cr ^ ((uint32_t)jl & (uint32_t)(CH - 1))) * 16u);   // (a launch's slab of the panel stays below 4 GiB: sweep3_args selects this streamer only then)
       s3_dma16s(reinterpret_cast<const unsigned char *>(Xs + (size_t)j_lo * R), voff, la0 + (uint32_t)pc * 1024u);
     }
+    drej_issue(t + 1);
   };
 
   // the included markers of block bs (relative index): e -= x_k * corr_k for this wave's rows.  `pre` holds words 0..63 of
@@ -679,8 +695,8 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   // loads: younger than tile b at the barrier of step b are (NTB - 1 - b) * PPW prologue pieces less tile b's own, one prologue load and b * (PPW + 2)
   // loop loads -- 7 at step 0, 9 at step 1, 12 from step 2 on for <128, 4>, against WN = 10).  The prologue's __syncthreads() compiles to
   // lgkmcnt(0) + s_barrier and drains no DMA, so the prologue tiles are drained here, once per launch. ----
+  if (wvs >= 6) drej_issue(0);
   for (int t = 0; t < NTB - 1; ++t) tile_issue(t);
-  float drej_pre = a.ps.blocks[a.blk_begin].drej[tid & (SW_MAXM - 1)];   // (used by the last two waves)
   unsigned long long lpre = 0ull;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -691,8 +707,8 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   // so "at most WN outstanding", with WN = the loads a dots wave issues in NTB - 2 steps (per step: two small requests and PPW pieces), holds only
   // once every load older than those -- the step's tile among them -- is back, whatever the atomics (no order against loads) are doing; and it
   // leaves the younger tiles in flight.  (The update waves issue no pieces: the count is harmless there.)
-  constexpr int WN = (NTB - 2) * (PPW + 2);
-#define S3_DMA_BARRIER() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"(WN) : "memory")
+  constexpr int WN = (NTB - 2) * LPS;
+#define S3_DMA_BARRIER() do { if (wvs >= 6) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WN) : "memory"); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
   auto step = [&](int b) -> bool {
     const int mB = blk_m(b), par = b & 1;
     S3ST(0, st_u || st_d);
@@ -707,7 +723,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
       if ((unsigned long long)(e_own + (1ll << 54)) >> 55) ctl_s[1] = 1u;       // left the 55-bit range
       s3_put_digits7(e_own, edig + 64 * wave + lane, Rp);
     } else if (tid >= SW_THREADS - SW_MAXM) {                                    // the last two waves (never update waves)
-      const double qd = (tid - (SW_THREADS - SW_MAXM) < mB) ? rint((double)drej_pre * S) : 0.0;   // (unused markers: zero steps)
+      const double qd = (tid - (SW_THREADS - SW_MAXM) < mB) ? rint((double)drej_s[(b % NTB) * SW_MAXM + (tid - (SW_THREADS - SW_MAXM))] * S) : 0.0;   // (unused markers: zero steps; set b - 1 landed behind the last barrier)
       if (!(fabs(qd) < 18014398509481984.0)) ctl_s[1] = 1u;                      // 2^54
       s3_put_digits7((long long)qd, ddig + (tid - (SW_THREADS - SW_MAXM)), S2_DP);
     }
@@ -728,8 +744,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
     {   // the small requests first (older than the tile loads on the in-order memory counter, so waiting for them does not wait
         // for the tile), every one unconditional: a load under a branch makes the compiler drain the counter in front of it
       const int bn1 = min(b + 1, nb - 1);
-      drej_pre = a.ps.blocks[a.blk_begin + bn1].drej[tid & (SW_MAXM - 1)];
-      lpre = ld_agent_raw64(A.lists + (size_t)(a.blk_begin + max(bn1 - D, 0)) * S3_LSTRIDE + lane);
+      if (wvs < NU) lpre = ld_agent_raw64(A.lists + (size_t)(a.blk_begin + max(bn1 - D, 0)) * S3_LSTRIDE + lane);   // (the update waves only: no other wave keeps a compiler-visible load)
     }
     S3ST(7, st_u || st_d);
     S3ST(4, st_u || st_d);
@@ -788,8 +803,8 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
     } else {
       // ---- slab dots of block b against the digits of e: markers in groups of 16, groups gm and gm + ND together on wave
       // NU + gm (the two groups' MFMAs, LDS round trips and atomics overlap) ----
-      for (int gm = wave - NU; 16 * gm < m; gm += 2 * ND) {
-        const int gm2 = gm + ND;
+      for (int gm = wave - NU; wvs < NU + NDOT && 16 * gm < m; gm += 2 * NDOT) {
+        const int gm2 = gm + NDOT;
         const bool two = 16 * gm2 < m;
         const int8_t *bp = edig + (size_t)m16 * Rp + 16 * grp;
         const int8_t *ap = tile + (size_t)(16 * gm + m16) * R3;           // (both groups' markers have jj & 15 = m16)
