@@ -2991,7 +2991,8 @@ extern "C" int bwgr_group_destroy(bwgr_group *Gp) {
 
 // X: HOST matrix, column-major n x p (ldx >= n), any bwgr_xtype; y: n host floats.  Device g of `devices` stages the
 // block-aligned column shard [lo_g, hi_g) (as bwgr_amd/dist.py::shard_bounds) and runs the chain of that shard.
-// markers_per_sync: markers swept per device between two residual all-reduces (0: 131072 / ndev, the benchmark's default).
+// markers_per_sync: markers swept per device between two residual all-reduces (0: 131072 / ndev, the benchmark's default; 131072 for shards
+// side by side on one device).
 // ---- are a panel's columns centred?  The marker-sharded partitioned sampler is statistically sound only then (DESIGN.md section 8:
 // uncentred genotypes are all collinear through the mean direction, every shard corrects the same stale residual mean and the summed
 // corrections overshoot; on centred columns 2 / 4 / 8 shards follow the exact chain: tools/centred_shard_probe.py).  From the panel's
@@ -3083,7 +3084,7 @@ static int group_create_impl(bwgr_group **out, int ndev, const int *devices, con
       if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) return bail(fail(BWGR_EHIP, "group_create: hipStreamCreate failed"));
       Gp->streams.push_back(q);
       Gp->P[g]->stream = q;
-      if (ndev > 2) Gp->P[g]->solo3 = false;
+      if (ndev > 2 && !getenv("BWGR_SOLO3")) Gp->P[g]->solo3 = false;   // (an explicit BWGR_SOLO3 decides otherwise: experiments)
     }
     if (centre) { rc = bwgr_panel_set_centred(Gp->P[g], 1); if (rc != BWGR_OK) return bail(rc); }   // the shard's own column means (rows are not sharded)
     msx += (double)Gp->P[g]->MSx;
@@ -3108,7 +3109,9 @@ static int group_create_impl(bwgr_group **out, int ndev, const int *devices, con
         hipMalloc(&Gp->sums[g], sizeof(double) * 2) != hipSuccess) return bail(fail(BWGR_ENOMEM, "group_create: device allocation failed"));
     if (Gp->P[g]->ld != Gp->P[0]->ld) return bail(fail(BWGR_EINVAL, "group_create: shards disagree on the padded row count"));
   }
-  const int64_t mps = markers_per_sync > 0 ? markers_per_sync : std::max<int64_t>(m, 131072 / ndev);
+  // (shards side by side exchange through one kernel on the same card, not a ring over xGMI, but every exchange is a launch boundary for all of
+  // them: 131072 markers per shard between two exchanges there)
+  const int64_t mps = markers_per_sync > 0 ? markers_per_sync : std::max<int64_t>(m, Gp->same_dev ? 131072 : 131072 / ndev);
   Gp->bps = (int)std::max<int64_t>(1, mps / m);
   int64_t nbmax = 0;
   for (int g = 0; g < ndev; ++g) nbmax = std::max<int64_t>(nbmax, Gp->P[g]->nblocks);

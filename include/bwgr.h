@@ -265,7 +265,7 @@ int bwgr_synth_genotypes(void *Xdev, int64_t n, int64_t p, int64_t ldx, int64_t 
  * exact Gibbs sampler would not notice; bWGR's own chain does, a little (its xx_j carry the squared means: DESIGN.md section 8 -- ve 1.47 uncentred
  * against 1.56 centred on the probe panel), so "sound" here means: follows the exact chain on the SAME centred panel.  X is a HOST matrix (column-major n x p, ldx >= n), y n host floats; device g
  * of `devices` takes the block-aligned column shard g.  markers_per_sync: markers swept per device between two all-reduces
- * (0: 131072 / ndev).  bwgr_group_result returns the Bayes* return list over the whole panel (b, d, pval: p floats; vb: p
+ * (0: 131072 / ndev; 131072 when the shards share one device, where an exchange costs a launch boundary, not a ring).  bwgr_group_result returns the Bayes* return list over the whole panel (b, d, pval: p floats; vb: p
  * floats for BayesA/B/L/Dpi, else 1; hat: n floats).  info: {devices, exchange rounds per sweep, markers per round, RCCL in use}. */
 typedef struct bwgr_group bwgr_group;
 int bwgr_group_create(bwgr_group **out, int ndev, const int *devices, const void *X, int xtype, int64_t n, int64_t p, int64_t ldx,

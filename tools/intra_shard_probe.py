@@ -13,7 +13,7 @@ X = synth.genotypes(n, p)
 y = synth.scale_phenotype(synth.phenotype(X, n))
 for S in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 5]:
     try:
-        g = bwgr_amd.Group("BayesB", y, X, devices=[0] * S, it=W + K, bi=W, pi=0.99, seed=synth.SEED, centre=True, n=n)
+        g = bwgr_amd.Group("BayesB", y, X, devices=[0] * S, it=W + K, bi=W, pi=0.99, seed=synth.SEED, centre=True, n=n, markers_per_sync=int(os.environ.get("AB_MPS", "0")))
         g.run(W); g.sync(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         g.run(K); g.sync(); torch.cuda.synchronize()

@@ -15,11 +15,12 @@ y = synth.scale_phenotype(synth.phenotype(X, n))
 res = {}
 for S in [1] + ([int(a) for a in sys.argv[1:]] or [3, 6]):
     t0 = time.perf_counter()
-    g = bwgr_amd.Group("BayesB", y, X, devices=[0] * S, it=IT, bi=BI, pi=0.99, seed=synth.SEED, centre=True, n=n)
+    g = bwgr_amd.Group("BayesB", y, X, devices=[0] * S, it=IT, bi=BI, pi=0.99, seed=synth.SEED, centre=True, n=n, markers_per_sync=int(os.environ.get("AB_MPS", "0")))
+    info = g.info()
     g.run(IT); g.sync()
     r = g.result(); g.close()
     res[S] = r
-    line = {"shards": S, "ve": float(r["ve"]), "h2": float(r["h2"]), "mean_d": float(r["d"].mean()), "seconds": round(time.perf_counter() - t0, 1)}
+    line = {"shards": S, "rounds_per_sweep": info["rounds_per_sweep"], "ve": float(r["ve"]), "h2": float(r["h2"]), "mean_d": float(r["d"].mean()), "seconds": round(time.perf_counter() - t0, 1)}
     if S > 1:
         a = res[1]
         line.update({"cor_hat_vs_exact": float(np.corrcoef(r["hat"], a["hat"])[0, 1]), "cor_b_vs_exact": float(np.corrcoef(r["b"], a["b"])[0, 1]),
