@@ -4,7 +4,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "libbwgr_hip.so")
+# (BWGR_LIB: an already built library to load instead -- tools/variants.py compares compile-time variants of the kernels that way; never built here)
+LIB = os.environ.get("BWGR_LIB") or os.path.join(_HERE, "libbwgr_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("bwgr_hip.hip",)]
 # every file under csrc/ (the kernels live in headers that bwgr_hip.hip includes) plus the public header
 DEPS = sorted(glob.glob(os.path.join(_HERE, "csrc", "*"))) + [os.path.join(_HERE, "..", "include", "bwgr.h")]
@@ -15,6 +16,8 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp
 
 
 def needs_build():
+    if os.environ.get("BWGR_LIB"):
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)

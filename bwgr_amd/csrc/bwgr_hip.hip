@@ -1197,7 +1197,7 @@ static int sweep3_build(bwgr_panel *P) {
   int R3 = (P->R % 256 == 0) ? 256 : 128;
   if (const char *rv = getenv("BWGR_R3")) { const int v = atoi(rv); if ((v == 64 || v == 128 || v == 256) && P->R % v == 0) { R3 = v; P->solo3 = false; } }   // (an explicit height holds for every launch)
   const int sub = P->R / R3, K3 = P->K * sub;
-  int D = 8;
+  int D = 10;   // (the streamers fold a list whose words they saw a step ahead: two more blocks of lag than the fold itself needs -- C4: 12.45 ms at 8, 11.25 at 9, 10.98 at 10, 11.15 at 11)
   // (at least 2: a block's list leaves the sequencer while the next block is in its rounds)
   if (const char *dv = getenv("BWGR_D3")) { const int v = atoi(dv); if (v >= 2 && v <= S3_MAXD) D = v; }
   D = (int)std::min<int64_t>(D, std::max<int64_t>(2, P->nblocks));

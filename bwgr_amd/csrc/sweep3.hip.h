@@ -31,7 +31,7 @@ namespace bwgr {
 #define S3ST_DECL unsigned long long ph3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl3 = __builtin_amdgcn_s_memtime()
 // (BWGR_STAMPS=2: only the stamps around the block barrier, slots 0 and 4 -- "busy" and "waiting" per role; a stamp costs a few
 // hundred cycles because it drains the wave's LDS / scalar counter, so the full set distorts the roles it measures)
-#define S3ST(k, cond) do { if ((BWGR_STAMPS == 1 || (BWGR_STAMPS == 2 && ((k) == 0 || (k) == 1 || (k) == 4)) || (BWGR_STAMPS == 3 && ((k) == 0 || (k) == 4) && blockIdx.x == 0 && threadIdx.x == 0)) && (cond)) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph3[k] += t_ - tl3; tl3 = t_; } } while (0)
+#define S3ST(k, cond) do { if ((BWGR_STAMPS == 1 || (BWGR_STAMPS == 2 && ((k) == 0 || (k) == 1 || (k) == 4)) || (BWGR_STAMPS == 3 && ((k) == 0 || (k) == 4) && blockIdx.x == 0 && threadIdx.x == 0) || (BWGR_STAMPS == 4 && (k) <= 5 && blockIdx.x == 0 && threadIdx.x == 0)) && (cond)) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph3[k] += t_ - tl3; tl3 = t_; } } while (0)
 #define S3ST_FLUSH(base, cond) do { if ((cond) && a.stamps) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&a.stamps[(base) + k_], ph3[k_]); } while (0)
 #else
 #define S3ST_DECL do { } while (0)
@@ -254,6 +254,23 @@ __device__ __forceinline__ void s3_dma16s_sc1(const unsigned char *gbase, uint32
 }
 #pragma clang diagnostic pop
 
+// wait until at most n of this wave's memory operations are still in flight (n known only at run time: the instruction takes an immediate)
+__device__ __forceinline__ void s3_wait_vmcnt(int n) {
+  switch (n) {
+#define S3_WV(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
+    S3_WV(1) S3_WV(2) S3_WV(3) S3_WV(4) S3_WV(5) S3_WV(6) S3_WV(7) S3_WV(8) S3_WV(9) S3_WV(10) S3_WV(11) S3_WV(12) S3_WV(13) S3_WV(14) S3_WV(15) S3_WV(16)
+    S3_WV(17) S3_WV(18) S3_WV(19) S3_WV(20) S3_WV(21) S3_WV(22) S3_WV(23) S3_WV(24) S3_WV(25) S3_WV(26) S3_WV(27) S3_WV(28) S3_WV(29) S3_WV(30) S3_WV(31) S3_WV(32)
+#undef S3_WV
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // (0, or more than the cases cover: everything)
+  }
+}
+
+// which streamer a workgroup is (blockIdx 0 is the sequencer, A.pf the prefetcher)
+__device__ __forceinline__ int s3_stream_index(const Sweep3Args &A) {
+  const int x = (int)blockIdx.x;
+  return x - 1 - ((A.pf >= 0 && x > A.pf) ? 1 : 0);
+}
+
 __host__ __device__ inline size_t s3_streamer_dma_lds(int R3 = 128) {   // (four unpadded tiles at 128 rows, three at 256)
   const size_t Rp = (size_t)R3 + 16;
   return (R3 == 128 ? 4 : 3) * (size_t)SW_MAXM * R3 + 2 * 16 * Rp + 2 * 16 * (size_t)S2_DP + (size_t)64 * S3_OS * 4 * 4 + (size_t)8 * 32 * S3_OS * 4 + 64 + (size_t)4 * SW_MAXM * 4;
@@ -271,7 +288,7 @@ __host__ __device__ inline size_t s3_seq_lds(int D, bool g16) {
   s += (size_t)2 * 2 * 16 * SW_MAXM * (g16 ? 2 : 4);                               // far-field rows in flight (two waves)
   if (g16) s += (size_t)3 * S3_GPD_BYTES + (size_t)S3_NRX * S3_ROWSLOT;       // the packed diagonal block of three blocks, distance-1 / 2 rows of this block's included markers
   s += (size_t)3 * S3_QRAW_BYTES;                                                  // the slab-dot sums of three blocks as they land (two phases ahead)
-  return s + 256;
+  return s + 256 + 512;   // ... the far-field touches' landing pad, the control words and the array bases
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -287,7 +304,8 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
   const SweepArgs &a = A.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m16 = lane & 15, grp = lane >> 4;
-  const int w = (int)blockIdx.x - 1 - ((A.pf >= 0 && (int)blockIdx.x > A.pf) ? 1 : 0);
+  const int w = s3_stream_index(A);
+  const unsigned long long *lists_w = A.lists;
   const int m = a.m, R = a.R, R3 = A.R3, Rp = R3 + 16, D = A.D;
   const int slab = w / A.sub, hsub = w - slab * A.sub;
   const int nb = a.blk_end - a.blk_begin;
@@ -333,7 +351,7 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
   // the list as requested one iteration ago (a list of up to 31 entries arrives with that single load)
   auto fold_list = [&](int bs, unsigned long long pre) -> int {
     const int Bs = a.blk_begin + bs;
-    const unsigned long long *L = A.lists + (size_t)Bs * S3_LSTRIDE;
+    const unsigned long long *L = lists_w + (size_t)Bs * S3_LSTRIDE;
     const int8_t *col = Xs + (size_t)(Bs * m) * R + 64 * wave + lane;
     const uint64_t t0 = wall_clock64();
     unsigned spins = 0;
@@ -434,7 +452,7 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
         // for the tile), every one unconditional: a load under a branch makes the compiler drain the counter in front of it
       const int bn1 = min(b + 1, nb - 1);
       drej_pre = a.ps.blocks[a.blk_begin + bn1].drej[tid & (SW_MAXM - 1)];
-      lpre = ld_agent_raw64(A.lists + (size_t)(a.blk_begin + max(bn1 - D, 0)) * S3_LSTRIDE + lane);
+      lpre = ld_agent_raw64(lists_w + (size_t)(a.blk_begin + max(bn1 - D, 0)) * S3_LSTRIDE + lane);
     }
     S3ST(7, st_u || st_d);
     if (b + 3 < nb && !(SDBG & 16)) S3_TILE_ISSUE(b + 3);
@@ -560,7 +578,8 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   const SweepArgs &a = A.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m16 = lane & 15, grp = lane >> 4;
-  const int w = (int)blockIdx.x - 1 - ((A.pf >= 0 && (int)blockIdx.x > A.pf) ? 1 : 0);
+  const int w = s3_stream_index(A);
+  const unsigned long long *lists_w = A.lists;
   const int m = a.m, R = a.R, D = A.D;
   constexpr int Rp = R3 + 16;         // (the digit rows' stride; the tiles are unpadded)
   constexpr int CH = R3 / 16;         // 16-byte chunks per marker
@@ -638,9 +657,9 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
 
   // the included markers of block bs (relative index): e -= x_k * corr_k for this wave's rows.  `pre` holds words 0..63 of
   // the list as requested one iteration ago (a list of up to 31 entries arrives with that single load)
-  auto fold_list = [&](int bs, unsigned long long pre) -> int {
+  auto fold_list = [&](int bs, unsigned long long pre, int e_first = 0) -> int {   // (entries before e_first are folded already: fold_pre)
     const int Bs = a.blk_begin + bs;
-    const unsigned long long *L = A.lists + (size_t)Bs * S3_LSTRIDE;
+    const unsigned long long *L = lists_w + (size_t)Bs * S3_LSTRIDE;
     const int8_t *col = Xs + (size_t)(Bs * m) * R + 64 * wave + lane;
     const uint64_t t0 = wall_clock64();
     unsigned spins = 0;
@@ -672,7 +691,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
         __builtin_amdgcn_s_sleep(1);
       }
       const uint32_t wlo = (uint32_t)wv, whi = (uint32_t)(wv >> 32);
-      for (int e0 = 0; e0 < nw / 2; e0 += 8) {              // eight columns in flight
+      for (int e0 = (c0 == 0) ? e_first : 0; e0 < nw / 2; e0 += 8) {              // eight columns in flight
         int xb[8]; long long cq[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -690,6 +709,43 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
     return 1;
   };
 
+  // The fold a step ahead.  A streamer that has fallen behind the sequencer finds the next step's list published already; its fold is then two
+  // dependent round trips (the list's words, then the included markers' column bytes) in front of the step's barrier, on the update waves, while the
+  // other six waves wait -- 0.6 us of a 1.5 us step, and the streamers, not the sequencer, set the period.  So the words are requested TWO steps ahead;
+  // a step ahead (fold_prefetch, after the barrier) they are looked at, and if the list is complete the column bytes of its first NPRE markers are
+  // requested and stay in flight through the step's matrix work; the next step's fold (fold_pre) is then a few multiply-adds.  A list that is not
+  // there yet a step ahead takes the old path (fold_list) -- the streamer is ahead of the sequencer then, and waiting anyway.
+  constexpr int NPRE = 4;
+  int xp0 = 0, xp1 = 0, xp2 = 0, xp3 = 0;                 // the prefetched column bytes (this lane's row)
+  long long cp0 = 0, cp1 = 0, cp2 = 0, cp3 = 0;           // their steps on the fixed-point grid
+  int np = -1;                                            // entries of the list the next fold takes (-1: not seen a step ahead)
+  unsigned long long lmid = 0ull;                         // the words requested one step ago (no copy of them is kept for fold_list: a register rotation
+                                                          // makes the compiler land the load in a temporary and wait for it at once)
+  auto fold_prefetch = [&](int bs) {                      // bs: the block whose list the NEXT step folds (relative; < 0: none)
+    // (straight-line code, every load unconditional: where a loaded value meets another one at the join of a branch the compiler copies registers
+    // and waits for the load in front of the copy -- right after its issue)
+    const unsigned long long wv = lmid;
+    const unsigned long long hv = __builtin_amdgcn_readfirstlane((uint32_t)wv) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(wv >> 32)) << 32);
+    const int cnt = (int)(uint32_t)hv, nw = min(62, 2 * max(cnt, 0));
+    const bool ok = bs >= 0 && s3_epoch_is(hv, A.epoch) && __ballot(lane >= 1 && lane <= nw && !s3_epoch_is(wv, A.epoch)) == 0ull;   // (all its words there)
+    const int8_t *col = Xs + (size_t)((a.blk_begin + max(bs, 0)) * m) * R + 64 * wave + lane;
+    const uint32_t wlo = (uint32_t)wv, whi = (uint32_t)(wv >> 32);
+    const int ne = ok ? nw / 2 : 0;
+#define S3_PRE1(U_, XP_, CP_) { \
+      const int ee = min(U_, max(ne - 1, 0)); \
+      const uint32_t a0 = __builtin_amdgcn_readlane(wlo, 1 + 2 * ee), a1 = __builtin_amdgcn_readlane(whi, 1 + 2 * ee), b0 = __builtin_amdgcn_readlane(wlo, 2 + 2 * ee); \
+      CP_ = (U_ < ne) ? (long long)(((unsigned long long)b0 << 32) | (unsigned long long)a0) : 0ll; \
+      XP_ = (int)col[(size_t)(ne > 0 ? (int)(a1 & 0xFFu) : 0) * R]; }
+    S3_PRE1(0, xp0, cp0) S3_PRE1(1, xp1, cp1) S3_PRE1(2, xp2, cp2) S3_PRE1(3, xp3, cp3)
+#undef S3_PRE1
+    np = (bs < 0) ? 0 : (ok ? cnt : -1);
+  };
+  auto fold_pre = [&](int bs) -> int {                    // the fold of block bs's list with what fold_prefetch left
+    if (np < 0) return fold_list(bs, 0ull);               // (reads the words itself)
+    e_own -= (long long)xp0 * cp0 + (long long)xp1 * cp1 + (long long)xp2 * cp2 + (long long)xp3 * cp3;
+    return (np > NPRE) ? fold_list(bs, 0ull, NPRE) : 1;
+  };
+
   // ---- prologue: tiles 0 .. NTB - 2 requested and waited for.  The counted wait in front of a step's barrier (S3_DMA_BARRIER) proves tile b landed
   // only when at least WN younger loads have been issued, which holds from step NTB - 1 on (per step a dots wave issues PPW pieces and two small
   // loads: younger than tile b at the barrier of step b are (NTB - 1 - b) * PPW prologue pieces less tile b's own, one prologue load and b * (PPW + 2)
@@ -697,7 +753,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   // lgkmcnt(0) + s_barrier and drains no DMA, so the prologue tiles are drained here, once per launch. ----
   if (wvs >= 6) drej_issue(0);
   for (int t = 0; t < NTB - 1; ++t) tile_issue(t);
-  unsigned long long lpre = 0ull;
+  if (wvs < NU) lmid = ld_agent_raw64(lists_w + (size_t)(a.blk_begin + max(min(1, nb - 1) - D, 0)) * S3_LSTRIDE + lane);   // (step 1's: never folded before step D)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   S3ST_DECL;
@@ -716,7 +772,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
     int8_t *edig = edig0 + (size_t)par * 16 * Rp;
     int8_t *ddig = ddig0 + (size_t)par * 16 * S2_DP;
     // A: what the included markers of block b - D changed
-    if (b >= D && upd && !(SDBG & 512)) { if (!fold_list(b - D, lpre)) ctl_s[0] = 1u; }
+    if (b >= D && upd && !(SDBG & 512)) { if (!fold_pre(b - D)) ctl_s[0] = 1u; }
     S3ST(1, st_u);
     // B: digits of the residual rows and of this block's rejected steps
     if (upd) {
@@ -743,8 +799,11 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
     S3ST(6, st_u || st_d);
     {   // the small requests first (older than the tile loads on the in-order memory counter, so waiting for them does not wait
         // for the tile), every one unconditional: a load under a branch makes the compiler drain the counter in front of it
-      const int bn1 = min(b + 1, nb - 1);
-      if (wvs < NU) lpre = ld_agent_raw64(A.lists + (size_t)(a.blk_begin + max(bn1 - D, 0)) * S3_LSTRIDE + lane);   // (the update waves only: no other wave keeps a compiler-visible load)
+      if (wvs < NU) {   // (the update waves only: no other wave keeps a compiler-visible load)
+        // the words of the list step b + 1 folds were requested a step ago: look at them, request its columns; then the words for step b + 2
+        if (!(SDBG & 512)) fold_prefetch((b + 1 < nb) ? b + 1 - D : -1);
+        lmid = ld_agent_raw64(lists_w + (size_t)(a.blk_begin + max(min(b + 2, nb - 1) - D, 0)) * S3_LSTRIDE + lane);
+      }
     }
     S3ST(7, st_u || st_d);
     S3ST(4, st_u || st_d);
@@ -892,6 +951,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   unsigned char *gpd_s = smem + off; if (G16) off += (size_t)3 * S3_GPD_BYTES;
   unsigned char *rowx_s = smem + off; if (G16) off += (size_t)S3_NRX * S3_ROWSLOT;
   unsigned char *qraw_s = smem + off; off += (size_t)3 * S3_QRAW_BYTES;   // [block % 3]: the block's slab-dot words, landed by LDS-DMA two phases before they are adopted
+  unsigned char *touch_s = smem + off; off += 256;     // where wave 0's far-field touches land (never read)
   int *ctrl_s = reinterpret_cast<int *>(smem + off);   // [0] ok flag
   int *pos_s = ctrl_s + 8;                             // [b & 31]: ring position where block b's entries begin
   const unsigned char **gx_s = reinterpret_cast<const unsigned char **>(ctrl_s + 40);   // the cross Gram arrays' base addresses (a table in LDS: indexed per entry)
@@ -995,6 +1055,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   constexpr int ROWB = SW_MAXM * (int)sizeof(GT);   // bytes reserved per row (256 or 512)
   constexpr int NPC = ROWB / 256;
   int f_p0 = 0, f_cnt = 0, f_n = 0;
+  const uint32_t rowf_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)rowf_s);
   const int rowbytes = m * (int)sizeof(GT);
   auto far_src = [&](int c, int sl) -> const unsigned char * {
     const int kb = accK[sl];                         // k | (source block, relative) << 8
@@ -1010,7 +1071,29 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   // address one entry at a time costs two dependent LDS latencies per entry.)
   unsigned long long f_ptr = 0ull;   // lane i: source row of this wave's i-th entry
   double f_cf = 0.0;                 // lane i: its coefficient
-  auto far_issue = [&](int c, int hw) {
+  // Wave 4 makes the far-field rows L2 hits.  While wave 0 runs block c - 1, the markers block c - 2 included are final: their rows against blocks
+  // c + 1 .. c - 3 + D -- what the far-field waves request from the end of this phase on, HBM misses of about a block period each, waited for inside
+  // those waves' phase -- are touched here, one 128-byte line per lane (32 lanes per marker, two markers per request), landing in an LDS pad nobody
+  // reads.  Nothing ever waits for a touch.
+#ifndef BWGR_FARTOUCH
+#define BWGR_FARTOUCH 1
+#endif
+  auto far_touch = [&](int c) {
+    if (!G16 || !BWGR_FARTOUCH || c < 2 || D < 4 || (SDBG & 32)) return;
+    const int s_blk = c - 2;
+    const int p0 = pos_s[s_blk & 31], cnt = (pos_s[(s_blk + 1) & 31] - p0) & (ring - 1);
+    const int q = lane & 31, d = 3 + (q >> 1);
+    for (int e0 = 0; e0 < cnt; e0 += 2) {
+      const int e = e0 + (lane >> 5);
+      if (e < cnt && d <= D - 1 && s_blk + d < nb && (q & 1) * 128 < rowbytes) {   // (a row of a small block is one line: nothing past the array's end)
+        const int k = accK[(p0 + e) & (ring - 1)] & 0xFF;
+        s3_dma4(gx_s[d - 1] + ((size_t)(a.blk_begin + s_blk + d) * m * m + (size_t)k * m) * sizeof(GT) + (size_t)(q & 1) * 128, touch_s);
+      }
+    }
+  };
+  // far_plan(c): which rows (LDS reads only: the lists' positions, entries, array bases) -- this runs under the wait for the previous request's rows;
+  // far_request(c): the requests themselves, after far_consume, at the end of the wave's phase
+  auto far_plan = [&](int c, int hw) {
     f_cnt = 0; f_n = 0;
     if (c < 3 || D < 4 || c >= nb || (SDBG & 32)) return;
     f_p0 = pos_s[max(c - D + 1, 0) & 31];
@@ -1021,20 +1104,21 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       f_ptr = (f_n > 0) ? (unsigned long long)far_src(c, sl) : 0ull;
       f_cf = (lane < f_n) ? accC[sl] : 0.0;
     }
-    unsigned char *dst = rowf_s + (size_t)(((c & 1) * 2 + hw) * NFL) * ROWB;
+  };
+  auto far_request = [&](int c, int hw) {
+    // (inline-asm requests: the compiler must not see them, or it drains them in front of the next LDS read -- the wait is the caller's, counted)
+    const uint32_t dst_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rowf_la + (uint32_t)(((c & 1) * 2 + hw) * NFL) * (uint32_t)ROWB));
     for (int n = 0; n < f_n; ++n) {
       const unsigned char *src = reinterpret_cast<const unsigned char *>(
           (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f_ptr, n) |
           ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(f_ptr >> 32), n) << 32));
 #pragma unroll
-      for (int pc = 0; pc < NPC; ++pc)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + min(lane * 4 + 256 * pc, rowbytes - 4)),
-                                         (__attribute__((address_space(3))) void *)(dst + (size_t)n * ROWB + 256 * pc), 4, 0, 0);
+      for (int pc = 0; pc < NPC; ++pc) s3_dma4s(src, (uint32_t)min(lane * 4 + 256 * pc, rowbytes - 4), dst_la + (uint32_t)(n * ROWB + 256 * pc));
     }
   };
-  auto far_consume = [&](int c, int hw) {
+  // (the caller has waited for the rows)
+  auto far_consume = [&](int c, int hw, int f_p0, int f_cnt, int f_n, double f_cf) {
     double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows requested one phase ago
     const unsigned char *src = rowf_s + (size_t)(((c & 1) * 2 + hw) * NFL) * ROWB;
     int n = 0;
     for (; n + 2 <= f_n; n += 2) {                      // two rows per trip: their LDS reads overlap
@@ -1139,13 +1223,15 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       stage_issue(c + 1);
       S3_STG_WAIT();
     } S3ST(2, tid == 128 || tid == 192); S3_ROLE_BARRIER(); }
-    else if (wvu == 4) { S3_ROLE_BARRIER(); }   // idle: the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots
+    else if (wvu == 4) { far_touch(c); S3_ROLE_BARRIER(); }   // (the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots: a handful of instructions only)
     else if (wvu <= 6) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int o_p0 = f_p0, o_cnt = f_cnt, o_n = f_n; const double o_cf = f_cf;
+      far_plan(c + 1, wave - 5);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       S3ST(5, tid == 320);
-      far_consume(c, wave - 5);
+      far_consume(c, wave - 5, o_p0, o_cnt, o_n, o_cf);
       S3ST(6, tid == 320);
-      far_issue(c + 1, wave - 5);
+      far_request(c + 1, wave - 5);
       S3ST(7, tid == 320);
       S3ST(2, tid == 384);
       S3_ROLE_BARRIER();
@@ -1159,7 +1245,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   __syncthreads();
   if (wave == 1) { poll_request(0); poll_request(1); if (!poll_q(0)) ctrl_s[0] = 0; }
   else if (wave == 2 || wave == 3) { stage_issue(0); stage_issue(1); S3_STG_WAIT(); }
-  else if (wave >= 5 && wave <= 6) { far_consume(0, wave - 5); far_issue(1, wave - 5); }
+  else if (wave >= 5 && wave <= 6) { far_consume(0, wave - 5, 0, 0, 0, 0.0); far_plan(1, wave - 5); far_request(1, wave - 5); }
   else if (wave == 7) { for (int c = 0; c < PF; ++c) touch(c); chi_request(0); }
   __syncthreads();
   if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
@@ -1180,6 +1266,8 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   if (wave == 0 && !(SDBG & 1)) __builtin_amdgcn_s_setprio(3);   // the chain's wave goes first wherever it shares an issue port
   // wave 0: what the included markers of block b change in blocks b+1 and b+2 (distances 1 and 2), accumulated as they appear
   double rnext0 = 0.0, rnext1 = 0.0, rnxt20 = 0.0, rnxt21 = 0.0;
+  int pend_n = 0, pend_p = 0;              // row slots requested by the block before and not applied yet; ring position of their first entry
+  bool pend_u1 = false, pend_u2 = false;   // ... and whether that block had a block at distance 1 / 2
   // implicitly centred columns (CEN): wave 0 carries U = -(E_0 + cpre[first block]) / n + sum over the included markers so far of (s_k / n) corr_k;
   // a lane's centred dot is its raw one plus s_j * U (the rejected steps' share sits in the staged spec), an included marker's row G_kj becomes
   // G_kj - s_j s_k / n for the later lanes of its own block, and every later block sees it through U
@@ -1216,8 +1304,26 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       const double xba = (double)st.xxb0[l0], xbb = (double)st.xxb0[l1];
       const double rda = st.rden[l0], rdb = st.rden[l1], sza = st.sdz1[l0], szb = st.sdz1[l1];
       double gja = sps[SW_MAXM + l0], gjb = sps[SW_MAXM + l1];
-      double r0 = ((qd[l0] - sps[l0]) - (fd[l0] + fd[SW_MAXM + l0])) + rnext0;
-      double r1 = ((qd[l1] - sps[l1]) - (fd[l1] + fd[SW_MAXM + l1])) + rnext1;
+      double r0 = (qd[l0] - sps[l0]) - (fd[l0] + fd[SW_MAXM + l0]);
+      double r1 = (qd[l1] - sps[l1]) - (fd[l1] + fd[SW_MAXM + l1]);
+      // The distance-1 / 2 rows of the PREVIOUS block's included markers (requested by DMA as the markers appeared) are waited for here, at their
+      // point of use: their round trip runs under the block's outputs, the barrier and this block's constants instead of ending the last round.
+      if constexpr (G16) {
+        if (pend_n > 0) {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          for (int i_ = 0; i_ < pend_n; ++i_) {
+            const double cf_ = accC[(pend_p + i_) & (ring - 1)];
+            const uint16_t *rw1_ = reinterpret_cast<const uint16_t *>(rowx_s + (size_t)i_ * S3_ROWSLOT);
+            const uint16_t *rw2_ = rw1_ + m;
+            const uint32_t x1a_ = rw1_[l0c], x1b_ = rw1_[l1c], x2a_ = rw2_[l0c], x2b_ = rw2_[l1c];
+            const double c1_ = pend_u1 ? cf_ : 0.0, c2_ = pend_u2 ? cf_ : 0.0;
+            rnext0 = fma(-(double)x1a_, c1_, rnext0); rnext1 = fma(-(double)x1b_, c1_, rnext1);
+            rnxt20 = fma(-(double)x2a_, c2_, rnxt20); rnxt21 = fma(-(double)x2b_, c2_, rnxt21);
+          }
+          pend_n = 0;
+        }
+      }
+      r0 += rnext0; r1 += rnext1;
       int csa = 0, csb = 0;
       double sA = 0.0, sB = 0.0;
       if constexpr (CEN) {   // the Gram-diagonal slot holds {G_jj, s_j} as two 32-bit integers (k_spec3)
@@ -1339,7 +1445,8 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       }
 #undef S3_EVAL
 #undef S3_INCLUDE
-      if constexpr (G16) { if (nslot > 0) S3_APPLY_ROWS() }   // the distance-1 / 2 rows requested as the markers appeared
+      S3ST(5, sq0);
+      if constexpr (G16) { pend_n = nslot; pend_p = pos0 + napp; pend_u1 = use1; pend_u2 = use2; }   // the rows requested as the markers appeared: applied where the next block needs them
 #undef S3_APPLY_ROWS
       S3ST(2, sq0);
       // the block's new effects (every lane's r is final for its own marker); the rest of the outputs is wave 7's
@@ -1366,7 +1473,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   }
   S3ST_FLUSH(16, sq0); S3ST_FLUSH(24, sq1); S3ST_FLUSH(32, sq2); S3ST_FLUSH(40, sq4); S3ST_FLUSH(48, sq3); S3ST_FLUSH(56, sq6); S3ST_FLUSH(64, sq7);
   if constexpr (CEN) { if (tid == 0) a.sc->cen_c = cenU - cen_u0; }   // the included markers' share of the shift (k_cen_end)
-  if (wave >= 1 && wave <= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the poll and staging waves' requests past the end)
+  if (wave >= 1 && wave <= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the poll and staging waves' requests past the end; wave 4's touches)
   if (wave == 7) {   // the last two blocks
     if (nb >= 2) finish_block(nb - 2);
     finish_block(nb - 1);

@@ -5,11 +5,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import subprocess
 from bwgr_amd import build as B
-so = os.path.join(ROOT, "gpurun_out", "libbwgr_hip_exp.so")     # the experiment switches live in a build of their own (-DBWGR_EXPERIMENTS)
-os.makedirs(os.path.dirname(so), exist_ok=True)
-if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in B.DEPS):
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DBWGR_EXPERIMENTS", "-o", so] + B.SOURCES)
-B.LIB = so
+if not os.environ.get("AB_PREBUILT"):   # (tools/variants.py hands over an experiment build through BWGR_LIB)
+    so = os.path.join(ROOT, "gpurun_out", "libbwgr_hip_exp.so")     # the experiment switches live in a build of their own (-DBWGR_EXPERIMENTS)
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in B.DEPS):
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DBWGR_EXPERIMENTS", "-o", so] + B.SOURCES)
+    B.LIB = so
 import torch, bwgr_amd
 from bwgr_amd import synth
 n, p = 10000, int(os.environ.get("AB_P", "200000"))

@@ -18,7 +18,7 @@ from bwgr_amd import synth, _lib
 wl = {"c4x": (10000, int(os.environ.get("AB_P", "500000")), "BayesB", 0.99), "c4s": (10000, 200000, "BayesB", 0.99), "c4b": (10000, 200000, "BayesB", 0.95), "c4d": (10000, 100000, "BayesCpi", 0.5)}
 rows = [("streamer 0, update wave", 0, ["loop top", "fold the list of block b-D", "digits of e and drej", "barrier", "requests (drej, list) after the issue", "update MFMA + recombine", "abort check + tile commit", "next tile issue"]),
         ("streamer 0, first dots wave", 8, ["loop top", "-", "-", "barrier (incl. waiting for the update waves)", "requests (drej, list) after the issue", "dots MFMA + recombine + atomics", "abort check + tile commit", "next tile issue"]),
-        ("sequencer wave 0", 16, ["loop top", "constants + r0", "rounds", "outputs + list publish", "barrier", "(inside rounds) waiting for the on-demand rows", "(included markers per block)", "-"]),
+        ("sequencer wave 0", 16, ["loop top", "constants + r0", "waiting for the distance-1 / 2 rows after the last round", "outputs", "barrier", "rounds", "-", "-"]),
         ("sequencer wave 1 (q poll)", 24, ["loop top", "wait at the block barrier (rest of the phase)", "poll + convert (until the next block's slab dots are complete)", "-", "barrier", "-", "-", "-"]),
         ("sequencer wave 2 (staging)", 32, ["loop top", "wait at the block barrier (rest of the phase)", "commit + request", "-", "barrier", "-", "-", "-"]),
         ("sequencer wave 5 (far field)", 40, ["loop top", "(rest)", "-", "-", "barrier", "wait for last phase's rows", "consume", "issue"]),
