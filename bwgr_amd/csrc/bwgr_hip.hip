@@ -1197,7 +1197,7 @@ static int sweep3_build(bwgr_panel *P) {
   int R3 = (P->R % 256 == 0) ? 256 : 128;
   if (const char *rv = getenv("BWGR_R3")) { const int v = atoi(rv); if ((v == 64 || v == 128 || v == 256) && P->R % v == 0) { R3 = v; P->solo3 = false; } }   // (an explicit height holds for every launch)
   const int sub = P->R / R3, K3 = P->K * sub;
-  int D = 10;   // (the streamers fold a list whose words they saw a step ahead: two more blocks of lag than the fold itself needs -- C4: 12.45 ms at 8, 11.25 at 9, 10.98 at 10, 11.15 at 11)
+  int D = 11;   // (the streamers fold a list whose words they saw a step ahead: more lag than the fold itself needs -- C4: 12.45 ms at 8, 11.27 at 9, 10.68 at 10, 10.58 at 11, 10.57 at 12)
   // (at least 2: a block's list leaves the sequencer while the next block is in its rounds)
   if (const char *dv = getenv("BWGR_D3")) { const int v = atoi(dv); if (v >= 2 && v <= S3_MAXD) D = v; }
   D = (int)std::min<int64_t>(D, std::max<int64_t>(2, P->nblocks));
@@ -1274,7 +1274,7 @@ static void sweep3_args(bwgr_panel *P, const SweepArgs &a, Sweep3Args &A) {
   A.D = P->e3_D; A.K3 = P->K3; A.R3 = P->R3; A.sub = P->sub3; A.g16 = root->gram16 ? 1 : 0;
   A.qsum = P->qsum3; A.lists = P->lists3;
   A.gx12 = root->gram16 ? root->gx12 : nullptr;
-  A.pf = -1;
+  A.pf = -1; A.pf2 = -1;
 #ifdef BWGR_EXPERIMENTS
   if (const char *dv = getenv("BWGR_DBG3")) A.dbg = atoi(dv);   // (timing switches, some of which break the chain: the experiment build only)
 #endif
@@ -1308,7 +1308,10 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
   // not counted by bwgr_panel_max_concurrent, so it stays off there; BWGR_PF3=0|1 decides otherwise)
   const bool pf_on = (pv ? pv[0] == '1' : solo) && A.K3 + 2 <= 256;
   A.pf = pf_on ? ((A.K3 + 2 > 8) ? 8 : A.K3 + 1) : -1;
-  const dim3 grid(A.K3 + 1 + (pf_on ? 1 : 0)), blk(SW_THREADS);
+  const char *p2v = getenv("BWGR_PF3B");
+  const bool pf2_on = pf_on && A.pf == 8 && A.gx12 && A.K3 + 3 > 16 && A.K3 + 3 <= 256 && !(p2v && p2v[0] == '0');
+  A.pf2 = pf2_on ? 16 : -1;
+  const dim3 grid(A.K3 + 1 + (pf_on ? 1 : 0) + (pf2_on ? 1 : 0)), blk(SW_THREADS);
   const bool cen = (a.flags & SWF_CENTRE) != 0;
   if (cen && !SWEEP_DRY) hipLaunchKernelGGL(k_cen_begin, dim3(1), dim3(1024), 0, P->stream, a, 0);
   if (A.g16) { if (cen) SPIN_LAUNCH((k_sweep3<uint16_t, true>), grid, blk, P->lds3_bytes, P->stream, A); else SPIN_LAUNCH((k_sweep3<uint16_t, false>), grid, blk, P->lds3_bytes, P->stream, A); }
@@ -1848,7 +1851,7 @@ static int panel_alloc(bwgr_panel **out, int is_f32, int64_t n, int64_t p, int d
   PCHK(hipMalloc(&P->xpart, sizeof(double) * 2 * (size_t)K * SW_MAXM));
   PCHK(alloc_exchange(P));
   PCHK(hipMalloc(&P->ps.blocks, sizeof(StageBuf) * (size_t)P->nblocks));
-#ifdef BWGR_STAMPS
+#if defined(BWGR_STAMPS) || defined(BWGR_EXPERIMENTS)
   PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 256));
   PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 256));
 #endif
@@ -1901,8 +1904,8 @@ extern "C" int bwgr_panel_create(bwgr_panel **out, const void *X, int xtype, int
   return BWGR_OK;
 }
 
-#ifdef BWGR_STAMPS
-// diagnostic build only: cumulative per-phase s_memtime ticks of workgroup 0 (not part of include/bwgr.h)
+#if defined(BWGR_STAMPS) || defined(BWGR_EXPERIMENTS)
+// diagnostic builds only: cumulative per-phase s_memtime ticks of workgroup 0, event counters (not part of include/bwgr.h)
 extern "C" int bwgr_debug_stamps(bwgr_panel *P, unsigned long long out[256]) {
   HIPCHK(d2h(P->stream, out, P->stamps, sizeof(unsigned long long) * 256));
   HIPCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 256));
@@ -1936,7 +1939,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   PCHK(hipMalloc(&P->ps.blocks, sizeof(StageBuf) * (size_t)P->nblocks));
   PCHK(hipMalloc(&P->xpart, sizeof(double) * 2 * (size_t)K * SW_MAXM));
   PCHK(alloc_exchange(P));
-#ifdef BWGR_STAMPS
+#if defined(BWGR_STAMPS) || defined(BWGR_EXPERIMENTS)
   PCHK(hipMalloc(&P->stamps, sizeof(unsigned long long) * 256));
   PCHK(hipMemset(P->stamps, 0, sizeof(unsigned long long) * 256));
 #endif

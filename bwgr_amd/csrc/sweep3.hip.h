@@ -47,6 +47,8 @@ static constexpr int S3_GPD_BYTES = 16384;            // LDS copy of a packed di
 static constexpr int S3_ROWSLOT = 1024;               // bytes of LDS per such marker: a 64-lane x 16-byte DMA (the two rows are its first 4 m bytes)
 static constexpr int S3_NRX = 8;                      // distance-1 / 2 rows of the first S3_NRX included markers of a block land in LDS by DMA
 static constexpr int S3_OS = 12;                      // dwords per row of the int32 recombination scratch (8 used; b128 reads conflict-free)
+static constexpr int S3_NFW = 4;                      // far-field waves of the sequencer: 5, 6 and the two staging waves (2, 3)
+static constexpr int S3_NFL = 8;                      // rows a far-field wave keeps in flight (the rest of a dense block's rows are read in place)
 static constexpr int S3_QRAW_BYTES = SW_MAXM * 16;    // a block's slab-dot sums as the streamers' atomics leave them: two 8-byte words per marker
 
 struct Sweep3Args {
@@ -61,6 +63,7 @@ struct Sweep3Args {
   uint32_t epoch;                // this launch's tag (24 bits, never 0)
   int dbg;                       // experiment switches (BWGR_DBG3)
   int pf;                        // blockIdx of the prefetcher workgroup (shares the sequencer's XCD), or -1
+  int pf2;                       // ... of the second one (the included markers' distance-1 / 2 rows), or -1
   const unsigned char *gx12;     // 16-bit panels: [nblocks][m][2][m] uint16, marker k of block b against blocks b+1 and b+2 side by side (k_near_rows):
                                  // an included marker's distance-1 and distance-2 rows in ONE LDS-DMA; nullptr: two requests from gx[0], gx[1]
 };
@@ -268,7 +271,7 @@ __device__ __forceinline__ void s3_wait_vmcnt(int n) {
 // which streamer a workgroup is (blockIdx 0 is the sequencer, A.pf the prefetcher)
 __device__ __forceinline__ int s3_stream_index(const Sweep3Args &A) {
   const int x = (int)blockIdx.x;
-  return x - 1 - ((A.pf >= 0 && x > A.pf) ? 1 : 0);
+  return x - 1 - ((A.pf >= 0 && x > A.pf) ? 1 : 0) - ((A.pf2 >= 0 && x > A.pf2) ? 1 : 0);
 }
 
 __host__ __device__ inline size_t s3_streamer_dma_lds(int R3 = 128) {   // (four unpadded tiles at 128 rows, three at 256)
@@ -281,11 +284,11 @@ __host__ __device__ inline size_t s3_streamer_lds(int R3) {
 }
 __host__ __device__ inline size_t s3_seq_lds(int D, bool g16) {
   size_t s = 3 * sizeof(StageBuf) + 3 * 2 * SW_MAXM * sizeof(double);            // constants, spec + gjj: rings of three blocks (landed by DMA)
-  s += 2 * SW_MAXM * sizeof(double) + 2 * 3 * SW_MAXM * sizeof(double);          // q sums, far-field partial sums (three waves)
+  s += 2 * SW_MAXM * sizeof(double) + 2 * S3_NFW * SW_MAXM * sizeof(double);     // q sums, far-field partial sums
   s += 2 * 3 * SW_MAXM * sizeof(float);                                          // state of a block
   (void)D;
   s += (size_t)S3_RING * (sizeof(double) + sizeof(long long) + sizeof(int));       // the included markers of the last D blocks
-  s += (size_t)2 * 2 * 16 * SW_MAXM * (g16 ? 2 : 4);                               // far-field rows in flight (two waves)
+  s += (size_t)2 * S3_NFW * S3_NFL * SW_MAXM * (g16 ? 2 : 4);                      // far-field rows in flight
   if (g16) s += (size_t)3 * S3_GPD_BYTES + (size_t)S3_NRX * S3_ROWSLOT;       // the packed diagonal block of three blocks, distance-1 / 2 rows of this block's included markers
   s += (size_t)3 * S3_QRAW_BYTES;                                                  // the slab-dot sums of three blocks as they land (two phases ahead)
   return s + 256 + 512;   // ... the far-field touches' landing pad, the control words and the array bases
@@ -741,6 +744,9 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
     np = (bs < 0) ? 0 : (ok ? cnt : -1);
   };
   auto fold_pre = [&](int bs) -> int {                    // the fold of block bs's list with what fold_prefetch left
+#ifdef BWGR_EXPERIMENTS
+    if (w == 0 && tid == 0 && a.stamps) { atomicAdd(&a.stamps[203], 1ull); if (np < 0) atomicAdd(&a.stamps[202], 1ull); }   // folds; ... whose list was not there a step ahead
+#endif
     if (np < 0) return fold_list(bs, 0ull);               // (reads the words itself)
     e_own -= (long long)xp0 * cp0 + (long long)xp1 * cp1 + (long long)xp2 * cp2 + (long long)xp3 * cp3;
     return (np > NPRE) ? fold_list(bs, 0ull, NPRE) : 1;
@@ -934,12 +940,12 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   StageBuf *stage = reinterpret_cast<StageBuf *>(smem + off); off += 3 * sizeof(StageBuf);                        // [block % 3]
   double *spec_s = reinterpret_cast<double *>(smem + off); off += (size_t)3 * 2 * SW_MAXM * sizeof(double);   // [block % 3][spec | gjj][marker]
   double *q_s = reinterpret_cast<double *>(smem + off); off += (size_t)2 * SW_MAXM * sizeof(double);
-  double *far_s = reinterpret_cast<double *>(smem + off); off += (size_t)2 * 3 * SW_MAXM * sizeof(double);    // [parity][far wave][marker]
+  double *far_s = reinterpret_cast<double *>(smem + off); off += (size_t)2 * S3_NFW * SW_MAXM * sizeof(double);    // [parity][far wave][marker]
   float *state_s = reinterpret_cast<float *>(smem + off); off += (size_t)2 * 3 * SW_MAXM * sizeof(float);    // [parity][b | d][marker]
   double *accC = reinterpret_cast<double *>(smem + off); off += (size_t)S3_RING * sizeof(double);         // included markers of the last D blocks: what marker k changed beyond drej
   float2 *accS = reinterpret_cast<float2 *>(smem + off); off += (size_t)S3_RING * sizeof(float2);          // ... as the two float steps {included, rejected}
   int *accK = reinterpret_cast<int *>(smem + off); off += (size_t)S3_RING * sizeof(int);                    // k | source block << 8
-  unsigned char *rowf_s = smem + off; off += (size_t)2 * 2 * 16 * SW_MAXM * sizeof(GT);                     // far-field rows landing by LDS-DMA [parity][wave][row]
+  unsigned char *rowf_s = smem + off; off += (size_t)2 * S3_NFW * S3_NFL * SW_MAXM * sizeof(GT);            // far-field rows landing by LDS-DMA [parity][wave][row]
   constexpr bool G16 = (sizeof(GT) == 2);
 #ifndef BWGR_GPD3
 #define BWGR_GPD3 1
@@ -1021,9 +1027,15 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     if (__builtin_expect(__ballot(!((l0 & 0xFFull) == need && (h0 & 0xFFull) == need && (l1 & 0xFFull) == need && (h1 & 0xFFull) == need)) != 0ull, 0)) {
       const uint64_t t0 = wall_clock64();
       unsigned spins = 0;
+#ifdef BWGR_EXPERIMENTS
+      if (lane == 0 && a.stamps) atomicAdd(&a.stamps[200], 1ull);   // blocks whose slab-dot words were not complete when they landed
+#endif
       for (;;) {
         if ((l0 & 0xFFull) == need && (h0 & 0xFFull) == need && (l1 & 0xFFull) == need && (h1 & 0xFFull) == need) break;
         if (SDBG & 8) break;   // (timing experiment only: the streamers publish nothing)
+#ifdef BWGR_EXPERIMENTS
+        if (lane == 0 && a.stamps) atomicAdd(&a.stamps[201], 1ull);   // ... and the polls that took
+#endif
         if ((++spins & 63u) == 0u) {
           if (ld_agent_u32(abortw) != 0u) return 0;
           if (wall_clock64() - t0 > SW_TIMEOUT_TICKS) { st_agent_u32(abortw, 1u); return 0; }
@@ -1050,8 +1062,9 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   // counter); far_consume(c), one block period later, waits for them, multiplies and leaves the sum in LDS.  Every third entry
   // of the flat list per wave; lane = the row's dword(s) lane (markers 2 lane, 2 lane + 1 for 16-bit entries; lane and 64 + lane
   // for 32-bit ones).
-  constexpr int NFL = 16;
-  constexpr int NFW = 2;                            // far-field waves: 5 and 6 (wave 4 shares wave 0's SIMD and stays idle)
+  constexpr int NFL = S3_NFL;
+  constexpr int NFW = S3_NFW;                       // far-field shares: waves 5 and 6 (0, 1) and the staging waves 2 and 3 (2, 3), whose phase is mostly waiting;
+                                                    // wave 4, on wave 0's SIMD, must stay light (a third of the far field there cost 30 % of the sweep)
   constexpr int ROWB = SW_MAXM * (int)sizeof(GT);   // bytes reserved per row (256 or 512)
   constexpr int NPC = ROWB / 256;
   int f_p0 = 0, f_cnt = 0, f_n = 0;
@@ -1107,7 +1120,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   };
   auto far_request = [&](int c, int hw) {
     // (inline-asm requests: the compiler must not see them, or it drains them in front of the next LDS read -- the wait is the caller's, counted)
-    const uint32_t dst_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rowf_la + (uint32_t)(((c & 1) * 2 + hw) * NFL) * (uint32_t)ROWB));
+    const uint32_t dst_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rowf_la + (uint32_t)(((c & 1) * NFW + hw) * NFL) * (uint32_t)ROWB));
     for (int n = 0; n < f_n; ++n) {
       const unsigned char *src = reinterpret_cast<const unsigned char *>(
           (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f_ptr, n) |
@@ -1119,8 +1132,21 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   // (the caller has waited for the rows)
   auto far_consume = [&](int c, int hw, int f_p0, int f_cnt, int f_n, double f_cf) {
     double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
-    const unsigned char *src = rowf_s + (size_t)(((c & 1) * 2 + hw) * NFL) * ROWB;
+    const unsigned char *src = rowf_s + (size_t)(((c & 1) * NFW + hw) * NFL) * ROWB;
     int n = 0;
+    if constexpr (sizeof(GT) == 2) {
+      // four rows per trip, their LDS reads issued together (one round trip where the two-row loop had two); the sums keep the two-row loop's order
+      // -- even rows into (s0, s1), odd ones into (t0, t1) -- so the chain is the same bit for bit
+      for (; n + 4 <= f_n; n += 4) {
+        const uint32_t *r_ = reinterpret_cast<const uint32_t *>(src + (size_t)n * ROWB);
+        const uint32_t v0 = r_[lane], v1 = r_[ROWB / 4 + lane], v2 = r_[2 * (ROWB / 4) + lane], v3 = r_[3 * (ROWB / 4) + lane];
+        const double c0 = readlane_f64(f_cf, n), c1 = readlane_f64(f_cf, n + 1), c2 = readlane_f64(f_cf, n + 2), c3 = readlane_f64(f_cf, n + 3);
+        s0 = fma((double)(v0 & 0xFFFFu), c0, s0); s1 = fma((double)(v0 >> 16), c0, s1);
+        t0 = fma((double)(v1 & 0xFFFFu), c1, t0); t1 = fma((double)(v1 >> 16), c1, t1);
+        s0 = fma((double)(v2 & 0xFFFFu), c2, s0); s1 = fma((double)(v2 >> 16), c2, s1);
+        t0 = fma((double)(v3 & 0xFFFFu), c3, t0); t1 = fma((double)(v3 >> 16), c3, t1);
+      }
+    }
     for (; n + 2 <= f_n; n += 2) {                      // two rows per trip: their LDS reads overlap
       far_add(reinterpret_cast<const uint32_t *>(src + (size_t)n * ROWB), readlane_f64(f_cf, n), s0, s1);
       far_add(reinterpret_cast<const uint32_t *>(src + (size_t)(n + 1) * ROWB), readlane_f64(f_cf, n + 1), t0, t1);
@@ -1136,7 +1162,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       if constexpr (sizeof(GT) == 2) { s0 = fma((double)(v0 & 0xFFFFu), cf, s0); s1 = fma((double)(v0 >> 16), cf, s1); }
       else { s0 = fma((double)(int)v0, cf, s0); s1 = fma((double)(int)v1, cf, s1); }
     }
-    double *fd = far_s + ((size_t)(c & 1) * 3 + hw) * SW_MAXM;
+    double *fd = far_s + ((size_t)(c & 1) * NFW + hw) * SW_MAXM;
     if constexpr (sizeof(GT) == 2) { if (2 * lane < m) { fd[2 * lane] = s0; fd[2 * lane + 1] = s1; } }
     else { fd[lane] = s0; fd[64 + lane] = s1; }
   };
@@ -1220,8 +1246,12 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
     else if (wvu <= 3) { if (!(SDBG & 8192)) {
       // the requests for block c + 1 (always: past the end the last block again, the wait counts rely on it), then the wait for block c's, which were
       // issued a phase ago and are used by wave 0 after this phase's barrier
+      const int o_p0 = f_p0, o_cnt = f_cnt, o_n = f_n; const double o_cf = f_cf;
       stage_issue(c + 1);
-      S3_STG_WAIT();
+      far_plan(c + 1, wave);         // (far-field shares 2 and 3)
+      S3_STG_WAIT();                 // ... whose rows, requested at the end of the last phase, are older than the pieces just requested: landed too
+      far_consume(c, wave, o_p0, o_cnt, o_n, o_cf);
+      far_request(c + 1, wave);
     } S3ST(2, tid == 128 || tid == 192); S3_ROLE_BARRIER(); }
     else if (wvu == 4) { far_touch(c); S3_ROLE_BARRIER(); }   // (the fourth SIMD's other wave is wave 0, whose dependent chain wants the issue slots: a handful of instructions only)
     else if (wvu <= 6) {
@@ -1244,7 +1274,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   if (tid >= 64 && tid < 64 + S3_MAXD) gx_s[tid - 64] = reinterpret_cast<const unsigned char *>(A.gx[tid - 64]);
   __syncthreads();
   if (wave == 1) { poll_request(0); poll_request(1); if (!poll_q(0)) ctrl_s[0] = 0; }
-  else if (wave == 2 || wave == 3) { stage_issue(0); stage_issue(1); S3_STG_WAIT(); }
+  else if (wave == 2 || wave == 3) { stage_issue(0); stage_issue(1); S3_STG_WAIT(); far_consume(0, wave, 0, 0, 0, 0.0); far_plan(1, wave); far_request(1, wave); }
   else if (wave >= 5 && wave <= 6) { far_consume(0, wave - 5, 0, 0, 0, 0.0); far_plan(1, wave - 5); far_request(1, wave - 5); }
   else if (wave == 7) { for (int c = 0; c < PF; ++c) touch(c); chi_request(0); }
   __syncthreads();
@@ -1286,7 +1316,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       const StageBuf &st = stage[b % 3];
       const double *sps = spec_s + (size_t)(b % 3) * 2 * SW_MAXM;
       const double *qd = q_s + (size_t)(b & 1) * SW_MAXM;
-      const double *fd = far_s + (size_t)(b & 1) * 3 * SW_MAXM;
+      const double *fd = far_s + (size_t)(b & 1) * S3_NFW * SW_MAXM;
       const int pos0 = pos_s[b & 31];
       const GT *gp = gp_all + (size_t)blk * pstride;
       const bool use1 = have_next && D >= 2;   // (D = 1: the streamers fold block b's list in before the dots of block b+1)
@@ -1304,8 +1334,8 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       const double xba = (double)st.xxb0[l0], xbb = (double)st.xxb0[l1];
       const double rda = st.rden[l0], rdb = st.rden[l1], sza = st.sdz1[l0], szb = st.sdz1[l1];
       double gja = sps[SW_MAXM + l0], gjb = sps[SW_MAXM + l1];
-      double r0 = (qd[l0] - sps[l0]) - (fd[l0] + fd[SW_MAXM + l0]);
-      double r1 = (qd[l1] - sps[l1]) - (fd[l1] + fd[SW_MAXM + l1]);
+      double r0 = (qd[l0] - sps[l0]) - ((fd[l0] + fd[SW_MAXM + l0]) + (fd[2 * SW_MAXM + l0] + fd[3 * SW_MAXM + l0]));
+      double r1 = (qd[l1] - sps[l1]) - ((fd[l1] + fd[SW_MAXM + l1]) + (fd[2 * SW_MAXM + l1] + fd[3 * SW_MAXM + l1]));
       // The distance-1 / 2 rows of the PREVIOUS block's included markers (requested by DMA as the markers appeared) are waited for here, at their
       // point of use: their round trip runs under the block's outputs, the barrier and this block's constants instead of ending the last round.
       if constexpr (G16) {
@@ -1489,7 +1519,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
 // blocks of distance 1 and 2, 80 KB per block -- so that those reads are L2 hits (a few hundred cycles) instead of HBM misses
 // (about 2 us on a loaded chip, on the chain's critical path).  Paced by the lists the sequencer publishes; speed only.
 // ------------------------------------------------------------------------------------------------------------------
-template <typename GT>
+template <typename GT, bool ROWS>
 __device__ __forceinline__ void s3_prefetcher(const Sweep3Args &A) {
   const SweepArgs &a = A.a;
   const int tid = threadIdx.x, nb = a.blk_end - a.blk_begin;
@@ -1516,15 +1546,23 @@ __device__ __forceinline__ void s3_prefetcher(const Sweep3Args &A) {
     // what the staging waves will ask for: the blocks' constants, speculative terms and packed diagonal Gram blocks, one dword per 128-byte line
     // (their loads are HBM misses ~2 us away on the sequencer's CU, and they must be back within one block period)
     uint32_t v[NPB][3];
+    const size_t g12bytes = (size_t)a.m * 2 * a.m * sizeof(GT);
 #pragma unroll
     for (int u = 0; u < NPB; ++u) {
       const int blk = a.blk_begin + min(c0 + u, nb - 1);
-      const unsigned char *gpb = reinterpret_cast<const unsigned char *>(A.gp) + (size_t)blk * gpbytes;
-      const unsigned char *stb = reinterpret_cast<const unsigned char *>(a.ps.blocks + blk);
-      const unsigned char *spb = reinterpret_cast<const unsigned char *>(a.ps.spec + blk);
-      v[u][0] = *reinterpret_cast<const uint32_t *>(stb + min(o, sizeof(StageBuf) - 4));
-      v[u][1] = *reinterpret_cast<const uint32_t *>(spb + min(o, sizeof(SpecBuf) - 4));
-      v[u][2] = *reinterpret_cast<const uint32_t *>(gpb + min(o, gpbytes - 4));
+      if (ROWS) {
+        // the second prefetcher: what wave 0 asks for when it includes a marker -- the marker's distance-1 / 2 rows (16-bit panels: one record of
+        // 4 m bytes per marker, 64 KB a block), an HBM miss of a block period otherwise, waited for at the top of the next block
+        v[u][0] = *reinterpret_cast<const uint32_t *>(A.gx12 + (size_t)blk * g12bytes + min(o, g12bytes - 4));
+        v[u][1] = 0u; v[u][2] = 0u;
+      } else {
+        const unsigned char *gpb = reinterpret_cast<const unsigned char *>(A.gp) + (size_t)blk * gpbytes;
+        const unsigned char *stb = reinterpret_cast<const unsigned char *>(a.ps.blocks + blk);
+        const unsigned char *spb = reinterpret_cast<const unsigned char *>(a.ps.spec + blk);
+        v[u][0] = *reinterpret_cast<const uint32_t *>(stb + min(o, sizeof(StageBuf) - 4));
+        v[u][1] = *reinterpret_cast<const uint32_t *>(spb + min(o, sizeof(SpecBuf) - 4));
+        v[u][2] = *reinterpret_cast<const uint32_t *>(gpb + min(o, gpbytes - 4));
+      }
     }
 #pragma unroll
     for (int u = 0; u < NPB; ++u) sink += v[u][0] + v[u][1] + v[u][2];
@@ -1535,7 +1573,8 @@ __device__ __forceinline__ void s3_prefetcher(const Sweep3Args &A) {
 template <typename GT, bool CEN = false>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep3(const Sweep3Args A) {
   if (!(A.a.sc->inc_rate < A.a.gate3)) return;   // this sweep is k_sweep2's (dense inclusion: every workgroup sees the same scalar)
-  if ((int)blockIdx.x == A.pf) { s3_prefetcher<GT>(A); return; }
+  if ((int)blockIdx.x == A.pf) { s3_prefetcher<GT, false>(A); return; }
+  if ((int)blockIdx.x == A.pf2) { s3_prefetcher<GT, true>(A); return; }
   if (blockIdx.x == 0) { if (!(A.dbg & 1024)) s3_sequencer<GT, CEN>(A); }
   else if ((A.a.flags & SWF_DEBUG_WITHHOLD) && blockIdx.x == 1 && A.pf != 1) return;   // test hook: a streamer that never shows up
   else if (A.dbg & 2048) return;

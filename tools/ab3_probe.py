@@ -45,7 +45,14 @@ for cfg in sys.argv[1:] or [""]:
             nredo = ch.redo_count()
         except Exception:
             nredo = "n/a"
-        print("%-40s sweep %8.3f ms  %6.3f us/block  mean_d %s  %s redo %s ve %s" % (cfg, ms, 1e3 * ms / nb, "%.4f" % st["d"].mean() if st else "n/a", P.pipeline(sel), nredo, st["ve"] if st else "n/a"), flush=True)
+        try:
+            import ctypes as C
+            from bwgr_amd import _lib
+            out = (C.c_ulonglong * 256)(); _lib.lib().bwgr_debug_stamps(P._h, out)
+            ev = " ev[poll incomplete %d spins %d | folds %d late %d]" % (out[200], out[201], out[203], out[202])
+        except Exception as ex:
+            ev = " ev[%r]" % (ex,)
+        print("%-40s sweep %8.3f ms  %6.3f us/block  mean_d %s  %s redo %s ve %s" % (cfg, ms, 1e3 * ms / nb, "%.4f" % st["d"].mean() if st else "n/a", P.pipeline(sel), nredo, st["ve"] if st else "n/a") + ev, flush=True)
     finally:
         try:
             ch.close(); P.close()
