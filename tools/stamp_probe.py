@@ -11,7 +11,7 @@ B.LIB = so
 import numpy as np, torch
 import bwgr_amd
 from bwgr_amd import synth, _lib
-wl = {"c2": (5000, 50000, "BayesA", 0.0), "c4s": (10000, 100000, "BayesB", 0.99), "c4d": (10000, 100000, "BayesCpi", 0.5), "c4m": (10000, 100000, "BayesB", 0.95)}
+wl = {"c2": (5000, 50000, "BayesA", 0.0), "c4s": (10000, 100000, "BayesB", 0.99), "c4d": (10000, 100000, "BayesCpi", 0.5), "c4m": (10000, 100000, "BayesB", 0.95), "c5s": (50000, 100000, "BayesCpi", 0.5)}
 names2 = {0: "streamer: loop top + tile issue", 9: "streamer: tile commit (vmcnt(0) + LDS stores)", 10: "streamer: delta poll (early request or loop)", 11: "streamer: wave max + LDS atomic", 1: "streamer: barrier after the poll", 2: "streamer: delta digits", 3: "streamer: update MFMA (wave 0)", 4: "streamer: update barrier", 5: "streamer: e update + max", 6: "streamer: e digits", 7: "streamer: dots (barrier, MFMA, barrier)", 8: "streamer: q recombine + store",
           16: "sequencer: top barrier", 21: "sequencer: lane constants", 22: "sequencer: recurrence rounds", 17: "sequencer: outputs + delta store", 18: "sequencer: wait at barrier A (helpers, q_{b+1})", 19: "sequencer: post (state, r0 of next block)", 20: "sequencer: post tail"}
 names = ["top-barrier", "dot", "combine+exchange", "wait for prefetch waves", "outputs+update", "spec matvec", "recurrence (wave 0)", "-", "wave1: prefetch until tile+stage stored", "wave1: residual vmcnt(0)", "wave1: t(gram loads landed)", "wave1: t(+stage landed)"]
