@@ -361,6 +361,17 @@ def main():
 
     # ---- single GPU ----
     out, P, y, Xs_host, pl = single_leg(args.workload, K, W, dev, args, keep=True)
+    # BASELINE configs 2 and 3 on the same box, same timing discipline (a barrier-free single GPU: synchronize on both sides, K steps
+    # timed exactly, kernel time by hipEvents on the kernel's stream): driver-visible beside the headline, each with its own roofline.
+    # (Before the legs that open further streams: c2 is about 1 ms and fifteen launches a step, and once the process holds several hardware
+    # queues the gaps between its launches double -- 1.84 against 1.07 ms a step at the same kernel time when this ran last.)
+    if not args.no_extra and args.workload == "c4":
+        out["workloads"] = {}
+        for wl in ("c2", "c3"):
+            try:
+                out["workloads"][wl] = single_leg(wl, max(K, 10) * (5 if wl == "c2" else 1), max(W, 2), dev, args, keep=False)   # (c2 is 1 ms per step: more of them)
+            except Exception as ex:
+                out["workloads"][wl] = {"error": str(ex)}
     nch = args.chains if args.chains > 0 else P.max_concurrent(bool(pi))
     nch = min(nch, P.max_concurrent(bool(pi)))
     if nch > 1:
@@ -386,15 +397,6 @@ def main():
             out["intra_gpu_shards"] = intra_gpu_shards_leg(model, pi, args.shards, K, W, n, p, dev)
         except Exception as ex:
             out["intra_gpu_shards"] = {"shards": args.shards, "error": str(ex)}
-    # BASELINE configs 2 and 3 on the same box, same timing discipline (a barrier-free single GPU: synchronize on both sides, K steps
-    # timed exactly, kernel time by hipEvents on the kernel's stream): driver-visible beside the headline, each with its own roofline
-    if not args.no_extra and args.workload == "c4":
-        out["workloads"] = {}
-        for wl in ("c2", "c3"):
-            try:
-                out["workloads"][wl] = single_leg(wl, max(K, 10) * (5 if wl == "c2" else 1), max(W, 2), dev, args, keep=False)   # (c2 is 1 ms per step: more of them)
-            except Exception as ex:
-                out["workloads"][wl] = {"error": str(ex)}
     print(json.dumps(out))
 
 
