@@ -745,7 +745,7 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   };
   auto fold_pre = [&](int bs) -> int {                    // the fold of block bs's list with what fold_prefetch left
 #ifdef BWGR_EXPERIMENTS
-    if (w == 0 && tid == 0 && a.stamps) { atomicAdd(&a.stamps[203], 1ull); if (np < 0) atomicAdd(&a.stamps[202], 1ull); }   // folds; ... whose list was not there a step ahead
+    if (w == 0 && tid == 0 && a.stamps && (SDBG & (1 << 21))) { atomicAdd(&a.stamps[203], 1ull); if (np < 0) atomicAdd(&a.stamps[202], 1ull); }   // folds; ... whose list was not there a step ahead
 #endif
     if (np < 0) return fold_list(bs, 0ull);               // (reads the words itself)
     e_own -= (long long)xp0 * cp0 + (long long)xp1 * cp1 + (long long)xp2 * cp2 + (long long)xp3 * cp3;
@@ -1028,13 +1028,13 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       const uint64_t t0 = wall_clock64();
       unsigned spins = 0;
 #ifdef BWGR_EXPERIMENTS
-      if (lane == 0 && a.stamps) atomicAdd(&a.stamps[200], 1ull);   // blocks whose slab-dot words were not complete when they landed
+      if (lane == 0 && a.stamps && (SDBG & (1 << 21))) atomicAdd(&a.stamps[200], 1ull);   // (BWGR_DBG3 bit 21) blocks whose slab-dot words were not complete when they landed
 #endif
       for (;;) {
         if ((l0 & 0xFFull) == need && (h0 & 0xFFull) == need && (l1 & 0xFFull) == need && (h1 & 0xFFull) == need) break;
         if (SDBG & 8) break;   // (timing experiment only: the streamers publish nothing)
 #ifdef BWGR_EXPERIMENTS
-        if (lane == 0 && a.stamps) atomicAdd(&a.stamps[201], 1ull);   // ... and the polls that took
+        if (lane == 0 && a.stamps && (SDBG & (1 << 21))) atomicAdd(&a.stamps[201], 1ull);   // ... and the polls that took
 #endif
         if ((++spins & 63u) == 0u) {
           if (ld_agent_u32(abortw) != 0u) return 0;
