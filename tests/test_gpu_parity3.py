@@ -416,3 +416,28 @@ def test_row_shards_give_the_same_chain_bit_for_bit():
             ref = st
         else:
             assert np.array_equal(st["d"], ref["d"]) and np.array_equal(st["b"], ref["b"]) and np.array_equal(st["e"], ref["e"]) and st["ve"] == ref["ve"], nwg
+
+
+# ---- k_sweep3's lag: the streamers fold a list D blocks late and prepare the fold a step ahead; the sequencer's far field covers the gap ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"BWGR_D3": "4"}, {"BWGR_D3": "8"}, {"BWGR_D3": "16"}, {"BWGR_D3": "11", "BWGR_SOLO3": "0"}])
+@pytest.mark.parametrize("pi", [0.98, 0.85])
+def test_fold_a_step_ahead_is_the_same_chain_at_every_lag(env, pi, monkeypatch):
+    """src/Rcpp20260726ai.cpp:666-688 on a panel of 63 blocks (many more than the lag): sparse inclusion (lists of 0-3 markers: the prefetched
+    columns are the whole fold) and dense (10 of 64 markers a block: more than the four prefetched, the far field's in-place rows), the DMA streamers
+    (a chain alone) and the register-tile ones; same decisions as the oracle, b and e to 1e-6."""
+    import bwgr_amd
+    from oracle import oracle as O
+    monkeypatch.setenv("BWGR_ENG3_THR", "1")   # (k_sweep3 at every inclusion rate)
+    X, y = synth_small(600, 4000, seed=23)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    P = bwgr_amd.Panel(X, block=64)
+    ch = bwgr_amd.Chain(P, "BayesB", y, it=5, bi=1, pi=pi, seed=31)
+    ch.run(5)
+    st = ch.state()
+    assert P.pipeline(True)["generation"] == 3
+    ch.close(); P.close()
+    o = O.bayes("BayesB", y, X, it=5, bi=1, pi=pi, seed=31)["last"]
+    assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL
+    assert np.array_equal(st["d"], o["d"])
