@@ -958,6 +958,9 @@ struct bwgr_panel {
   unsigned long long *stamps = nullptr;   // diagnostic build only
   PreStage ps = {};
   const void *ps_owner = nullptr; int ps_iter = -1;   // whose sweep constants the scratch holds (a chain pre-stages a whole iteration once)
+  // k_draws: the next iteration's state-independent variates, drawn on a second (low-priority) stream beside this iteration's sweep
+  double *draws = nullptr; hipStream_t draws_stream = nullptr; hipEvent_t draws_ready = nullptr, draws_free = nullptr;
+  bool draws_valid = false; Rng draws_rng = {}; uint32_t draws_iter = 0, draws_marker0 = 0; int draws_flags = 0, draws_j0 = 0, draws_j1 = 0; const void *draws_sc = nullptr;
   int gram_maxdist = 3;           // panel_build_gram stops at this block distance (the EM scratch panel needs 1)
   bwgr_panel *parent = nullptr;   // a clone shares the parent's read-only arrays (X, Gram, xx, vx) and owns only the scratch
   int nclones = 0;
@@ -1353,7 +1356,18 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
   int sh_add = 0;
   if (const char *dv = getenv("BWGR_DEBUG_SH_ADD")) sh_add = atoi(dv);   // test hook: less headroom, to leave the range on purpose
   if (s3 || fxa) hipLaunchKernelGGL(k_escale_reset, dim3(1), dim3(1), 0, P->stream, a.sc);
-  hipLaunchKernelGGL(k_prestage, dim3((unsigned)std::min<int64_t>(4096, (tasks + 255) / 256)), dim3(256), 0, P->stream, a, j0, j1);
+  // the variates drawn ahead (draws_ahead, below) when they are this very iteration's: same streams, same counters, same flags, this range inside theirs
+  const int dflags = a.flags & (SWF_SELECT | SWF_VB_VEC);
+  const bool have_draws = !SWEEP_DRY && P->draws_valid && P->draws_iter == a.iter && P->draws_marker0 == a.marker0 && P->draws_flags == dflags &&
+                          P->draws_sc == (const void *)a.sc && P->draws_j0 <= j0 && P->draws_j1 >= j1 && memcmp(&P->draws_rng, &a.rng, sizeof(Rng)) == 0 &&
+                          !(a.flags & (SWF_MH | SWF_EM_ANY));
+  a.draws = nullptr;
+  if (have_draws) { const hipError_t he = hipStreamWaitEvent(P->stream, P->draws_ready, 0); if (he == hipSuccess) a.draws = P->draws; else { fprintf(stderr, "bwgr: draws wait failed: %s\n", hipGetErrorString(he)); (void)hipGetLastError(); } }
+  if (a.draws) {
+    hipLaunchKernelGGL(k_prestage_fin, dim3((unsigned)std::min<int64_t>(2048, (j1 - j0 + 255) / 256)), dim3(256), 0, P->stream, a, j0, j1);
+    { const hipError_t he = hipEventRecord(P->draws_free, P->stream); if (he != hipSuccess) { fprintf(stderr, "bwgr: draws_free record failed: %s\n", hipGetErrorString(he)); (void)hipGetLastError(); } }
+    P->draws_valid = false;   // (consumed: the buffer is the next iteration's from here)
+  } else hipLaunchKernelGGL(k_prestage, dim3((unsigned)std::min<int64_t>(4096, (tasks + 255) / 256)), dim3(256), 0, P->stream, a, j0, j1);
   if (s3) {   // the sweep's fixed-point scale, then the in-block speculative terms on that grid
     int xbits = 0; while ((1 << xbits) < std::max(1, (P->parent ? P->parent : P)->xmax)) ++xbits;
     hipLaunchKernelGGL(k_escale, dim3(1), dim3(1024), 0, P->stream, a.e, P->ld, a.sc, xbits, a.gate3, sh_add);
@@ -1382,6 +1396,38 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
     if (P->is_f32) hipLaunchKernelGGL(k_spec<double>, dim3(nb), dim3(128), 0, P->stream, a, a.blk_begin, sel);
     else hipLaunchKernelGGL(k_spec<int32_t>, dim3(nb), dim3(128), 0, P->stream, a, a.blk_begin, sel);
   }
+}
+
+// The next iteration's variates, enqueued beside this iteration's sweep (see k_draws).  `a` = this iteration's arguments over the whole panel.  Selection
+// models with the logistic step on panels whose sweeps leave most of the chip idle; BWGR_DRAWS=0 switches it off.  Failing to set it up is not an error:
+// k_prestage draws for itself whenever the buffer is not this iteration's.
+static void draws_ahead(bwgr_panel *P, const SweepArgs &a, hipEvent_t before_sweep) {
+  if (SWEEP_DRY || !(a.flags & SWF_SELECT) || (a.flags & (SWF_MH | SWF_EM_ANY))) return;
+  static const bool off = [] { const char *v = getenv("BWGR_DRAWS"); return v && v[0] == '0'; }();
+  if (off) return;
+  if (!P->draws) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // (lo: the numerically largest = the lowest priority)
+    if (hipMalloc(&P->draws, sizeof(double) * 5 * (size_t)P->p) != hipSuccess || hipStreamCreateWithPriority(&P->draws_stream, hipStreamNonBlocking, lo) != hipSuccess ||
+        hipEventCreateWithFlags(&P->draws_ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&P->draws_free, hipEventDisableTiming) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_draws), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+      hipFree(P->draws); P->draws = nullptr;
+      return;
+    }
+    (void)hipEventRecord(P->draws_free, P->stream);
+  }
+  const int j0 = a.blk_begin * a.m, j1 = (int)std::min<int64_t>(P->p, (int64_t)a.blk_end * a.m);
+  // after this iteration's k_prestage has read the buffer (draws_free) -- or, the first time, after what is enqueued so far; 160 workgroups with 96 KB of
+  // LDS each: at most 160 compute units, none of them one that runs a workgroup of the sweep
+  // (... and after the iteration's speculative terms, which are bandwidth-bound and would share the chip with it: the event in front of the sweep)
+  { const hipError_t h1 = hipStreamWaitEvent(P->draws_stream, P->draws_free, 0), h2 = hipStreamWaitEvent(P->draws_stream, before_sweep, 0);
+    if (h1 != hipSuccess || h2 != hipSuccess) { fprintf(stderr, "bwgr: draws_ahead waits failed: %s / %s\n", hipGetErrorString(h1), hipGetErrorString(h2)); (void)hipGetLastError(); return; } }
+  hipLaunchKernelGGL(k_draws, dim3(160), dim3(1024), 96 * 1024, P->draws_stream, a.rng, a.marker0, a.iter + 1u, a.flags, (const ChainScalars *)a.sc, (int64_t)P->p, j0, j1, P->draws);
+  { const hipError_t h1 = hipGetLastError(); const hipError_t h2 = (h1 == hipSuccess) ? hipEventRecord(P->draws_ready, P->draws_stream) : hipSuccess;
+    if (h1 != hipSuccess || h2 != hipSuccess) { fprintf(stderr, "bwgr: k_draws launch / record failed: %s / %s\n", hipGetErrorString(h1), hipGetErrorString(h2)); (void)hipGetLastError(); P->draws_valid = false; return; } }
+  P->draws_valid = true; P->draws_rng = a.rng; P->draws_iter = a.iter + 1u; P->draws_marker0 = a.marker0; P->draws_flags = a.flags & (SWF_SELECT | SWF_VB_VEC);
+  P->draws_j0 = j0; P->draws_j1 = j1; P->draws_sc = (const void *)a.sc;
 }
 
 static void launch_sweep_kernel_inner(bwgr_panel *P, const SweepArgs &a_in, bool redo);
@@ -1616,6 +1662,10 @@ extern "C" int bwgr_panel_destroy(bwgr_panel *P) {
   hipFree(P->cpre); if (!P->parent) { hipFree(P->csum); hipFree(P->xxc); }
   hipFree(P->xspec2); hipFree(P->xspec3); hipFree(P->ps.spec); hipFree(P->ps.blocks); hipFree(P->ps.quick); hipFree(P->xpart); hipFree(P->xchg); hipFree(P->stamps);
   guard_forget(P);
+  if (P->draws_stream) { (void)hipStreamSynchronize(P->draws_stream); hipStreamDestroy(P->draws_stream); }
+  if (P->draws_ready) hipEventDestroy(P->draws_ready);
+  if (P->draws_free) hipEventDestroy(P->draws_free);
+  hipFree(P->draws);
   if (P->own_stream) hipStreamDestroy(P->own_stream);
   for (hipStream_t q : P->pair_streams) hipStreamDestroy(q);
   delete P;
@@ -1924,6 +1974,7 @@ extern "C" int bwgr_panel_clone(bwgr_panel **out, bwgr_panel *src) {
   bwgr_panel *P = new bwgr_panel(*root);
   P->parent = root; P->nclones = 0; P->nchains = 0; P->own_stream = nullptr; P->stream = nullptr; P->ps_owner = nullptr; P->ps_iter = -1;
   P->pair_streams.clear();   // (the root's: a clone owns none)
+  P->draws = nullptr; P->draws_stream = nullptr; P->draws_ready = nullptr; P->draws_free = nullptr; P->draws_valid = false;   // (its own, made on first use)
   P->pre_pair_stream = nullptr; P->pre_pair_set = false; P->guard_ev = nullptr; P->guard_cus = 0; P->guard_stream = nullptr; P->guard_listed = false;
   P->qsum3 = P->lists3 = nullptr; P->epoch3 = 0;
   P->snap_e = nullptr; P->snap_b = P->snap_d = P->snap_vb = nullptr; P->xmax_dev = nullptr; P->winv = nullptr; P->qsumw = nullptr;
@@ -2235,13 +2286,19 @@ extern "C" int bwgr_chain_sweep_blocks(bwgr_chain *C, int blk_begin, int blk_end
   // the per-marker constants and speculative terms of an iteration depend on the state at its start only (a block's b is
   // untouched until the block is swept), so a chain that sweeps its panel in several ranges -- the exchange rounds of the
   // marker-sharded sampler -- pre-stages all of them with the first range
+  bool prestaged = false;
   if (P->ps_owner != C || P->ps_iter != C->done) {
     SweepArgs all = a; all.blk_begin = 0; all.blk_end = (int)P->nblocks;
     launch_prestage(P, all);
     P->ps_owner = C; P->ps_iter = C->done;
+    prestaged = true;
   }
   hipError_t he = hipEventRecord(e0, P->stream);
   if (he == hipSuccess) { launch_sweep_kernel(P, a); he = hipGetLastError(); }
+  if (he == hipSuccess && prestaged && C->done + 1 < C->iit) {   // the next iteration's variates, beside this sweep
+    SweepArgs all = a; all.blk_begin = 0; all.blk_end = (int)P->nblocks;
+    draws_ahead(P, all, e0);
+  }
   if (he == hipSuccess) he = hipEventRecord(e1, P->stream);
   if (he != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail(BWGR_EHIP, "sweep_blocks: %s", hipGetErrorString(he)); }
   C->ev.push_back(e0); C->ev.push_back(e1);

@@ -122,6 +122,7 @@ struct SweepArgs {
   unsigned long long *dgran;    // k_sweep2: [S2_NSLOT][SW_MAXM] {epoch, float delta} granules
   uint32_t *xflags;             // [K*SW_FLAG_STRIDE] epochs, then the abort word
   unsigned long long *stamps;   // diagnostic build only (-DBWGR_STAMPS): per-phase cycle sums of workgroup 0
+  const double *draws;          // k_draws' output for THIS iteration (five arrays of p: z1, z2, the two threshold logits, chi), or null: k_prestage draws itself
   int redo_only;                // this launch is the fp64 fallback of a fixed-point sweep: it runs only when sc->redo is set
   float gate3;                  // > 0: both engines of the selection models are launched and the device picks one -- k_sweep3 (and its
                                 // k_escale / k_spec3) runs when sc->inc_rate < gate3, k_sweep2 (and k_spec) otherwise; 0: no gating
@@ -240,18 +241,31 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
       st.xxb0[t] = k2 ? b0 : xxj * b0;
       st.rden[t] = 1.0 / (double)den;
       const double sdz1 = (a.flags & SWF_EM_BL) ? 1.0 / (double)(xxj + sc.Sb)             // emBL's second denominator xx + cxx, :380
-                                                : (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z1, 0);
+                                                : (double)sd * (a.draws ? a.draws[j] : rng_normal(a.rng, mk, a.iter, RNG_Z1, 0));
       st.sdz1[t] = sdz1;
       // affine sweeps on the fixed-point residual (k_sweep2w): a marker's step is not known before the sweep, but |b0| and the noise
       // term bound what it can be when the residual itself is tiny (a KMUP call with e = 0); k_escale sizes the grid by the larger
       if (!sel && !(a.flags & SWF_EM_ANY)) atomicMax(&dex_s, (__float_as_uint(fmaxf(fabsf(b0), fabsf((float)sdz1))) >> 23) & 0xFFu);
     } else if (piece == 1) {
-      const float b2 = sel ? (float)((double)0.0f + (double)sd * rng_normal(a.rng, mk, a.iter, RNG_Z2, 0)) : 0.0f;
+      const float b2 = sel ? (float)((double)0.0f + (double)sd * (a.draws ? a.draws[(size_t)a.p + j] : rng_normal(a.rng, mk, a.iter, RNG_Z2, 0))) : 0.0f;
       st.b2[t] = b2;
       const float drej = sel ? (b2 - b0) : 0.0f;   // the step a marker takes when it is NOT included
       st.drej[t] = drej;
       if (sel) atomicMax(&dex_s, (__float_as_uint(drej) >> 23) & 0xFFu);   // k_sweep3 sizes its fixed-point grid by the largest step
     } else if (piece == 2) {
+      if (a.draws) {   // (k_draws: selection models other than BayesDpi) the uniform's share of the thresholds came ahead; the odds' is this iteration's
+        float ta = -INFINITY, tr = INFINITY;
+        const double la = a.draws[2 * (size_t)a.p + j], lr = a.draws[3 * (size_t)a.p + j];   // log1p(-u(1 +- eta)) - log(u(1 +- eta)); NaN: no threshold
+        if (sc.odds > 0.0f && lr == lr) {
+          const double lo = log((double)sc.odds);
+          if (la == la) ta = (float)(la - lo);
+          tr = (float)(lr - lo);
+          ta = nextafterf(ta, -INFINITY); tr = nextafterf(tr, INFINITY);
+          if (!(ta < tr)) { ta = -INFINITY; tr = INFINITY; }
+        }
+        st.tacc[t] = ta; st.trej[t] = tr;
+        continue;
+      }
       const double uj = sel ? rng_uniform(a.rng, mk, a.iter, RNG_U, 0) : 0.0;
       // The Bernoulli step accepts iff u < pj with pj a float function of x = C*(|e2|^2 - |e1|^2):
       //   pj = 1/(1 + odds*expf(x))  or (BayesDpi)  min(1, (1-pi)*expf(-x)).
@@ -274,13 +288,99 @@ __global__ void k_prestage(const SweepArgs a, int j_begin, int j_end) {
       }
       st.tacc[t] = ta; st.trej[t] = tr;
     } else {
-      st.chi[t] = (a.flags & SWF_VB_VEC) ? rng_chisq(a.rng, (double)dfp1, mk, a.iter, RNG_CHI) : 1.0;
+      st.chi[t] = a.draws ? a.draws[4 * (size_t)a.p + j] : ((a.flags & SWF_VB_VEC) ? rng_chisq(a.rng, (double)dfp1, mk, a.iter, RNG_CHI) : 1.0);
     }
   }
   // the unused entries of every block (blocks narrower than SW_MAXM, the ragged last block): constants with which a lane rejects
   // for certain and changes nothing (k_sweep3's recurrence wave runs without dead-lane masks, its streamers digitise all
   // SW_MAXM steps of a block)
   if (j_end > j_begin && (a.m < SW_MAXM || (j_end % a.m) != 0)) {
+    const int blk0 = j_begin / a.m, blk1 = (j_end - 1) / a.m;
+    for (int blk = blk0 + (int)blockIdx.x; blk <= blk1; blk += (int)gridDim.x) {
+      StageBuf &st = a.ps.blocks[blk];
+      for (int t = min(a.m, j_end - blk * a.m) + (int)threadIdx.x; t < SW_MAXM; t += (int)blockDim.x) {
+        st.b0[t] = 0.0f; st.xxb0[t] = 0.0f; st.b2[t] = 0.0f; st.drej[t] = 0.0f;
+        st.rden[t] = 0.0; st.sdz1[t] = 0.0; st.chi[t] = 1.0;
+        st.tacc[t] = -INFINITY; st.trej[t] = -INFINITY;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && dex_s != 0u) atomicMax(&a.sc->e3_dex, dex_s);
+}
+// k_draws: the variates of iteration `iter` that do not depend on the chain's state -- the two normals, the Bernoulli uniform as the two threshold
+// logits before the odds are subtracted, the chi-square -- for markers [j_begin, j_end): what k_prestage spends most of its 0.2 ms per C4 iteration on
+// (fp64 logarithms, Box-Muller, the gamma sampler).  The streams are counter-based (marker, iteration, purpose), so they are drawn one iteration AHEAD,
+// on a second stream, beside the sweep (which leaves two thirds of the chip idle); k_prestage then only combines them with ve, the variances and the odds.
+// Selection models with the logistic step (not BayesDpi's Metropolis form, whose threshold takes pi inside the logarithm).  Same values bit for bit:
+// the expressions are k_prestage's own, cut where the state enters.  A large dynamic LDS request keeps its workgroups off the sweep's compute units.
+__global__ void k_draws(Rng rng, uint32_t marker0, uint32_t iter, int flags, const ChainScalars *sc_in, int64_t p, int j_begin, int j_end, double *out) {
+  const float dfp1 = sc_in->dfp1;   // (df + 1: a constant of the chain)
+  const int64_t nm = j_end - j_begin;
+  const bool sel = (flags & SWF_SELECT) != 0;
+  for (int64_t task = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; task < 4 * nm; task += (int64_t)gridDim.x * blockDim.x) {
+    const int piece = (int)(task / nm);
+    const int j = j_begin + (int)(task - (int64_t)piece * nm);
+    const uint32_t mk = marker0 + (uint32_t)j;
+    if (piece == 0) out[j] = rng_normal(rng, mk, iter, RNG_Z1, 0);
+    else if (piece == 1) out[(size_t)p + j] = sel ? rng_normal(rng, mk, iter, RNG_Z2, 0) : 0.0;
+    else if (piece == 2) {
+      const double uj = sel ? rng_uniform(rng, mk, iter, RNG_U, 0) : 0.0;
+      double la = NAN, lr = NAN;
+      if (sel && uj > 0.0) {
+        const double eta = 1e-6, ua = uj * (1.0 + eta), ur = uj * (1.0 - eta);
+        if (ua < 1.0) la = log1p(-ua) - log(ua);
+        lr = log1p(-ur) - log(ur);
+      }
+      out[2 * (size_t)p + j] = la; out[3 * (size_t)p + j] = lr;
+    } else out[4 * (size_t)p + j] = (flags & SWF_VB_VEC) ? rng_chisq(rng, (double)dfp1, mk, iter, RNG_CHI) : 1.0;
+  }
+}
+// k_prestage_fin: k_prestage for an iteration whose variates k_draws drew ahead -- one thread per marker, the marker's scalars read and its
+// denominator and standard deviation formed once for the four pieces, log(odds) once per workgroup.  The same expressions as k_prestage's, so the same
+// StageBuf bit for bit (tests: the chains do not move).  Selection models with the logistic step only (launch_prestage).
+__global__ __launch_bounds__(256) void k_prestage_fin(const SweepArgs a, int j_begin, int j_end) {
+  const ChainScalars &sc = *a.sc;
+  const float ve = sc.ve, lam_common = sc.lam;
+  __shared__ uint32_t dex_s;
+  __shared__ double lo_s;
+  if (threadIdx.x == 0) { dex_s = 0u; lo_s = (sc.odds > 0.0f) ? log((double)sc.odds) : 0.0; }
+  __syncthreads();
+  const bool odds_pos = sc.odds > 0.0f;
+  const double lo = lo_s;
+  const bool k2 = (a.flags & SWF_KMUP2) != 0;
+  const size_t p = (size_t)a.p;
+  uint32_t dex = 0u;
+  for (int j = j_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x); j < j_end; j += (int)(gridDim.x * blockDim.x)) {
+    StageBuf &st = a.ps.blocks[j / a.m];
+    const int t = j % a.m;
+    const float b0 = a.b[j];
+    const float xxj = a.xx[j];
+    const float lamj = (a.flags & SWF_LAM_VEC) ? a.lam[j] : lam_common;
+    const float den = k2 ? (xxj * sc.bg + lamj) : (xxj + lamj);
+    const float sd = sqrtf(ve / den);
+    st.b0[t] = b0;
+    st.xxb0[t] = k2 ? b0 : xxj * b0;
+    st.rden[t] = 1.0 / (double)den;
+    st.sdz1[t] = (double)sd * a.draws[j];
+    const float b2 = (float)((double)0.0f + (double)sd * a.draws[p + j]);
+    st.b2[t] = b2;
+    const float drej = b2 - b0;
+    st.drej[t] = drej;
+    dex = max(dex, (__float_as_uint(drej) >> 23) & 0xFFu);
+    float ta = -INFINITY, tr = INFINITY;
+    const double la = a.draws[2 * p + j], lr = a.draws[3 * p + j];   // log1p(-u(1 +- eta)) - log(u(1 +- eta)); NaN: no threshold
+    if (odds_pos && lr == lr) {
+      if (la == la) ta = (float)(la - lo);
+      tr = (float)(lr - lo);
+      ta = nextafterf(ta, -INFINITY); tr = nextafterf(tr, INFINITY);
+      if (!(ta < tr)) { ta = -INFINITY; tr = INFINITY; }
+    }
+    st.tacc[t] = ta; st.trej[t] = tr;
+    st.chi[t] = a.draws[4 * p + j];
+  }
+  if (dex) atomicMax(&dex_s, dex);
+  if (j_end > j_begin && (a.m < SW_MAXM || (j_end % a.m) != 0)) {   // the unused entries of every block: as k_prestage
     const int blk0 = j_begin / a.m, blk1 = (j_end - 1) / a.m;
     for (int blk = blk0 + (int)blockIdx.x; blk <= blk1; blk += (int)gridDim.x) {
       StageBuf &st = a.ps.blocks[blk];
