@@ -1375,7 +1375,8 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
       hipLaunchKernelGGL(k_cen_tot, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin, 0);
       hipLaunchKernelGGL(k_cen_scan, dim3(1), dim3(1024), 0, P->stream, a, (int)P->nblocks, 0);
     }
-    hipLaunchKernelGGL(k_spec3, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin);
+    { const bwgr_panel *root = P->parent ? P->parent : P;
+      hipLaunchKernelGGL(k_spec3, dim3((unsigned)(a.blk_end - a.blk_begin)), dim3(128), 0, P->stream, a, a.blk_begin, root->gram16 ? (const uint16_t *)root->gramp16 : (const uint16_t *)nullptr); }
     if (std::isinf(a.gate3)) return;
   }
   if (use_winv(P, a.flags) && P->winv) {

@@ -173,7 +173,7 @@ __global__ void k_cen_end(const SweepArgs a, int mode) {
 // and the Gram diagonal.  One workgroup of 128 threads per block, thread = marker j, four partial sums.
 // SWF_CENTRE: spec_j -= (s_j / n) * (cpre[blk] + sum_{k<j, same block} s_k drej_k) -- the rejected steps' share of -(s_j / n) E -- and the
 // Gram-diagonal slot carries {G_jj, s_j} as two 32-bit integers (the sequencer forms G_jj - s_j^2 / n).
-__global__ __launch_bounds__(128) void k_spec3(const SweepArgs a, int blk_begin) {
+__global__ __launch_bounds__(128) void k_spec3(const SweepArgs a, int blk_begin, const uint16_t *gp16 = nullptr) {
   if (!(a.sc->inc_rate < a.gate3)) return;   // this sweep is k_sweep2's
   const int blk = blk_begin + blockIdx.x, j = threadIdx.x, m = a.m;
   const int mB = min(m, a.p - blk * m);
@@ -192,6 +192,21 @@ __global__ __launch_bounds__(128) void k_spec3(const SweepArgs a, int blk_begin)
   if (j < mB) {
     gjj = (double)G[(size_t)j * m + j];
     int k = 0;
+    if (gp16) {
+      // 16-bit panels: the same entries from the packed strict upper triangle (16 KB a block instead of the 64 KB square: the kernel is bound by
+      // HBM, 0.5 GB a C4 iteration through the square); entry (k, j > k) at prow(k) + j - k - 1, the same summation order
+      const uint16_t *Gp = gp16 + (size_t)blk * a.pstride + (j - 1);
+      int pr = 0;   // prow(k) - k, stepped: prow(k) = k (m - 1) - k (k - 1) / 2
+      for (; k + 4 <= j; k += 4) {
+        const int p0 = pr, p1 = p0 + (m - 2 - k), p2 = p1 + (m - 3 - k), p3 = p2 + (m - 4 - k);
+        s0 = fma((double)Gp[p0], dr[k], s0);
+        s1 = fma((double)Gp[p1], dr[k + 1], s1);
+        s2 = fma((double)Gp[p2], dr[k + 2], s2);
+        s3 = fma((double)Gp[p3], dr[k + 3], s3);
+        pr = p3 + (m - 5 - k);
+      }
+      for (; k < j; ++k) { s0 = fma((double)Gp[pr], dr[k], s0); pr += m - 2 - k; }
+    } else {
     for (; k + 4 <= j; k += 4) {
       s0 = fma((double)G[(size_t)k * m + j], dr[k], s0);
       s1 = fma((double)G[(size_t)(k + 1) * m + j], dr[k + 1], s1);
@@ -199,6 +214,7 @@ __global__ __launch_bounds__(128) void k_spec3(const SweepArgs a, int blk_begin)
       s3 = fma((double)G[(size_t)(k + 3) * m + j], dr[k + 3], s3);
     }
     for (; k < j; ++k) s0 = fma((double)G[(size_t)k * m + j], dr[k], s0);
+    }
     if (cen) for (int k2 = 0; k2 < j; ++k2) ib += cs[k2];
   }
   double spec = (s0 + s1) + (s2 + s3);
