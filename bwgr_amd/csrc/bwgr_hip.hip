@@ -1404,6 +1404,9 @@ static void launch_prestage(bwgr_panel *P, const SweepArgs &a_in) {
 // k_prestage draws for itself whenever the buffer is not this iteration's.
 static void draws_ahead(bwgr_panel *P, const SweepArgs &a, hipEvent_t before_sweep) {
   if (SWEEP_DRY || !(a.flags & SWF_SELECT) || (a.flags & (SWF_MH | SWF_EM_ANY))) return;
+  // only for a chain that has the GPU to itself (as the 128-row streamers and the prefetcher workgroups): beside other chains or shards the idle
+  // compute units it would run on are theirs (five chains side by side 255 -> 226 chain-iter/s, three shards 163 -> 119 iter/s with it)
+  if (!(P->solo3 && !P->parent && P->nclones == 0)) return;
   static const bool off = [] { const char *v = getenv("BWGR_DRAWS"); return v && v[0] == '0'; }();
   if (off) return;
   if (!P->draws) {
