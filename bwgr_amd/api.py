@@ -506,6 +506,12 @@ def fit_many(X, jobs, concurrent=None, chunk=4, pair=None, **panel_kw):
             nslot = max(1, min((len(paired) + 1) // 2, cap if concurrent is None else min(int(concurrent), cap)))
             need(2 * nslot)
             queue, active = list(paired), {}
+
+            def unpair(rec):   # BWGR_ERANGE: a pair sweep left the fixed-point range (no redo on that path, include/bwgr.h): the job again, alone
+                i, ch, _ = rec
+                ch.close(); live.remove(ch)
+                single.append(i)
+
             while queue or active:
                 for s_ in range(nslot):
                     rec = active.setdefault(s_, [None, None])
@@ -516,8 +522,13 @@ def fit_many(X, jobs, concurrent=None, chunk=4, pair=None, **panel_kw):
                     a_, b_ = rec
                     if a_ is not None and b_ is not None:
                         step = min(int(chunk), a_[2], b_[2])
-                        a_[1].run_pair(b_[1], step)
-                        a_[2] -= step; b_[2] -= step
+                        try:
+                            a_[1].run_pair(b_[1], step)
+                            a_[2] -= step; b_[2] -= step
+                        except BwgrError as ex:   # (surfaces when an earlier pair sweep's status is read: either chain may be the one)
+                            if ex.code != 6:
+                                raise
+                            unpair(a_); unpair(b_); rec[0] = rec[1] = None
                     else:
                         for r in (a_, b_):
                             if r is not None:
@@ -525,7 +536,13 @@ def fit_many(X, jobs, concurrent=None, chunk=4, pair=None, **panel_kw):
                 for s_, rec in list(active.items()):
                     for h in (0, 1):
                         if rec[h] is not None and rec[h][2] == 0:
-                            finish(rec[h]); rec[h] = None
+                            try:
+                                finish(rec[h])
+                            except BwgrError as ex:
+                                if ex.code != 6:
+                                    raise
+                                single.append(rec[h][0])   # (finish closed the chain)
+                            rec[h] = None
                     if rec[0] is None and rec[1] is None and not queue:
                         del active[s_]
         # ---- the rest, one chain per handle ----

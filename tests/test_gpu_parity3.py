@@ -441,3 +441,22 @@ def test_fold_a_step_ahead_is_the_same_chain_at_every_lag(env, pi, monkeypatch):
     o = O.bayes("BayesB", y, X, it=5, bi=1, pi=pi, seed=31)["last"]
     assert scaled_err(st["b"], o["b"]) < TOL and scaled_err(st["e"], o["e"]) < TOL
     assert np.array_equal(st["d"], o["d"])
+
+
+def test_fit_many_reruns_a_pair_that_left_the_range_unpaired(monkeypatch):
+    """include/bwgr.h, BWGR_ERANGE: a pair sweep (bwgr_chain_run_pair) has no redo on the fp64 residual; fit_many runs such a job again, alone, where
+    the sweep is guarded.  BWGR_DEBUG_SH_ADD takes fourteen bits of headroom off the fixed-point grid, so every pair sweep leaves the range; the
+    results must be the chains the jobs run alone (whose every sweep is then redone on the fp64 engine), bit for bit."""
+    import bwgr_amd
+    monkeypatch.setenv("BWGR_DEBUG_SH_ADD", "14")
+    X, y = synth_small(500, 900, seed=5)
+    P = bwgr_amd.Panel(X)
+    try:
+        jobs = [dict(model="BayesB", y=y, it=9, bi=2, pi=0.97, seed=40 + i) for i in range(3)]
+        got = bwgr_amd.fit_many(P, jobs, pair=True, chunk=4)
+        for i, j in enumerate(jobs):
+            alone = bwgr_amd.BayesB(y, P, it=9, bi=2, pi=0.97, seed=40 + i)
+            for k in alone:
+                np.testing.assert_array_equal(np.asarray(got[i][k]), np.asarray(alone[k]), err_msg="job %d %s" % (i, k))
+    finally:
+        P.close()
