@@ -634,14 +634,12 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   const bool upd = wave < NU;
   if (upd) e_own = __double2ll_rn(a.e[row0 + 64 * wave + lane] * S);
 
-  // tile moves: LDS-DMA, NPC 1 KiB pieces per tile (MPP markers each), PPW per DOTS wave (128 rows: sixteen pieces over six waves, the last
-  // two waves repeat piece 15; 256 rows: thirty-two over four: every dots wave issues the same number of requests, the wait counts rely on it).  The update waves issue none: their fold waits for a list
-  // word that is younger than anything they issued before, and the compiler -- which does not see the asm requests -- would wait them out.  Lane l of piece pc fills LDS slot (marker
-  // 8 pc + (l >> 3), position l & 7) with the marker's 16-byte chunk (l & 7) ^ ((l >> 3) & 7): chunk c of marker jj sits at position
-  // c ^ (jj & (CH - 1)), so that sixteen markers' equal chunks fall on different banks without padding.  NTB tile buffers: tile t + NTB - 1
-  // is requested at the END of step t, into the buffer tile t - 1 left a whole step ago, and is first read after the barrier of step
-  // t + NTB - 1 -- NTB - 2 block periods (and the rest of a step) to land; four buffers at 128 rows, three (96 KB) at 256.  The requests are the LAST memory instructions a wave issues in a step, so that no wait for a younger
-  // load (the in-order counter) waits for them; before a step's barrier a counted wait (S3_DMA_BARRIER) covers the tile the step reads.
+  // tile moves: LDS-DMA, NPC 1 KiB pieces per tile (MPP markers each), PPW = NPC / 2 per DMA wave (waves 6 and 7: every DMA wave issues the same number of
+  // requests per step, the wait count relies on it).  Lane l of piece pc fills LDS slot (marker 8 pc + (l >> 3), position l & 7) with the marker's
+  // 16-byte chunk (l & 7) ^ ((l >> 3) & 7): chunk c of marker jj sits at position c ^ (jj & (CH - 1)), so that sixteen markers' equal chunks fall on
+  // different banks without padding.  NTB tile buffers: tile t + NTB - 1 is requested right after the barrier of step t, into the buffer tile t - 1 left a
+  // whole step ago, and is first read after the barrier of step t + NTB - 1 -- NTB - 2 block periods (and the rest of a step) to land; four buffers at
+  // 128 rows.  Before a step's barrier a counted wait on the DMA waves (S3_DMA_BARRIER) covers the tile the step reads.
   // Roles by what a wave keeps on its (in-order) memory counter -- round 4: update waves 0-1 (the list words, compiler-managed waits); dots waves 2-5
   // (no load at all: their atomics are fire-and-forget, nothing ever waits behind them); DMA waves 6-7 (nothing but LDS-DMA requests, eight tile
   // pieces and the next block's rejected steps each per step, behind ONE counted wait).  Round 3 had all six non-update waves issue pieces, small
