@@ -2200,6 +2200,10 @@ static bool has_d(int model) { return model == BWGR_BAYESB || model == BWGR_BAYE
 extern "C" int bwgr_chain_destroy(bwgr_chain *C) {
   if (!C) return BWGR_OK;
   if (C->P && C->P->ps_owner == C) C->P->ps_owner = nullptr;   // (a later chain may be allocated at this address)
+  if (C->P && C->P->draws_sc == (const void *)C->sc) {          // ... and so may its scalars: variates drawn ahead for this chain are nobody's now
+    if (C->P->draws_stream) (void)hipStreamSynchronize(C->P->draws_stream);   // (k_draws reads the chain's df from them)
+    C->P->draws_valid = false; C->P->draws_sc = nullptr;
+  }
   if (C->P) { C->P->nchains--; (void)hipSetDevice(C->P->device); }
   for (hipEvent_t ev : C->ev) hipEventDestroy(ev);
   hipFree(C->e0); hipFree(C->y); if (C->e_owned) hipFree(C->e); hipFree(C->b); hipFree(C->d); hipFree(C->vb); hipFree(C->lam);
