@@ -1200,7 +1200,7 @@ static int sweep3_build(bwgr_panel *P) {
   int R3 = (P->R % 256 == 0) ? 256 : 128;
   if (const char *rv = getenv("BWGR_R3")) { const int v = atoi(rv); if ((v == 64 || v == 128 || v == 256) && P->R % v == 0) { R3 = v; P->solo3 = false; } }   // (an explicit height holds for every launch)
   const int sub = P->R / R3, K3 = P->K * sub;
-  int D = 11;   // (the streamers fold a list whose words they saw a step ahead: more lag than the fold itself needs -- C4: 12.45 ms at 8, 11.27 at 9, 10.68 at 10, 10.58 at 11, 10.57 at 12)
+  int D = 12;   // (the streamers fold a list whose words they saw a step ahead: more lag than the fold itself needs -- C4: 12.45 ms at 8, 11.27 at 9, 10.78 at 10, 10.41 at 11, 10.37 at 12, 10.48 at 13)
   // (at least 2: a block's list leaves the sequencer while the next block is in its rounds)
   if (const char *dv = getenv("BWGR_D3")) { const int v = atoi(dv); if (v >= 2 && v <= S3_MAXD) D = v; }
   D = (int)std::min<int64_t>(D, std::max<int64_t>(2, P->nblocks));

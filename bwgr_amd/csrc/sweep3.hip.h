@@ -736,12 +736,19 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   int xp0 = 0, xp1 = 0, xp2 = 0, xp3 = 0;                 // the prefetched column bytes (this lane's row)
   long long cp0 = 0, cp1 = 0, cp2 = 0, cp3 = 0;           // their steps on the fixed-point grid
   int np = -1;                                            // entries of the list the next fold takes (-1: not seen a step ahead)
-  unsigned long long lmid = 0ull;                         // the words requested one step ago (no copy of them is kept for fold_list: a register rotation
+#ifndef BWGR_WORDS2
+#define BWGR_WORDS2 0
+#endif
+  // (BWGR_WORDS2: the words requested TWO steps before they are looked at -- they are read past the caches, about 2 us, longer than a step: two registers
+  // by the step's parity, the step compiled twice, so that a request lands in the register its consumer reads)
+  unsigned long long lmid = 0ull, lw1 = 0ull;             // the words requested one step ago (no copy of them is kept for fold_list: a register rotation
                                                           // makes the compiler land the load in a temporary and wait for it at once)
-  auto fold_prefetch = [&](int bs) {                      // bs: the block whose list the NEXT step folds (relative; < 0: none)
+#define S3_PAR(A0_, A1_) (*((!BWGR_WORDS2 || PP == 0) ? &(A0_) : &(A1_)))
+  auto fold_prefetch = [&](int bs, auto par_c) {          // bs: the block whose list the NEXT step folds (relative; < 0: none)
+    constexpr int PP = decltype(par_c)::value;
     // (straight-line code, every load unconditional: where a loaded value meets another one at the join of a branch the compiler copies registers
     // and waits for the load in front of the copy -- right after its issue)
-    const unsigned long long wv = lmid;
+    const unsigned long long wv = S3_PAR(lmid, lw1);
     const unsigned long long hv = __builtin_amdgcn_readfirstlane((uint32_t)wv) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(wv >> 32)) << 32);
     const int cnt = (int)(uint32_t)hv, nw = min(62, 2 * max(cnt, 0));
     const bool ok = bs >= 0 && s3_epoch_is(hv, A.epoch) && __ballot(lane >= 1 && lane <= nw && !s3_epoch_is(wv, A.epoch)) == 0ull;   // (all its words there)
@@ -773,7 +780,10 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   // lgkmcnt(0) + s_barrier and drains no DMA, so the prologue tiles are drained here, once per launch. ----
   if (wvs >= 6) drej_issue(0);
   for (int t = 0; t < NTB - 1; ++t) tile_issue(t);
-  if (wvs < NU) lmid = ld_agent_raw64(lists_w + (size_t)(a.blk_begin + max(min(1, nb - 1) - D, 0)) * S3_LSTRIDE + lane);   // (step 1's: never folded before step D)
+  if (wvs < NU) {   // (what steps 0 and 1 look at: never folded before step D)
+    lmid = ld_agent_raw64(lists_w + (size_t)(a.blk_begin + max(min(1, nb - 1) - D, 0)) * S3_LSTRIDE + lane);
+    if (BWGR_WORDS2) lw1 = ld_agent_raw64(lists_w + (size_t)(a.blk_begin + max(min(2, nb - 1) - D, 0)) * S3_LSTRIDE + lane);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   S3ST_DECL;
@@ -785,7 +795,8 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
   // leaves the younger tiles in flight.  (The update waves issue no pieces: the count is harmless there.)
   constexpr int WN = (NTB - 2) * LPS;
 #define S3_DMA_BARRIER() do { if (wvs >= 6) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WN) : "memory"); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
-  auto step = [&](int b) -> bool {
+  auto step = [&](int b, auto par_c) -> bool {
+    constexpr int PP = decltype(par_c)::value;   // b & 1 (BWGR_WORDS2)
     const int mB = blk_m(b), par = b & 1;
     S3ST(0, st_u || st_d);
     int8_t *tile = tile0 + (size_t)(b % NTB) * tile_b;
@@ -793,6 +804,15 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
     int8_t *ddig = ddig0 + (size_t)par * 16 * S2_DP;
     // A: what the included markers of block b - D changed
     if (b >= D && upd && !(SDBG & 512)) { if (!fold_pre(b - D)) ctl_s[0] = 1u; }
+#ifndef BWGR_FOLD_EARLY
+#define BWGR_FOLD_EARLY 1
+#endif
+    if (BWGR_FOLD_EARLY && wvs < NU) {   // (the update waves only: no other wave keeps a compiler-visible load)
+      // right behind this step's fold: the words of the list step b + 1 folds were requested a step ago -- look at them, request its columns (they
+      // get the whole step to land); then the words for step b + 2
+      if (!(SDBG & 512)) fold_prefetch((b + 1 < nb) ? b + 1 - D : -1, par_c);
+      S3_PAR(lmid, lw1) = ld_agent_raw64(lists_w + (size_t)(a.blk_begin + max(min(b + 2 + BWGR_WORDS2, nb - 1) - D, 0)) * S3_LSTRIDE + lane);
+    }
     S3ST(1, st_u);
     // B: digits of the residual rows and of this block's rejected steps
     if (upd) {
@@ -819,10 +839,10 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
     S3ST(6, st_u || st_d);
     {   // the small requests first (older than the tile loads on the in-order memory counter, so waiting for them does not wait
         // for the tile), every one unconditional: a load under a branch makes the compiler drain the counter in front of it
-      if (wvs < NU) {   // (the update waves only: no other wave keeps a compiler-visible load)
+      if (!BWGR_FOLD_EARLY && wvs < NU) {   // (the update waves only: no other wave keeps a compiler-visible load)
         // the words of the list step b + 1 folds were requested a step ago: look at them, request its columns; then the words for step b + 2
-        if (!(SDBG & 512)) fold_prefetch((b + 1 < nb) ? b + 1 - D : -1);
-        lmid = ld_agent_raw64(lists_w + (size_t)(a.blk_begin + max(min(b + 2, nb - 1) - D, 0)) * S3_LSTRIDE + lane);
+        if (!(SDBG & 512)) fold_prefetch((b + 1 < nb) ? b + 1 - D : -1, par_c);
+        S3_PAR(lmid, lw1) = ld_agent_raw64(lists_w + (size_t)(a.blk_begin + max(min(b + 2 + BWGR_WORDS2, nb - 1) - D, 0)) * S3_LSTRIDE + lane);
       }
     }
     S3ST(7, st_u || st_d);
@@ -920,9 +940,13 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
     }
     return true;
   };
-  for (int b = 0; b < nb; ++b) if (!step(b)) return;
+  for (int b = 0; b < nb; b += 2) {
+    if (!step(b, std::integral_constant<int, 0>{})) return;
+    if (b + 1 < nb && !step(b + 1, std::integral_constant<int, 1>{})) return;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the requests past the end)
 #undef S3_DMA_BARRIER
+#undef S3_PAR
   S3ST_FLUSH(0, st_u); S3ST_FLUSH(8, st_d);
   // the lists of the last D blocks
   if (upd && !(SDBG & 512)) for (int bs = max(0, nb - D); bs < nb; ++bs) {
