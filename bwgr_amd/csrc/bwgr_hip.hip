@@ -1311,6 +1311,7 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
   // not counted by bwgr_panel_max_concurrent, so it stays off there; BWGR_PF3=0|1 decides otherwise)
   const bool pf_on = (pv ? pv[0] == '1' : solo) && A.K3 + 2 <= 256;
   A.pf = pf_on ? ((A.K3 + 2 > 8) ? 8 : A.K3 + 1) : -1;
+  { const char *sv = getenv("BWGR_SKIPVB"); A.skip_vb = ((a.flags & SWF_VB_VEC) && !(sv && sv[0] == '0')) ? 1 : 0; }
   const char *p2v = getenv("BWGR_PF3B");
   const bool pf2_on = pf_on && A.pf == 8 && A.gx12 && A.K3 + 3 > 16 && A.K3 + 3 <= 256 && !(p2v && p2v[0] == '0');
   A.pf2 = pf2_on ? 16 : -1;
@@ -1320,6 +1321,10 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
   if (A.g16) { if (cen) SPIN_LAUNCH((k_sweep3<uint16_t, true>), grid, blk, P->lds3_bytes, P->stream, A); else SPIN_LAUNCH((k_sweep3<uint16_t, false>), grid, blk, P->lds3_bytes, P->stream, A); }
   else { if (cen) SPIN_LAUNCH((k_sweep3<int32_t, true>), grid, blk, P->lds3_bytes, P->stream, A); else SPIN_LAUNCH((k_sweep3<int32_t, false>), grid, blk, P->lds3_bytes, P->stream, A); }
   if (cen && !SWEEP_DRY) hipLaunchKernelGGL(k_cen_end, dim3(64), dim3(256), 0, P->stream, a, 0);
+  if (A.skip_vb && !SWEEP_DRY) {   // (every launch: idempotent -- after a range redo the fp64 engine has written the same values from the same expression)
+    const int j0 = a.blk_begin * a.m, j1 = (int)std::min<int64_t>(P->p, (int64_t)a.blk_end * a.m);
+    hipLaunchKernelGGL(k_vb_fill, dim3((unsigned)std::min<int64_t>(1024, (j1 - j0 + 255) / 256)), dim3(256), 0, P->stream, a, j0, j1);
+  }
 }
 
 // The selection models' sweeps on a panel that has k_sweep3: the device picks the engine from the chain's current inclusion

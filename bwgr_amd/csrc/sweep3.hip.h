@@ -64,6 +64,7 @@ struct Sweep3Args {
   int dbg;                       // experiment switches (BWGR_DBG3)
   int pf;                        // blockIdx of the prefetcher workgroup (shares the sequencer's XCD), or -1
   int pf2;                       // ... of the second one (the included markers' distance-1 / 2 rows), or -1
+  int skip_vb;                   // 1: the per-marker variances are formed after the sweep (k_vb_fill), not by the sequencer's wave 7
   const unsigned char *gx12;     // 16-bit panels: [nblocks][m][2][m] uint16, marker k of block b against blocks b+1 and b+2 side by side (k_near_rows):
                                  // an included marker's distance-1 and distance-2 rows in ONE LDS-DMA; nullptr: two requests from gx[0], gx[1]
 };
@@ -223,6 +224,16 @@ __global__ __launch_bounds__(128) void k_spec3(const SweepArgs a, int blk_begin,
     gjj = __hiloint2double(sj, (j < mB) ? (int)G[(size_t)j * m + j] : 0);
   }
   sp.spec[j] = spec; sp.xspec[j] = 0.0; sp.gjj[j] = gjj;
+}
+
+// k_vb_fill: the per-marker variances of the markers a k_sweep3 launch swept, vb_j = (Sb + b_j^2) / chi_j (src/Rcpp20260726ai.cpp, BayesA / B) -- the
+// expression every sweep engine uses, formed chip-wide after the sweep instead of by the sequencer's wave 7 (Sweep3Args::skip_vb)
+__global__ void k_vb_fill(const SweepArgs a, int j_begin, int j_end) {
+  const float Sb = a.sc->Sb;
+  for (int j = j_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x); j < j_end; j += (int)(gridDim.x * blockDim.x)) {
+    const float bn = a.b[j];
+    a.vb[j] = (float)((double)(Sb + bn * bn) / a.ps.blocks[j / a.m].chi[j % a.m]);
+  }
 }
 
 // The seven signed base-256 digits of q (|q| < 2^55) as bytes: adding 0x80 to each of the seven low bytes turns the signed digits
@@ -1236,9 +1247,9 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   auto finish_block = [&](int c) {
     const int blk = a.blk_begin + c, j0c = blk * m, mBc = blk_m(c);
     const float *sp = state_s + (size_t)(c & 1) * 2 * SW_MAXM;
-    const bool vbv = (a.flags & SWF_VB_VEC) != 0;
+    const bool vbv = (a.flags & SWF_VB_VEC) != 0 && !A.skip_vb;   // (skip_vb: k_vb_fill forms the variances after the sweep -- two fp64 divisions a lane less on this wave)
     const double ch0 = chn0, ch1 = chn1;
-    chi_request(c + 1);
+    if (vbv) chi_request(c + 1);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int t = lane + 64 * h;
@@ -1314,7 +1325,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   if (wave == 1) { poll_request(0); poll_request(1); if (!poll_q(0)) ctrl_s[0] = 0; }
   else if (wave == 2 || wave == 3) { stage_issue(0); stage_issue(1); S3_STG_WAIT(); far_consume(0, wave, 0, 0, 0, 0.0); far_plan(1, wave); far_request(1, wave); }
   else if (wave >= 5 && wave <= 6) { far_consume(0, wave - 5, 0, 0, 0, 0.0); far_plan(1, wave - 5); far_request(1, wave - 5); }
-  else if (wave == 7) { for (int c = 0; c < PF; ++c) touch(c); chi_request(0); }
+  else if (wave == 7) { for (int c = 0; c < PF; ++c) touch(c); if ((a.flags & SWF_VB_VEC) && !A.skip_vb) chi_request(0); }
   __syncthreads();
   if (ctrl_s[0] == 0) { if (tid == 0) a.sc->error = 1u; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
 
