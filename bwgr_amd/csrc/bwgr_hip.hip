@@ -1311,6 +1311,7 @@ static void launch_sweep3(bwgr_panel *P, const SweepArgs &a) {
   // not counted by bwgr_panel_max_concurrent, so it stays off there; BWGR_PF3=0|1 decides otherwise)
   const bool pf_on = (pv ? pv[0] == '1' : solo) && A.K3 + 2 <= 256;
   A.pf = pf_on ? ((A.K3 + 2 > 8) ? 8 : A.K3 + 1) : -1;
+  A.qsplit = 1;
   { const char *sv = getenv("BWGR_SKIPVB"); A.skip_vb = ((a.flags & SWF_VB_VEC) && !(sv && sv[0] == '0')) ? 1 : 0; }
   const char *p2v = getenv("BWGR_PF3B");
   const bool pf2_on = pf_on && A.pf == 8 && A.gx12 && A.K3 + 3 > 16 && A.K3 + 3 <= 256 && !(p2v && p2v[0] == '0');

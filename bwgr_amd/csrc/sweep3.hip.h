@@ -64,6 +64,7 @@ struct Sweep3Args {
   int dbg;                       // experiment switches (BWGR_DBG3)
   int pf;                        // blockIdx of the prefetcher workgroup (shares the sequencer's XCD), or -1
   int pf2;                       // ... of the second one (the included markers' distance-1 / 2 rows), or -1
+  int qsplit;                    // 1: a marker's two slab-dot words hold digits 0-3 and 4-6 (k_sweep3's streamers: no LDS round trip between MFMA and atomics); 0: digits 0-2 and 3-6 (k_sweep3p)
   int skip_vb;                   // 1: the per-marker variances are formed after the sweep (k_vb_fill), not by the sequencer's wave 7
   const unsigned char *gx12;     // 16-bit panels: [nblocks][m][2][m] uint16, marker k of block b against blocks b+1 and b+2 side by side (k_near_rows):
                                  // an included marker's distance-1 and distance-2 rows in ONE LDS-DMA; nullptr: two requests from gx[0], gx[1]
@@ -547,29 +548,20 @@ __device__ __forceinline__ void s3_streamer(const Sweep3Args &A) {
         s2_v4i acc = {0, 0, 0, 0}, acc2 = acc;
         for (int r = 0; r < ((SDBG & 256) ? 0 : R3); r += 64) {
           const s2_v4i bv = *reinterpret_cast<const s2_v4i *>(bp + r);
-          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap + r), bv, acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap2 + r), bv, acc2, 0, 0, 0);
+          // (digits as the A operand, genotypes as B: the output tile is [digit][marker], so that lane (marker m16, group grp) holds the marker's digits
+          // 4 grp .. 4 grp + 3 and the two words are formed in registers -- the other order scattered a marker's digits over seven lanes and went through LDS)
+          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(bv, *reinterpret_cast<const s2_v4i *>(ap + r), acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bv, *reinterpret_cast<const s2_v4i *>(ap2 + r), acc2, 0, 0, 0);
         }
-        int *od = outd + (size_t)wave * 32 * S3_OS;
-        if (m16 < 8) {      // lane: digit n = m16 of markers 16 gm + 4 grp + reg (rows 0..15 of the scratch) and of group gm2 (rows 16..31)
-          int *op = od + (size_t)(4 * grp) * S3_OS + m16;
-          op[0] = acc[0]; op[S3_OS] = acc[1]; op[2 * S3_OS] = acc[2]; op[3 * S3_OS] = acc[3];
-          op[16 * S3_OS] = acc2[0]; op[17 * S3_OS] = acc2[1]; op[18 * S3_OS] = acc2[2]; op[19 * S3_OS] = acc2[3];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane < (two ? 32 : 16)) {
-          const int4 o0 = *reinterpret_cast<const int4 *>(od + (size_t)lane * S3_OS);
-          const int4 o1 = *reinterpret_cast<const int4 *>(od + (size_t)lane * S3_OS + 4);
-          const long long lo = (long long)o0.x + ((long long)o0.y << 8) + ((long long)o0.z << 16);
-          const long long hi = (long long)o0.w + ((long long)o1.x << 8) + ((long long)o1.y << 16) + ((long long)o1.z << 24);
-          const int mk = 16 * ((lane < 16) ? gm : gm2) + (lane & 15);
-          unsigned long long *qs = A.qsum + ((size_t)(a.blk_begin + b) * SW_MAXM + mk) * 2;
+        if (grp < 2) {   // word grp of the marker: digits 0-3 (weight 1) or 4-6 (weight 2^32, the sequencer's), with the arrival count in the low byte
+          const long long w1 = (long long)acc[0] + ((long long)acc[1] << 8) + ((long long)acc[2] << 16) + ((long long)acc[3] << 24);
+          const long long w2 = (long long)acc2[0] + ((long long)acc2[1] << 8) + ((long long)acc2[2] << 16) + ((long long)acc2[3] << 24);
+          unsigned long long *qs = A.qsum + ((size_t)(a.blk_begin + b) * SW_MAXM + 16 * gm + m16) * 2 + grp;
           if (!(SDBG & 8)) {
-          __hip_atomic_fetch_add((gu64_t *)qs, (unsigned long long)((lo << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_fetch_add((gu64_t *)(qs + 1), (unsigned long long)((hi << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add((gu64_t *)qs, (unsigned long long)((w1 << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (two) __hip_atomic_fetch_add((gu64_t *)(qs + (size_t)(16 * (gm2 - gm)) * 2), (unsigned long long)((w2 << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch is read before the next pass overwrites it
       }
       S3ST(5, st_d);
     }
@@ -923,29 +915,20 @@ __device__ __forceinline__ void s3_streamer_dma(const Sweep3Args &A) {
         for (int r = 0; r < ((SDBG & 256) ? 0 : R3); r += 64) {
           const s2_v4i bv = *reinterpret_cast<const s2_v4i *>(bp + r);
           const int so = (((grp + (r >> 4)) ^ (m16 & (CH - 1))) << 4);   // rows r + 16 grp .. + 15 = chunk grp + r / 16
-          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap + so), bv, acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const s2_v4i *>(ap2 + so), bv, acc2, 0, 0, 0);
+          // (digits as the A operand, genotypes as B: the output tile is [digit][marker], so that lane (marker m16, group grp) holds the marker's digits
+          // 4 grp .. 4 grp + 3 and the two words are formed in registers -- the other order scattered a marker's digits over seven lanes and went through LDS)
+          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(bv, *reinterpret_cast<const s2_v4i *>(ap + so), acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(bv, *reinterpret_cast<const s2_v4i *>(ap2 + so), acc2, 0, 0, 0);
         }
-        int *od = outd + (size_t)wave * 32 * S3_OS;
-        if (m16 < 8) {      // lane: digit n = m16 of markers 16 gm + 4 grp + reg (rows 0..15 of the scratch) and of group gm2 (rows 16..31)
-          int *op = od + (size_t)(4 * grp) * S3_OS + m16;
-          op[0] = acc[0]; op[S3_OS] = acc[1]; op[2 * S3_OS] = acc[2]; op[3 * S3_OS] = acc[3];
-          op[16 * S3_OS] = acc2[0]; op[17 * S3_OS] = acc2[1]; op[18 * S3_OS] = acc2[2]; op[19 * S3_OS] = acc2[3];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane < (two ? 32 : 16)) {
-          const int4 o0 = *reinterpret_cast<const int4 *>(od + (size_t)lane * S3_OS);
-          const int4 o1 = *reinterpret_cast<const int4 *>(od + (size_t)lane * S3_OS + 4);
-          const long long lo = (long long)o0.x + ((long long)o0.y << 8) + ((long long)o0.z << 16);
-          const long long hi = (long long)o0.w + ((long long)o1.x << 8) + ((long long)o1.y << 16) + ((long long)o1.z << 24);
-          const int mk = 16 * ((lane < 16) ? gm : gm2) + (lane & 15);
-          unsigned long long *qs = A.qsum + ((size_t)(a.blk_begin + b) * SW_MAXM + mk) * 2;
+        if (grp < 2) {   // word grp of the marker: digits 0-3 (weight 1) or 4-6 (weight 2^32, the sequencer's), with the arrival count in the low byte
+          const long long w1 = (long long)acc[0] + ((long long)acc[1] << 8) + ((long long)acc[2] << 16) + ((long long)acc[3] << 24);
+          const long long w2 = (long long)acc2[0] + ((long long)acc2[1] << 8) + ((long long)acc2[2] << 16) + ((long long)acc2[3] << 24);
+          unsigned long long *qs = A.qsum + ((size_t)(a.blk_begin + b) * SW_MAXM + 16 * gm + m16) * 2 + grp;
           if (!(SDBG & 8)) {
-          __hip_atomic_fetch_add((gu64_t *)qs, (unsigned long long)((lo << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_fetch_add((gu64_t *)(qs + 1), (unsigned long long)((hi << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add((gu64_t *)qs, (unsigned long long)((w1 << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (two) __hip_atomic_fetch_add((gu64_t *)(qs + (size_t)(16 * (gm2 - gm)) * 2), (unsigned long long)((w2 << 8) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch is read before the next pass overwrites it
       }
       S3ST(5, st_d);
     }
@@ -1058,6 +1041,7 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   // atomics are performed there), and every helper role's request -> consume chain was one phase long (profiles/NOTES.md, round 4).  The counted
   // wait leaves the younger block's two pieces in flight; an incomplete sum (the streamers are D blocks ahead: rare) falls back to polling.
   const uint32_t qraw_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)qraw_s);
+  const double qweight = A.qsplit ? 4294967296.0 : 16777216.0;   // the second word's weight: digits 4-6 (k_sweep3's streamers) or 3-6 (k_sweep3p's)
   auto poll_request = [&](int c) {   // (clamped block: the requests past the end re-read the last block)
     const unsigned char *g = reinterpret_cast<const unsigned char *>(A.qsum + (size_t)(a.blk_begin + min(c, nb - 1)) * SW_MAXM * 2);
     const uint32_t la = qraw_la + (uint32_t)((c % 3) * S3_QRAW_BYTES);
@@ -1095,8 +1079,8 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       }
     }
     double *qd = q_s + (size_t)(c & 1) * SW_MAXM;
-    qd[lane] = n0 ? fma((double)((long long)h0 >> 8), 16777216.0, (double)((long long)l0 >> 8)) * invS : 0.0;
-    qd[64 + lane] = n1 ? fma((double)((long long)h1 >> 8), 16777216.0, (double)((long long)l1 >> 8)) * invS : 0.0;
+    qd[lane] = n0 ? fma((double)((long long)h0 >> 8), qweight, (double)((long long)l0 >> 8)) * invS : 0.0;
+    qd[64 + lane] = n1 ? fma((double)((long long)h1 >> 8), qweight, (double)((long long)l1 >> 8)) * invS : 0.0;
     poll_request(c + 2);
     return 1;
   };
