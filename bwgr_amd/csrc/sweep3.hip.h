@@ -1015,21 +1015,29 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   const uint32_t stage_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)stage);
   const uint32_t spec_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)spec_s);
   static_assert(sizeof(StageBuf) == 6 * 1024, "six 1 KiB pieces of constants");
-  auto stage_issue = [&](int c) {
+  auto stage_issue = [&](int c, int part = -1) {   // part 0: the constants and speculative terms, 1 / 2: the packed block's first / second half; -1: all
     const int blk = a.blk_begin + min(c, nb - 1), slot = c % 3, wv2 = __builtin_amdgcn_readfirstlane(wave) - 2;
     const unsigned char *stb = reinterpret_cast<const unsigned char *>(a.ps.blocks + blk);
     const unsigned char *spb = reinterpret_cast<const unsigned char *>(a.ps.spec + blk);
     const uint32_t lo16 = (uint32_t)lane * 16u;
     // pieces 0-5: the constants; 6: spec; 7: the Gram diagonal (SpecBuf: spec at 0, gjj at 2 KB) -- even pieces on wave 2, odd ones on wave 3
+    if (part <= 0) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) { const int pc = wv2 + 2 * u; s3_dma16s(stb, (uint32_t)pc * 1024u + lo16, stage_la + (uint32_t)slot * (uint32_t)sizeof(StageBuf) + (uint32_t)pc * 1024u); }
     s3_dma16s(spb, (uint32_t)wv2 * 2048u + lo16, spec_la + (uint32_t)slot * 2048u + (uint32_t)wv2 * 1024u);
+    }
     if constexpr (GPD) {
       const int gpbytes = pstride * 2;   // (pstride is a multiple of 8 entries: whole 16-byte chunks)
       const unsigned char *src = reinterpret_cast<const unsigned char *>(gp_all + (size_t)blk * pstride);
       const uint32_t gla = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)gpd_s) + (uint32_t)slot * (uint32_t)S3_GPD_BYTES;
+      if (part < 0 || part == 1) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int pc = wv2 + 2 * u; s3_dma16s(src, (uint32_t)min(pc * 1024 + lane * 16, gpbytes - 16), gla + (uint32_t)pc * 1024u); }
+      for (int u = 0; u < 4; ++u) { const int pc = wv2 + 2 * u; s3_dma16s(src, (uint32_t)min(pc * 1024 + lane * 16, gpbytes - 16), gla + (uint32_t)pc * 1024u); }
+      }
+      if (part < 0 || part == 2) {
+#pragma unroll
+      for (int u = 4; u < 8; ++u) { const int pc = wv2 + 2 * u; s3_dma16s(src, (uint32_t)min(pc * 1024 + lane * 16, gpbytes - 16), gla + (uint32_t)pc * 1024u); }
+      }
     }
   };
 #define S3_STG_WAIT() asm volatile("s_waitcnt vmcnt(%0)" : : "n"(S3_STG_PIECES) : "memory")   /* all but the block just requested have landed */
@@ -1139,18 +1147,27 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
   };
   // far_plan(c): which rows (LDS reads only: the lists' positions, entries, array bases) -- this runs under the wait for the previous request's rows;
   // far_request(c): the requests themselves, after far_consume, at the end of the wave's phase
-  auto far_plan = [&](int c, int hw) {
-    f_cnt = 0; f_n = 0;
-    if (c < 3 || D < 4 || c >= nb || (SDBG & 32)) return;
-    f_p0 = pos_s[max(c - D + 1, 0) & 31];
-    f_cnt = (pos_s[(c - 2) & 31] - f_p0) & (ring - 1);   // [f_p0, +f_cnt): blocks c-D+1 .. c-3
-    f_n = (f_cnt > hw) ? min(NFL, (f_cnt - hw + NFW - 1) / NFW) : 0;
-    {
-      const int sl = (f_p0 + hw + NFW * min(lane, max(f_n - 1, 0))) & (ring - 1);
-      f_ptr = (f_n > 0) ? (unsigned long long)far_src(c, sl) : 0ull;
-      f_cf = (lane < f_n) ? accC[sl] : 0.0;
-    }
+  // (the plan is three dependent LDS round trips -- the lists' positions, the entries, the array bases -- some 500 cycles of latency; the staging waves
+  // take them one at a time between the thirds of their twelve requests, whose issue is a thousand cycles of its own: far_plan_a / _b / _c)
+  int fp_a = 0, fp_b = 0, fp_kb = 0; double fp_cf = 0.0; bool fp_on = false;
+  auto far_plan_a = [&](int c) {
+    fp_on = !(c < 3 || D < 4 || c >= nb || (SDBG & 32));
+    fp_a = pos_s[max(c - D + 1, 0) & 31]; fp_b = pos_s[(max(c, 2) - 2) & 31];
   };
+  auto far_plan_b = [&](int c, int hw) {
+    f_p0 = fp_a;
+    f_cnt = fp_on ? ((fp_b - fp_a) & (ring - 1)) : 0;    // [f_p0, +f_cnt): blocks c-D+1 .. c-3
+    f_n = (f_cnt > hw) ? min(NFL, (f_cnt - hw + NFW - 1) / NFW) : 0;
+    const int sl = (f_p0 + hw + NFW * min(lane, max(f_n - 1, 0))) & (ring - 1);
+    fp_kb = accK[sl]; fp_cf = accC[sl];
+  };
+  auto far_plan_c = [&](int c) {
+    const int d = min(max(c - (fp_kb >> 8), 1), S3_MAXD);   // (clamped: without entries the slot holds anything)
+    const unsigned char *src = gx_s[d - 1] + ((size_t)(a.blk_begin + c) * m * m + (size_t)(fp_kb & 0xFF) * m) * sizeof(GT);
+    f_ptr = (f_n > 0) ? (unsigned long long)src : 0ull;
+    f_cf = (lane < f_n) ? fp_cf : 0.0;
+  };
+  auto far_plan = [&](int c, int hw) { far_plan_a(c); far_plan_b(c, hw); far_plan_c(c); };
   auto far_request = [&](int c, int hw) {
     // (inline-asm requests: the compiler must not see them, or it drains them in front of the next LDS read -- the wait is the caller's, counted)
     const uint32_t dst_la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rowf_la + (uint32_t)(((c & 1) * NFW + hw) * NFL) * (uint32_t)ROWB));
@@ -1280,8 +1297,12 @@ __device__ __forceinline__ void s3_sequencer(const Sweep3Args &A) {
       // the requests for block c + 1 (always: past the end the last block again, the wait counts rely on it), then the wait for block c's, which were
       // issued a phase ago and are used by wave 0 after this phase's barrier
       const int o_p0 = f_p0, o_cnt = f_cnt, o_n = f_n; const double o_cf = f_cf;
-      stage_issue(c + 1);
-      far_plan(c + 1, wave);         // (far-field shares 2 and 3)
+      far_plan_a(c + 1);             // (far-field shares 2 and 3: the plan's LDS round trips under the requests' issue)
+      stage_issue(c + 1, 0);
+      far_plan_b(c + 1, wave);
+      stage_issue(c + 1, 1);
+      far_plan_c(c + 1);
+      stage_issue(c + 1, 2);
       S3_STG_WAIT();                 // ... whose rows, requested at the end of the last phase, are older than the pieces just requested: landed too
       far_consume(c, wave, o_p0, o_cnt, o_n, o_cf);
       far_request(c + 1, wave);
